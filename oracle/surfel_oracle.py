@@ -1,0 +1,150 @@
+"""ctypes front-end for oracle/surfel_oracle.c (CPU restatement of the surfel rasterizer).
+
+TEST INFRASTRUCTURE ONLY.  May be imported from tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg -- never from the product packages
+(streetunveiler_amd/, diff_surfel_rasterization/).
+
+Parity status: "parity unpinned" for the rasterizer as a whole (see the header
+of surfel_oracle.c); SH / camera matrices / quaternion pieces are pinned by
+tests/golden/ against the importable reference python.
+
+The argument names and tensor layouts mirror the operator boundary
+[REF /root/reference/gaussian_renderer/__init__.py:39-52,129-138].
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsurfel_oracle.so")
+_lib = None
+
+TILE = 16
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle with gcc (idempotent)."""
+    src = os.path.join(_HERE, "surfel_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsurfel_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.so_count_duplicates.restype = C.c_uint64
+        _lib.so_bin.restype = C.c_int
+        _lib.so_num_threads.restype = C.c_int
+    return _lib
+
+
+def num_threads() -> int:
+    return int(lib().so_num_threads())
+
+
+def _f32(a) -> Optional[np.ndarray]:
+    if a is None:
+        return None
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _p(a, ty=C.c_float):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None, colors_precomp=None,
+                      transMat_precomp=None, *, viewmatrix, projmatrix, campos, bg, image_width: int,
+                      image_height: int, sh_degree: int = 0, scale_modifier: float = 1.0,
+                      stages: bool = True) -> Dict[str, np.ndarray]:
+    """K1..K6. Returns every stage's outputs (dict of numpy arrays)."""
+    L = lib()
+    means3D = _f32(means3D); P = means3D.shape[0]
+    opacities = _f32(opacities).reshape(P)
+    scales = _f32(scales); rotations = _f32(rotations); shs = _f32(shs)
+    colors_precomp = _f32(colors_precomp); transMat_precomp = _f32(transMat_precomp)
+    assert (shs is None) != (colors_precomp is None), "exactly one of shs / colors_precomp"
+    assert (transMat_precomp is None) != (scales is None or rotations is None), "exactly one of (scales,rotations) / transMat_precomp"
+    view = _f32(viewmatrix).reshape(16); proj = _f32(projmatrix).reshape(16)
+    cam = _f32(campos).reshape(3); bgc = _f32(bg).reshape(3)
+    W, H = int(image_width), int(image_height)
+    M = shs.shape[1] if shs is not None else 0
+    o = dict(
+        radii=np.zeros(P, np.int32), means2D=np.zeros((P, 2), np.float32), depths=np.zeros(P, np.float32),
+        transMat=np.zeros((P, 9), np.float32), normal_opacity=np.zeros((P, 4), np.float32),
+        rgb=np.zeros((P, 3), np.float32), clamped=np.zeros((P, 3), np.uint8),
+        tiles_touched=np.zeros(P, np.uint32), rect=np.zeros((P, 4), np.int32))
+    L.so_preprocess_forward(P, int(sh_degree), M, _p(means3D), _p(scales), _p(rotations), _p(opacities), _p(shs),
+                            _p(colors_precomp), _p(transMat_precomp), _p(view), _p(proj), _p(cam), W, H,
+                            C.c_float(scale_modifier), _p(o["radii"], C.c_int32), _p(o["means2D"]), _p(o["depths"]),
+                            _p(o["transMat"]), _p(o["normal_opacity"]), _p(o["rgb"]), _p(o["clamped"], C.c_uint8),
+                            _p(o["tiles_touched"], C.c_uint32), _p(o["rect"], C.c_int32))
+    D = int(L.so_count_duplicates(P, _p(o["tiles_touched"], C.c_uint32)))
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    o["num_rendered"] = D
+    o["keys"] = np.zeros(max(D, 1), np.uint64)[:D]
+    o["point_list"] = np.zeros(max(D, 1), np.uint32)[:D]
+    o["ranges"] = np.zeros((gx * gy, 2), np.uint32)
+    keys_buf = np.zeros(max(D, 1), np.uint64); vals_buf = np.zeros(max(D, 1), np.uint32)
+    rc = L.so_bin(P, W, H, _p(o["radii"], C.c_int32), _p(o["depths"]), _p(o["rect"], C.c_int32),
+                  _p(o["tiles_touched"], C.c_uint32), C.c_uint64(D), _p(keys_buf, C.c_uint64),
+                  _p(vals_buf, C.c_uint32), _p(o["ranges"], C.c_uint32))
+    assert rc == 0, f"so_bin failed: {rc}"
+    o["keys"] = keys_buf[:D]; o["point_list"] = vals_buf[:D]
+    o["color"] = np.zeros((3, H, W), np.float32); o["allmap"] = np.zeros((7, H, W), np.float32)
+    o["final_T"] = np.zeros((3, H, W), np.float32); o["n_contrib"] = np.zeros((2, H, W), np.uint32)
+    tested = C.c_uint64(0)
+    L.so_render_forward(W, H, _p(o["ranges"], C.c_uint32), _p(vals_buf, C.c_uint32), _p(o["means2D"]),
+                        _p(o["transMat"]), _p(o["normal_opacity"]), _p(o["rgb"]), _p(bgc), _p(o["color"]),
+                        _p(o["allmap"]), _p(o["final_T"]), _p(o["n_contrib"], C.c_uint32), C.byref(tested))
+    o["tested_pairs"] = int(tested.value)
+    o["_inputs"] = dict(means3D=means3D, opacities=opacities, scales=scales, rotations=rotations, shs=shs,
+                        colors_precomp=colors_precomp, transMat_precomp=transMat_precomp, view=view, proj=proj,
+                        cam=cam, bg=bgc, W=W, H=H, deg=int(sh_degree), M=M, scale_modifier=float(scale_modifier),
+                        vals_buf=vals_buf)
+    return o
+
+
+def rasterize_backward(fwd: Dict[str, np.ndarray], dL_dcolor, dL_dallmap) -> Dict[str, np.ndarray]:
+    """K7 + K8 on the state returned by rasterize_forward."""
+    L = lib()
+    i = fwd["_inputs"]; P = i["means3D"].shape[0]; W, H, M = i["W"], i["H"], i["M"]
+    dL_dcolor = _f32(dL_dcolor).reshape(3, H, W); dL_dallmap = _f32(dL_dallmap).reshape(7, H, W)
+    g = dict(dL_dcolors=np.zeros((P, 3), np.float32), dL_dnormal3D=np.zeros((P, 3), np.float32),
+             dL_dtransMat=np.zeros((P, 9), np.float32), dL_dmean2D_raw=np.zeros((P, 2), np.float32),
+             dL_dopacity=np.zeros((P, 1), np.float32))
+    L.so_render_backward(W, H, _p(fwd["ranges"], C.c_uint32), _p(i["vals_buf"], C.c_uint32), _p(fwd["means2D"]),
+                         _p(fwd["transMat"]), _p(fwd["normal_opacity"]), _p(fwd["rgb"]), _p(i["bg"]),
+                         _p(fwd["final_T"]), _p(fwd["n_contrib"], C.c_uint32), _p(dL_dcolor), _p(dL_dallmap),
+                         _p(g["dL_dcolors"]), _p(g["dL_dnormal3D"]), _p(g["dL_dtransMat"]), _p(g["dL_dmean2D_raw"]),
+                         _p(g["dL_dopacity"]))
+    g["dL_dtransMat_render"] = g["dL_dtransMat"].copy()
+    g["dL_dmeans3D"] = np.zeros((P, 3), np.float32); g["dL_dscales"] = np.zeros((P, 2), np.float32)
+    g["dL_drotations"] = np.zeros((P, 4), np.float32); g["dL_dmeans2D"] = np.zeros((P, 3), np.float32)
+    g["dL_dsh"] = np.zeros((P, max(M, 1), 3), np.float32)[:, :M]
+    dsh_buf = np.zeros((P, max(M, 1), 3), np.float32)
+    L.so_preprocess_backward(P, i["deg"], M, _p(i["means3D"]), _p(i["scales"]), _p(i["rotations"]), _p(i["shs"]),
+                             _p(i["transMat_precomp"]), _p(i["view"]), _p(i["proj"]), _p(i["cam"]), W, H,
+                             C.c_float(i["scale_modifier"]), _p(fwd["radii"], C.c_int32), _p(fwd["clamped"], C.c_uint8),
+                             _p(fwd["transMat"]), _p(g["dL_dtransMat"]), _p(g["dL_dnormal3D"]), _p(g["dL_dmean2D_raw"]),
+                             _p(g["dL_dcolors"]), _p(g["dL_dmeans3D"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]),
+                             _p(dsh_buf), _p(g["dL_dmeans2D"]))
+    if M:
+        g["dL_dsh"] = dsh_buf
+    return g
+
+
+def mark_visible(means3D, viewmatrix) -> np.ndarray:
+    means3D = _f32(means3D); P = means3D.shape[0]
+    out = np.zeros(P, np.uint8)
+    lib().so_mark_visible(P, _p(means3D), _p(_f32(viewmatrix).reshape(16)), _p(out, C.c_uint8))
+    return out.astype(bool)

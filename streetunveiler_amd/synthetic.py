@@ -1,0 +1,59 @@
+"""Seeded synthetic surfel scenes for the benchmark and the parity tests.
+
+Camera at the origin looking +z, fx = fy = 0.8*W; Gaussians: z ~ U(1,50),
+x,y ~ U(-1.1,1.1)*z*tan(FoV/2), per-axis scale z*exp(U(log 5e-4, log 5e-3)),
+random unit quaternions, opacity sigmoid(N(0,1.5^2)), SH DC ~ N(0,1), rest
+~ N(0,0.1^2), background 0.  Everything is drawn on the CPU with
+torch.Generator().manual_seed(seed) and moved afterwards, so the CPU oracle
+and the GPU path see identical bits.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from .camera import SimpleCamera, focal2fov, make_camera, yaw_rotation
+
+
+def synthetic_camera(width: int, height: int, index: int = None, n_cams: int = 8) -> SimpleCamera:
+    fx = fy = 0.8 * width
+    fovx, fovy = focal2fov(fx, width), focal2fov(fy, height)
+    if index is None:
+        return make_camera(width, height, fovx, fovy)
+    # 8-camera batch: camera k yawed by (k - 3.5) * 5 degrees, same Gaussians
+    R = yaw_rotation((index - (n_cams - 1) / 2.0) * 5.0)
+    return make_camera(width, height, fovx, fovy, R=R)
+
+
+def synthetic_gaussians(P: int, width: int, height: int, seed: int = 0, sh_coeffs: int = 16,
+                        scale_lo: float = 5e-4, scale_hi: float = 5e-3) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    cam = synthetic_camera(width, height)
+    tx, ty = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    z = torch.rand(P, generator=g) * 49.0 + 1.0
+    x = (torch.rand(P, generator=g) * 2.2 - 1.1) * z * tx
+    y = (torch.rand(P, generator=g) * 2.2 - 1.1) * z * ty
+    means3D = torch.stack([x, y, z], dim=1).contiguous()
+    lo, hi = math.log(scale_lo), math.log(scale_hi)
+    scales = (z[:, None] * torch.exp(torch.rand(P, 2, generator=g) * (hi - lo) + lo)).contiguous()
+    q = torch.randn(P, 4, generator=g)
+    rotations = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    opacities = torch.sigmoid(torch.randn(P, 1, generator=g) * 1.5).contiguous()
+    shs = torch.randn(P, sh_coeffs, 3, generator=g)
+    shs[:, 1:] *= 0.1
+    return dict(means3D=means3D.float(), scales=scales.float(), rotations=rotations.float(),
+                opacities=opacities.float(), shs=shs.float().contiguous())
+
+
+def synthetic_upstream_grads(width: int, height: int, seed: int = 1, aux: bool = True):
+    """dL_dcolor ~ N(0,1)[3,H,W], dL_dallmap ~ N(0,1)[7,H,W]; aux=False keeps colour + alpha only (C2)."""
+    g = torch.Generator().manual_seed(seed)
+    dcolor = torch.randn(3, height, width, generator=g)
+    dallmap = torch.randn(7, height, width, generator=g)
+    if not aux:
+        keep = torch.zeros(7, 1, 1)
+        keep[1] = 1.0
+        dallmap = dallmap * keep
+    return dcolor.contiguous(), dallmap.contiguous()
