@@ -82,7 +82,7 @@ def forward_backward64(fwd, dL_dcolor, dL_dallmap):
     p_view = means3D @ V3 + view[12:15]
     if use_T_pre:
         Tm = Tpre.view(P, 3, 3)
-        normal = torch.tensor([0.0, 0.0, 1.0], dtype=dd).expand(P, 3)
+        normal = torch.tensor([0.0, 0.0, 1.0], dtype=dd).expand(P, 3).clone().requires_grad_()
     else:
         R = quat_to_R64(rots)
         L0 = R[:, :, 0] * (m * scales[:, 0:1]); L1 = R[:, :, 1] * (m * scales[:, 1:2])
