@@ -1,0 +1,165 @@
+"""`diff_surfel_rasterization._C` -- the three native entry points the reference's autograd shim calls,
+implemented on the C-ABI of libsurfel_raster.so (HIP, gfx950).
+
+Call shapes follow the reference extension (SURVEY.md 8b "Native signatures"; the only call site of
+the package is /root/reference/gaussian_renderer/__init__.py:11,129-138):
+
+    rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
+                        transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree,
+                        campos, prefiltered, debug)
+        -> (num_rendered, color[3,H,W], allmap[7,H,W], radii[P] i32, geomBuffer, binningBuffer, imgBuffer)
+    rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier,
+                        transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap,
+                        sh, degree, campos, geomBuffer, num_rendered, binningBuffer, imgBuffer, debug)
+        -> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9],
+            dL_dsh[P,M,3], dL_dscales[P,2], dL_drotations[P,4])
+    mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]
+
+Empty tensors stand for "not provided", as in the reference.  No CPU fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from streetunveiler_amd import _lib as L
+
+
+def _ptr(t: torch.Tensor):
+    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.SurfelRasterError(f"{name} must be a CUDA (ROCm) tensor; the surfel rasterizer has no CPU path")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug):
+    keep = [_f32c(bg, "bg"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")]
+    fr = L.SrFrame(int(H), int(W), float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree),
+                   int(bool(prefiltered)), int(bool(debug)), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]))
+    return fr, keep
+
+
+def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp):
+    P = int(means3D.shape[0])
+    M = int(sh.shape[1]) if sh is not None and sh.numel() else 0
+    g = L.SrGaussians(P, M, _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(sh),
+                      _ptr(colors_precomp), _ptr(transMat_precomp))
+    return g
+
+
+def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    lib = L.load()
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise L.SurfelRasterError("means3D must have dimensions (num_points, 3)")
+    means3D = _f32c(means3D, "means3D"); opacities = _f32c(opacities, "opacities")
+    colors_precomp = _f32c(colors_precomp, "colors_precomp"); scales = _f32c(scales, "scales")
+    rotations = _f32c(rotations, "rotations"); transMat_precomp = _f32c(transMat_precomp, "transMat_precomp")
+    sh = _f32c(sh, "sh")
+    dev = means3D.device
+    P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
+    with torch.cuda.device(dev):
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug)
+        g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp)
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        allmap = torch.empty((7, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty((lib.sr_geom_bytes(P),), dtype=torch.uint8, device=dev)
+        img = torch.empty((lib.sr_image_bytes(W, H),), dtype=torch.uint8, device=dev)
+        stream = _stream(dev)
+        D = C.c_uint32(0)
+        L.check(lib.sr_forward_plan(C.byref(fr), C.byref(g), _ptr(geom), geom.numel(), _ptr(radii), C.byref(D), stream),
+                "sr_forward_plan")
+        num_rendered = int(D.value)
+        binning = torch.empty((lib.sr_binning_bytes(P, num_rendered, W, H),), dtype=torch.uint8, device=dev)
+        L.check(lib.sr_forward_render(C.byref(fr), C.byref(g), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
+                                      _ptr(img), img.numel(), num_rendered, _ptr(color), _ptr(allmap), stream),
+                "sr_forward_render")
+    del keep
+    return num_rendered, color, allmap, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier, transMat_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap, sh, degree, campos,
+                                 geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None):
+    """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry."""
+    lib = L.load()
+    means3D = _f32c(means3D, "means3D")
+    colors_precomp = _f32c(colors_precomp, "colors_precomp"); scales = _f32c(scales, "scales")
+    rotations = _f32c(rotations, "rotations"); transMat_precomp = _f32c(transMat_precomp, "transMat_precomp")
+    sh = _f32c(sh, "sh")
+    dL_dcolor = _f32c(dL_dcolor, "dL_dcolor"); dL_dallmap = _f32c(dL_dallmap, "dL_dallmap")
+    dev = means3D.device
+    P = int(means3D.shape[0])
+    H, W = int(dL_dcolor.shape[1]), int(dL_dcolor.shape[2])
+    M = int(sh.shape[1]) if sh is not None and sh.numel() else 0
+    with torch.cuda.device(dev):
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, False, debug)
+        # the backward never dereferences opacities (it reads the packed record); pass means3D as a non-NULL stand-in
+        g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D = e(P, 3), e(P, 3), e(P, 1), e(P, 3)
+        dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = e(P, 9), e(P, M, 3), e(P, 2), e(P, 4)
+        ws = torch.empty((lib.sr_backward_workspace_bytes(P),), dtype=torch.uint8, device=dev)
+        grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),
+                              _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations))
+        L.check(lib.sr_backward(C.byref(fr), C.byref(g), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(),
+                                _ptr(binningBuffer), binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(),
+                                int(num_rendered), _ptr(dL_dcolor), _ptr(dL_dallmap), _ptr(ws), ws.numel(),
+                                C.byref(grads), _stream(dev)), "sr_backward")
+    del keep
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    lib = L.load()
+    means3D = _f32c(means3D, "means3D"); viewmatrix = _f32c(viewmatrix, "viewmatrix"); projmatrix = _f32c(projmatrix, "projmatrix")
+    P = int(means3D.shape[0])
+    present = torch.empty((P,), dtype=torch.bool, device=means3D.device)
+    with torch.cuda.device(means3D.device):
+        L.check(lib.sr_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), _ptr(present),
+                                    _stream(means3D.device)), "sr_mark_visible")
+    return present
+
+
+# ---- state-buffer views (tests / profiling) ---------------------------------------------------------
+def _view(buf: torch.Tensor, ptr, nbytes: int, dtype: torch.dtype) -> torch.Tensor:
+    off = int(ptr) - buf.data_ptr()
+    return buf[off:off + nbytes].view(dtype)
+
+
+def geom_view(geom: torch.Tensor, P: int):
+    v = L.SrGeomView()
+    L.check(L.load().sr_geom_view(_ptr(geom), geom.numel(), P, C.byref(v)), "sr_geom_view")
+    return dict(splats=_view(geom, v.splats, P * 80, torch.float32).view(P, 20),
+                depth_keys=_view(geom, v.depth_keys, P * 4, torch.int32), tiles_touched=_view(geom, v.tiles_touched, P * 4, torch.int32),
+                clamped=_view(geom, v.clamped, P, torch.uint8), sorted_gid=_view(geom, v.sorted_gid, P * 4, torch.int32),
+                sorted_offsets=_view(geom, v.sorted_offsets, P * 4, torch.int32))
+
+
+def binning_view(binning: torch.Tensor, P: int, D: int, W: int, H: int):
+    v = L.SrBinningView()
+    L.check(L.load().sr_binning_view(_ptr(binning), binning.numel(), P, D, W, H, C.byref(v)), "sr_binning_view")
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    return dict(tile_keys=_view(binning, v.tile_keys, D * 4, torch.int32), point_list=_view(binning, v.point_list, D * 4, torch.int32),
+                ranges=_view(binning, v.ranges, tiles * 8, torch.int32).view(tiles, 2))
+
+
+def image_view(img: torch.Tensor, W: int, H: int):
+    v = L.SrImageView()
+    L.check(L.load().sr_image_view(_ptr(img), img.numel(), W, H, C.byref(v)), "sr_image_view")
+    return dict(final_T=_view(img, v.final_T, 3 * H * W * 4, torch.float32).view(3, H, W),
+                n_contrib=_view(img, v.n_contrib, 2 * H * W * 4, torch.int32).view(2, H, W))

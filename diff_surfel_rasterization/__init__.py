@@ -1,0 +1,127 @@
+"""Drop-in `diff_surfel_rasterization` package for StreetUnveiler's render operator.
+
+Exports exactly what the reference imports -- `GaussianRasterizationSettings`, `GaussianRasterizer`
+[REF /root/reference/gaussian_renderer/__init__.py:11] -- with the same constructor / call keywords
+[REF :39-54, :129-138] and the same 3-tuple result `(color[3,H,W], radii[P] int32, allmap[7,H,W])`
+[REF :129, channel meaning :149-165].  The native half (`_C`) is hand-written HIP for gfx950 behind
+a C-ABI (include/surfel_raster.h); the upstream CUDA extension it replaces is an un-vendored
+submodule of the reference (/root/reference/.gitmodules:9-12).
+
+Gradients flow to means3D, means2D (densification proxy, [P,3] with z = 0), shs, colors_precomp,
+opacities, scales, rotations and cov3D_precomp (= a precomputed [P,9] transMat in 2DGS), through
+both `color` and `allmap`.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _cpu_snapshot(args):
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        s = raster_settings
+        args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
+                s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
+                s.debug)
+        if s.debug:
+            snapshot = _cpu_snapshot(args)  # taken before the call so a crashing kernel cannot corrupt it
+            try:
+                out = _C.rasterize_gaussians(*args)
+            except Exception:
+                torch.save(snapshot, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            out = _C.rasterize_gaussians(*args)
+        num_rendered, color, allmap, radii, geomBuffer, binningBuffer, imgBuffer = out
+        ctx.raster_settings = s
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, allmap
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_allmap):
+        s = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
+        if grad_allmap is None:
+            grad_allmap = torch.zeros((7, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
+        args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
+                s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, grad_allmap, sh, s.sh_degree, s.campos, geomBuffer,
+                ctx.num_rendered, binningBuffer, imgBuffer, s.debug)
+        if s.debug:
+            snapshot = _cpu_snapshot(args)
+            try:
+                out = _C.rasterize_gaussians_backward(*args)
+            except Exception:
+                torch.save(snapshot, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            out = _C.rasterize_gaussians_backward(*args)
+        grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations = out
+        none_if_empty = lambda g, ref: g if ref.numel() else None
+        return (grad_means3D, grad_means2D, none_if_empty(grad_sh, sh), none_if_empty(grad_colors_precomp, colors_precomp),
+                grad_opacities, none_if_empty(grad_scales, scales), none_if_empty(grad_rotations, rotations),
+                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            s = self.raster_settings
+            return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        s = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.Tensor([]).to(means3D.device)
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s)

@@ -1,0 +1,168 @@
+/*
+ * surfel_raster.h -- C-ABI of the MI355X-native 2D-Gaussian (surfel) splatting rasterizer.
+ *
+ * This is the drop-in boundary for the ONE hot path of StreetUnveiler:
+ *     gaussian_renderer.render -> diff_surfel_rasterization.GaussianRasterizer
+ *         -> _C.rasterize_gaussians / _C.rasterize_gaussians_backward / _C.mark_visible
+ * The reference binds that path through a torch C++ extension (`diff_surfel_rasterization._C`,
+ * an un-vendored submodule: /root/reference/.gitmodules:9-12; only importer:
+ * /root/reference/gaussian_renderer/__init__.py:11).  The entry points below are what that
+ * extension's three functions bind to in this build; the python shim that reproduces the `_C`
+ * call shape on top of them is diff_surfel_rasterization/__init__.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every `const float*` / buffer argument is a DEVICE pointer owned by the caller (a torch
+ *     tensor kept alive by the autograd ctx) unless the name ends in `_host`.
+ *   - the library allocates nothing persistent; all scratch lives in the three caller-owned state
+ *     buffers (geom / binning / image) whose sizes come from the sr_*_bytes() queries -- the
+ *     counterpart of the reference's resize-callback buffers geomBuffer / binningBuffer / imgBuffer
+ *     (call shape: SURVEY.md 8b "Native signatures").
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - return value: 0 on success, negative SrStatus on failure; sr_last_error() gives the text of
+ *     the last failure on the calling thread.  No exceptions cross the ABI.
+ *   - tensor layouts are the operator's: float32, contiguous; means3D[P,3], opacities[P,1],
+ *     scales[P,2], rotations[P,4] (r,x,y,z), shs[P,M,3] (coefficient-major), colors_precomp[P,3],
+ *     transMat_precomp[P,9]; images are planar [C,H,W]
+ *     (/root/reference/gaussian_renderer/__init__.py:56-138; allmap channel order :149-165).
+ */
+#ifndef SURFEL_RASTER_H
+#define SURFEL_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_ABI_VERSION 1
+#define SR_TILE 16            /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
+#define SR_SPLAT_FLOATS 20    /* floats per packed splat record / gradient record (80 B) */
+
+typedef enum SrStatus {
+    SR_OK = 0,
+    SR_ERR_INVALID_ARGUMENT = -1, /* NULL where a pointer is required, bad sizes, both/neither of an exclusive pair */
+    SR_ERR_HIP = -2,              /* a HIP runtime call or kernel launch failed */
+    SR_ERR_BUFFER_TOO_SMALL = -3, /* a state buffer is smaller than sr_*_bytes() reports */
+    SR_ERR_UNSUPPORTED = -4       /* e.g. sh_degree > 3 */
+} SrStatus;
+
+/* Per-call camera / raster settings == GaussianRasterizationSettings
+ * (/root/reference/gaussian_renderer/__init__.py:39-52). */
+typedef struct SrFrame {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;     /* active degree (0..3) */
+    int32_t prefiltered;   /* always 0 at the reference's call sites; accepted, ignored */
+    int32_t debug;         /* 1: synchronise + check after every kernel */
+    const float* bg;          /* device [3] */
+    const float* viewmatrix;  /* device [16] = world_view_transform (W2C^T), row-major */
+    const float* projmatrix;  /* device [16] = full_proj_transform ((P*W2C)^T), row-major */
+    const float* campos;      /* device [3] */
+} SrFrame;
+
+/* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
+ * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp
+ * and exactly one of (scales, rotations) / transMat_precomp must be non-NULL. */
+typedef struct SrGaussians {
+    int32_t P;          /* number of Gaussians */
+    int32_t sh_coeffs;  /* M = shs.size(1) (16 for max degree 3); 0 with colors_precomp */
+    const float* means3D;
+    const float* opacities;
+    const float* scales;
+    const float* rotations;
+    const float* shs;
+    const float* colors_precomp;
+    const float* transMat_precomp;  /* the reference's `cov3D_precomp` slot carries a [P,9] transMat in 2DGS */
+} SrGaussians;
+
+/* Gradient outputs of the backward == return tuple of _C.rasterize_gaussians_backward.
+ * Every non-NULL pointer is fully written (zeros for invisible Gaussians); NULL = not wanted. */
+typedef struct SrGradients {
+    float* dL_dmeans2D;    /* [P,3] densification proxy (x, y, 0) -- what viewspace_points.grad receives */
+    float* dL_dcolors;     /* [P,3] */
+    float* dL_dopacity;    /* [P,1] */
+    float* dL_dmeans3D;    /* [P,3] */
+    float* dL_dtransMat;   /* [P,9] */
+    float* dL_dsh;         /* [P,M,3] */
+    float* dL_dscales;     /* [P,2] */
+    float* dL_drotations;  /* [P,4] */
+} SrGradients;
+
+/* Views into the caller-owned state buffers (for tests / debugging; all device pointers). */
+typedef struct SrGeomView {
+    const float* splats;           /* [P,20] packed record: Tu.xyz Tv.x | Tv.yz Tw.xy | Tw.z xy.x xy.y opacity | n.xyz depth | r g b radius */
+    const uint32_t* depth_keys;    /* [P] float bits of view-space depth; 0xFFFFFFFF when culled */
+    const uint32_t* tiles_touched; /* [P] */
+    const uint8_t* clamped;        /* [P] bit c set when SH colour channel c was clamped at 0 */
+    const uint32_t* sorted_gid;    /* [P] Gaussian ids in ascending (depth bits, id) order; culled last */
+    const uint32_t* sorted_offsets;/* [P] inclusive scan of tiles_touched in that order */
+} SrGeomView;
+
+typedef struct SrBinningView {
+    const uint32_t* tile_keys;   /* [D] tile id of every sorted duplicate */
+    const uint32_t* point_list;  /* [D] Gaussian id of every sorted duplicate (tile-major, then depth, then id) */
+    const uint32_t* ranges;      /* [tiles,2] (begin, end) into point_list; (0,0) for empty tiles */
+} SrBinningView;
+
+typedef struct SrImageView {
+    const float* final_T;       /* [3,H,W]: T_final, M1, M2 */
+    const uint32_t* n_contrib;  /* [2,H,W]: last_contributor, median_contributor */
+} SrImageView;
+
+int sr_abi_version(void);
+const char* sr_last_error(void);
+
+/* Sizes of the three state buffers (bytes). num_rendered = D from sr_forward_plan. */
+size_t sr_geom_bytes(int32_t P);
+size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t image_width, int32_t image_height);
+size_t sr_image_bytes(int32_t image_width, int32_t image_height);
+size_t sr_backward_workspace_bytes(int32_t P);
+
+int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out);
+int sr_binning_view(void* binning, size_t binning_bytes, int32_t P, uint32_t num_rendered, int32_t image_width,
+                    int32_t image_height, SrBinningView* out);
+int sr_image_view(void* image, size_t image_bytes, int32_t image_width, int32_t image_height, SrImageView* out);
+
+/* Forward, phase 1 (K1 preprocess + depth ordering + tile-count scan).
+ * Writes radii[P] (int32) and the geometry state; returns D = number of (tile, Gaussian) duplicates in
+ * *num_rendered_host after ONE stream synchronisation (the same host read-back the reference does
+ * between its scan and duplicateWithKeys). */
+int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, int32_t* radii,
+                    uint32_t* num_rendered_host, void* stream);
+
+/* Forward, phase 2 (K3 duplicate emission, K4 tile sort, K5 ranges, K6 blend).
+ * out_color [3,H,W], out_allmap [7,H,W] (0 sum w*depth, 1 alpha, 2-4 sum w*normal (view space),
+ * 5 median depth, 6 distortion). */
+int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning,
+                      size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
+                      float* out_color, float* out_allmap, void* stream);
+
+/* Backward (K7 blend backward + K8 preprocess backward).  dL_dcolor [3,H,W], dL_dallmap [7,H,W].
+ * workspace: sr_backward_workspace_bytes(P) bytes, contents undefined on entry. */
+int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
+                void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
+                const float* dL_dcolor, const float* dL_dallmap, void* workspace, size_t workspace_bytes,
+                const SrGradients* grads, void* stream);
+
+/* K9: present[i] = (view-space z of means3D[i] > 0.2).  present is uint8 (torch.bool storage). */
+int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                    uint8_t* present, void* stream);
+
+/* Profiling aid: time (ms) HIP events recorded around each stage of the LAST forward/backward issued
+ * from this thread with sr_set_stage_timing(1).  stage ids: see SrStage. Returns <0 if not recorded. */
+typedef enum SrStage {
+    SR_STAGE_PREPROCESS = 0, SR_STAGE_DEPTH_SORT = 1, SR_STAGE_SCAN = 2, SR_STAGE_EMIT = 3, SR_STAGE_TILE_SORT = 4,
+    SR_STAGE_RANGES = 5, SR_STAGE_BLEND_FWD = 6, SR_STAGE_BLEND_BWD = 7, SR_STAGE_PREPROCESS_BWD = 8, SR_STAGE_COUNT = 9
+} SrStage;
+void sr_set_stage_timing(int enable);
+float sr_stage_ms(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURFEL_RASTER_H */

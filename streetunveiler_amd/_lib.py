@@ -1,0 +1,101 @@
+"""ctypes binding of include/surfel_raster.h (the C-ABI of the HIP library).
+
+Fails loudly when the library is missing: there is NO CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsurfel_raster.so")
+
+SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
+                  "preprocess_bwd"]
+
+
+class SrFrame(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float), ("sh_degree", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+class SrGaussians(C.Structure):
+    _fields_ = [("P", C.c_int32), ("sh_coeffs", C.c_int32), ("means3D", C.c_void_p), ("opacities", C.c_void_p),
+                ("scales", C.c_void_p), ("rotations", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("transMat_precomp", C.c_void_p)]
+
+
+class SrGradients(C.Structure):
+    _fields_ = [("dL_dmeans2D", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dopacity", C.c_void_p),
+                ("dL_dmeans3D", C.c_void_p), ("dL_dtransMat", C.c_void_p), ("dL_dsh", C.c_void_p),
+                ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p)]
+
+
+class SrGeomView(C.Structure):
+    _fields_ = [("splats", C.c_void_p), ("depth_keys", C.c_void_p), ("tiles_touched", C.c_void_p), ("clamped", C.c_void_p),
+                ("sorted_gid", C.c_void_p), ("sorted_offsets", C.c_void_p)]
+
+
+class SrBinningView(C.Structure):
+    _fields_ = [("tile_keys", C.c_void_p), ("point_list", C.c_void_p), ("ranges", C.c_void_p)]
+
+
+class SrImageView(C.Structure):
+    _fields_ = [("final_T", C.c_void_p), ("n_contrib", C.c_void_p)]
+
+
+# every symbol include/surfel_raster.h declares (checked by tests/test_abi.py)
+EXPORTS = ["sr_abi_version", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
+           "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan",
+           "sr_forward_render", "sr_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_ms"]
+
+_lib = None
+
+
+class SurfelRasterError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsurfel_raster.so; raise (never fall back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SurfelRasterError(
+            f"{LIB_PATH} is missing: build it with `python -m streetunveiler_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the rasterizer.")
+    lib = C.CDLL(LIB_PATH)
+    lib.sr_abi_version.restype = C.c_int
+    lib.sr_last_error.restype = C.c_char_p
+    for name in ("sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes", "sr_backward_workspace_bytes"):
+        getattr(lib, name).restype = C.c_size_t
+    lib.sr_geom_bytes.argtypes = [C.c_int32]
+    lib.sr_binning_bytes.argtypes = [C.c_int32, C.c_uint32, C.c_int32, C.c_int32]
+    lib.sr_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.sr_backward_workspace_bytes.argtypes = [C.c_int32]
+    lib.sr_geom_view.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(SrGeomView)]
+    lib.sr_binning_view.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(SrBinningView)]
+    lib.sr_image_view.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(SrImageView)]
+    lib.sr_forward_plan.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.POINTER(C.c_uint32), C.c_void_p]
+    lib.sr_forward_render.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sr_backward.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_size_t, C.POINTER(SrGradients), C.c_void_p]
+    lib.sr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sr_set_stage_timing.argtypes = [C.c_int]
+    lib.sr_stage_ms.argtypes = [C.c_int]
+    lib.sr_stage_ms.restype = C.c_float
+    if lib.sr_abi_version() != 1:
+        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sr_last_error().decode("utf-8", "replace")
+        raise SurfelRasterError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,356 @@
+// api.hip -- the C-ABI (include/surfel_raster.h): buffer layouts, argument checks, stage sequencing.
+// No torch types, no exceptions across the boundary, nothing allocated persistently.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+
+namespace sr {
+// preprocess.hip
+hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians& g, float4* recs, uint32_t* depth_keys,
+                                     uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii, hipStream_t s);
+hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
+                                      const uint8_t* clamped, const float4* recs, const float4* grecs,
+                                      const SrGradients& out, hipStream_t s);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+// binning.hip
+size_t depth_sort_temp_bytes(int P);
+size_t tile_sort_temp_bytes(uint32_t D, int n_tiles);
+hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* iota,
+                           uint32_t* sorted_keys, uint32_t* sorted_gid, uint32_t* tt_sorted, uint32_t* sorted_offsets,
+                           void* temp, size_t temp_bytes, hipStream_t s, hipEvent_t ev_sorted);
+hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
+                    const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, hipStream_t s);
+hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
+                         uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s);
+// render.hip
+hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
+                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, hipStream_t s);
+hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
+                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                                  const float* dL_dallmap, float* grecs, hipStream_t s);
+}  // namespace sr
+
+using namespace sr;
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local int g_timing = 0;
+thread_local hipEvent_t g_ev[SR_STAGE_COUNT + 1][2];
+thread_local bool g_ev_init = false;
+thread_local bool g_ev_set[SR_STAGE_COUNT] = {false};
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define SR_HIP(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) return fail(SR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                          __FILE__, __LINE__);                                               \
+    } while (0)
+
+struct StageTimer {
+    int stage; hipStream_t s;
+    StageTimer(int st, hipStream_t stream) : stage(st), s(stream) {
+        if (!g_timing) return;
+        if (!g_ev_init) {
+            for (auto& e : g_ev) { (void)hipEventCreate(&e[0]); (void)hipEventCreate(&e[1]); }
+            g_ev_init = true;
+        }
+        (void)hipEventRecord(g_ev[stage][0], s);
+    }
+    ~StageTimer() {
+        if (!g_timing) return;
+        (void)hipEventRecord(g_ev[stage][1], s);
+        g_ev_set[stage] = true;
+    }
+};
+
+int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
+    if (!frame->debug) return SR_OK;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail(SR_ERR_HIP, "[debug] after %s: %s", what, hipGetErrorString(e));
+    return SR_OK;
+}
+
+// ---- buffer layouts ------------------------------------------------------------------------------
+struct GeomLayout {
+    size_t recs, depth_keys, tiles_touched, clamped, iota, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, temp, temp_bytes, total;
+};
+GeomLayout geom_layout(int P) {
+    GeomLayout L{};
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.recs = take(n * kRecFloats * 4);
+    L.depth_keys = take(n * 4);
+    L.tiles_touched = take(n * 4);
+    L.clamped = take(n);
+    L.iota = take(n * 4);
+    L.sorted_keys = take(n * 4);
+    L.sorted_gid = take(n * 4);
+    L.tt_sorted = take(n * 4);
+    L.sorted_offsets = take(n * 4);
+    static thread_local int memo_P = -1;
+    static thread_local size_t memo_bytes = 0;
+    if (memo_P != P) { memo_bytes = depth_sort_temp_bytes(P); memo_P = P; }
+    L.temp_bytes = memo_bytes;
+    L.temp = take(L.temp_bytes);
+    L.total = off;
+    return L;
+}
+
+struct BinLayout {
+    size_t keys_unsorted, vals_unsorted, tile_keys, point_list, ranges, temp, temp_bytes, total;
+};
+BinLayout bin_layout(uint32_t D, int W, int H) {
+    BinLayout L{};
+    const size_t n = (size_t)(D > 0 ? D : 1);
+    const int tiles = ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.keys_unsorted = take(n * 4);
+    L.vals_unsorted = take(n * 4);
+    L.tile_keys = take(n * 4);
+    L.point_list = take(n * 4);
+    L.ranges = take((size_t)(tiles > 0 ? tiles : 1) * 8);
+    static thread_local uint32_t memo_D = 0xFFFFFFFFu;
+    static thread_local int memo_tiles = -1;
+    static thread_local size_t memo_bytes = 0;
+    if (memo_D != D || memo_tiles != tiles) { memo_bytes = tile_sort_temp_bytes(D, tiles > 0 ? tiles : 1); memo_D = D; memo_tiles = tiles; }
+    L.temp_bytes = memo_bytes;
+    L.temp = take(L.temp_bytes);
+    L.total = off;
+    return L;
+}
+
+struct ImgLayout { size_t final_T, n_contrib, total; };
+ImgLayout img_layout(int W, int H) {
+    ImgLayout L{};
+    const size_t hw = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
+    L.final_T = 0;
+    L.n_contrib = align_up(hw * 3 * 4, 256);
+    L.total = align_up(L.n_contrib + hw * 2 * 4, 256);
+    return L;
+}
+
+int check_common(const SrFrame* frame, const SrGaussians* g) {
+    if (!frame || !g) return fail(SR_ERR_INVALID_ARGUMENT, "frame / gaussians is NULL");
+    if (frame->image_width <= 0 || frame->image_height <= 0) return fail(SR_ERR_INVALID_ARGUMENT, "bad image size %dx%d", frame->image_width, frame->image_height);
+    if (g->P < 0) return fail(SR_ERR_INVALID_ARGUMENT, "P < 0");
+    if (!frame->bg || !frame->viewmatrix || !frame->projmatrix || !frame->campos) return fail(SR_ERR_INVALID_ARGUMENT, "bg / viewmatrix / projmatrix / campos must be non-NULL device pointers");
+    if (g->P > 0) {
+        if (!g->means3D || !g->opacities) return fail(SR_ERR_INVALID_ARGUMENT, "means3D / opacities is NULL");
+        if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return fail(SR_ERR_INVALID_ARGUMENT, "Please provide exactly one of either SHs or precomputed colors!");
+        const bool sr_pair = g->scales != nullptr && g->rotations != nullptr;
+        if ((g->scales != nullptr) != (g->rotations != nullptr) || sr_pair == (g->transMat_precomp != nullptr))
+            return fail(SR_ERR_INVALID_ARGUMENT, "Please provide exactly one of either scale/rotation pair or precomputed transMat!");
+        if (g->shs) {
+            if (frame->sh_degree < 0 || frame->sh_degree > 3) return fail(SR_ERR_UNSUPPORTED, "sh_degree %d not in 0..3", frame->sh_degree);
+            if (g->sh_coeffs < (frame->sh_degree + 1) * (frame->sh_degree + 1)) return fail(SR_ERR_INVALID_ARGUMENT, "shs has %d coefficients, degree %d needs %d", g->sh_coeffs, frame->sh_degree, (frame->sh_degree + 1) * (frame->sh_degree + 1));
+        }
+    }
+    return SR_OK;
+}
+
+FrameDev make_frame(const SrFrame* frame, const SrGaussians* g) {
+    FrameDev f{};
+    f.W = frame->image_width; f.H = frame->image_height;
+    f.tiles_x = (f.W + kTile - 1) / kTile; f.tiles_y = (f.H + kTile - 1) / kTile;
+    f.sh_degree = frame->sh_degree; f.sh_coeffs = g->sh_coeffs;
+    f.scale_modifier = frame->scale_modifier;
+    f.bg = frame->bg; f.view = frame->viewmatrix; f.proj = frame->projmatrix; f.campos = frame->campos;
+    return f;
+}
+
+template <class T> T* at(void* base, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
+
+}  // namespace
+
+extern "C" {
+
+int sr_abi_version(void) { return SR_ABI_VERSION; }
+const char* sr_last_error(void) { return g_err; }
+
+size_t sr_geom_bytes(int32_t P) { return geom_layout(P).total; }
+size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t W, int32_t H) { (void)P; return bin_layout(num_rendered, W, H).total; }
+size_t sr_image_bytes(int32_t W, int32_t H) { return img_layout(W, H).total; }
+size_t sr_backward_workspace_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * kRecFloats * 4, 256); }
+
+int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out) {
+    if (!geom || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    const GeomLayout L = geom_layout(P);
+    if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
+    out->splats = at<float>(geom, L.recs); out->depth_keys = at<uint32_t>(geom, L.depth_keys);
+    out->tiles_touched = at<uint32_t>(geom, L.tiles_touched); out->clamped = at<uint8_t>(geom, L.clamped);
+    out->sorted_gid = at<uint32_t>(geom, L.sorted_gid); out->sorted_offsets = at<uint32_t>(geom, L.sorted_offsets);
+    return SR_OK;
+}
+
+int sr_binning_view(void* binning, size_t binning_bytes, int32_t P, uint32_t D, int32_t W, int32_t H, SrBinningView* out) {
+    (void)P;
+    if (!binning || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    const BinLayout L = bin_layout(D, W, H);
+    if (binning_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, L.total);
+    out->tile_keys = at<uint32_t>(binning, L.tile_keys); out->point_list = at<uint32_t>(binning, L.point_list);
+    out->ranges = at<uint32_t>(binning, L.ranges);
+    return SR_OK;
+}
+
+int sr_image_view(void* image, size_t image_bytes, int32_t W, int32_t H, SrImageView* out) {
+    if (!image || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    const ImgLayout L = img_layout(W, H);
+    if (image_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, L.total);
+    out->final_T = at<float>(image, L.final_T); out->n_contrib = at<uint32_t>(image, L.n_contrib);
+    return SR_OK;
+}
+
+int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, int32_t* radii,
+                    uint32_t* num_rendered_host, void* stream) {
+    if (int rc = check_common(frame, g)) return rc;
+    if (!num_rendered_host) return fail(SR_ERR_INVALID_ARGUMENT, "num_rendered_host is NULL");
+    *num_rendered_host = 0;
+    const int P = g->P;
+    if (P == 0) return SR_OK;
+    if (!geom || !radii) return fail(SR_ERR_INVALID_ARGUMENT, "geom / radii is NULL");
+    const GeomLayout L = geom_layout(P);
+    if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame(frame, g);
+    {
+        StageTimer t(SR_STAGE_PREPROCESS, s);
+        SR_HIP(launch_preprocess_forward(P, f, *g, at<float4>(geom, L.recs), at<uint32_t>(geom, L.depth_keys),
+                                         at<uint32_t>(geom, L.tiles_touched), at<uint8_t>(geom, L.clamped), radii, s));
+    }
+    if (int rc = debug_sync(frame, s, "preprocess_forward")) return rc;
+    {
+        // depth sort + scan are timed together as DEPTH_SORT; SCAN marks the gather+scan tail
+        StageTimer t(SR_STAGE_DEPTH_SORT, s);
+        SR_HIP(run_depth_order(P, at<uint32_t>(geom, L.depth_keys), at<uint32_t>(geom, L.tiles_touched),
+                               at<uint32_t>(geom, L.iota), at<uint32_t>(geom, L.sorted_keys), at<uint32_t>(geom, L.sorted_gid),
+                               at<uint32_t>(geom, L.tt_sorted), at<uint32_t>(geom, L.sorted_offsets), at<void>(geom, L.temp),
+                               L.temp_bytes, s, nullptr));
+    }
+    if (int rc = debug_sync(frame, s, "depth_order")) return rc;
+    // the one host read-back of the forward (the reference does the same between scan and duplicateWithKeys)
+    SR_HIP(hipMemcpyAsync(num_rendered_host, at<uint32_t>(geom, L.sorted_offsets) + (P - 1), 4, hipMemcpyDeviceToHost, s));
+    SR_HIP(hipStreamSynchronize(s));
+    return SR_OK;
+}
+
+int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning,
+                      size_t binning_bytes, void* image, size_t image_bytes, uint32_t D, float* out_color,
+                      float* out_allmap, void* stream) {
+    if (int rc = check_common(frame, g)) return rc;
+    if (!binning || !image || !out_color || !out_allmap) return fail(SR_ERR_INVALID_ARGUMENT, "binning / image / out_color / out_allmap is NULL");
+    const int P = g->P;
+    const int W = frame->image_width, H = frame->image_height;
+    const BinLayout B = bin_layout(D, W, H);
+    const ImgLayout I = img_layout(W, H);
+    if (binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, B.total);
+    if (image_bytes < I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, I.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame(frame, g);
+    const int n_tiles = f.tiles_x * f.tiles_y;
+    const float4* recs = nullptr;
+    if (P > 0 && D > 0) {
+        if (!geom) return fail(SR_ERR_INVALID_ARGUMENT, "geom is NULL");
+        const GeomLayout L = geom_layout(P);
+        if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
+        recs = at<float4>(geom, L.recs);
+        {
+            StageTimer t(SR_STAGE_EMIT, s);
+            SR_HIP(run_emit(P, f.tiles_x, f.tiles_y, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), recs,
+                            at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted), s));
+        }
+        if (int rc = debug_sync(frame, s, "emit_duplicates")) return rc;
+        {
+            StageTimer t(SR_STAGE_TILE_SORT, s);
+            SR_HIP(run_tile_sort(D, n_tiles, at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
+                                 at<uint32_t>(binning, B.tile_keys), at<uint32_t>(binning, B.point_list),
+                                 at<void>(binning, B.temp), B.temp_bytes, s));
+        }
+        if (int rc = debug_sync(frame, s, "tile_sort")) return rc;
+    }
+    {
+        StageTimer t(SR_STAGE_RANGES, s);
+        SR_HIP(run_tile_ranges((P > 0) ? D : 0, n_tiles, at<uint32_t>(binning, B.tile_keys), at<uint2>(binning, B.ranges), s));
+    }
+    if (int rc = debug_sync(frame, s, "tile_ranges")) return rc;
+    {
+        StageTimer t(SR_STAGE_BLEND_FWD, s);
+        SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), recs, out_color,
+                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), s));
+    }
+    return debug_sync(frame, s, "render_forward");
+}
+
+int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
+                void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t D, const float* dL_dcolor,
+                const float* dL_dallmap, void* workspace, size_t workspace_bytes, const SrGradients* grads, void* stream) {
+    if (int rc = check_common(frame, g)) return rc;
+    if (!grads) return fail(SR_ERR_INVALID_ARGUMENT, "grads is NULL");
+    const int P = g->P;
+    if (P == 0) return SR_OK;
+    if (!radii || !geom || !binning || !image || !dL_dcolor || !dL_dallmap || !workspace) return fail(SR_ERR_INVALID_ARGUMENT, "NULL buffer argument");
+    const int W = frame->image_width, H = frame->image_height;
+    const GeomLayout L = geom_layout(P);
+    const BinLayout B = bin_layout(D, W, H);
+    const ImgLayout I = img_layout(W, H);
+    if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
+    if (binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, B.total);
+    if (image_bytes < I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, I.total);
+    if (workspace_bytes < sr_backward_workspace_bytes(P)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame(frame, g);
+    float* grecs = static_cast<float*>(workspace);
+    {
+        StageTimer t(SR_STAGE_BLEND_BWD, s);
+        SR_HIP(hipMemsetAsync(grecs, 0, (size_t)P * kRecFloats * 4, s));
+        if (D > 0)
+            SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
+                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, grecs, s));
+    }
+    if (int rc = debug_sync(frame, s, "render_backward")) return rc;
+    {
+        StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
+        SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs),
+                                          reinterpret_cast<const float4*>(grecs), *grads, s));
+    }
+    return debug_sync(frame, s, "preprocess_backward");
+}
+
+int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                    void* stream) {
+    (void)projmatrix;
+    if (P < 0) return fail(SR_ERR_INVALID_ARGUMENT, "P < 0");
+    if (P == 0) return SR_OK;
+    if (!means3D || !viewmatrix || !present) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    SR_HIP(launch_mark_visible(P, means3D, viewmatrix, present, static_cast<hipStream_t>(stream)));
+    return SR_OK;
+}
+
+void sr_set_stage_timing(int enable) {
+    g_timing = enable;
+    for (auto& b : g_ev_set) b = false;
+}
+
+float sr_stage_ms(int stage) {
+    if (stage < 0 || stage >= SR_STAGE_COUNT || !g_ev_init || !g_ev_set[stage]) return -1.f;
+    if (hipEventSynchronize(g_ev[stage][1]) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, g_ev[stage][0], g_ev[stage][1]) != hipSuccess) return -1.f;
+    return ms;
+}
+
+}  // extern "C"

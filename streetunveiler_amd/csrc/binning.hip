@@ -1,0 +1,170 @@
+// binning.hip -- K2..K5: depth ordering of Gaussians, tile-count scan, duplicate emission,
+// stable tile partition, tile ranges.
+//
+// The reference algorithm emits one (tile<<32 | depth_bits, gaussian)
+// pair per touched tile and LSD-radix-sorts all D 64-bit keys.  The result is the list ordered by
+// (tile, depth bits, gaussian id).  This build produces the *same list, bit for bit*, with ~1/3 of
+// the HBM traffic by splitting the key:
+//   1. sort the P Gaussians once by their 32-bit depth key (stable => ties keep ascending id);
+//   2. emit duplicates in that order (coalesced, wave-cooperative);
+//   3. stable-partition the D duplicates by tile id only (ceil(log2(tiles)) bits, 2 radix passes
+//      of 8-byte pairs instead of 6 passes of 12-byte pairs).
+// Stability of both sorts makes (tile, depth, id) the final order.  Integer work only.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace sr {
+
+__global__ void iota_kernel(int n, uint32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+
+__global__ void gather_u32_kernel(int n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src,
+                                  uint32_t* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// K3: wave-cooperative duplicate emission.  Each wave owns 64 consecutive depth ranks; the lanes
+// then walk the wave's contiguous output span 64 slots at a time (coalesced 4-B stores), finding the
+// owning Gaussian of each slot by a 6-step binary search over the wave's exclusive offsets in LDS.
+__global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x, int tiles_y,
+                                                              const uint32_t* __restrict__ sorted_gid,
+                                                              const uint32_t* __restrict__ sorted_offsets,
+                                                              const float4* __restrict__ recs,
+                                                              uint32_t* __restrict__ keys_out,
+                                                              uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t s_start[4][65];
+    __shared__ uint32_t s_gid[4][64];
+    __shared__ int s_minx[4][64], s_miny[4][64], s_w[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t incl = 0, count = 0, gid = 0;
+    int minx = 0, miny = 0, w = 0;
+    if (r < P) {
+        gid = sorted_gid[r];
+        incl = sorted_offsets[r];
+        const uint32_t prev = r > 0 ? sorted_offsets[r - 1] : 0u;
+        count = incl - prev;
+        if (count) {
+            const float4 q2 = recs[(size_t)gid * kRecQuads + 2];
+            const float radius = recs[(size_t)gid * kRecQuads + 4].w;
+            const float cx = q2.y, cy = q2.z;
+            // same expressions as K1 (and upstream getRect) -> identical rectangle
+            minx = (int)((cx - radius) / (float)kTile); miny = (int)((cy - radius) / (float)kTile);
+            int maxx = (int)((cx + radius + (float)(kTile - 1)) / (float)kTile);
+            int maxy = (int)((cy + radius + (float)(kTile - 1)) / (float)kTile);
+            minx = min(tiles_x, max(0, minx)); maxx = min(tiles_x, max(0, maxx));
+            miny = min(tiles_y, max(0, miny)); maxy = min(tiles_y, max(0, maxy));
+            w = maxx - minx;
+        }
+    } else {
+        // ranks past P: inherit the last inclusive offset so the search stays monotone
+        incl = sorted_offsets[P - 1];
+    }
+    const uint32_t excl = incl - count;
+    s_start[wave][lane] = excl;
+    if (lane == 63) s_start[wave][64] = incl;
+    s_gid[wave][lane] = gid; s_minx[wave][lane] = minx; s_miny[wave][lane] = miny; s_w[wave][lane] = w;
+    __syncthreads();
+    const uint32_t span_begin = s_start[wave][0], span_end = s_start[wave][64];
+    for (uint32_t slot = span_begin + lane; slot < span_end; slot += 64) {
+        // largest j with s_start[j] <= slot  (counts of zero are skipped automatically)
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (s_start[wave][lo + step] <= slot) lo += step;
+        const uint32_t local = slot - s_start[wave][lo];
+        const int ww = s_w[wave][lo];
+        const int dy = (int)(local / (uint32_t)ww), dx = (int)(local - (uint32_t)dy * (uint32_t)ww);
+        keys_out[slot] = (uint32_t)((s_miny[wave][lo] + dy) * tiles_x + s_minx[wave][lo] + dx);
+        vals_out[slot] = s_gid[wave][lo];
+    }
+}
+
+// K5: tile ranges from the sorted tile keys.
+__global__ void tile_ranges_kernel(uint32_t D, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D) return;
+    const uint32_t t = tile_keys[j];
+    if (j == 0) ranges[t].x = 0;
+    else {
+        const uint32_t p = tile_keys[j - 1];
+        if (p != t) { ranges[p].y = j; ranges[t].x = j; }
+    }
+    if (j == D - 1) ranges[t].y = D;
+}
+
+static int bits_for(uint32_t n) {  // number of bits needed to represent values in [0, n)
+    int b = 0;
+    while ((1ull << b) < (unsigned long long)n) ++b;
+    return b < 1 ? 1 : b;
+}
+
+// temp-storage sizes ------------------------------------------------------------------------------
+size_t depth_sort_temp_bytes(int P) {
+    size_t a = 0, b = 0;
+    uint32_t* p = nullptr;
+    hipError_t e1 = hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, P > 0 ? P : 1, 0, 32, (hipStream_t)0);
+    hipError_t e2 = hipcub::DeviceScan::InclusiveSum(nullptr, b, p, p, P > 0 ? P : 1, (hipStream_t)0);
+    if (e1 != hipSuccess || e2 != hipSuccess) {  // no device visible (CPU-only build box): conservative bound
+        (void)hipGetLastError();
+        a = (size_t)(P > 0 ? P : 1) * 16 + (4u << 20);
+        b = 0;
+    }
+    return align_up(a > b ? a : b, 256);
+}
+
+size_t tile_sort_temp_bytes(uint32_t D, int n_tiles) {
+    size_t a = 0;
+    uint32_t* p = nullptr;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, D > 0 ? D : 1, 0, bits_for((uint32_t)n_tiles),
+                                                      (hipStream_t)0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        a = (size_t)(D > 0 ? D : 1) * 16 + (4u << 20);
+    }
+    return align_up(a, 256);
+}
+
+// launchers ---------------------------------------------------------------------------------------
+hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* iota,
+                           uint32_t* sorted_keys, uint32_t* sorted_gid, uint32_t* tt_sorted, uint32_t* sorted_offsets,
+                           void* temp, size_t temp_bytes, hipStream_t s, hipEvent_t ev_sorted) {
+    if (P == 0) return hipSuccess;
+    const int nb = (P + 255) / 256;
+    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, s, P, iota);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, depth_keys, sorted_keys, iota, sorted_gid, P, 0, 32, s);
+    if (e != hipSuccess) return e;
+    if (ev_sorted) (void)hipEventRecord(ev_sorted, s);
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(nb), dim3(256), 0, s, P, sorted_gid, tiles_touched, tt_sorted);
+    e = hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, tt_sorted, sorted_offsets, P, s);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
+                    const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_duplicates_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, tiles_x, tiles_y, sorted_gid,
+                       sorted_offsets, recs, keys_unsorted, vals_unsorted);
+    return hipGetLastError();
+}
+
+hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
+                         uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (D == 0) return hipSuccess;
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_unsorted, tile_keys, vals_unsorted, point_list, D, 0,
+                                              bits_for((uint32_t)n_tiles), s);
+}
+
+hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
+    if (e != hipSuccess || D == 0) return e;
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((D + 255) / 256), dim3(256), 0, s, D, tile_keys, ranges);
+    return hipGetLastError();
+}
+
+}  // namespace sr

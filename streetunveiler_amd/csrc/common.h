@@ -1,0 +1,42 @@
+// common.h -- shared device/host definitions for the surfel rasterizer kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/surfel_raster.h"
+
+namespace sr {
+
+constexpr int kTile = SR_TILE;
+constexpr int kBlock = kTile * kTile;  // 256 threads = 4 wave64
+constexpr float kNear = 0.2f;
+constexpr float kFar = 100.0f;
+constexpr float kFilterSize = 0.707106f;
+constexpr float kFilterInvSquare = 2.0f;
+constexpr float kCutoff = 3.0f;
+constexpr float kAlphaCap = 0.99f;
+constexpr float kAlphaFloor = 1.0f / 255.0f;
+constexpr float kTStop = 0.0001f;
+constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
+
+// Packed per-Gaussian record, 5 x float4 = 80 B, 16-B aligned (one gather = five dwordx4 loads):
+//   q0 = Tu.x Tu.y Tu.z Tv.x | q1 = Tv.y Tv.z Tw.x Tw.y | q2 = Tw.z xy.x xy.y opacity
+//   q3 = n.x n.y n.z depth   | q4 = r g b radius
+// The gradient record written by the blend backward uses the same slots
+// (slot 15 and 19 unused): d/dT[0..8], d/dxy[9,10], d/dopacity[11], d/dnormal[12..14], d/drgb[16..18].
+constexpr int kRecQuads = 5;
+constexpr int kRecFloats = SR_SPLAT_FLOATS;
+
+struct FrameDev {
+    int W, H, tiles_x, tiles_y;
+    int sh_degree, sh_coeffs;
+    float scale_modifier;
+    const float* bg;
+    const float* view;
+    const float* proj;
+    const float* campos;
+};
+
+__host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace sr

@@ -1,0 +1,368 @@
+// preprocess.hip -- K1 (per-Gaussian forward), K8 (per-Gaussian backward), K9 (mark_visible).
+//
+// Compiled with -ffp-contract=off: every value that feeds an integer output (radius, tile
+// rectangle, depth-key bits) is computed with the same single mul/add sequence as the CPU oracle,
+// so radii / tiles_touched / sort keys are bit-exact against it.  These kernels are HBM-streaming
+// (one thread per Gaussian, ~230 B in / ~90 B out), the extra non-fused ops are free.
+//
+// Behavioural contract: SURVEY.md Appendix A.2 / A.6; operator inputs
+// [REF /root/reference/gaussian_renderer/__init__.py:56-138]; SH polynomial
+// [REF /root/reference/utils/sh_utils.py:57-112]; quaternion convention
+// [REF /root/reference/utils/general_utils.py:85-98].
+#include "common.h"
+
+namespace sr {
+
+__device__ __constant__ float kSH_C0 = 0.28209479177387814f;
+__device__ __constant__ float kSH_C1 = 0.4886025119029199f;
+__device__ __constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                            -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                            -0.5900435899266435f};
+
+__device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z);       R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y);       R[7] = 2.f * (y * z + r * x);       R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// B = viewport^T * full_projection (3x4): rows map a world point to (px*w, py*w, w).
+__device__ __forceinline__ void build_B(const float* __restrict__ proj, int W, int H, float B[12]) {
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    const float cw = 0.5f * (float)(W - 1), ch = 0.5f * (float)(H - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float a0 = proj[4 * k + 0], a1 = proj[4 * k + 1], a3 = proj[4 * k + 3];
+        B[0 + k] = hw * a0 + cw * a3;
+        B[4 + k] = hh * a1 + ch * a3;
+        B[8 + k] = a3;
+    }
+}
+
+__device__ __forceinline__ float dot3(const float* a, float x, float y, float z) { return (a[0] * x + a[1] * y) + a[2] * z; }
+
+// ---------------------------------------------------------------------------------------------
+// K1
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_forward_kernel(
+    int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, const float* __restrict__ transMat_precomp,
+    float4* __restrict__ recs, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ tiles_touched,
+    uint8_t* __restrict__ clamped, int32_t* __restrict__ radii) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    // defaults for a culled Gaussian
+    int32_t out_radius = 0;
+    uint32_t out_tiles = 0, out_key = kCulledKey;
+    uint8_t out_clamped = 0;
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
+
+    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    const float* v = f.view;
+    const float vx = ((v[0] * px + v[4] * py) + v[8] * pz) + v[12];
+    const float vy = ((v[1] * px + v[5] * py) + v[9] * pz) + v[13];
+    const float vz = ((v[2] * px + v[6] * py) + v[10] * pz) + v[14];
+    bool alive = vz > kNear;
+    if (alive) {
+        float Tm[9], nrm[3];
+        if (transMat_precomp) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Tm[k] = transMat_precomp[9 * (size_t)i + k];
+            nrm[0] = 0.f; nrm[1] = 0.f; nrm[2] = 1.f;
+        } else {
+            float B[12], R[9];
+            build_B(f.proj, f.W, f.H, B);
+            quat_to_R(reinterpret_cast<const float4*>(rotations)[i], R);
+            const float2 s = reinterpret_cast<const float2*>(scales)[i];
+            const float su = f.scale_modifier * s.x, sv = f.scale_modifier * s.y;
+            const float L0[3] = {R[0] * su, R[3] * su, R[6] * su};
+            const float L1[3] = {R[1] * sv, R[4] * sv, R[7] * sv};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float* b = B + 4 * r;
+                Tm[3 * r + 0] = dot3(b, L0[0], L0[1], L0[2]);
+                Tm[3 * r + 1] = dot3(b, L1[0], L1[1], L1[2]);
+                Tm[3 * r + 2] = dot3(b, px, py, pz) + b[3];
+            }
+            const float nx = R[2], ny = R[5], nz = R[8];
+            nrm[0] = (v[0] * nx + v[4] * ny) + v[8] * nz;
+            nrm[1] = (v[1] * nx + v[5] * ny) + v[9] * nz;
+            nrm[2] = (v[2] * nx + v[6] * ny) + v[10] * nz;
+        }
+        const float cosv = -((vx * nrm[0] + vy * nrm[1]) + vz * nrm[2]);
+        alive = cosv != 0.f;
+        const float mult = cosv > 0.f ? 1.f : -1.f;
+        nrm[0] *= mult; nrm[1] *= mult; nrm[2] *= mult;
+
+        const float* Tu = Tm; const float* Tv = Tm + 3; const float* Tw = Tm + 6;
+        const float c2 = kCutoff * kCutoff;
+        const float t0 = c2, t1 = c2, t2 = -1.f;
+        const float dist = ((Tw[0] * Tw[0]) * t0 + (Tw[1] * Tw[1]) * t1) + (Tw[2] * Tw[2]) * t2;
+        alive = alive && (dist != 0.f);
+        if (alive) {
+            const float inv = 1.f / dist;
+            const float f0 = inv * t0, f1 = inv * t1, f2 = inv * t2;
+            const float cx = ((f0 * Tu[0]) * Tw[0] + (f1 * Tu[1]) * Tw[1]) + (f2 * Tu[2]) * Tw[2];
+            const float cy = ((f0 * Tv[0]) * Tw[0] + (f1 * Tv[1]) * Tw[1]) + (f2 * Tv[2]) * Tw[2];
+            const float tx = ((f0 * Tu[0]) * Tu[0] + (f1 * Tu[1]) * Tu[1]) + (f2 * Tu[2]) * Tu[2];
+            const float ty = ((f0 * Tv[0]) * Tv[0] + (f1 * Tv[1]) * Tv[1]) + (f2 * Tv[2]) * Tv[2];
+            const float hx = cx * cx - tx, hy = cy * cy - ty;
+            const float ex = sqrtf(fmaxf(1e-4f, hx)), ey = sqrtf(fmaxf(1e-4f, hy));
+            const float radius = ceilf(fmaxf(fmaxf(ex, ey), kCutoff * kFilterSize));
+            int minx = (int)((cx - radius) / (float)kTile), miny = (int)((cy - radius) / (float)kTile);
+            int maxx = (int)((cx + radius + (float)(kTile - 1)) / (float)kTile);
+            int maxy = (int)((cy + radius + (float)(kTile - 1)) / (float)kTile);
+            minx = min(f.tiles_x, max(0, minx)); maxx = min(f.tiles_x, max(0, maxx));
+            miny = min(f.tiles_y, max(0, miny)); maxy = min(f.tiles_y, max(0, maxy));
+            const int area = (maxx - minx) * (maxy - miny);
+            if (area > 0) {
+                float rgb[3];
+                if (colors_precomp) {
+                    rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1]; rgb[2] = colors_precomp[3 * (size_t)i + 2];
+                } else {
+                    const float* sh = shs + (size_t)i * f.sh_coeffs * 3;
+                    const int deg = f.sh_degree;
+                    float dx = px - f.campos[0], dy = py - f.campos[1], dz = pz - f.campos[2];
+                    const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+                    dx /= len; dy /= len; dz /= len;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float res = kSH_C0 * sh[c];
+                        if (deg > 0) {
+                            const float x = dx, y = dy, z = dz;
+                            res = res - kSH_C1 * y * sh[3 + c] + kSH_C1 * z * sh[6 + c] - kSH_C1 * x * sh[9 + c];
+                            if (deg > 1) {
+                                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                                res = res + kSH_C2[0] * xy * sh[12 + c] + kSH_C2[1] * yz * sh[15 + c] +
+                                      kSH_C2[2] * (2.f * zz - xx - yy) * sh[18 + c] + kSH_C2[3] * xz * sh[21 + c] +
+                                      kSH_C2[4] * (xx - yy) * sh[24 + c];
+                                if (deg > 2) {
+                                    res = res + kSH_C3[0] * y * (3.f * xx - yy) * sh[27 + c] + kSH_C3[1] * xy * z * sh[30 + c] +
+                                          kSH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + c] +
+                                          kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + c] +
+                                          kSH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + c] +
+                                          kSH_C3[5] * z * (xx - yy) * sh[42 + c] + kSH_C3[6] * x * (xx - 3.f * yy) * sh[45 + c];
+                                }
+                            }
+                        }
+                        res += 0.5f;
+                        if (res < 0.f) out_clamped |= (uint8_t)(1u << c);
+                        rgb[c] = fmaxf(res, 0.f);
+                    }
+                }
+                out_radius = (int32_t)radius;
+                out_tiles = (uint32_t)area;
+                out_key = __float_as_uint(vz);
+                q0 = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
+                q1 = make_float4(Tv[1], Tv[2], Tw[0], Tw[1]);
+                q2 = make_float4(Tw[2], cx, cy, opacities[i]);
+                q3 = make_float4(nrm[0], nrm[1], nrm[2], vz);
+                q4 = make_float4(rgb[0], rgb[1], rgb[2], radius);
+            }
+        }
+    }
+    radii[i] = out_radius;
+    tiles_touched[i] = out_tiles;
+    depth_keys[i] = out_key;
+    clamped[i] = out_clamped;
+    float4* rec = recs + (size_t)i * kRecQuads;
+    rec[0] = q0; rec[1] = q1; rec[2] = q2; rec[3] = q3; rec[4] = q4;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(
+    int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
+    const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float4* __restrict__ recs,
+    const float4* __restrict__ grecs, SrGradients out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int M = f.sh_coeffs;
+    float g_means3D[3] = {0, 0, 0}, g_scales[2] = {0, 0}, g_rot[4] = {0, 0, 0, 0}, g_m2d[2] = {0, 0};
+    float dT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dTr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_col[3] = {0, 0, 0}, g_opa = 0.f;
+    const bool vis = radii[i] > 0;
+    float* dsh = out.dL_dsh ? out.dL_dsh + (size_t)i * M * 3 : nullptr;
+    if (vis) {
+        const float4* rec = recs + (size_t)i * kRecQuads;
+        const float4* gr = grecs + (size_t)i * kRecQuads;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4];
+        const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
+        dT[0] = g0.x; dT[1] = g0.y; dT[2] = g0.z; dT[3] = g0.w; dT[4] = g1.x; dT[5] = g1.y; dT[6] = g1.z; dT[7] = g1.w; dT[8] = g2.x;
+        const float gx2 = g2.y, gy2 = g2.z;
+        g_opa = g2.w;
+        const float gn[3] = {g3.x, g3.y, g3.z};
+        g_col[0] = g4.x; g_col[1] = g4.y; g_col[2] = g4.z;
+        // densification proxy from the blend-only dL/dT (Appendix A.6, last paragraph)
+        g_m2d[0] = dT[2] * Tw[2] * 0.5f * (float)f.W;
+        g_m2d[1] = dT[5] * Tw[2] * 0.5f * (float)f.H;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dTr[k] = dT[k];
+        if (gx2 != 0.f || gy2 != 0.f) {
+            const float t[3] = {9.f, 9.f, -1.f};
+            const float d = (t[0] * Tw[0] * Tw[0] + t[1] * Tw[1] * Tw[1]) + t[2] * Tw[2] * Tw[2];
+            float fv[3], dLdd = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { fv[c] = t[c] / d; dLdd += (gx2 * Tu[c] * Tw[c] + gy2 * Tv[c] * Tw[c]) * fv[c]; }
+            dLdd *= (-1.f / d);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dT[0 + c] += gx2 * fv[c] * Tw[c];
+                dT[3 + c] += gy2 * fv[c] * Tw[c];
+                dT[6 + c] += gx2 * fv[c] * Tu[c] + gy2 * fv[c] * Tv[c] + dLdd * (t[c] * Tw[c] * 2.f);
+            }
+        }
+        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        if (!transMat_precomp) {
+            float B[12], R[9];
+            build_B(f.proj, f.W, f.H, B);
+            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+            quat_to_R(q, R);
+            const float2 s = reinterpret_cast<const float2*>(scales)[i];  // modifier 1.0 (upstream quirk, A.6)
+            float dL0[3], dL1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dL0[k] = B[0 + k] * dT[0] + B[4 + k] * dT[3] + B[8 + k] * dT[6];
+                dL1[k] = B[0 + k] * dT[1] + B[4 + k] * dT[4] + B[8 + k] * dT[7];
+                g_means3D[k] = B[0 + k] * dT[2] + B[4 + k] * dT[5] + B[8 + k] * dT[8];
+            }
+            const float* v = f.view;
+            float dtn[3] = {v[0] * gn[0] + v[1] * gn[1] + v[2] * gn[2], v[4] * gn[0] + v[5] * gn[1] + v[6] * gn[2],
+                            v[8] * gn[0] + v[9] * gn[1] + v[10] * gn[2]};
+            const float vx = ((v[0] * px + v[4] * py) + v[8] * pz) + v[12];
+            const float vy = ((v[1] * px + v[5] * py) + v[9] * pz) + v[13];
+            const float vz = ((v[2] * px + v[6] * py) + v[10] * pz) + v[14];
+            const float nx = R[2], ny = R[5], nz = R[8];
+            const float n0 = (v[0] * nx + v[4] * ny) + v[8] * nz;
+            const float n1 = (v[1] * nx + v[5] * ny) + v[9] * nz;
+            const float n2 = (v[2] * nx + v[6] * ny) + v[10] * nz;
+            const float cosv = -((vx * n0 + vy * n1) + vz * n2);
+            const float mult = cosv > 0.f ? 1.f : -1.f;
+            dtn[0] *= mult; dtn[1] *= mult; dtn[2] *= mult;
+            float G[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { G[3 * k + 0] = dL0[k] * s.x; G[3 * k + 1] = dL1[k] * s.y; G[3 * k + 2] = dtn[k]; }
+            g_scales[0] = dL0[0] * R[0] + dL0[1] * R[3] + dL0[2] * R[6];
+            g_scales[1] = dL1[0] * R[1] + dL1[1] * R[4] + dL1[2] * R[7];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            g_rot[0] = 2.f * (-z * G[1] + y * G[2] + z * G[3] - x * G[5] - y * G[6] + x * G[7]);
+            g_rot[1] = 2.f * (y * G[1] + z * G[2] + y * G[3] - 2.f * x * G[4] - r * G[5] + z * G[6] + r * G[7] - 2.f * x * G[8]);
+            g_rot[2] = 2.f * (-2.f * y * G[0] + x * G[1] + r * G[2] + x * G[3] + z * G[5] - r * G[6] + z * G[7] - 2.f * y * G[8]);
+            g_rot[3] = 2.f * (-2.f * z * G[0] - r * G[1] + x * G[2] + r * G[3] - 2.f * z * G[4] + y * G[5] + x * G[6] + y * G[7]);
+        }
+        if (shs) {
+            const float* sh = shs + (size_t)i * M * 3;
+            const int deg = f.sh_degree;
+            const float ox = px - f.campos[0], oy = py - f.campos[1], oz = pz - f.campos[2];
+            const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
+            const float x = ox / len, y = oy / len, z = oz / len;
+            const uint8_t cl = clamped[i];
+            float ddir[3] = {0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float g = ((cl >> c) & 1) ? 0.f : g_col[c];
+                float dx = 0.f, dy = 0.f, dz = 0.f;
+                if (dsh) dsh[c] = kSH_C0 * g;
+                if (deg > 0) {
+                    if (dsh) { dsh[3 + c] = -kSH_C1 * y * g; dsh[6 + c] = kSH_C1 * z * g; dsh[9 + c] = -kSH_C1 * x * g; }
+                    dx = -kSH_C1 * sh[9 + c]; dy = -kSH_C1 * sh[3 + c]; dz = kSH_C1 * sh[6 + c];
+                    if (deg > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        if (dsh) {
+                            dsh[12 + c] = kSH_C2[0] * xy * g; dsh[15 + c] = kSH_C2[1] * yz * g;
+                            dsh[18 + c] = kSH_C2[2] * (2.f * zz - xx - yy) * g;
+                            dsh[21 + c] = kSH_C2[3] * xz * g; dsh[24 + c] = kSH_C2[4] * (xx - yy) * g;
+                        }
+                        dx += kSH_C2[0] * y * sh[12 + c] + kSH_C2[2] * 2.f * -x * sh[18 + c] + kSH_C2[3] * z * sh[21 + c] + kSH_C2[4] * 2.f * x * sh[24 + c];
+                        dy += kSH_C2[0] * x * sh[12 + c] + kSH_C2[1] * z * sh[15 + c] + kSH_C2[2] * 2.f * -y * sh[18 + c] + kSH_C2[4] * 2.f * -y * sh[24 + c];
+                        dz += kSH_C2[1] * y * sh[15 + c] + kSH_C2[2] * 2.f * 2.f * z * sh[18 + c] + kSH_C2[3] * x * sh[21 + c];
+                        if (deg > 2) {
+                            if (dsh) {
+                                dsh[27 + c] = kSH_C3[0] * y * (3.f * xx - yy) * g;
+                                dsh[30 + c] = kSH_C3[1] * xy * z * g;
+                                dsh[33 + c] = kSH_C3[2] * y * (4.f * zz - xx - yy) * g;
+                                dsh[36 + c] = kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                                dsh[39 + c] = kSH_C3[4] * x * (4.f * zz - xx - yy) * g;
+                                dsh[42 + c] = kSH_C3[5] * z * (xx - yy) * g;
+                                dsh[45 + c] = kSH_C3[6] * x * (xx - 3.f * yy) * g;
+                            }
+                            dx += kSH_C3[0] * sh[27 + c] * 3.f * 2.f * xy + kSH_C3[1] * sh[30 + c] * yz + kSH_C3[2] * sh[33 + c] * -2.f * xy +
+                                  kSH_C3[3] * sh[36 + c] * -3.f * 2.f * xz + kSH_C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
+                                  kSH_C3[5] * sh[42 + c] * 2.f * xz + kSH_C3[6] * sh[45 + c] * 3.f * (xx - yy);
+                            dy += kSH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + kSH_C3[1] * sh[30 + c] * xz + kSH_C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) +
+                                  kSH_C3[3] * sh[36 + c] * -3.f * 2.f * yz + kSH_C3[4] * sh[39 + c] * -2.f * xy + kSH_C3[5] * sh[42 + c] * -2.f * yz +
+                                  kSH_C3[6] * sh[45 + c] * -3.f * 2.f * xy;
+                            dz += kSH_C3[1] * sh[30 + c] * xy + kSH_C3[2] * sh[33 + c] * 4.f * 2.f * yz + kSH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) +
+                                  kSH_C3[4] * sh[39 + c] * 4.f * 2.f * xz + kSH_C3[5] * sh[42 + c] * (xx - yy);
+                        }
+                    }
+                }
+                ddir[0] += dx * g; ddir[1] += dy * g; ddir[2] += dz * g;
+            }
+            if (dsh) {
+                const int used = (deg + 1) * (deg + 1);
+                for (int k = used * 3; k < M * 3; ++k) dsh[k] = 0.f;
+            }
+            const float nd = (x * ddir[0] + y * ddir[1]) + z * ddir[2];
+            g_means3D[0] += (ddir[0] - x * nd) / len;
+            g_means3D[1] += (ddir[1] - y * nd) / len;
+            g_means3D[2] += (ddir[2] - z * nd) / len;
+        }
+    } else if (dsh) {
+        for (int k = 0; k < M * 3; ++k) dsh[k] = 0.f;
+    }
+    if (out.dL_dmeans3D) { out.dL_dmeans3D[3 * (size_t)i] = g_means3D[0]; out.dL_dmeans3D[3 * (size_t)i + 1] = g_means3D[1]; out.dL_dmeans3D[3 * (size_t)i + 2] = g_means3D[2]; }
+    if (out.dL_dmeans2D) { out.dL_dmeans2D[3 * (size_t)i] = g_m2d[0]; out.dL_dmeans2D[3 * (size_t)i + 1] = g_m2d[1]; out.dL_dmeans2D[3 * (size_t)i + 2] = 0.f; }
+    if (out.dL_dscales) { out.dL_dscales[2 * (size_t)i] = g_scales[0]; out.dL_dscales[2 * (size_t)i + 1] = g_scales[1]; }
+    if (out.dL_drotations) { reinterpret_cast<float4*>(out.dL_drotations)[i] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]); }
+    if (out.dL_dopacity) out.dL_dopacity[i] = g_opa;
+    if (out.dL_dcolors) { out.dL_dcolors[3 * (size_t)i] = g_col[0]; out.dL_dcolors[3 * (size_t)i + 1] = g_col[1]; out.dL_dcolors[3 * (size_t)i + 2] = g_col[2]; }
+    if (out.dL_dtransMat) {
+        // upstream writes the AABB-centre-augmented dL/dT back only when transMat is an input (A.6)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out.dL_dtransMat[9 * (size_t)i + k] = transMat_precomp ? dT[k] : dTr[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K9
+// ---------------------------------------------------------------------------------------------
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view,
+                                    uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float vz = ((view[2] * means3D[3 * i] + view[6] * means3D[3 * i + 1]) + view[10] * means3D[3 * i + 2]) + view[14];
+    present[i] = vz > kNear ? 1 : 0;
+}
+
+// host launchers ---------------------------------------------------------------------------------
+hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians& g, float4* recs, uint32_t* depth_keys,
+                                     uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(preprocess_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, f, g.means3D, g.opacities,
+                       g.scales, g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys,
+                       tiles_touched, clamped, radii);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
+                                      const uint8_t* clamped, const float4* recs, const float4* grecs,
+                                      const SrGradients& out, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, f, g.means3D, g.scales,
+                       g.rotations, g.shs, g.transMat_precomp, radii, clamped, recs, grecs, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+    return hipGetLastError();
+}
+
+}  // namespace sr

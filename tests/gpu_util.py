@@ -1,0 +1,105 @@
+"""Helpers shared by the -m gpu parity tests: run the HIP operator through the drop-in package (i.e. through
+the C-ABI) and the CPU oracle on identical seeded inputs."""
+import math
+
+import numpy as np
+import torch
+
+from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+from oracle import surfel_oracle as so
+
+DEV = "cuda:0"
+
+
+def settings_for(cam, bg, deg, debug=False, dev=DEV):
+    return GaussianRasterizationSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2),
+                                         torch.as_tensor(bg, dtype=torch.float32).to(dev), 1.0, cam.world_view_transform.to(dev),
+                                         cam.full_proj_transform.to(dev), deg, cam.camera_center.to(dev), False, debug)
+
+
+def run_oracle(g, cam, bg, deg, dc=None, da=None, mode="sh", colors=None, Tpre=None):
+    kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
+              campos=cam.camera_center.numpy(), bg=np.asarray(bg, np.float32), image_width=cam.image_width,
+              image_height=cam.image_height, sh_degree=deg)
+    n = lambda k: g[k].numpy()
+    if Tpre is not None:
+        fwd = so.rasterize_forward(n("means3D"), n("opacities"), shs=n("shs") if colors is None else None,
+                                   colors_precomp=colors, transMat_precomp=Tpre, **kw)
+    elif colors is not None:
+        fwd = so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), colors_precomp=colors, **kw)
+    else:
+        fwd = so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), shs=n("shs"), **kw)
+    bwd = so.rasterize_backward(fwd, dc.numpy(), da.numpy()) if dc is not None else None
+    return fwd, bwd
+
+
+def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=False):
+    """Returns dict with outputs, internal state views and (if dc given) input gradients, all numpy."""
+    dev = DEV
+    s = settings_for(cam, bg, deg, debug)
+    P = g["means3D"].shape[0]
+    t = {k: v.to(dev).requires_grad_() for k, v in g.items()}
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    kw = dict(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"])
+    if colors is not None:
+        t["colors"] = torch.as_tensor(colors).to(dev).requires_grad_(); kw["colors_precomp"] = t["colors"]
+    else:
+        kw["shs"] = t["shs"]
+    if Tpre is not None:
+        t["Tpre"] = torch.as_tensor(Tpre).to(dev).requires_grad_(); kw["cov3D_precomp"] = t["Tpre"]
+    else:
+        kw["scales"] = t["scales"]; kw["rotations"] = t["rotations"]
+    color, radii, allmap = GaussianRasterizer(s)(**kw)
+    out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), allmap=allmap.detach().cpu().numpy())
+    if dc is not None:
+        ((color * dc.to(dev)).sum() + (allmap * da.to(dev)).sum()).backward()
+        torch.cuda.synchronize()
+        z = lambda x: None if x.grad is None else x.grad.cpu().numpy()
+        out.update(dL_dmeans3D=z(t["means3D"]), dL_dopacity=z(t["opacities"]), dL_dmeans2D=z(means2D))
+        if colors is None: out["dL_dsh"] = z(t["shs"])
+        else: out["dL_dcolors"] = z(t["colors"])
+        if Tpre is None: out.update(dL_dscales=z(t["scales"]), dL_drotations=z(t["rotations"]))
+        else: out["dL_dtransMat"] = z(t["Tpre"])
+    return out
+
+
+def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None):
+    """Calls _C.rasterize_gaussians directly and returns the state-buffer views as numpy (for bit-exact checks)."""
+    dev = DEV
+    s = settings_for(cam, bg, deg)
+    e = torch.empty(0, device=dev)
+    d = lambda k: g[k].to(dev)
+    P = g["means3D"].shape[0]
+    sh = d("shs") if colors is None else e
+    col = e if colors is None else torch.as_tensor(colors).to(dev)
+    sc, ro = (d("scales"), d("rotations")) if Tpre is None else (e, e)
+    tp = e if Tpre is None else torch.as_tensor(Tpre).to(dev)
+    D, color, allmap, radii, geom, binning, img = _C.rasterize_gaussians(
+        s.bg, d("means3D"), col, d("opacities"), sc, ro, 1.0, tp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
+        s.image_height, s.image_width, sh, deg, s.campos, False, False)
+    torch.cuda.synchronize()
+    W, H = cam.image_width, cam.image_height
+    gv = {k: v.cpu().numpy() for k, v in _C.geom_view(geom, P).items()} if P else {}
+    bv = {k: v.cpu().numpy() for k, v in _C.binning_view(binning, P, D, W, H).items()}
+    iv = {k: v.cpu().numpy() for k, v in _C.image_view(img, W, H).items()}
+    return dict(D=D, color=color.cpu().numpy(), allmap=allmap.cpu().numpy(), radii=radii.cpu().numpy(), geom=gv, bin=bv, img=iv)
+
+
+def assert_close_frac(a, b, atol, rtol, max_bad_frac, hard, name=""):
+    """|a-b| <= atol + rtol*|b| for all but `max_bad_frac` of the elements (alpha>=1/255 and T<1e-4 are hard
+    thresholds: an ulp difference in exp()/rcp() can flip a contributor); every element within `hard`."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = np.abs(a - b)
+    bad = err > (atol + rtol * np.abs(b))
+    frac = bad.mean() if bad.size else 0.0
+    assert frac <= max_bad_frac, f"{name}: {frac:.3e} of elements off by more than tol (max err {err.max():.3e})"
+    assert (err <= hard * max(1.0, np.abs(b).max())).all(), f"{name}: max err {err.max():.3e} exceeds hard bound"
+
+
+def assert_grads_close(got, ref, rel, name=""):
+    """Per-tensor: max |got-ref| <= rel * max|ref| (float atomics reorder sums; fast rcp/exp in the blend)."""
+    got = np.asarray(got, np.float64).reshape(np.asarray(ref).shape); ref = np.asarray(ref, np.float64)
+    scale = np.abs(ref).max() + 1e-20
+    err = np.abs(got - ref).max()
+    assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e} > {rel})"

@@ -1,0 +1,69 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/surfel_raster.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from streetunveiler_amd import _lib
+from streetunveiler_amd.build import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build()
+    return _lib.load()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "surfel_raster.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    declared = _declared_functions()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/surfel_raster.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_abi_version_and_sizes(lib):
+    assert lib.sr_abi_version() == 1
+    # pure host arithmetic (no GPU): image state = 3 float planes + 2 u32 planes, 256-B aligned
+    assert lib.sr_image_bytes(1920, 1080) >= 1920 * 1080 * 20
+    assert lib.sr_backward_workspace_bytes(1000) >= 1000 * 80
+    assert lib.sr_geom_bytes(1000) >= 1000 * (80 + 4 * 7 + 1)
+
+
+def test_struct_layouts_match_header():
+    # field counts / order mirror the header; sizes follow the C layout rules (8-B pointers)
+    assert ctypes.sizeof(_lib.SrFrame) == 8 * 4 + 4 * 8
+    assert ctypes.sizeof(_lib.SrGaussians) == 2 * 4 + 7 * 8
+    assert ctypes.sizeof(_lib.SrGradients) == 8 * 8
+    assert [f[0] for f in _lib.SrFrame._fields_][:3] == ["image_height", "image_width", "tanfovx"]
+
+
+def test_argument_errors_without_gpu(lib):
+    fr = _lib.SrFrame(0, 0, 1.0, 1.0, 1.0, 0, 0, 0, None, None, None, None)
+    g = _lib.SrGaussians(0, 0, None, None, None, None, None, None, None)
+    d = ctypes.c_uint32(7)
+    rc = lib.sr_forward_plan(ctypes.byref(fr), ctypes.byref(g), None, 0, None, ctypes.byref(d), None)
+    assert rc == -1 and b"image size" in lib.sr_last_error()
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    import torch
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    s = GaussianRasterizationSettings(8, 8, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0, torch.zeros(3), False, False)
+    r = GaussianRasterizer(s)
+    with pytest.raises(Exception, match="excatly one"):
+        r(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.ones(4, 1), scales=torch.ones(4, 2), rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match="exactly one"):
+        r(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.ones(4, 1), colors_precomp=torch.zeros(4, 3))
+    with pytest.raises(_lib.SurfelRasterError, match="no CPU path"):
+        r(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.ones(4, 1), colors_precomp=torch.zeros(4, 3),
+          scales=torch.ones(4, 2), rotations=torch.ones(4, 4))

@@ -1,0 +1,170 @@
+"""GPU (-m gpu): the HIP path, called through the drop-in package -> C-ABI, against the CPU oracle.
+
+Bars (BASELINE.json north_star): integer / index outputs bit-exact (radii, tiles_touched, depth keys, sorted
+(tile, depth, id) lists, tile ranges, contributor counts up to threshold flips); float outputs within 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run through gpurun)"
+    from streetunveiler_amd import _lib
+    _lib.load()  # fail loudly if the HIP library was not built
+
+
+def _scene(P, W, H, seed, lo, hi, cam_index=None):
+    cam = synthetic_camera(W, H, index=cam_index)
+    g = synthetic_gaussians(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi)
+    return cam, g
+
+
+def _check_binning(raw, fwd):
+    from tests.gpu_util import np as _np  # noqa: F401
+    P = fwd["radii"].shape[0]
+    assert raw["D"] == fwd["num_rendered"]
+    np.testing.assert_array_equal(raw["radii"], fwd["radii"])
+    np.testing.assert_array_equal(raw["geom"]["tiles_touched"].view(np.uint32), fwd["tiles_touched"])
+    vis = fwd["radii"] > 0
+    keys = raw["geom"]["depth_keys"].view(np.uint32)
+    np.testing.assert_array_equal(keys[vis], fwd["depths"][vis].view(np.uint32))
+    assert (keys[~vis] == 0xFFFFFFFF).all()
+    # packed records: transMat, centre, normal, rgb (K1 runs the oracle's op order -> tight)
+    rec = raw["geom"]["splats"]
+    np.testing.assert_array_equal(rec[vis][:, 0:9], fwd["transMat"][vis])
+    np.testing.assert_array_equal(rec[vis][:, 9:11], fwd["means2D"][vis])
+    np.testing.assert_array_equal(rec[vis][:, 12:15], fwd["normal_opacity"][vis][:, :3])
+    np.testing.assert_allclose(rec[vis][:, 16:19], fwd["rgb"][vis], atol=2e-6)
+    # the sorted duplicate list == the reference's 64-bit (tile<<32 | depth) stable sort, bit for bit
+    pl = raw["bin"]["point_list"].view(np.uint32)
+    np.testing.assert_array_equal(pl, fwd["point_list"])
+    key64 = (raw["bin"]["tile_keys"].view(np.uint32).astype(np.uint64) << np.uint64(32)) | keys[pl].astype(np.uint64)
+    np.testing.assert_array_equal(key64, fwd["keys"])
+    np.testing.assert_array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])
+
+
+def _check_images(out, fwd, tag):
+    from tests.gpu_util import assert_close_frac
+    assert_close_frac(out["color"], fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, tag + " color")
+    # allmap: depth-like channels are O(10), use rtol too
+    assert_close_frac(out["allmap"], fwd["allmap"], 1e-4, 1e-4, 5e-4, 2e-2, tag + " allmap")
+
+
+def _check_grads(out, bwd, names, tag, rel=2e-3):
+    from tests.gpu_util import assert_grads_close
+    for k in names:
+        assert out[k] is not None, k
+        assert_grads_close(out[k], bwd[k], rel, f"{tag} {k}")
+
+
+def test_golden_small_scene(golden_dir):
+    """The committed oracle fixture (64 Gaussians, 32x32, SH3): every stage."""
+    from tests.gpu_util import run_hip, run_hip_raw, run_oracle
+    from streetunveiler_amd.camera import SimpleCamera
+    z = np.load(os.path.join(golden_dir, "oracle_small.npz"))
+    g = {k: torch.tensor(z["in_" + k]) for k in ["means3D", "scales", "rotations", "opacities", "shs"]}
+    base = synthetic_camera(32, 32, index=2)
+    cam = SimpleCamera(32, 32, base.FoVx, base.FoVy, torch.tensor(z["in_view"]), torch.tensor(z["in_proj"]), torch.tensor(z["in_campos"]))
+    dc, da = torch.tensor(z["in_dL_dcolor"]), torch.tensor(z["in_dL_dallmap"])
+    raw = run_hip_raw(g, cam, z["in_bg"], 3)
+    fwd = {k[4:]: z[k] for k in z.files if k.startswith("fwd_")}
+    fwd["num_rendered"] = int(z["fwd_num_rendered"])
+    _check_binning(raw, fwd)
+    np.testing.assert_array_equal(raw["img"]["n_contrib"].view(np.uint32), fwd["n_contrib"])
+    np.testing.assert_allclose(raw["img"]["final_T"], fwd["final_T"], rtol=1e-4, atol=1e-5)
+    out = run_hip(g, cam, z["in_bg"], 3, dc, da)
+    np.testing.assert_allclose(out["color"], fwd["color"], atol=1e-4)
+    np.testing.assert_allclose(out["allmap"], fwd["allmap"], rtol=1e-4, atol=1e-4)
+    bwd = {k[4:]: z[k] for k in z.files if k.startswith("bwd_")}
+    _check_grads(out, bwd, ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"], "golden")
+
+
+@pytest.mark.parametrize("P,W,H,deg,lo,hi,cam_index", [
+    (20000, 320, 200, 3, 2e-3, 3e-2, 2),      # ragged height (200 = 12.5 tiles), yawed camera
+    (5000, 250, 130, 1, 5e-3, 1e-1, None),    # big splats, many tiles per Gaussian, ragged both ways
+    (50000, 256, 256, 0, 5e-4, 5e-3, None),   # the C1-style scene (radius floor, thin splats -> low-pass branch)
+])
+def test_forward_backward_vs_oracle(P, W, H, deg, lo, hi, cam_index):
+    from tests.gpu_util import run_hip, run_hip_raw, run_oracle
+    cam, g = _scene(P, W, H, P, lo, hi, cam_index)
+    bg = np.array([0.3, 0.1, 0.7], np.float32)
+    dc, da = synthetic_upstream_grads(W, H, seed=P)
+    fwd, bwd = run_oracle(g, cam, bg, deg, dc, da)
+    assert fwd["num_rendered"] > P // 2
+    raw = run_hip_raw(g, cam, bg, deg)
+    _check_binning(raw, fwd)
+    nc = raw["img"]["n_contrib"].view(np.uint32)
+    assert (nc != fwd["n_contrib"]).mean() < 1e-3   # contributor counts: equal up to rare threshold flips
+    out = run_hip(g, cam, bg, deg, dc, da)
+    _check_images(out, fwd, f"P{P}")
+    _check_grads(out, bwd, ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"], f"P{P}")
+    # invisible Gaussians get exactly zero gradient
+    inv = fwd["radii"] == 0
+    for k in ["dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D", "dL_dopacity"]:
+        assert not np.asarray(out[k])[inv].any(), k
+
+
+def test_colors_precomp_and_transmat_precomp():
+    from tests.gpu_util import run_hip, run_oracle
+    P, W, H = 3000, 200, 120
+    cam, g = _scene(P, W, H, 11, 5e-3, 6e-2, 5)
+    bg = np.array([0.0, 1.0, 0.0], np.float32)   # render_semantic-style one-hot background
+    dc, da = synthetic_upstream_grads(W, H, seed=3)
+    colors = np.random.default_rng(0).random((P, 3)).astype(np.float32)
+    fwd, bwd = run_oracle(g, cam, bg, 0, dc, da, colors=colors)
+    out = run_hip(g, cam, bg, 0, dc, da, colors=colors)
+    np.testing.assert_array_equal(out["radii"], fwd["radii"])
+    _check_images(out, fwd, "colors_precomp")
+    _check_grads(out, bwd, ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dcolors", "dL_dmeans2D"], "colors_precomp")
+    # precomputed transMat (the reference's cov3D_precomp slot)
+    Tpre = fwd["transMat"].copy()
+    Tpre[fwd["radii"] == 0] = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], np.float32)
+    fwd2, bwd2 = run_oracle(g, cam, bg, 2, dc, da, Tpre=Tpre)
+    out2 = run_hip(g, cam, bg, 2, dc, da, Tpre=Tpre)
+    np.testing.assert_array_equal(out2["radii"], fwd2["radii"])
+    _check_images(out2, fwd2, "transMat_precomp")
+    _check_grads(out2, bwd2, ["dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dtransMat", "dL_dmeans2D"], "transMat_precomp")
+
+
+def test_empty_and_all_culled_inputs():
+    from tests.gpu_util import run_hip
+    W, H = 64, 48
+    cam = synthetic_camera(W, H)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    dc, da = synthetic_upstream_grads(W, H)
+    # P == 0
+    g0 = {k: v[:0] for k, v in synthetic_gaussians(4, W, H).items()}
+    out = run_hip(g0, cam, bg, 3, dc, da)
+    np.testing.assert_allclose(out["color"], np.broadcast_to(bg[:, None, None], (3, H, W)))
+    assert not out["allmap"].any() and out["radii"].shape == (0,)
+    # everything behind the camera: D == 0
+    g = synthetic_gaussians(100, W, H)
+    g["means3D"][:, 2] *= -1
+    out = run_hip(g, cam, bg, 3, dc, da)
+    assert not out["radii"].any()
+    np.testing.assert_allclose(out["color"], np.broadcast_to(bg[:, None, None], (3, H, W)))
+    for k in ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"]:
+        assert not out[k].any(), k
+
+
+def test_mark_visible_and_debug_mode():
+    from diff_surfel_rasterization import GaussianRasterizer
+    from oracle import surfel_oracle as so
+    from tests.gpu_util import DEV, run_hip, settings_for
+    W, H = 96, 64
+    cam, g = _scene(2000, W, H, 5, 2e-3, 3e-2, 1)
+    g["means3D"][::3, 2] *= -1
+    vis = GaussianRasterizer(settings_for(cam, [0, 0, 0], 0)).markVisible(g["means3D"].to(DEV))
+    assert vis.dtype == torch.bool
+    np.testing.assert_array_equal(vis.cpu().numpy(), so.mark_visible(g["means3D"].numpy(), cam.world_view_transform.numpy()))
+    # debug=True: sync-and-check after every kernel, same numbers
+    a = run_hip(g, cam, [0, 0, 0], 2, debug=False)
+    b = run_hip(g, cam, [0, 0, 0], 2, debug=True)
+    np.testing.assert_array_equal(a["color"], b["color"])
