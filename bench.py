@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: one full surfel-rasterizer forward + backward (K1..K8) per step.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): 3 M synthetic Gaussians,
+1920x1080, SH degree 3, all 7 aux-map gradients live, inputs resident in HBM before the timed region.
+N > 1: frames shard one-per-GPU (camera k yawed), then ONE gradient all-reduce (58 floats/Gaussian) per step
+over RCCL -- weak scaling, value = P * frames / s summed over ranks.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=3_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--no-aux", action="store_true", help="C2 variant: only colour + alpha gradients live")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-oracle work for the cpu_baseline leg")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(P, V, D, npx, deg):
+    """SURVEY.md 8(d) 'Algorithmic bytes' per frame, per stage."""
+    S = 12 * (deg + 1) ** 2
+    return {
+        "preprocess": V * (12 + 8 + 16 + 4 + S) + P * 16 + V * 87,
+        "binning": D * (12 + 8) + D * 24,
+        "blend_fwd": D * 76 + npx * 60,
+        "blend_bwd": D * 76 + D * 72 * 2 + npx * (60 + 40),
+        "preprocess_bwd": V * (232 + 36 + 72 + 240),
+    }
+
+
+def cpu_baseline(args, g, cam, dc, da):
+    """The CPU oracle (a port: the reference has no CPU rasterizer) timed on a bounded sub-sample of the
+    same scene, forward + backward, OpenMP over all host threads."""
+    from oracle import surfel_oracle as so
+    threads = so.num_threads()
+    kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
+              campos=cam.camera_center.numpy(), bg=np.zeros(3, np.float32), image_width=args.width,
+              image_height=args.height, sh_degree=args.sh_degree)
+    best = None
+    spent = 0.0
+    for n in (25_000, 100_000, 400_000, 1_600_000):
+        n = min(n, args.gaussians)
+        sub = {k: v[:n].numpy() for k, v in g.items()}
+        t0 = time.perf_counter()
+        fwd = so.rasterize_forward(sub["means3D"], sub["opacities"], sub["scales"], sub["rotations"], shs=sub["shs"], **kw)
+        so.rasterize_backward(fwd, dc.numpy(), da.numpy())
+        dt = time.perf_counter() - t0
+        spent += dt
+        best = (n, dt, fwd["num_rendered"])
+        if dt * 4 + spent > args.cpu_seconds * 1.5 or n == args.gaussians:
+            break
+    n, dt, D = best
+    return {"value": n / dt / 1e6, "unit": "Msplats/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/surfel_oracle.c fwd+bwd, first {n} Gaussians of the same scene at {args.width}x{args.height} "
+                      f"(D={D}), {dt:.1f} s wall, OpenMP {threads} threads"}
+
+
+def main():
+    args = parse()
+    from streetunveiler_amd.parallel import allreduce_gradients, init_distributed
+    rank, world, local_rank = init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    from streetunveiler_amd import _lib
+    from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
+    lib = _lib.load()
+
+    P, W, H, deg = args.gaussians, args.width, args.height, args.sh_degree
+    g_cpu = synthetic_gaussians(P, W, H, seed=0)
+    cam = synthetic_camera(W, H) if world == 1 else synthetic_camera(W, H, index=rank, n_cams=world)
+    dc_cpu, da_cpu = synthetic_upstream_grads(W, H, seed=1, aux=not args.no_aux)
+    params = {k: v.to(dev).requires_grad_() for k, v in g_cpu.items()}
+    dc, da = dc_cpu.to(dev), da_cpu.to(dev)
+    settings = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3, device=dev),
+                                             1.0, cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), deg,
+                                             cam.camera_center.to(dev), False, False)
+    rasterizer = GaussianRasterizer(settings)
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    leaves = [params["means3D"], params["shs"], params["opacities"], params["scales"], params["rotations"], means2D]
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        color, radii, allmap = rasterizer(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                          opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
+        torch.autograd.backward([color, allmap], [dc, da])
+        if world > 1:
+            allreduce_gradients([t.grad for t in leaves[:5]])
+        return radii
+
+    # scene statistics (outside the timed region)
+    with torch.no_grad():
+        e = torch.empty(0, device=dev)
+        D, _, _, radii0, *_ = _C.rasterize_gaussians(settings.bg, params["means3D"].detach(), e, params["opacities"].detach(),
+                                                     params["scales"].detach(), params["rotations"].detach(), 1.0, e,
+                                                     settings.viewmatrix, settings.projmatrix, settings.tanfovx, settings.tanfovy,
+                                                     H, W, params["shs"].detach(), deg, settings.campos, False, False)
+        V = int((radii0 > 0).sum().item())
+    del radii0
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    lib.sr_set_stage_timing(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    stats = _lib.stage_stats()
+    lib.sr_set_stage_timing(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = P * world * args.steps / elapsed / 1e6
+        npx = W * H
+        ab = algorithmic_bytes(P, V, D, npx, deg)
+        stage_ms = {k: (ms / n if n else None) for k, (ms, n) in stats.items()}
+        groups = {"preprocess": ["preprocess"], "binning": ["depth_sort", "emit", "tile_sort", "ranges"],
+                  "blend_fwd": ["blend_fwd"], "blend_bwd": ["blend_bwd"], "preprocess_bwd": ["preprocess_bwd"]}
+        group_ms = {k: sum(stage_ms[s] or 0.0 for s in v) for k, v in groups.items()}
+        dominant = max(("blend_fwd", "blend_bwd"), key=lambda k: group_ms[k])  # the north-star kernels
+        ach = ab[dominant] / (group_ms[dominant] * 1e-3) / 1e9 if group_ms[dominant] else None
+        blend_ms = group_ms["blend_fwd"] + group_ms["blend_bwd"]
+        blend_gbs = (ab["blend_fwd"] + ab["blend_bwd"]) / (blend_ms * 1e-3) / 1e9 if blend_ms else None
+        kernels_ms = sum(group_ms.values())
+        out = {
+            "metric": "Msplats/s fwd+bwd @1920x1080, 3M Gaussians", "value": round(value, 3), "unit": "Msplats/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: {P} synthetic Gaussians, {W}x{H}, SH degree {deg}, fwd+bwd, "
+                                   f"{'colour+alpha' if args.no_aux else 'all 7 aux-map'} gradients live",
+                       "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D,
+                       "frames_per_step": world, "parallelism": f"frame-sharded dp{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "render_backward_kernel" if dominant == "blend_bwd" else "render_forward_kernel",
+                         "achieved": None if ach is None else round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 5),
+                         "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_ms": round(group_ms[dominant], 4),
+                         "traffic": None,
+                         "north_star_blend_fwd_bwd": {"algorithmic_bytes": ab["blend_fwd"] + ab["blend_bwd"], "ms": round(blend_ms, 4),
+                                                      "achieved": None if blend_gbs is None else round(blend_gbs, 2),
+                                                      "frac": None if blend_gbs is None else round(blend_gbs / HBM_PEAK_GBS, 5)},
+                         "whole_op": {"algorithmic_bytes": sum(ab.values()), "kernel_ms": round(kernels_ms, 4),
+                                      "frac": round(sum(ab.values()) / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kernels_ms else None}},
+            "stage_ms": {k: (None if v is None else round(v, 4)) for k, v in stage_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, g_cpu, cam, dc_cpu, da_cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,14 +153,16 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
 int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     uint8_t* present, void* stream);
 
-/* Profiling aid: time (ms) HIP events recorded around each stage of the LAST forward/backward issued
- * from this thread with sr_set_stage_timing(1).  stage ids: see SrStage. Returns <0 if not recorded. */
+/* Profiling aid.  sr_set_stage_timing(1) makes every later call from this thread bracket each stage with a
+ * pair of HIP events recorded on the caller's stream (no host sync while recording; up to 512 launches per
+ * stage).  sr_stage_stats() waits for the recorded events and returns the summed duration (ms) and the
+ * number of launches of one stage since timing was (re-)enabled.  DEPTH_SORT covers sort + gather + scan. */
 typedef enum SrStage {
     SR_STAGE_PREPROCESS = 0, SR_STAGE_DEPTH_SORT = 1, SR_STAGE_SCAN = 2, SR_STAGE_EMIT = 3, SR_STAGE_TILE_SORT = 4,
     SR_STAGE_RANGES = 5, SR_STAGE_BLEND_FWD = 6, SR_STAGE_BLEND_BWD = 7, SR_STAGE_PREPROCESS_BWD = 8, SR_STAGE_COUNT = 9
 } SrStage;
 void sr_set_stage_timing(int enable);
-float sr_stage_ms(int stage);
+int sr_stage_stats(int stage, float* total_ms, int* launches);
 
 #ifdef __cplusplus
 }

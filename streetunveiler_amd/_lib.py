@@ -48,7 +48,7 @@ class SrImageView(C.Structure):
 # every symbol include/surfel_raster.h declares (checked by tests/test_abi.py)
 EXPORTS = ["sr_abi_version", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
            "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan",
-           "sr_forward_render", "sr_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_ms"]
+           "sr_forward_render", "sr_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats"]
 
 _lib = None
 
@@ -87,8 +87,7 @@ def load():
                                 C.c_size_t, C.POINTER(SrGradients), C.c_void_p]
     lib.sr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sr_set_stage_timing.argtypes = [C.c_int]
-    lib.sr_stage_ms.argtypes = [C.c_int]
-    lib.sr_stage_ms.restype = C.c_float
+    lib.sr_stage_stats.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     if lib.sr_abi_version() != 1:
         raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 1")
     _lib = lib
@@ -99,3 +98,14 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().sr_last_error().decode("utf-8", "replace")
         raise SurfelRasterError(f"{what} failed ({rc}): {msg}")
+
+
+def stage_stats():
+    """{stage name: (total_ms, launches)} since sr_set_stage_timing(1)."""
+    lib = load()
+    out = {}
+    for i, name in enumerate(SR_STAGE_NAMES):
+        ms, n = C.c_float(0), C.c_int(0)
+        check(lib.sr_stage_stats(i, C.byref(ms), C.byref(n)), "sr_stage_stats")
+        out[name] = (float(ms.value), int(n.value))
+    return out

@@ -3,6 +3,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 
 #include "common.h"
 
@@ -38,10 +40,9 @@ using namespace sr;
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local int g_timing = 0;
-thread_local hipEvent_t g_ev[SR_STAGE_COUNT + 1][2];
-thread_local bool g_ev_init = false;
-thread_local bool g_ev_set[SR_STAGE_COUNT] = {false};
+// timing state is process-wide: autograd runs the backward on its own thread
+std::atomic<int> g_timing{0};
+std::mutex g_ring_mu;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -58,20 +59,35 @@ int fail(int code, const char* fmt, ...) {
                                           __FILE__, __LINE__);                                               \
     } while (0)
 
+// Stage timing: a ring of HIP event pairs per stage, recorded on the caller's stream (no sync while
+// recording); sr_stage_stats() synchronises on the recorded events and returns total ms + launch count.
+constexpr int kEvRing = 512;
+struct EvRing {
+    hipEvent_t ev[kEvRing][2];
+    int created = 0, used = 0;
+};
+EvRing g_ring[SR_STAGE_COUNT];
+
 struct StageTimer {
-    int stage; hipStream_t s;
+    int stage; hipStream_t s; int slot = -1;
     StageTimer(int st, hipStream_t stream) : stage(st), s(stream) {
-        if (!g_timing) return;
-        if (!g_ev_init) {
-            for (auto& e : g_ev) { (void)hipEventCreate(&e[0]); (void)hipEventCreate(&e[1]); }
-            g_ev_init = true;
+        if (!g_timing.load()) return;
+        std::lock_guard<std::mutex> lk(g_ring_mu);
+        EvRing& r = g_ring[stage];
+        if (r.used >= kEvRing) return;  // ring full: stop recording (stats stay valid for the recorded part)
+        if (r.used >= r.created) {
+            if (hipEventCreate(&r.ev[r.created][0]) != hipSuccess || hipEventCreate(&r.ev[r.created][1]) != hipSuccess) return;
+            ++r.created;
         }
-        (void)hipEventRecord(g_ev[stage][0], s);
+        slot = r.used;
+        (void)hipEventRecord(r.ev[slot][0], s);
     }
     ~StageTimer() {
-        if (!g_timing) return;
-        (void)hipEventRecord(g_ev[stage][1], s);
-        g_ev_set[stage] = true;
+        if (slot < 0) return;
+        std::lock_guard<std::mutex> lk(g_ring_mu);
+        EvRing& r = g_ring[stage];
+        (void)hipEventRecord(r.ev[slot][1], s);
+        r.used = slot + 1;
     }
 };
 
@@ -341,16 +357,25 @@ int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, co
 }
 
 void sr_set_stage_timing(int enable) {
-    g_timing = enable;
-    for (auto& b : g_ev_set) b = false;
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    g_timing.store(enable);
+    if (enable) for (auto& r : g_ring) r.used = 0;
 }
 
-float sr_stage_ms(int stage) {
-    if (stage < 0 || stage >= SR_STAGE_COUNT || !g_ev_init || !g_ev_set[stage]) return -1.f;
-    if (hipEventSynchronize(g_ev[stage][1]) != hipSuccess) return -1.f;
-    float ms = -1.f;
-    if (hipEventElapsedTime(&ms, g_ev[stage][0], g_ev[stage][1]) != hipSuccess) return -1.f;
-    return ms;
+int sr_stage_stats(int stage, float* total_ms, int* launches) {
+    if (stage < 0 || stage >= SR_STAGE_COUNT || !total_ms || !launches) return fail(SR_ERR_INVALID_ARGUMENT, "bad stage / NULL output");
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    EvRing& r = g_ring[stage];
+    float sum = 0.f;
+    for (int i = 0; i < r.used; ++i) {
+        float ms = 0.f;
+        SR_HIP(hipEventSynchronize(r.ev[i][1]));
+        SR_HIP(hipEventElapsedTime(&ms, r.ev[i][0], r.ev[i][1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = r.used;
+    return SR_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,91 @@
+"""Frame-sharded data parallelism for the render operator.
+
+The path shards by camera: every rank holds the full Gaussian set, renders its own frame (K1..K8 need no
+collective), and the ranks meet once per optimisation step:
+  * SUM all-reduce of the parameter gradients (58 floats / Gaussian with SH degree 3);
+  * densification statistics, which are per-view norms and therefore cannot be derived from the summed
+    gradient: SUM of xyz_gradient_accum / denom, MAX of max_radii2D
+    [REF /root/reference/scene/gaussian_model.py:555-557; /root/reference/train.py:166-169].
+One process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI on ROCm); "gloo" for the CPU tests.
+xGMI is point-to-point, so few large messages beat many small ones: small tensors are packed into one
+bucket, large ones (the SH gradient is 83 % of the bytes) are reduced in place without a staging copy.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+_BUCKET_INPLACE_BYTES = 32 << 20  # tensors at least this large are all-reduced in place
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment. Returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
+    """Camera k -> rank k mod world."""
+    return [k for k in range(n_frames) if k % world == rank]
+
+
+def allreduce_gradients(grads: Sequence[torch.Tensor], group=None, average: bool = False) -> None:
+    """In-place SUM (or mean) all-reduce of a list of gradient tensors across the frame-parallel ranks."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    small = [g for g in grads if g is not None and g.numel() * g.element_size() < _BUCKET_INPLACE_BYTES]
+    large = [g for g in grads if g is not None and g.numel() * g.element_size() >= _BUCKET_INPLACE_BYTES]
+    handles = []
+    for g in large:  # largest first so the long transfer starts immediately
+        handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    if small:
+        flat = torch.cat([g.reshape(-1) for g in small])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for g in small:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+    for h in handles:
+        h.wait()
+    if average:
+        for g in grads:
+            if g is not None:
+                g.div_(world)
+
+
+def reduce_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, xyz_gradient_accum: torch.Tensor,
+                               denom: torch.Tensor, max_radii2D: torch.Tensor, group=None) -> None:
+    """Per-rank contribution of one rendered view, then cross-rank SUM / SUM / MAX.
+
+    Mirrors GaussianModel.add_densification_stats + the max_radii2D update for this rank's frame and makes
+    the three statistics identical on every rank."""
+    vis = radii > 0
+    local_accum = torch.zeros_like(xyz_gradient_accum)
+    local_denom = torch.zeros_like(denom)
+    local_accum[vis] = torch.norm(viewspace_grad[vis], dim=-1, keepdim=True)
+    local_denom[vis] = 1
+    local_max = torch.where(vis, radii.to(max_radii2D.dtype), torch.zeros_like(max_radii2D))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local_accum, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(local_denom, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(local_max, op=dist.ReduceOp.MAX, group=group)
+    xyz_gradient_accum += local_accum
+    denom += local_denom
+    torch.maximum(max_radii2D, local_max, out=max_radii2D)
