@@ -113,7 +113,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D = e(P, 3), e(P, 3), e(P, 1), e(P, 3)
         dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = e(P, 9), e(P, M, 3), e(P, 2), e(P, 4)
-        ws = torch.empty((lib.sr_backward_workspace_bytes(P),), dtype=torch.uint8, device=dev)
+        ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered)),), dtype=torch.uint8, device=dev)
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),
                               _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations))
         L.check(lib.sr_backward(C.byref(fr), C.byref(g), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(),

@@ -121,7 +121,7 @@ const char* sr_last_error(void);
 size_t sr_geom_bytes(int32_t P);
 size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t image_width, int32_t image_height);
 size_t sr_image_bytes(int32_t image_width, int32_t image_height);
-size_t sr_backward_workspace_bytes(int32_t P);
+size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered);
 
 int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out);
 int sr_binning_view(void* binning, size_t binning_bytes, int32_t P, uint32_t num_rendered, int32_t image_width,
@@ -143,7 +143,8 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
                       float* out_color, float* out_allmap, void* stream);
 
 /* Backward (K7 blend backward + K8 preprocess backward).  dL_dcolor [3,H,W], dL_dallmap [7,H,W].
- * workspace: sr_backward_workspace_bytes(P) bytes, contents undefined on entry. */
+ * workspace: sr_backward_workspace_bytes(P, num_rendered) bytes (one 80-B gradient record per (tile, Gaussian)
+ * duplicate), contents undefined on entry. */
 int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
                 void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
                 const float* dL_dcolor, const float* dL_dallmap, void* workspace, size_t workspace_bytes,

@@ -74,7 +74,7 @@ def load():
     lib.sr_geom_bytes.argtypes = [C.c_int32]
     lib.sr_binning_bytes.argtypes = [C.c_int32, C.c_uint32, C.c_int32, C.c_int32]
     lib.sr_image_bytes.argtypes = [C.c_int32, C.c_int32]
-    lib.sr_backward_workspace_bytes.argtypes = [C.c_int32]
+    lib.sr_backward_workspace_bytes.argtypes = [C.c_int32, C.c_uint32]
     lib.sr_geom_view.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(SrGeomView)]
     lib.sr_binning_view.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(SrBinningView)]
     lib.sr_image_view.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(SrImageView)]

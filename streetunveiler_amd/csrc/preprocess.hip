@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float4* __restrict__ recs,
-    const float4* __restrict__ grecs, SrGradients out) {
+    const float4* __restrict__ inst_grads, const uint32_t* __restrict__ inst_begin,
+    const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ inv_perm, SrGradients out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const int M = f.sh_coeffs;
@@ -189,9 +190,22 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     float* dsh = out.dL_dsh ? out.dL_dsh + (size_t)i * M * 3 : nullptr;
     if (vis) {
         const float4* rec = recs + (size_t)i * kRecQuads;
-        const float4* gr = grecs + (size_t)i * kRecQuads;
         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-        const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4];
+        // sum this Gaussian's per-(tile, Gaussian) gradient records (written by K7 at the duplicates' sorted
+        // positions); ascending emission order -> deterministic
+        float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0;
+        {
+            const uint32_t e0 = inst_begin[i], n = tiles_touched[i];
+            for (uint32_t e = e0; e < e0 + n; ++e) {
+                const float4* gr = inst_grads + (size_t)inv_perm[e] * kRecQuads;
+                const float4 a0 = gr[0], a1 = gr[1], a2 = gr[2], a3 = gr[3], a4 = gr[4];
+                g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w;
+                g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
+                g2.x += a2.x; g2.y += a2.y; g2.z += a2.z; g2.w += a2.w;
+                g3.x += a3.x; g3.y += a3.y; g3.z += a3.z; g3.w += a3.w;
+                g4.x += a4.x; g4.y += a4.y; g4.z += a4.z; g4.w += a4.w;
+            }
+        }
         const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
         dT[0] = g0.x; dT[1] = g0.y; dT[2] = g0.z; dT[3] = g0.w; dT[4] = g1.x; dT[5] = g1.y; dT[6] = g1.z; dT[7] = g1.w; dT[8] = g2.x;
         const float gx2 = g2.y, gy2 = g2.z;
@@ -351,11 +365,13 @@ hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians
 }
 
 hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
-                                      const uint8_t* clamped, const float4* recs, const float4* grecs,
+                                      const uint8_t* clamped, const float4* recs, const float4* inst_grads,
+                                      const uint32_t* inst_begin, const uint32_t* tiles_touched, const uint32_t* inv_perm,
                                       const SrGradients& out, hipStream_t s) {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, f, g.means3D, g.scales,
-                       g.rotations, g.shs, g.transMat_precomp, radii, clamped, recs, grecs, out);
+                       g.rotations, g.shs, g.transMat_precomp, radii, clamped, recs, inst_grads, inst_begin, tiles_touched,
+                       inv_perm, out);
     return hipGetLastError();
 }
 

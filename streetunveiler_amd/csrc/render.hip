@@ -7,8 +7,9 @@
 // address (broadcast ds_read_b128, conflict-free).  No MFMA: there is no dense contraction here.
 //
 // K7 replaces the reference's ~18 global float atomics per (pixel, splat) pair with a wave-level
-// multi-value transpose-reduction (24 cross-lane ops for 18 values) and ONE atomic per value per
-// (wave, splat) -- and none at all when no lane of the wave is touched by the splat.
+// multi-value transpose-reduction (v_permlane32/16_swap + DPP), an LDS combine across the tile's 4
+// waves and ONE plain 80-B store per (tile, splat): no global atomics, and nothing at all for a wave
+// no lane of which is touched by the splat.
 //
 // Behavioural contract: SURVEY.md Appendix A.4 / A.5; output channel order
 // [REF /root/reference/gaussian_renderer/__init__.py:149-165].
@@ -132,33 +133,47 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(FrameDev f, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave-level transpose-reduction: N values per lane -> lane l returns the 64-lane total of value
-// index l / (64/N).  Stage with mask m folds the value set in half (upper-half lanes keep the upper
-// half of the values), so the cost is N-1 cross-lane adds + log2(64/N) butterflies instead of 6*N.
+// wave-level transpose-reduction of 20 values per lane (gfx950):
+//   fold across the two 32-lane halves with v_permlane32_swap (value k <-> k+10), across row pairs with
+//   v_permlane16_swap (k <-> k+5), then a 4-step DPP row rotation sum.  50 VALU ops for 20 values (a plain
+//   butterfly needs 120 cross-lane ops).  Afterwards every lane of 16-lane row g holds, in v[0..4], the
+//   64-lane totals of values 5g .. 5g+4.
 // ---------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ float wave_reduce_multi(float (&v)[N], int lane) {
-    static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "N must be a power of two");
-    int m = 32;
+__device__ __forceinline__ void fold32(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void fold16(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int kCtrl>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), kCtrl, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp_mov<0x128>(x);  // row_ror:8
+    x += dpp_mov<0x124>(x);  // row_ror:4
+    x += dpp_mov<0x122>(x);  // row_ror:2
+    x += dpp_mov<0x121>(x);  // row_ror:1
+    return x;
+}
+__device__ __forceinline__ void wave_reduce20(float (&v)[20]) {
 #pragma unroll
-    for (int n = N; n > 1; n >>= 1, m >>= 1) {
-        const bool hi = (lane & m) != 0;
+    for (int k = 0; k < 10; ++k) fold32(v[k], v[k + 10]);
 #pragma unroll
-        for (int k = 0; k < n / 2; ++k) {
-            const float keep = hi ? v[k + n / 2] : v[k];
-            const float send = hi ? v[k] : v[k + n / 2];
-            v[k] = keep + __shfl_xor(send, m);
-        }
-    }
-    float r = v[0];
+    for (int k = 0; k < 5; ++k) fold16(v[k], v[k + 5]);
 #pragma unroll
-    for (int mm = (64 / N) >> 1; mm > 0; mm >>= 1) r += __shfl_xor(r, mm);
-    return r;
+    for (int k = 0; k < 5; ++k) v[k] = row_sum16(v[k]);
 }
 
 // ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
+// Output: one 80-B gradient record per (tile, Gaussian) duplicate, at the duplicate's sorted position
+// (inst_grads[pos]); K8 sums a Gaussian's records.  No global atomics: per (wave, splat) the 18 partial
+// sums are wave-reduced, the 4 waves of the tile combine in LDS, and each record is stored exactly once
+// (coalesced, 5 x dwordx4 per thread).  Records of list entries no pixel reached are written as zeros.
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                   const uint32_t* __restrict__ point_list,
                                                                   const float4* __restrict__ recs,
@@ -166,9 +181,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
                                                                   const uint32_t* __restrict__ n_contrib,
                                                                   const float* __restrict__ dL_dcolor,
                                                                   const float* __restrict__ dL_dallmap,
-                                                                  float* __restrict__ grecs) {
+                                                                  float4* __restrict__ inst_grads) {
     __shared__ float4 s_q[kRecQuads][kBlock];
-    __shared__ uint32_t s_gid[kBlock];
+    __shared__ __attribute__((aligned(16))) float s_acc[kBlock][kRecFloats];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x, lane = tid & 63;
     const int tile = blockIdx.x;
@@ -195,6 +210,11 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
     const float bg_dot = f.bg[0] * gpix[0] + f.bg[1] * gpix[1] + f.bg[2] * gpix[2];
 
     if (tid == 0) s_max = 0;
+    {
+        float4* z = reinterpret_cast<float4*>(&s_acc[tid][0]);
+#pragma unroll
+        for (int q = 0; q < kRecQuads; ++q) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
     // deepest entry any pixel of this wave / this tile needs
     uint32_t wave_last = last_contributor;
@@ -203,6 +223,17 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
     if (lane == 0) atomicMax(&s_max, wave_last);
     __syncthreads();
     const uint32_t total = s_max;
+    const uint32_t count = range.y - range.x;
+
+    // entries behind the deepest contributor: zero records
+    {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t e = total + tid; e < count; e += kBlock) {
+            float4* o = inst_grads + (size_t)(range.x + e) * kRecQuads;
+#pragma unroll
+            for (int q = 0; q < kRecQuads; ++q) o[q] = zero;
+        }
+    }
 
     float T = T_final;
     float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
@@ -211,98 +242,104 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
 
     const int rounds = (int)((total + kBlock - 1) / kBlock);
     for (int rd = rounds - 1; rd >= 0; --rd) {
-        __syncthreads();
         const uint32_t rbase = (uint32_t)rd * kBlock;
         const uint32_t n = min((uint32_t)kBlock, total - rbase);
         if ((uint32_t)tid < n) {
-            const uint32_t gid = point_list[range.x + rbase + tid];
-            s_gid[tid] = gid;
-            const float4* r = recs + (size_t)gid * kRecQuads;
+            const float4* r = recs + (size_t)point_list[range.x + rbase + tid] * kRecQuads;
 #pragma unroll
             for (int q = 0; q < kRecQuads; ++q) s_q[q][tid] = r[q];
         }
         __syncthreads();
-        if (wave_last <= rbase) continue;  // nothing in this round for this wave
-        const int jstart = (int)min(n, wave_last - rbase) - 1;
-        for (int j = jstart; j >= 0; --j) {
-            const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
-            Hit h;
-            const float4 q0 = s_q[0][j], q1 = s_q[1][j], q2 = s_q[2][j];
-            const bool valid = (cidx < last_contributor) && intersect(pxf, pyf, q0, q1, q2, h);
-            if (__ballot(valid) == 0) continue;
-            float vA[16], vB[4];
+        if (wave_last > rbase) {
+            const int jstart = (int)min(n, wave_last - rbase) - 1;
+            for (int j = jstart; j >= 0; --j) {
+                const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
+                Hit h;
+                const float4 q0 = s_q[0][j], q1 = s_q[1][j], q2 = s_q[2][j];
+                const bool valid = (cidx < last_contributor) && intersect(pxf, pyf, q0, q1, q2, h);
+                if (__ballot(valid) == 0) continue;
+                float v[20];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) vA[k] = 0.f;
+                for (int k = 0; k < 20; ++k) v[k] = 0.f;
+                if (valid) {
+                    const float4 q3 = s_q[3][j], q4 = s_q[4][j];
+                    const float Twx = q1.z, Twy = q1.w;
+                    const float one_m_inv = fast_rcp(1.f - h.alpha);
+                    T = T * one_m_inv;
+                    const float w = h.alpha * T;
+                    float dL_dalpha = 0.f;
+                    const float col[3] = {q4.x, q4.y, q4.z}, nrm[3] = {q3.x, q3.y, q3.z};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) vB[k] = 0.f;
-            if (valid) {
-                const float4 q3 = s_q[3][j], q4 = s_q[4][j];
-                const float Twx = q1.z, Twy = q1.w;
-                const float one_m_inv = fast_rcp(1.f - h.alpha);
-                T = T * one_m_inv;
-                const float w = h.alpha * T;
-                float dL_dalpha = 0.f;
-                const float col[3] = {q4.x, q4.y, q4.z}, nrm[3] = {q3.x, q3.y, q3.z};
+                    for (int c = 0; c < 3; ++c) {
+                        accum_rec[c] = last_alpha * last_color[c] + (1.f - last_alpha) * accum_rec[c];
+                        last_color[c] = col[c];
+                        dL_dalpha += (col[c] - accum_rec[c]) * gpix[c];
+                        v[16 + c] = w * gpix[c];
+                    }
+                    float dL_dz = 0.f;
+                    const float inv_depth = fast_rcp(h.depth);
+                    const float m_d = kFar / (kFar - kNear) * (1.f - kNear * inv_depth);
+                    const float dmd_dd = (kFar * kNear) / (kFar - kNear) * inv_depth * inv_depth;
+                    if (cidx == median_contributor - 1u) dL_dz += g_median;
+                    const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * g_reg;
+                    dL_dalpha += dL_dweight - last_dL_dT;
+                    last_dL_dT = dL_dweight * h.alpha + (1.f - h.alpha) * last_dL_dT;
+                    const float dL_dmd = 2.f * w * (m_d * final_A - final_D) * g_reg;
+                    dL_dz += dL_dmd * dmd_dd;
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    last_depth = h.depth;
+                    dL_dalpha += (h.depth - accum_depth_rec) * g_depth;
+                    accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
+                    dL_dalpha += (1.f - accum_alpha_rec) * g_accum;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    accum_rec[c] = last_alpha * last_color[c] + (1.f - last_alpha) * accum_rec[c];
-                    last_color[c] = col[c];
-                    dL_dalpha += (col[c] - accum_rec[c]) * gpix[c];
-                    vB[c] = w * gpix[c];
+                    for (int c = 0; c < 3; ++c) {
+                        accum_normal_rec[c] = last_alpha * last_normal[c] + (1.f - last_alpha) * accum_normal_rec[c];
+                        last_normal[c] = nrm[c];
+                        dL_dalpha += (nrm[c] - accum_normal_rec[c]) * gN[c];
+                        v[12 + c] = w * gN[c];
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = h.alpha;
+                    dL_dalpha += (-T_final * one_m_inv) * bg_dot;
+                    const float dL_dG = q2.w * dL_dalpha;
+                    dL_dz += w * g_depth;
+                    if (h.use3d) {
+                        const float dLdsx = dL_dG * -h.G * h.sx + dL_dz * Twx;
+                        const float dLdsy = dL_dG * -h.G * h.sy + dL_dz * Twy;
+                        const float ax = dLdsx * h.pz_inv, ay = dLdsy * h.pz_inv;
+                        const float dpx = ax, dpy = ay, dpz = -(ax * h.sx + ay * h.sy);
+                        // dL_dk = l x dp ; dL_dl = dp x k
+                        const float dkx = h.ly * dpz - h.lz * dpy, dky = h.lz * dpx - h.lx * dpz, dkz = h.lx * dpy - h.ly * dpx;
+                        const float dlx = dpy * h.kz - dpz * h.ky, dly = dpz * h.kx - dpx * h.kz, dlz = dpx * h.ky - dpy * h.kx;
+                        v[0] = -dkx; v[1] = -dky; v[2] = -dkz;
+                        v[3] = -dlx; v[4] = -dly; v[5] = -dlz;
+                        v[6] = pxf * dkx + pyf * dlx + dL_dz * h.sx;
+                        v[7] = pxf * dky + pyf * dly + dL_dz * h.sy;
+                        v[8] = pxf * dkz + pyf * dlz + dL_dz;
+                    } else {
+                        v[9] = dL_dG * (-h.G * kFilterInvSquare * h.dx);
+                        v[10] = dL_dG * (-h.G * kFilterInvSquare * h.dy);
+                        v[8] = dL_dz;
+                    }
+                    v[11] = h.G * dL_dalpha;
                 }
-                float dL_dz = 0.f;
-                const float inv_depth = fast_rcp(h.depth);
-                const float m_d = kFar / (kFar - kNear) * (1.f - kNear * inv_depth);
-                const float dmd_dd = (kFar * kNear) / (kFar - kNear) * inv_depth * inv_depth;
-                if (cidx == median_contributor - 1u) dL_dz += g_median;
-                const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * g_reg;
-                dL_dalpha += dL_dweight - last_dL_dT;
-                last_dL_dT = dL_dweight * h.alpha + (1.f - h.alpha) * last_dL_dT;
-                const float dL_dmd = 2.f * w * (m_d * final_A - final_D) * g_reg;
-                dL_dz += dL_dmd * dmd_dd;
-                accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                last_depth = h.depth;
-                dL_dalpha += (h.depth - accum_depth_rec) * g_depth;
-                accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
-                dL_dalpha += (1.f - accum_alpha_rec) * g_accum;
+                wave_reduce20(v);
+                if ((lane & 15) == 0) {
+                    float* a = &s_acc[j][5 * (lane >> 4)];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    accum_normal_rec[c] = last_alpha * last_normal[c] + (1.f - last_alpha) * accum_normal_rec[c];
-                    last_normal[c] = nrm[c];
-                    dL_dalpha += (nrm[c] - accum_normal_rec[c]) * gN[c];
-                    vA[12 + c] = w * gN[c];
+                    for (int k = 0; k < 5; ++k) atomicAdd(a + k, v[k]);  // ds_add_f32: 4 waves combine per splat
                 }
-                dL_dalpha *= T;
-                last_alpha = h.alpha;
-                dL_dalpha += (-T_final * one_m_inv) * bg_dot;
-                const float dL_dG = q2.w * dL_dalpha;
-                dL_dz += w * g_depth;
-                if (h.use3d) {
-                    const float dLdsx = dL_dG * -h.G * h.sx + dL_dz * Twx;
-                    const float dLdsy = dL_dG * -h.G * h.sy + dL_dz * Twy;
-                    const float ax = dLdsx * h.pz_inv, ay = dLdsy * h.pz_inv;
-                    const float dpx = ax, dpy = ay, dpz = -(ax * h.sx + ay * h.sy);
-                    // dL_dk = l x dp ; dL_dl = dp x k
-                    const float dkx = h.ly * dpz - h.lz * dpy, dky = h.lz * dpx - h.lx * dpz, dkz = h.lx * dpy - h.ly * dpx;
-                    const float dlx = dpy * h.kz - dpz * h.ky, dly = dpz * h.kx - dpx * h.kz, dlz = dpx * h.ky - dpy * h.kx;
-                    vA[0] = -dkx; vA[1] = -dky; vA[2] = -dkz;
-                    vA[3] = -dlx; vA[4] = -dly; vA[5] = -dlz;
-                    vA[6] = pxf * dkx + pyf * dlx + dL_dz * h.sx;
-                    vA[7] = pxf * dky + pyf * dly + dL_dz * h.sy;
-                    vA[8] = pxf * dkz + pyf * dlz + dL_dz;
-                } else {
-                    vA[9] = dL_dG * (-h.G * kFilterInvSquare * h.dx);
-                    vA[10] = dL_dG * (-h.G * kFilterInvSquare * h.dy);
-                    vA[8] = dL_dz;
-                }
-                vA[11] = h.G * dL_dalpha;
             }
-            const float rA = wave_reduce_multi<16>(vA, lane);
-            const float rB = wave_reduce_multi<4>(vB, lane);
-            float* g = grecs + (size_t)s_gid[j] * kRecFloats;
-            if ((lane & 3) == 0 && (lane >> 2) < 15) atomicAdd(g + (lane >> 2), rA);
-            if ((lane & 15) == 0 && (lane >> 4) < 3) atomicAdd(g + 16 + (lane >> 4), rB);
         }
+        __syncthreads();
+        // flush this round's records (one coalesced 80-B store per thread) and re-zero the accumulators
+        if ((uint32_t)tid < n) {
+            float4* acc = reinterpret_cast<float4*>(&s_acc[tid][0]);
+            float4* o = inst_grads + (size_t)(range.x + rbase + tid) * kRecQuads;
+#pragma unroll
+            for (int q = 0; q < kRecQuads; ++q) { o[q] = acc[q]; acc[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+        // (the next round's staging writes s_q rows; all reads of s_q finished at the barrier above)
     }
 }
 
@@ -318,11 +355,11 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, float* grecs, hipStream_t s) {
+                                  const float* dL_dallmap, float4* inst_grads, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(render_backward_kernel, dim3(n_tiles), dim3(kBlock), 0, s, f, ranges, point_list, recs, final_T,
-                       n_contrib, dL_dcolor, dL_dallmap, grecs);
+                       n_contrib, dL_dcolor, dL_dallmap, inst_grads);
     return hipGetLastError();
 }
 

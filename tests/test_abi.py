@@ -35,7 +35,7 @@ def test_abi_version_and_sizes(lib):
     assert lib.sr_abi_version() == 1
     # pure host arithmetic (no GPU): image state = 3 float planes + 2 u32 planes, 256-B aligned
     assert lib.sr_image_bytes(1920, 1080) >= 1920 * 1080 * 20
-    assert lib.sr_backward_workspace_bytes(1000) >= 1000 * 80
+    assert lib.sr_backward_workspace_bytes(1000, 5000) >= 5000 * 80
     assert lib.sr_geom_bytes(1000) >= 1000 * (80 + 4 * 7 + 1)
 
 
