@@ -154,6 +154,13 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
 int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     uint8_t* present, void* stream);
 
+/* Process-wide tuning switches (results are identical for every setting; they exist for A/B timing and for
+ * the test that proves the culling is exact).
+ *   SR_OPT_QUADRANT_CULL (default 1): drop list entries that provably cannot reach alpha >= 1/255 inside a
+ *   wave's 8x8 pixel quadrant before the per-pixel test. */
+typedef enum SrOption { SR_OPT_QUADRANT_CULL = 0 } SrOption;
+int sr_set_option(int option, int value);
+
 /* Profiling aid.  sr_set_stage_timing(1) makes every later call from this thread bracket each stage with a
  * pair of HIP events recorded on the caller's stream (no host sync while recording; up to 512 launches per
  * stage).  sr_stage_stats() waits for the recorded events and returns the summed duration (ms) and the

@@ -33,10 +33,10 @@ hipError_t run_finalize_lists(uint32_t D, int n_tiles, const uint32_t* tile_keys
                               hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
-                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, hipStream_t s);
+                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, int cull, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, float4* inst_grads, hipStream_t s);
+                                  const float* dL_dallmap, float4* inst_grads, int cull, hipStream_t s);
 }  // namespace sr
 
 using namespace sr;
@@ -46,6 +46,7 @@ namespace {
 thread_local char g_err[512] = "";
 // timing state is process-wide: autograd runs the backward on its own thread
 std::atomic<int> g_timing{0};
+std::atomic<int> g_opt_cull{1};  // SR_OPT_QUADRANT_CULL
 std::mutex g_ring_mu;
 
 int fail(int code, const char* fmt, ...) {
@@ -317,7 +318,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), recs, out_color,
-                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), s));
+                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), g_opt_cull.load(), s));
     }
     return debug_sync(frame, s, "render_forward");
 }
@@ -346,7 +347,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0)
             SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
-                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, inst_grads, s));
+                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, inst_grads, g_opt_cull.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;
     {
@@ -366,6 +367,13 @@ int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, co
     if (!means3D || !viewmatrix || !present) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     SR_HIP(launch_mark_visible(P, means3D, viewmatrix, present, static_cast<hipStream_t>(stream)));
     return SR_OK;
+}
+
+int sr_set_option(int option, int value) {
+    switch (option) {
+        case SR_OPT_QUADRANT_CULL: g_opt_cull.store(value ? 1 : 0); return SR_OK;
+        default: return fail(SR_ERR_INVALID_ARGUMENT, "unknown option %d", option);
+    }
 }
 
 void sr_set_stage_timing(int enable) {

@@ -58,16 +58,92 @@ __device__ __forceinline__ void pixel_of(int tile, int tiles_x, int tid, int& px
 }
 
 // ---------------------------------------------------------------------------------------------
+// Quadrant culling.  A list entry can only contribute to a pixel if alpha = min(0.99, opacity*G) >= 1/255,
+// i.e. rho = min(rho3d, rho2d) <= thr = 2 ln(255 opacity).  {rho3d <= thr} is the image of the disc
+// u^2+v^2 <= thr under the splat's homography -- an ellipse with dual conic C* = Q diag(thr,thr,-1) Q^T --
+// and {rho2d <= thr} is a disc of radius sqrt(thr/2) around means2D.  Each staging thread bounds that
+// union by an octagon (support in directions x, y, x+y, x-y from the tangent-line equation
+// l^T C* l = 0) and tests it against the tile's four 8x8 quadrants.  Entries dropped here are entries the
+// per-pixel test would skip anyway (`continue` in Appendix A.4), so results are unchanged; the bound has
+// 0.3 px / 1 % slack for float rounding and keeps the entry whenever anything is degenerate or NaN.
+// Coordinates are taken relative to the tile centre to avoid cancellation in the conic.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quadrant_mask(const float4 q0, const float4 q1, const float4 q2, float Xc, float Yc) {
+    float thr = 2.f * __logf(255.f * q2.w);
+    thr = thr * 1.01f + 0.01f;
+    if (thr <= 0.f) return 0u;
+    const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
+    const float Tu0 = q0.x - Xc * Tw0, Tu1 = q0.y - Xc * Tw1, Tu2 = q0.z - Xc * Tw2;
+    const float Tv0 = q0.w - Yc * Tw0, Tv1 = q1.x - Yc * Tw1, Tv2 = q1.y - Yc * Tw2;
+    const float c22 = thr * (Tw0 * Tw0 + Tw1 * Tw1) - Tw2 * Tw2;
+    if (!(c22 < 0.f)) return 0xFu;  // the cutoff disc reaches the camera plane: unbounded footprint
+    const float c00 = thr * (Tu0 * Tu0 + Tu1 * Tu1) - Tu2 * Tu2;
+    const float c01 = thr * (Tu0 * Tv0 + Tu1 * Tv1) - Tu2 * Tv2;
+    const float c11 = thr * (Tv0 * Tv0 + Tv1 * Tv1) - Tv2 * Tv2;
+    const float c02 = thr * (Tu0 * Tw0 + Tu1 * Tw1) - Tu2 * Tw2;
+    const float c12 = thr * (Tv0 * Tw0 + Tv1 * Tw1) - Tv2 * Tw2;
+    const float inv = 1.f / c22;
+    const float r = sqrtf(0.5f * thr);
+    const float mx = q2.y - Xc, my = q2.z - Yc;
+    float lo[4], hi[4];
+    const float A[4] = {c00, c11, c00 + 2.f * c01 + c11, c00 - 2.f * c01 + c11};
+    const float B[4] = {c02, c12, c02 + c12, c02 - c12};
+    const float ctr[4] = {mx, my, mx + my, mx - my};
+    const float rad[4] = {r, r, r * 1.4142137f, r * 1.4142137f};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float disc = B[d] * B[d] - A[d] * c22;
+        const float half = sqrtf(fmaxf(disc, 0.f)) * (-inv) * 1.01f;
+        const float dc = B[d] * inv;
+        lo[d] = fminf(dc - half, ctr[d] - rad[d]);
+        hi[d] = fmaxf(dc + half, ctr[d] + rad[d]);
+    }
+    const float m = 0.3f;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = (q & 1) ? 0.f : -8.f, x1 = x0 + 7.f;
+        const float y0 = (q & 2) ? 0.f : -8.f, y1 = y0 + 7.f;
+        const bool out = lo[0] > x1 + m || hi[0] < x0 - m || lo[1] > y1 + m || hi[1] < y0 - m ||
+                         lo[2] > x1 + y1 + 2.f * m || hi[2] < x0 + y0 - 2.f * m ||
+                         lo[3] > x1 - y0 + 2.f * m || hi[3] < x0 - y1 - 2.f * m;
+        if (!out) mask |= 1u << q;
+    }
+    return mask;
+}
+
+// Wave `wave` compacts the indices (ascending) of the staged entries [0, n) whose mask has bit `wave` set and
+// whose index is < limit, into s_list[wave][...]; returns the count.  Wave-local: no workgroup barrier needed.
+__device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t (*s_list)[kBlock], int wave, int lane,
+                                               uint32_t n, uint32_t limit) {
+    int count = 0;
+#pragma unroll
+    for (int c = 0; c < kBlock / 64; ++c) {
+        const uint32_t j = (uint32_t)(c * 64 + lane);
+        const bool keep = j < n && j < limit && ((s_mask[j] >> wave) & 1u);
+        const unsigned long long b = __ballot(keep);
+        if (keep) s_list[wave][count + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)j;
+        count += __popcll(b);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return count;
+}
+
+// ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                  const uint32_t* __restrict__ point_list,
                                                                  const float4* __restrict__ recs,
                                                                  float* __restrict__ out_color, float* __restrict__ out_allmap,
-                                                                 float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+                                                                 float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                                 int cull) {
     __shared__ float4 s_q[kRecQuads][kBlock];
-    const int tid = threadIdx.x;
+    __shared__ uint8_t s_mask[kBlock];
+    __shared__ uint16_t s_list[kBlock / 64][kBlock];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tile = blockIdx.x;
+    const float Xc = (float)((tile % f.tiles_x) * kTile + 8), Yc = (float)((tile / f.tiles_x) * kTile + 8);
     int px, py;
     pixel_of(tile, f.tiles_x, tid, px, py);
     const bool inside = px < f.W && py < f.H;
@@ -84,12 +160,17 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(FrameDev f, cons
         const uint32_t n = min((uint32_t)kBlock, range.y - base);
         if ((uint32_t)tid < n) {
             const float4* r = recs + (size_t)point_list[base + tid] * kRecQuads;
+            float4 q[kRecQuads];
 #pragma unroll
-            for (int q = 0; q < kRecQuads; ++q) s_q[q][tid] = r[q];
+            for (int k = 0; k < kRecQuads; ++k) { q[k] = r[k]; s_q[k][tid] = q[k]; }
+            s_mask[tid] = cull ? (uint8_t)quadrant_mask(q[0], q[1], q[2], Xc, Yc) : (uint8_t)0xF;
         }
         __syncthreads();
         const uint32_t c0 = base - range.x;
-        for (uint32_t j = 0; j < n; ++j) {
+        if (__ballot(!done) == 0) continue;  // this wave is finished (it still takes part in the barriers)
+        const int cnt = build_wave_list(s_mask, s_list, wave, lane, n, n);
+        for (int idx = 0; idx < cnt; ++idx) {
+            const uint32_t j = s_list[wave][idx];
             if (__ballot(!done) == 0) break;  // whole wave finished
             Hit h;
             const float4 q2 = s_q[2][j];
@@ -181,12 +262,15 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
                                                                   const uint32_t* __restrict__ n_contrib,
                                                                   const float* __restrict__ dL_dcolor,
                                                                   const float* __restrict__ dL_dallmap,
-                                                                  float4* __restrict__ inst_grads) {
+                                                                  float4* __restrict__ inst_grads, int cull) {
     __shared__ float4 s_q[kRecQuads][kBlock];
     __shared__ __attribute__((aligned(16))) float s_acc[kBlock][kRecFloats];
+    __shared__ uint8_t s_mask[kBlock];
+    __shared__ uint16_t s_list[kBlock / 64][kBlock];
     __shared__ uint32_t s_max;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
+    const float Xc = (float)((tile % f.tiles_x) * kTile + 8), Yc = (float)((tile / f.tiles_x) * kTile + 8);
     int px, py;
     pixel_of(tile, f.tiles_x, tid, px, py);
     const bool inside = px < f.W && py < f.H;
@@ -246,13 +330,17 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
         const uint32_t n = min((uint32_t)kBlock, total - rbase);
         if ((uint32_t)tid < n) {
             const float4* r = recs + (size_t)point_list[range.x + rbase + tid] * kRecQuads;
+            float4 q[kRecQuads];
 #pragma unroll
-            for (int q = 0; q < kRecQuads; ++q) s_q[q][tid] = r[q];
+            for (int k = 0; k < kRecQuads; ++k) { q[k] = r[k]; s_q[k][tid] = q[k]; }
+            s_mask[tid] = cull ? (uint8_t)quadrant_mask(q[0], q[1], q[2], Xc, Yc) : (uint8_t)0xF;
         }
         __syncthreads();
         if (wave_last > rbase) {
-            const int jstart = (int)min(n, wave_last - rbase) - 1;
-            for (int j = jstart; j >= 0; --j) {
+            // entries of this round that can touch this wave's quadrant and are not behind its deepest contributor
+            const int cnt = build_wave_list(s_mask, s_list, wave, lane, n, wave_last - rbase);
+            for (int idx = cnt - 1; idx >= 0; --idx) {
+                const int j = (int)s_list[wave][idx];
                 const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
                 Hit h;
                 const float4 q0 = s_q[0][j], q1 = s_q[1][j], q2 = s_q[2][j];
@@ -345,21 +433,21 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
 
 // launchers ---------------------------------------------------------------------------------------
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
-                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, hipStream_t s) {
+                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(render_forward_kernel, dim3(n_tiles), dim3(kBlock), 0, s, f, ranges, point_list, recs, out_color,
-                       out_allmap, final_T, n_contrib);
+                       out_allmap, final_T, n_contrib, cull);
     return hipGetLastError();
 }
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, float4* inst_grads, hipStream_t s) {
+                                  const float* dL_dallmap, float4* inst_grads, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(render_backward_kernel, dim3(n_tiles), dim3(kBlock), 0, s, f, ranges, point_list, recs, final_T,
-                       n_contrib, dL_dcolor, dL_dallmap, inst_grads);
+                       n_contrib, dL_dcolor, dL_dallmap, inst_grads, cull);
     return hipGetLastError();
 }
 
