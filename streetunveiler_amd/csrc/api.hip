@@ -13,9 +13,10 @@ namespace sr {
 hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians& g, float4* recs, uint32_t* depth_keys,
                                      uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii, hipStream_t s);
 hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
-                                      const uint8_t* clamped, const float4* recs, const float4* inst_grads,
-                                      const uint32_t* inst_begin, const uint32_t* tiles_touched, const uint32_t* inv_perm,
+                                      const uint8_t* clamped, const float4* recs, const float4* grecs,
                                       const SrGradients& out, hipStream_t s);
+hipError_t launch_reduce_instance_grads(int P, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
+                                        const float4* inst_grads, float4* grecs, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 // binning.hip
 size_t depth_sort_temp_bytes(int P);
@@ -25,18 +26,17 @@ hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* ti
                            void* temp, size_t temp_bytes, hipStream_t s, hipEvent_t ev_sorted);
 hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
                     const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* slots_unsorted,
-                    uint32_t* inst_begin, hipStream_t s);
+                    hipStream_t s);
 hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* slots_unsorted,
                          uint32_t* tile_keys, uint32_t* perm, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t run_finalize_lists(uint32_t D, int n_tiles, const uint32_t* tile_keys, const uint32_t* perm,
-                              const uint32_t* vals_unsorted, uint32_t* point_list, uint32_t* inv_perm, uint2* ranges,
-                              hipStream_t s);
+                              const uint32_t* vals_unsorted, uint32_t* point_list, uint2* ranges, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                  float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, int cull, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, float4* inst_grads, int cull, hipStream_t s);
+                                  const float* dL_dallmap, const uint32_t* perm, float4* inst_grads, int cull, hipStream_t s);
 }  // namespace sr
 
 using namespace sr;
@@ -106,7 +106,7 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
 
 // ---- buffer layouts ------------------------------------------------------------------------------
 struct GeomLayout {
-    size_t recs, depth_keys, tiles_touched, clamped, iota, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, inst_begin, temp, temp_bytes, total;
+    size_t recs, depth_keys, tiles_touched, clamped, iota, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, temp, temp_bytes, total;
 };
 GeomLayout geom_layout(int P) {
     GeomLayout L{};
@@ -122,7 +122,6 @@ GeomLayout geom_layout(int P) {
     L.sorted_gid = take(n * 4);
     L.tt_sorted = take(n * 4);
     L.sorted_offsets = take(n * 4);
-    L.inst_begin = take(n * 4);
     static thread_local int memo_P = -1;
     static thread_local size_t memo_bytes = 0;
     if (memo_P != P) { memo_bytes = depth_sort_temp_bytes(P); memo_P = P; }
@@ -133,7 +132,7 @@ GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t keys_unsorted, vals_unsorted, slots_unsorted, tile_keys, perm, point_list, inv_perm, ranges, temp, temp_bytes, total;
+    size_t keys_unsorted, vals_unsorted, slots_unsorted, tile_keys, perm, point_list, ranges, temp, temp_bytes, total;
 };
 BinLayout bin_layout(uint32_t D, int W, int H) {
     BinLayout L{};
@@ -147,7 +146,6 @@ BinLayout bin_layout(uint32_t D, int W, int H) {
     L.tile_keys = take(n * 4);
     L.perm = take(n * 4);
     L.point_list = take(n * 4);
-    L.inv_perm = take(n * 4);
     L.ranges = take((size_t)(tiles > 0 ? tiles : 1) * 8);
     static thread_local uint32_t memo_D = 0xFFFFFFFFu;
     static thread_local int memo_tiles = -1;
@@ -210,7 +208,11 @@ const char* sr_last_error(void) { return g_err; }
 size_t sr_geom_bytes(int32_t P) { return geom_layout(P).total; }
 size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t W, int32_t H) { (void)P; return bin_layout(num_rendered, W, H).total; }
 size_t sr_image_bytes(int32_t W, int32_t H) { return img_layout(W, H).total; }
-size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered) { (void)P; return align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * kRecFloats * 4, 256); }
+size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered) {
+    // D per-(tile, Gaussian) gradient records + P reduced per-Gaussian records, 80 B each
+    return align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * kRecFloats * 4, 256) +
+           align_up((size_t)(P > 0 ? P : 1) * kRecFloats * 4, 256);
+}
 
 int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out) {
     if (!geom || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -297,7 +299,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
             StageTimer t(SR_STAGE_EMIT, s);
             SR_HIP(run_emit(P, f.tiles_x, f.tiles_y, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), recs,
                             at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
-                            at<uint32_t>(binning, B.slots_unsorted), at<uint32_t>(geom, L.inst_begin), s));
+                            at<uint32_t>(binning, B.slots_unsorted), s));
         }
         if (int rc = debug_sync(frame, s, "emit_duplicates")) return rc;
         {
@@ -312,7 +314,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
         StageTimer t(SR_STAGE_RANGES, s);
         SR_HIP(run_finalize_lists((P > 0) ? D : 0, n_tiles, at<uint32_t>(binning, B.tile_keys), at<uint32_t>(binning, B.perm),
                                   at<uint32_t>(binning, B.vals_unsorted), at<uint32_t>(binning, B.point_list),
-                                  at<uint32_t>(binning, B.inv_perm), at<uint2>(binning, B.ranges), s));
+                                  at<uint2>(binning, B.ranges), s));
     }
     if (int rc = debug_sync(frame, s, "tile_ranges")) return rc;
     {
@@ -341,20 +343,22 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
     if (workspace_bytes < sr_backward_workspace_bytes(P, D)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P, D));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const FrameDev f = make_frame(frame, g);
-    // per-(tile, Gaussian) gradient records, indexed by sorted position; every one of the D records is written by K7
+    // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous); every one
+    // of the D records is written by K7.  Then one reduced record per Gaussian.
     float4* inst_grads = static_cast<float4*>(workspace);
+    float4* grecs = at<float4>(workspace, align_up((size_t)(D > 0 ? D : 1) * kRecFloats * 4, 256));
     {
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0)
             SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
-                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, inst_grads, g_opt_cull.load(), s));
+                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint32_t>(binning, B.perm), inst_grads, g_opt_cull.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;
     {
         StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
-        SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), inst_grads,
-                                          at<uint32_t>(geom, L.inst_begin), at<uint32_t>(geom, L.tiles_touched),
-                                          at<uint32_t>(binning, B.inv_perm), *grads, s));
+        SR_HIP(launch_reduce_instance_grads(P, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), inst_grads,
+                                            grecs, s));
+        SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), grecs, *grads, s));
     }
     return debug_sync(frame, s, "preprocess_backward");
 }

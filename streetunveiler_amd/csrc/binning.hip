@@ -36,8 +36,7 @@ __global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x
                                                               const float4* __restrict__ recs,
                                                               uint32_t* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out,
-                                                              uint32_t* __restrict__ slot_out,
-                                                              uint32_t* __restrict__ inst_begin) {
+                                                              uint32_t* __restrict__ slot_out) {
     __shared__ uint32_t s_start[4][65];
     __shared__ uint32_t s_gid[4][64];
     __shared__ int s_minx[4][64], s_miny[4][64], s_w[4][64];
@@ -67,7 +66,6 @@ __global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x
         incl = sorted_offsets[P - 1];
     }
     const uint32_t excl = incl - count;
-    if (r < P) inst_begin[gid] = excl;  // where this Gaussian's duplicates start in emission order
     s_start[wave][lane] = excl;
     if (lane == 63) s_start[wave][64] = incl;
     s_gid[wave][lane] = gid; s_minx[wave][lane] = minx; s_miny[wave][lane] = miny; s_w[wave][lane] = w;
@@ -89,17 +87,14 @@ __global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x
 }
 
 // K5: tile ranges from the sorted tile keys; also resolves the sorted permutation:
-//   point_list[pos] = gaussian id of the duplicate at sorted position pos
-//   inv_perm[e]     = sorted position of the duplicate with emission index e (used by K8 to find the
-//                     per-instance gradient records of a Gaussian, which are contiguous in e).
+//   point_list[pos] = gaussian id of the duplicate at sorted position pos  (perm[pos] = its emission index,
+//   kept for K7: gradient records are stored in emission order, where a Gaussian's duplicates are contiguous).
 __global__ void finalize_lists_kernel(uint32_t D, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ perm,
                                       const uint32_t* __restrict__ vals_unsorted, uint32_t* __restrict__ point_list,
-                                      uint32_t* __restrict__ inv_perm, uint2* __restrict__ ranges) {
+                                      uint2* __restrict__ ranges) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
-    const uint32_t e = perm[j];
-    point_list[j] = vals_unsorted[e];
-    inv_perm[e] = j;
+    point_list[j] = vals_unsorted[perm[j]];
     const uint32_t t = tile_keys[j];
     if (j == 0) ranges[t].x = 0;
     else {
@@ -159,10 +154,10 @@ hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* ti
 
 hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
                     const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* slots_unsorted,
-                    uint32_t* inst_begin, hipStream_t s) {
+                    hipStream_t s) {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(emit_duplicates_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, tiles_x, tiles_y, sorted_gid,
-                       sorted_offsets, recs, keys_unsorted, vals_unsorted, slots_unsorted, inst_begin);
+                       sorted_offsets, recs, keys_unsorted, vals_unsorted, slots_unsorted);
     return hipGetLastError();
 }
 
@@ -174,12 +169,11 @@ hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted,
 }
 
 hipError_t run_finalize_lists(uint32_t D, int n_tiles, const uint32_t* tile_keys, const uint32_t* perm,
-                              const uint32_t* vals_unsorted, uint32_t* point_list, uint32_t* inv_perm, uint2* ranges,
-                              hipStream_t s) {
+                              const uint32_t* vals_unsorted, uint32_t* point_list, uint2* ranges, hipStream_t s) {
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
     if (e != hipSuccess || D == 0) return e;
     hipLaunchKernelGGL(finalize_lists_kernel, dim3((D + 255) / 256), dim3(256), 0, s, D, tile_keys, perm, vals_unsorted,
-                       point_list, inv_perm, ranges);
+                       point_list, ranges);
     return hipGetLastError();
 }
 

@@ -43,16 +43,142 @@ __device__ __forceinline__ void build_B(const float* __restrict__ proj, int W, i
 
 __device__ __forceinline__ float dot3(const float* a, float x, float y, float z) { return (a[0] * x + a[1] * y) + a[2] * z; }
 
+// SH rows are 3*M floats per Gaussian (192 B for M = 16).  One thread per Gaussian reading its own row
+// would touch 64 different cache lines per load instruction; instead a 256-thread block moves its 256 rows
+// through LDS with fully coalesced 16-B accesses (48 KB in, and for K8 48 KB out), and each thread works on
+// its row in LDS.  Row stride 52 floats (48 + 4 pad) keeps per-thread ds_read_b128 conflict-free.
+constexpr int kShRowFloats = 48;   // fast path: M == 16
+constexpr int kShLdsStride = 52;
+
+__device__ __forceinline__ void sh_rows_to_lds(const float* __restrict__ shs, int base, int P, float* s_sh, int tid) {
+    const int nrows = min(256, P - base);
+    const int nvec = nrows * (kShRowFloats / 4);
+    const float4* src = reinterpret_cast<const float4*>(shs + (size_t)base * kShRowFloats);
+    float4* dst = reinterpret_cast<float4*>(s_sh);
+    for (int f = tid; f < nvec; f += 256) {
+        const int row = f / 12, c4 = f - row * 12;
+        dst[row * (kShLdsStride / 4) + c4] = src[f];
+    }
+}
+
+__device__ __forceinline__ void sh_rows_from_lds(float* __restrict__ out, int base, int P, const float* s_sh, int tid) {
+    const int nrows = min(256, P - base);
+    const int nvec = nrows * (kShRowFloats / 4);
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)base * kShRowFloats);
+    const float4* src = reinterpret_cast<const float4*>(s_sh);
+    for (int f = tid; f < nvec; f += 256) {
+        const int row = f / 12, c4 = f - row * 12;
+        dst[f] = src[row * (kShLdsStride / 4) + c4];
+    }
+}
+
+// colour = SH(deg, sh, dir) + 0.5, clamped at 0 (flags recorded)  [REF utils/sh_utils.py:57-112]
+template <class Row>
+__device__ __forceinline__ void sh_to_rgb(int deg, const Row sh, float dx, float dy, float dz, float rgb[3], uint8_t& clamped) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float res = kSH_C0 * sh[c];
+        if (deg > 0) {
+            const float x = dx, y = dy, z = dz;
+            res = res - kSH_C1 * y * sh[3 + c] + kSH_C1 * z * sh[6 + c] - kSH_C1 * x * sh[9 + c];
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                res = res + kSH_C2[0] * xy * sh[12 + c] + kSH_C2[1] * yz * sh[15 + c] +
+                      kSH_C2[2] * (2.f * zz - xx - yy) * sh[18 + c] + kSH_C2[3] * xz * sh[21 + c] +
+                      kSH_C2[4] * (xx - yy) * sh[24 + c];
+                if (deg > 2) {
+                    res = res + kSH_C3[0] * y * (3.f * xx - yy) * sh[27 + c] + kSH_C3[1] * xy * z * sh[30 + c] +
+                          kSH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + c] +
+                          kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + c] +
+                          kSH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + c] +
+                          kSH_C3[5] * z * (xx - yy) * sh[42 + c] + kSH_C3[6] * x * (xx - 3.f * yy) * sh[45 + c];
+                }
+            }
+        }
+        res += 0.5f;
+        if (res < 0.f) clamped |= (uint8_t)(1u << c);
+        rgb[c] = fmaxf(res, 0.f);
+    }
+}
+
+// SH backward.  Reads sh[k] and then overwrites the same slot of `dsh` with dL/dsh[k] (dsh may alias sh: the
+// LDS row is transformed in place); returns dL/d(dir) contributions in ddir.  Coefficients above the active
+// degree get 0.
+template <class RowIn, class RowOut>
+__device__ __forceinline__ void sh_backward(int deg, int M, const RowIn sh, RowOut dsh, bool want_dsh, float x, float y, float z,
+                                            const float gcol[3], float ddir[3]) {
+    ddir[0] = ddir[1] = ddir[2] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = gcol[c];
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (deg > 0) {
+            dx = -kSH_C1 * sh[9 + c]; dy = -kSH_C1 * sh[3 + c]; dz = kSH_C1 * sh[6 + c];
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                dx += kSH_C2[0] * y * sh[12 + c] + kSH_C2[2] * 2.f * -x * sh[18 + c] + kSH_C2[3] * z * sh[21 + c] + kSH_C2[4] * 2.f * x * sh[24 + c];
+                dy += kSH_C2[0] * x * sh[12 + c] + kSH_C2[1] * z * sh[15 + c] + kSH_C2[2] * 2.f * -y * sh[18 + c] + kSH_C2[4] * 2.f * -y * sh[24 + c];
+                dz += kSH_C2[1] * y * sh[15 + c] + kSH_C2[2] * 2.f * 2.f * z * sh[18 + c] + kSH_C2[3] * x * sh[21 + c];
+                if (deg > 2) {
+                    dx += kSH_C3[0] * sh[27 + c] * 3.f * 2.f * xy + kSH_C3[1] * sh[30 + c] * yz + kSH_C3[2] * sh[33 + c] * -2.f * xy +
+                          kSH_C3[3] * sh[36 + c] * -3.f * 2.f * xz + kSH_C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
+                          kSH_C3[5] * sh[42 + c] * 2.f * xz + kSH_C3[6] * sh[45 + c] * 3.f * (xx - yy);
+                    dy += kSH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + kSH_C3[1] * sh[30 + c] * xz + kSH_C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) +
+                          kSH_C3[3] * sh[36 + c] * -3.f * 2.f * yz + kSH_C3[4] * sh[39 + c] * -2.f * xy + kSH_C3[5] * sh[42 + c] * -2.f * yz +
+                          kSH_C3[6] * sh[45 + c] * -3.f * 2.f * xy;
+                    dz += kSH_C3[1] * sh[30 + c] * xy + kSH_C3[2] * sh[33 + c] * 4.f * 2.f * yz + kSH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) +
+                          kSH_C3[4] * sh[39 + c] * 4.f * 2.f * xz + kSH_C3[5] * sh[42 + c] * (xx - yy);
+                }
+            }
+        }
+        ddir[0] += dx * g; ddir[1] += dy * g; ddir[2] += dz * g;
+    }
+    if (want_dsh) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = gcol[c];
+            dsh[c] = kSH_C0 * g;
+            if (deg > 0) {
+                dsh[3 + c] = -kSH_C1 * y * g; dsh[6 + c] = kSH_C1 * z * g; dsh[9 + c] = -kSH_C1 * x * g;
+                if (deg > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    dsh[12 + c] = kSH_C2[0] * xy * g; dsh[15 + c] = kSH_C2[1] * yz * g;
+                    dsh[18 + c] = kSH_C2[2] * (2.f * zz - xx - yy) * g;
+                    dsh[21 + c] = kSH_C2[3] * xz * g; dsh[24 + c] = kSH_C2[4] * (xx - yy) * g;
+                    if (deg > 2) {
+                        dsh[27 + c] = kSH_C3[0] * y * (3.f * xx - yy) * g;
+                        dsh[30 + c] = kSH_C3[1] * xy * z * g;
+                        dsh[33 + c] = kSH_C3[2] * y * (4.f * zz - xx - yy) * g;
+                        dsh[36 + c] = kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                        dsh[39 + c] = kSH_C3[4] * x * (4.f * zz - xx - yy) * g;
+                        dsh[42 + c] = kSH_C3[5] * z * (xx - yy) * g;
+                        dsh[45 + c] = kSH_C3[6] * x * (xx - 3.f * yy) * g;
+                    }
+                }
+            }
+        }
+        const int used = (deg + 1) * (deg + 1);
+        for (int k = used * 3; k < M * 3; ++k) dsh[k] = 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------
+template <bool kLdsSH>
 __global__ __launch_bounds__(256) void preprocess_forward_kernel(
     int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ transMat_precomp,
     float4* __restrict__ recs, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ tiles_touched,
     uint8_t* __restrict__ clamped, int32_t* __restrict__ radii) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
+    const int tid = threadIdx.x, base = blockIdx.x * 256;
+    const int i = base + tid;
+    if (kLdsSH) {
+        sh_rows_to_lds(shs, base, P, s_sh, tid);
+        __syncthreads();
+    }
     if (i >= P) return;
     // defaults for a culled Gaussian
     int32_t out_radius = 0;
@@ -123,35 +249,11 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
                 if (colors_precomp) {
                     rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1]; rgb[2] = colors_precomp[3 * (size_t)i + 2];
                 } else {
-                    const float* sh = shs + (size_t)i * f.sh_coeffs * 3;
-                    const int deg = f.sh_degree;
                     float dx = px - f.campos[0], dy = py - f.campos[1], dz = pz - f.campos[2];
                     const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
                     dx /= len; dy /= len; dz /= len;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float res = kSH_C0 * sh[c];
-                        if (deg > 0) {
-                            const float x = dx, y = dy, z = dz;
-                            res = res - kSH_C1 * y * sh[3 + c] + kSH_C1 * z * sh[6 + c] - kSH_C1 * x * sh[9 + c];
-                            if (deg > 1) {
-                                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                                res = res + kSH_C2[0] * xy * sh[12 + c] + kSH_C2[1] * yz * sh[15 + c] +
-                                      kSH_C2[2] * (2.f * zz - xx - yy) * sh[18 + c] + kSH_C2[3] * xz * sh[21 + c] +
-                                      kSH_C2[4] * (xx - yy) * sh[24 + c];
-                                if (deg > 2) {
-                                    res = res + kSH_C3[0] * y * (3.f * xx - yy) * sh[27 + c] + kSH_C3[1] * xy * z * sh[30 + c] +
-                                          kSH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + c] +
-                                          kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + c] +
-                                          kSH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + c] +
-                                          kSH_C3[5] * z * (xx - yy) * sh[42 + c] + kSH_C3[6] * x * (xx - 3.f * yy) * sh[45 + c];
-                                }
-                            }
-                        }
-                        res += 0.5f;
-                        if (res < 0.f) out_clamped |= (uint8_t)(1u << c);
-                        rgb[c] = fmaxf(res, 0.f);
-                    }
+                    if (kLdsSH) sh_to_rgb(f.sh_degree, s_sh + tid * kShLdsStride, dx, dy, dz, rgb, out_clamped);
+                    else sh_to_rgb(f.sh_degree, shs + (size_t)i * f.sh_coeffs * 3, dx, dy, dz, rgb, out_clamped);
                 }
                 out_radius = (int32_t)radius;
                 out_tiles = (uint32_t)area;
@@ -173,173 +275,161 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// K8
+// K8a: sum the per-(tile, Gaussian) gradient records of each Gaussian.  K7 stores them in emission order,
+// where the records of depth-rank r are the contiguous span [offsets[r-1], offsets[r]); consecutive ranks
+// own consecutive spans, so a wave streams one contiguous region.  Ascending order -> deterministic sums.
 // ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_instance_grads_kernel(int P, const uint32_t* __restrict__ sorted_gid,
+                                                                    const uint32_t* __restrict__ sorted_offsets,
+                                                                    const float4* __restrict__ inst_grads,
+                                                                    float4* __restrict__ grecs) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P) return;
+    const uint32_t end = sorted_offsets[r];
+    const uint32_t begin = r > 0 ? sorted_offsets[r - 1] : 0u;
+    if (end == begin) return;  // culled / no tiles: K8b never reads its record
+    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0;
+    for (uint32_t e = begin; e < end; ++e) {
+        const float4* gr = inst_grads + (size_t)e * kRecQuads;
+        const float4 a0 = gr[0], a1 = gr[1], a2 = gr[2], a3 = gr[3], a4 = gr[4];
+        g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w;
+        g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
+        g2.x += a2.x; g2.y += a2.y; g2.z += a2.z; g2.w += a2.w;
+        g3.x += a3.x; g3.y += a3.y; g3.z += a3.z; g3.w += a3.w;
+        g4.x += a4.x; g4.y += a4.y; g4.z += a4.z; g4.w += a4.w;
+    }
+    float4* o = grecs + (size_t)sorted_gid[r] * kRecQuads;
+    o[0] = g0; o[1] = g1; o[2] = g2; o[3] = g3; o[4] = g4;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8b: per-Gaussian chain rule (Appendix A.6)
+// ---------------------------------------------------------------------------------------------
+template <bool kLdsSH>
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float4* __restrict__ recs,
-    const float4* __restrict__ inst_grads, const uint32_t* __restrict__ inst_begin,
-    const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ inv_perm, SrGradients out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const float4* __restrict__ grecs, SrGradients out) {
+    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
+    const int tid = threadIdx.x, base = blockIdx.x * 256;
+    const int i = base + tid;
     const int M = f.sh_coeffs;
-    float g_means3D[3] = {0, 0, 0}, g_scales[2] = {0, 0}, g_rot[4] = {0, 0, 0, 0}, g_m2d[2] = {0, 0};
-    float dT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dTr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_col[3] = {0, 0, 0}, g_opa = 0.f;
-    const bool vis = radii[i] > 0;
-    float* dsh = out.dL_dsh ? out.dL_dsh + (size_t)i * M * 3 : nullptr;
-    if (vis) {
-        const float4* rec = recs + (size_t)i * kRecQuads;
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-        // sum this Gaussian's per-(tile, Gaussian) gradient records (written by K7 at the duplicates' sorted
-        // positions); ascending emission order -> deterministic
-        float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0;
-        {
-            const uint32_t e0 = inst_begin[i], n = tiles_touched[i];
-            for (uint32_t e = e0; e < e0 + n; ++e) {
-                const float4* gr = inst_grads + (size_t)inv_perm[e] * kRecQuads;
-                const float4 a0 = gr[0], a1 = gr[1], a2 = gr[2], a3 = gr[3], a4 = gr[4];
-                g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w;
-                g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
-                g2.x += a2.x; g2.y += a2.y; g2.z += a2.z; g2.w += a2.w;
-                g3.x += a3.x; g3.y += a3.y; g3.z += a3.z; g3.w += a3.w;
-                g4.x += a4.x; g4.y += a4.y; g4.z += a4.z; g4.w += a4.w;
-            }
-        }
-        const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
-        dT[0] = g0.x; dT[1] = g0.y; dT[2] = g0.z; dT[3] = g0.w; dT[4] = g1.x; dT[5] = g1.y; dT[6] = g1.z; dT[7] = g1.w; dT[8] = g2.x;
-        const float gx2 = g2.y, gy2 = g2.z;
-        g_opa = g2.w;
-        const float gn[3] = {g3.x, g3.y, g3.z};
-        g_col[0] = g4.x; g_col[1] = g4.y; g_col[2] = g4.z;
-        // densification proxy from the blend-only dL/dT (Appendix A.6, last paragraph)
-        g_m2d[0] = dT[2] * Tw[2] * 0.5f * (float)f.W;
-        g_m2d[1] = dT[5] * Tw[2] * 0.5f * (float)f.H;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) dTr[k] = dT[k];
-        if (gx2 != 0.f || gy2 != 0.f) {
-            const float t[3] = {9.f, 9.f, -1.f};
-            const float d = (t[0] * Tw[0] * Tw[0] + t[1] * Tw[1] * Tw[1]) + t[2] * Tw[2] * Tw[2];
-            float fv[3], dLdd = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { fv[c] = t[c] / d; dLdd += (gx2 * Tu[c] * Tw[c] + gy2 * Tv[c] * Tw[c]) * fv[c]; }
-            dLdd *= (-1.f / d);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                dT[0 + c] += gx2 * fv[c] * Tw[c];
-                dT[3 + c] += gy2 * fv[c] * Tw[c];
-                dT[6 + c] += gx2 * fv[c] * Tu[c] + gy2 * fv[c] * Tv[c] + dLdd * (t[c] * Tw[c] * 2.f);
-            }
-        }
-        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
-        if (!transMat_precomp) {
-            float B[12], R[9];
-            build_B(f.proj, f.W, f.H, B);
-            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
-            quat_to_R(q, R);
-            const float2 s = reinterpret_cast<const float2*>(scales)[i];  // modifier 1.0 (upstream quirk, A.6)
-            float dL0[3], dL1[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                dL0[k] = B[0 + k] * dT[0] + B[4 + k] * dT[3] + B[8 + k] * dT[6];
-                dL1[k] = B[0 + k] * dT[1] + B[4 + k] * dT[4] + B[8 + k] * dT[7];
-                g_means3D[k] = B[0 + k] * dT[2] + B[4 + k] * dT[5] + B[8 + k] * dT[8];
-            }
-            const float* v = f.view;
-            float dtn[3] = {v[0] * gn[0] + v[1] * gn[1] + v[2] * gn[2], v[4] * gn[0] + v[5] * gn[1] + v[6] * gn[2],
-                            v[8] * gn[0] + v[9] * gn[1] + v[10] * gn[2]};
-            const float vx = ((v[0] * px + v[4] * py) + v[8] * pz) + v[12];
-            const float vy = ((v[1] * px + v[5] * py) + v[9] * pz) + v[13];
-            const float vz = ((v[2] * px + v[6] * py) + v[10] * pz) + v[14];
-            const float nx = R[2], ny = R[5], nz = R[8];
-            const float n0 = (v[0] * nx + v[4] * ny) + v[8] * nz;
-            const float n1 = (v[1] * nx + v[5] * ny) + v[9] * nz;
-            const float n2 = (v[2] * nx + v[6] * ny) + v[10] * nz;
-            const float cosv = -((vx * n0 + vy * n1) + vz * n2);
-            const float mult = cosv > 0.f ? 1.f : -1.f;
-            dtn[0] *= mult; dtn[1] *= mult; dtn[2] *= mult;
-            float G[9];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { G[3 * k + 0] = dL0[k] * s.x; G[3 * k + 1] = dL1[k] * s.y; G[3 * k + 2] = dtn[k]; }
-            g_scales[0] = dL0[0] * R[0] + dL0[1] * R[3] + dL0[2] * R[6];
-            g_scales[1] = dL1[0] * R[1] + dL1[1] * R[4] + dL1[2] * R[7];
-            const float r = q.x, x = q.y, y = q.z, z = q.w;
-            g_rot[0] = 2.f * (-z * G[1] + y * G[2] + z * G[3] - x * G[5] - y * G[6] + x * G[7]);
-            g_rot[1] = 2.f * (y * G[1] + z * G[2] + y * G[3] - 2.f * x * G[4] - r * G[5] + z * G[6] + r * G[7] - 2.f * x * G[8]);
-            g_rot[2] = 2.f * (-2.f * y * G[0] + x * G[1] + r * G[2] + x * G[3] + z * G[5] - r * G[6] + z * G[7] - 2.f * y * G[8]);
-            g_rot[3] = 2.f * (-2.f * z * G[0] - r * G[1] + x * G[2] + r * G[3] - 2.f * z * G[4] + y * G[5] + x * G[6] + y * G[7]);
-        }
-        if (shs) {
-            const float* sh = shs + (size_t)i * M * 3;
-            const int deg = f.sh_degree;
-            const float ox = px - f.campos[0], oy = py - f.campos[1], oz = pz - f.campos[2];
-            const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
-            const float x = ox / len, y = oy / len, z = oz / len;
-            const uint8_t cl = clamped[i];
-            float ddir[3] = {0, 0, 0};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float g = ((cl >> c) & 1) ? 0.f : g_col[c];
-                float dx = 0.f, dy = 0.f, dz = 0.f;
-                if (dsh) dsh[c] = kSH_C0 * g;
-                if (deg > 0) {
-                    if (dsh) { dsh[3 + c] = -kSH_C1 * y * g; dsh[6 + c] = kSH_C1 * z * g; dsh[9 + c] = -kSH_C1 * x * g; }
-                    dx = -kSH_C1 * sh[9 + c]; dy = -kSH_C1 * sh[3 + c]; dz = kSH_C1 * sh[6 + c];
-                    if (deg > 1) {
-                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                        if (dsh) {
-                            dsh[12 + c] = kSH_C2[0] * xy * g; dsh[15 + c] = kSH_C2[1] * yz * g;
-                            dsh[18 + c] = kSH_C2[2] * (2.f * zz - xx - yy) * g;
-                            dsh[21 + c] = kSH_C2[3] * xz * g; dsh[24 + c] = kSH_C2[4] * (xx - yy) * g;
-                        }
-                        dx += kSH_C2[0] * y * sh[12 + c] + kSH_C2[2] * 2.f * -x * sh[18 + c] + kSH_C2[3] * z * sh[21 + c] + kSH_C2[4] * 2.f * x * sh[24 + c];
-                        dy += kSH_C2[0] * x * sh[12 + c] + kSH_C2[1] * z * sh[15 + c] + kSH_C2[2] * 2.f * -y * sh[18 + c] + kSH_C2[4] * 2.f * -y * sh[24 + c];
-                        dz += kSH_C2[1] * y * sh[15 + c] + kSH_C2[2] * 2.f * 2.f * z * sh[18 + c] + kSH_C2[3] * x * sh[21 + c];
-                        if (deg > 2) {
-                            if (dsh) {
-                                dsh[27 + c] = kSH_C3[0] * y * (3.f * xx - yy) * g;
-                                dsh[30 + c] = kSH_C3[1] * xy * z * g;
-                                dsh[33 + c] = kSH_C3[2] * y * (4.f * zz - xx - yy) * g;
-                                dsh[36 + c] = kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
-                                dsh[39 + c] = kSH_C3[4] * x * (4.f * zz - xx - yy) * g;
-                                dsh[42 + c] = kSH_C3[5] * z * (xx - yy) * g;
-                                dsh[45 + c] = kSH_C3[6] * x * (xx - 3.f * yy) * g;
-                            }
-                            dx += kSH_C3[0] * sh[27 + c] * 3.f * 2.f * xy + kSH_C3[1] * sh[30 + c] * yz + kSH_C3[2] * sh[33 + c] * -2.f * xy +
-                                  kSH_C3[3] * sh[36 + c] * -3.f * 2.f * xz + kSH_C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
-                                  kSH_C3[5] * sh[42 + c] * 2.f * xz + kSH_C3[6] * sh[45 + c] * 3.f * (xx - yy);
-                            dy += kSH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + kSH_C3[1] * sh[30 + c] * xz + kSH_C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) +
-                                  kSH_C3[3] * sh[36 + c] * -3.f * 2.f * yz + kSH_C3[4] * sh[39 + c] * -2.f * xy + kSH_C3[5] * sh[42 + c] * -2.f * yz +
-                                  kSH_C3[6] * sh[45 + c] * -3.f * 2.f * xy;
-                            dz += kSH_C3[1] * sh[30 + c] * xy + kSH_C3[2] * sh[33 + c] * 4.f * 2.f * yz + kSH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) +
-                                  kSH_C3[4] * sh[39 + c] * 4.f * 2.f * xz + kSH_C3[5] * sh[42 + c] * (xx - yy);
-                        }
-                    }
-                }
-                ddir[0] += dx * g; ddir[1] += dy * g; ddir[2] += dz * g;
-            }
-            if (dsh) {
-                const int used = (deg + 1) * (deg + 1);
-                for (int k = used * 3; k < M * 3; ++k) dsh[k] = 0.f;
-            }
-            const float nd = (x * ddir[0] + y * ddir[1]) + z * ddir[2];
-            g_means3D[0] += (ddir[0] - x * nd) / len;
-            g_means3D[1] += (ddir[1] - y * nd) / len;
-            g_means3D[2] += (ddir[2] - z * nd) / len;
-        }
-    } else if (dsh) {
-        for (int k = 0; k < M * 3; ++k) dsh[k] = 0.f;
+    if (kLdsSH) {
+        sh_rows_to_lds(shs, base, P, s_sh, tid);
+        __syncthreads();
     }
-    if (out.dL_dmeans3D) { out.dL_dmeans3D[3 * (size_t)i] = g_means3D[0]; out.dL_dmeans3D[3 * (size_t)i + 1] = g_means3D[1]; out.dL_dmeans3D[3 * (size_t)i + 2] = g_means3D[2]; }
-    if (out.dL_dmeans2D) { out.dL_dmeans2D[3 * (size_t)i] = g_m2d[0]; out.dL_dmeans2D[3 * (size_t)i + 1] = g_m2d[1]; out.dL_dmeans2D[3 * (size_t)i + 2] = 0.f; }
-    if (out.dL_dscales) { out.dL_dscales[2 * (size_t)i] = g_scales[0]; out.dL_dscales[2 * (size_t)i + 1] = g_scales[1]; }
-    if (out.dL_drotations) { reinterpret_cast<float4*>(out.dL_drotations)[i] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]); }
-    if (out.dL_dopacity) out.dL_dopacity[i] = g_opa;
-    if (out.dL_dcolors) { out.dL_dcolors[3 * (size_t)i] = g_col[0]; out.dL_dcolors[3 * (size_t)i + 1] = g_col[1]; out.dL_dcolors[3 * (size_t)i + 2] = g_col[2]; }
-    if (out.dL_dtransMat) {
-        // upstream writes the AABB-centre-augmented dL/dT back only when transMat is an input (A.6)
+    if (i < P) {
+        float g_means3D[3] = {0, 0, 0}, g_scales[2] = {0, 0}, g_rot[4] = {0, 0, 0, 0}, g_m2d[2] = {0, 0};
+        float dT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dTr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_col[3] = {0, 0, 0}, g_opa = 0.f;
+        const bool vis = radii[i] > 0;
+        float* dsh_g = (!kLdsSH && out.dL_dsh) ? out.dL_dsh + (size_t)i * M * 3 : nullptr;
+        float* row = s_sh + tid * kShLdsStride;
+        if (vis) {
+            const float4* rec = recs + (size_t)i * kRecQuads;
+            const float4* gr = grecs + (size_t)i * kRecQuads;
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4];
+            const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
+            dT[0] = g0.x; dT[1] = g0.y; dT[2] = g0.z; dT[3] = g0.w; dT[4] = g1.x; dT[5] = g1.y; dT[6] = g1.z; dT[7] = g1.w; dT[8] = g2.x;
+            const float gx2 = g2.y, gy2 = g2.z;
+            g_opa = g2.w;
+            const float gn[3] = {g3.x, g3.y, g3.z};
+            g_col[0] = g4.x; g_col[1] = g4.y; g_col[2] = g4.z;
+            // densification proxy from the blend-only dL/dT (Appendix A.6, last paragraph)
+            g_m2d[0] = dT[2] * Tw[2] * 0.5f * (float)f.W;
+            g_m2d[1] = dT[5] * Tw[2] * 0.5f * (float)f.H;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) out.dL_dtransMat[9 * (size_t)i + k] = transMat_precomp ? dT[k] : dTr[k];
+            for (int k = 0; k < 9; ++k) dTr[k] = dT[k];
+            if (gx2 != 0.f || gy2 != 0.f) {
+                const float t[3] = {9.f, 9.f, -1.f};
+                const float d = (t[0] * Tw[0] * Tw[0] + t[1] * Tw[1] * Tw[1]) + t[2] * Tw[2] * Tw[2];
+                float fv[3], dLdd = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { fv[c] = t[c] / d; dLdd += (gx2 * Tu[c] * Tw[c] + gy2 * Tv[c] * Tw[c]) * fv[c]; }
+                dLdd *= (-1.f / d);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    dT[0 + c] += gx2 * fv[c] * Tw[c];
+                    dT[3 + c] += gy2 * fv[c] * Tw[c];
+                    dT[6 + c] += gx2 * fv[c] * Tu[c] + gy2 * fv[c] * Tv[c] + dLdd * (t[c] * Tw[c] * 2.f);
+                }
+            }
+            const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+            if (!transMat_precomp) {
+                float B[12], R[9];
+                build_B(f.proj, f.W, f.H, B);
+                const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+                quat_to_R(q, R);
+                const float2 sc = reinterpret_cast<const float2*>(scales)[i];  // modifier 1.0 (upstream quirk, A.6)
+                float dL0[3], dL1[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    dL0[k] = B[0 + k] * dT[0] + B[4 + k] * dT[3] + B[8 + k] * dT[6];
+                    dL1[k] = B[0 + k] * dT[1] + B[4 + k] * dT[4] + B[8 + k] * dT[7];
+                    g_means3D[k] = B[0 + k] * dT[2] + B[4 + k] * dT[5] + B[8 + k] * dT[8];
+                }
+                const float* v = f.view;
+                float dtn[3] = {v[0] * gn[0] + v[1] * gn[1] + v[2] * gn[2], v[4] * gn[0] + v[5] * gn[1] + v[6] * gn[2],
+                                v[8] * gn[0] + v[9] * gn[1] + v[10] * gn[2]};
+                const float vx = ((v[0] * px + v[4] * py) + v[8] * pz) + v[12];
+                const float vy = ((v[1] * px + v[5] * py) + v[9] * pz) + v[13];
+                const float vz = ((v[2] * px + v[6] * py) + v[10] * pz) + v[14];
+                const float nx = R[2], ny = R[5], nz = R[8];
+                const float n0 = (v[0] * nx + v[4] * ny) + v[8] * nz;
+                const float n1 = (v[1] * nx + v[5] * ny) + v[9] * nz;
+                const float n2 = (v[2] * nx + v[6] * ny) + v[10] * nz;
+                const float cosv = -((vx * n0 + vy * n1) + vz * n2);
+                const float mult = cosv > 0.f ? 1.f : -1.f;
+                dtn[0] *= mult; dtn[1] *= mult; dtn[2] *= mult;
+                float G[9];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { G[3 * k + 0] = dL0[k] * sc.x; G[3 * k + 1] = dL1[k] * sc.y; G[3 * k + 2] = dtn[k]; }
+                g_scales[0] = dL0[0] * R[0] + dL0[1] * R[3] + dL0[2] * R[6];
+                g_scales[1] = dL1[0] * R[1] + dL1[1] * R[4] + dL1[2] * R[7];
+                const float r = q.x, x = q.y, y = q.z, z = q.w;
+                g_rot[0] = 2.f * (-z * G[1] + y * G[2] + z * G[3] - x * G[5] - y * G[6] + x * G[7]);
+                g_rot[1] = 2.f * (y * G[1] + z * G[2] + y * G[3] - 2.f * x * G[4] - r * G[5] + z * G[6] + r * G[7] - 2.f * x * G[8]);
+                g_rot[2] = 2.f * (-2.f * y * G[0] + x * G[1] + r * G[2] + x * G[3] + z * G[5] - r * G[6] + z * G[7] - 2.f * y * G[8]);
+                g_rot[3] = 2.f * (-2.f * z * G[0] - r * G[1] + x * G[2] + r * G[3] - 2.f * z * G[4] + y * G[5] + x * G[6] + y * G[7]);
+            }
+            if (shs) {
+                const float ox = px - f.campos[0], oy = py - f.campos[1], oz = pz - f.campos[2];
+                const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
+                const float x = ox / len, y = oy / len, z = oz / len;
+                const uint8_t cl = clamped[i];
+                const float gc[3] = {(cl & 1) ? 0.f : g_col[0], (cl & 2) ? 0.f : g_col[1], (cl & 4) ? 0.f : g_col[2]};
+                float ddir[3];
+                if (kLdsSH) sh_backward(f.sh_degree, M, row, row, out.dL_dsh != nullptr, x, y, z, gc, ddir);
+                else sh_backward(f.sh_degree, M, shs + (size_t)i * M * 3, dsh_g, dsh_g != nullptr, x, y, z, gc, ddir);
+                const float nd = (x * ddir[0] + y * ddir[1]) + z * ddir[2];
+                g_means3D[0] += (ddir[0] - x * nd) / len;
+                g_means3D[1] += (ddir[1] - y * nd) / len;
+                g_means3D[2] += (ddir[2] - z * nd) / len;
+            }
+        } else if (shs) {
+            if (kLdsSH) {
+#pragma unroll
+                for (int k = 0; k < kShRowFloats / 4; ++k) reinterpret_cast<float4*>(row)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (dsh_g) {
+                for (int k = 0; k < M * 3; ++k) dsh_g[k] = 0.f;
+            }
+        }
+        if (out.dL_dmeans3D) { out.dL_dmeans3D[3 * (size_t)i] = g_means3D[0]; out.dL_dmeans3D[3 * (size_t)i + 1] = g_means3D[1]; out.dL_dmeans3D[3 * (size_t)i + 2] = g_means3D[2]; }
+        if (out.dL_dmeans2D) { out.dL_dmeans2D[3 * (size_t)i] = g_m2d[0]; out.dL_dmeans2D[3 * (size_t)i + 1] = g_m2d[1]; out.dL_dmeans2D[3 * (size_t)i + 2] = 0.f; }
+        if (out.dL_dscales) { out.dL_dscales[2 * (size_t)i] = g_scales[0]; out.dL_dscales[2 * (size_t)i + 1] = g_scales[1]; }
+        if (out.dL_drotations) { reinterpret_cast<float4*>(out.dL_drotations)[i] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]); }
+        if (out.dL_dopacity) out.dL_dopacity[i] = g_opa;
+        if (out.dL_dcolors) { out.dL_dcolors[3 * (size_t)i] = g_col[0]; out.dL_dcolors[3 * (size_t)i + 1] = g_col[1]; out.dL_dcolors[3 * (size_t)i + 2] = g_col[2]; }
+        if (out.dL_dtransMat) {
+            // upstream writes the AABB-centre-augmented dL/dT back only when transMat is an input (A.6)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) out.dL_dtransMat[9 * (size_t)i + k] = transMat_precomp ? dT[k] : dTr[k];
+        }
+    }
+    if (kLdsSH && out.dL_dsh) {
+        __syncthreads();
+        sh_rows_from_lds(out.dL_dsh, base, P, s_sh, tid);
     }
 }
 
@@ -355,23 +445,40 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }
 
 // host launchers ---------------------------------------------------------------------------------
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians& g, float4* recs, uint32_t* depth_keys,
                                      uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(preprocess_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, f, g.means3D, g.opacities,
-                       g.scales, g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys,
-                       tiles_touched, clamped, radii);
+    const dim3 grid((P + 255) / 256), block(256);
+    if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs))
+        hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, 0, s, P, f, g.means3D, g.opacities, g.scales,
+                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys, tiles_touched, clamped, radii);
+    else
+        hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, 0, s, P, f, g.means3D, g.opacities, g.scales,
+                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys, tiles_touched, clamped, radii);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_instance_grads(int P, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
+                                        const float4* inst_grads, float4* grecs, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_instance_grads_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, sorted_gid, sorted_offsets,
+                       inst_grads, grecs);
     return hipGetLastError();
 }
 
 hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
-                                      const uint8_t* clamped, const float4* recs, const float4* inst_grads,
-                                      const uint32_t* inst_begin, const uint32_t* tiles_touched, const uint32_t* inv_perm,
+                                      const uint8_t* clamped, const float4* recs, const float4* grecs,
                                       const SrGradients& out, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, f, g.means3D, g.scales,
-                       g.rotations, g.shs, g.transMat_precomp, radii, clamped, recs, inst_grads, inst_begin, tiles_touched,
-                       inv_perm, out);
+    const dim3 grid((P + 255) / 256), block(256);
+    if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs) && (!out.dL_dsh || aligned16(out.dL_dsh)))
+        hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
+                           g.transMat_precomp, radii, clamped, recs, grecs, out);
+    else
+        hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
+                           g.transMat_precomp, radii, clamped, recs, grecs, out);
     return hipGetLastError();
 }
 

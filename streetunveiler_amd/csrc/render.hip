@@ -251,8 +251,8 @@ __device__ __forceinline__ void wave_reduce20(float (&v)[20]) {
 // ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
-// Output: one 80-B gradient record per (tile, Gaussian) duplicate, at the duplicate's sorted position
-// (inst_grads[pos]); K8 sums a Gaussian's records.  No global atomics: per (wave, splat) the 18 partial
+// Output: one 80-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
+// (inst_grads[perm[pos]]), where the records of one Gaussian are contiguous; K8 sums them.  No global atomics: per (wave, splat) the 18 partial
 // sums are wave-reduced, the 4 waves of the tile combine in LDS, and each record is stored exactly once
 // (coalesced, 5 x dwordx4 per thread).  Records of list entries no pixel reached are written as zeros.
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
                                                                   const uint32_t* __restrict__ n_contrib,
                                                                   const float* __restrict__ dL_dcolor,
                                                                   const float* __restrict__ dL_dallmap,
+                                                                  const uint32_t* __restrict__ perm,
                                                                   float4* __restrict__ inst_grads, int cull) {
     __shared__ float4 s_q[kRecQuads][kBlock];
     __shared__ __attribute__((aligned(16))) float s_acc[kBlock][kRecFloats];
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
     {
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t e = total + tid; e < count; e += kBlock) {
-            float4* o = inst_grads + (size_t)(range.x + e) * kRecQuads;
+            float4* o = inst_grads + (size_t)perm[range.x + e] * kRecQuads;
 #pragma unroll
             for (int q = 0; q < kRecQuads; ++q) o[q] = zero;
         }
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, con
         // flush this round's records (one coalesced 80-B store per thread) and re-zero the accumulators
         if ((uint32_t)tid < n) {
             float4* acc = reinterpret_cast<float4*>(&s_acc[tid][0]);
-            float4* o = inst_grads + (size_t)(range.x + rbase + tid) * kRecQuads;
+            float4* o = inst_grads + (size_t)perm[range.x + rbase + tid] * kRecQuads;
 #pragma unroll
             for (int q = 0; q < kRecQuads; ++q) { o[q] = acc[q]; acc[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
         }
@@ -443,11 +444,11 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, float4* inst_grads, int cull, hipStream_t s) {
+                                  const float* dL_dallmap, const uint32_t* perm, float4* inst_grads, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(render_backward_kernel, dim3(n_tiles), dim3(kBlock), 0, s, f, ranges, point_list, recs, final_T,
-                       n_contrib, dL_dcolor, dL_dallmap, inst_grads, cull);
+                       n_contrib, dL_dcolor, dL_dallmap, perm, inst_grads, cull);
     return hipGetLastError();
 }
 
