@@ -1,15 +1,25 @@
-// render.hip -- K6 (per-tile front-to-back blend) and K7 (per-tile back-to-front backward).
+// render.hip -- K6 (per-tile front-to-back blend) and K7 (per-tile back-to-front backward), gfx950.
 //
-// One 256-thread workgroup (4 wave64) per 16x16 tile; each wave owns an 8x8 pixel quadrant so a
-// wave's footprint is compact (fewer splats overlap it -> more wave-uniform skips).  The tile's
-// depth-sorted splat list is staged through LDS 256 records at a time (each thread gathers one
-// 80-B packed record with five dwordx4 loads); in the inner loop all 64 lanes read the same LDS
-// address (broadcast ds_read_b128, conflict-free).  No MFMA: there is no dense contraction here.
+// Mapping: ONE wave64 per 16x16 tile, four pixels per lane -- lane l owns pixel (l&7, l>>3) of each of the
+// tile's four 8x8 quadrants.  A single-wave workgroup needs no barriers; the tile's depth-sorted splat list is
+// staged through LDS 64 entries at a time (each lane gathers one 80-B packed record with five dwordx4 loads,
+// the next round's records are already in flight while the current round is processed), and in the inner
+// loop all 64 lanes read the same LDS address (broadcast ds_read_b128).  One LDS read of an entry now serves
+// up to 256 pixel tests.  No MFMA: there is no dense contraction in this path.
 //
-// K7 replaces the reference's ~18 global float atomics per (pixel, splat) pair with a wave-level
-// multi-value transpose-reduction (v_permlane32/16_swap + DPP), an LDS combine across the tile's 4
-// waves and ONE plain 80-B store per (tile, splat): no global atomics, and nothing at all for a wave
-// no lane of which is touched by the splat.
+// Staging also rewrites each record into the form the inner loop wants (tile-local coordinates, which also
+// removes the cancellation of the textbook k x l form):
+//     p = k x l,  k = x Tw - Tu,  l = y Tw - Tv   ==   x (Tv x Tw) + y (Tw x Tu) + (Tu x Tv) = x A + y B + C
+// and computes a 4-bit quadrant mask (exact culling, see quadrant_mask).  The wave then walks only the
+// entries whose mask is non-zero (scalar bit-scan over a ballot), and inside an entry only the quadrants
+// whose bit is set.
+//
+// K7 keeps three floats of running state per pixel (T, R, X) instead of the reference's 17: with the
+// per-pixel upstream gradients folded in, the "colour/depth/normal accumulated behind" recurrences collapse
+// into R = sum_{k>i} w_k phi_k, phi_k = rgb_k.g_rgb + depth_k g_depth + n_k.g_n  (algebraically identical to
+// Appendix A.5).  Per entry the 18 partial sums of all touched quadrants are added per lane, reduced across
+// the wave ONCE (v_permlane32/16_swap + DPP: 50 VALU ops), and stored as one 80-B gradient record -- no
+// atomics anywhere, deterministic.
 //
 // Behavioural contract: SURVEY.md Appendix A.4 / A.5; output channel order
 // [REF /root/reference/gaussian_renderer/__init__.py:149-165].
@@ -17,74 +27,37 @@
 
 namespace sr {
 
+constexpr int kWave = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kFN = kFar / (kFar - kNear);
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
-struct Hit {
-    float sx, sy, dx, dy, depth, G, alpha, pz_inv;
-    float kx, ky, kz, lx, ly, lz;
-    bool use3d;
-};
-
-// Ray-splat intersection + alpha for pixel (pxf, pyf). Returns false when the entry is skipped.
-__device__ __forceinline__ bool intersect(float pxf, float pyf, const float4 q0, const float4 q1, const float4 q2, Hit& h) {
-    const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y, Twx = q1.z, Twy = q1.w, Twz = q2.x;
-    h.kx = pxf * Twx - Tux; h.ky = pxf * Twy - Tuy; h.kz = pxf * Twz - Tuz;
-    h.lx = pyf * Twx - Tvx; h.ly = pyf * Twy - Tvy; h.lz = pyf * Twz - Tvz;
-    const float ppx = h.ky * h.lz - h.kz * h.ly;
-    const float ppy = h.kz * h.lx - h.kx * h.lz;
-    const float ppz = h.kx * h.ly - h.ky * h.lx;
-    if (ppz == 0.f) return false;
-    h.pz_inv = fast_rcp(ppz);
-    h.sx = ppx * h.pz_inv; h.sy = ppy * h.pz_inv;
-    const float rho3d = h.sx * h.sx + h.sy * h.sy;
-    h.dx = q2.y - pxf; h.dy = q2.z - pyf;
-    const float rho2d = kFilterInvSquare * (h.dx * h.dx + h.dy * h.dy);
-    h.use3d = rho3d <= rho2d;
-    const float rho = fminf(rho3d, rho2d);
-    h.depth = h.use3d ? (h.sx * Twx + h.sy * Twy) + Twz : Twz;
-    if (h.depth < kNear) return false;
-    const float power = -0.5f * rho;
-    if (power > 0.f) return false;
-    h.G = __expf(power);
-    h.alpha = fminf(kAlphaCap, q2.w * h.G);
-    if (h.alpha < kAlphaFloor) return false;
-    return true;
-}
-
-__device__ __forceinline__ void pixel_of(int tile, int tiles_x, int tid, int& px, int& py) {
-    const int wave = tid >> 6, lane = tid & 63;
-    px = (tile % tiles_x) * kTile + (wave & 1) * 8 + (lane & 7);
-    py = (tile / tiles_x) * kTile + (wave >> 1) * 8 + (lane >> 3);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Quadrant culling.  A list entry can only contribute to a pixel if alpha = min(0.99, opacity*G) >= 1/255,
 // i.e. rho = min(rho3d, rho2d) <= thr = 2 ln(255 opacity).  {rho3d <= thr} is the image of the disc
 // u^2+v^2 <= thr under the splat's homography -- an ellipse with dual conic C* = Q diag(thr,thr,-1) Q^T --
-// and {rho2d <= thr} is a disc of radius sqrt(thr/2) around means2D.  Each staging thread bounds that
-// union by an octagon (support in directions x, y, x+y, x-y from the tangent-line equation
-// l^T C* l = 0) and tests it against the tile's four 8x8 quadrants.  Entries dropped here are entries the
-// per-pixel test would skip anyway (`continue` in Appendix A.4), so results are unchanged; the bound has
-// 0.3 px / 1 % slack for float rounding and keeps the entry whenever anything is degenerate or NaN.
-// Coordinates are taken relative to the tile centre to avoid cancellation in the conic.
+// and {rho2d <= thr} is a disc of radius sqrt(thr/2) around means2D.  The staging lane bounds that union by
+// an octagon (support in directions x, y, x+y, x-y from the tangent-line equation l^T C* l = 0) and tests it
+// against the tile's four 8x8 quadrants.  Entries dropped here are entries the per-pixel test would skip
+// anyway (`continue` in Appendix A.4), so results are unchanged; the bound has 0.3 px / 1 % slack for float
+// rounding and keeps the entry whenever anything is degenerate or NaN.  Inputs are tile-local (origin at
+// the tile centre), which keeps the conic free of cancellation.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t quadrant_mask(const float4 q0, const float4 q1, const float4 q2, float Xc, float Yc) {
-    float thr = 2.f * __logf(255.f * q2.w);
+__device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my,
+                                                  float opacity) {
+    float thr = 2.f * __logf(255.f * opacity);
     thr = thr * 1.01f + 0.01f;
     if (thr <= 0.f) return 0u;
-    const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
-    const float Tu0 = q0.x - Xc * Tw0, Tu1 = q0.y - Xc * Tw1, Tu2 = q0.z - Xc * Tw2;
-    const float Tv0 = q0.w - Yc * Tw0, Tv1 = q1.x - Yc * Tw1, Tv2 = q1.y - Yc * Tw2;
-    const float c22 = thr * (Tw0 * Tw0 + Tw1 * Tw1) - Tw2 * Tw2;
+    const float c22 = thr * (Tw[0] * Tw[0] + Tw[1] * Tw[1]) - Tw[2] * Tw[2];
     if (!(c22 < 0.f)) return 0xFu;  // the cutoff disc reaches the camera plane: unbounded footprint
-    const float c00 = thr * (Tu0 * Tu0 + Tu1 * Tu1) - Tu2 * Tu2;
-    const float c01 = thr * (Tu0 * Tv0 + Tu1 * Tv1) - Tu2 * Tv2;
-    const float c11 = thr * (Tv0 * Tv0 + Tv1 * Tv1) - Tv2 * Tv2;
-    const float c02 = thr * (Tu0 * Tw0 + Tu1 * Tw1) - Tu2 * Tw2;
-    const float c12 = thr * (Tv0 * Tw0 + Tv1 * Tw1) - Tv2 * Tw2;
+    const float c00 = thr * (Tu[0] * Tu[0] + Tu[1] * Tu[1]) - Tu[2] * Tu[2];
+    const float c01 = thr * (Tu[0] * Tv[0] + Tu[1] * Tv[1]) - Tu[2] * Tv[2];
+    const float c11 = thr * (Tv[0] * Tv[0] + Tv[1] * Tv[1]) - Tv[2] * Tv[2];
+    const float c02 = thr * (Tu[0] * Tw[0] + Tu[1] * Tw[1]) - Tu[2] * Tw[2];
+    const float c12 = thr * (Tv[0] * Tw[0] + Tv[1] * Tw[1]) - Tv[2] * Tw[2];
     const float inv = 1.f / c22;
     const float r = sqrtf(0.5f * thr);
-    const float mx = q2.y - Xc, my = q2.z - Yc;
     float lo[4], hi[4];
     const float A[4] = {c00, c11, c00 + 2.f * c01 + c11, c00 - 2.f * c01 + c11};
     const float B[4] = {c02, c12, c02 + c12, c02 - c12};
@@ -112,104 +85,167 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float4 q0, const float4 
     return mask;
 }
 
-// Wave `wave` compacts the indices (ascending) of the staged entries [0, n) whose mask has bit `wave` set and
-// whose index is < limit, into s_list[wave][...]; returns the count.  Wave-local: no workgroup barrier needed.
-__device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t (*s_list)[kBlock], int wave, int lane,
-                                               uint32_t n, uint32_t limit) {
-    int count = 0;
-#pragma unroll
-    for (int c = 0; c < kBlock / 64; ++c) {
-        const uint32_t j = (uint32_t)(c * 64 + lane);
-        const bool keep = j < n && j < limit && ((s_mask[j] >> wave) & 1u);
-        const unsigned long long b = __ballot(keep);
-        if (keep) s_list[wave][count + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)j;
-        count += __popcll(b);
+// ---------------------------------------------------------------------------------------------
+// Staged entry layout in LDS (struct-of-quads, s_e[quad][slot]):
+//   e0 = A.xyz B.x | e1 = B.yz C.xy | e2 = C.z Tw.xyz | e3 = xy'.x xy'.y opacity -
+//   e4 = n.xyz r   | e5 = g b - -    | (K7 only) e6 = Tu'.xyz Tv'.x | e7 = Tv'.yz - -
+// with A = Tv' x Tw, B = Tw x Tu', C = Tu' x Tv' and ' = relative to the tile centre (Xc, Yc).
+// ---------------------------------------------------------------------------------------------
+constexpr int kFwdQuads = 6;
+constexpr int kBwdQuads = 8;
+
+template <int kQuads>
+__device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], float Xc, float Yc, int cull,
+                                                float4 (*s_e)[kWave], int slot) {
+    const float Tw[3] = {q[1].z, q[1].w, q[2].x};
+    const float Tu[3] = {q[0].x - Xc * Tw[0], q[0].y - Xc * Tw[1], q[0].z - Xc * Tw[2]};
+    const float Tv[3] = {q[0].w - Yc * Tw[0], q[1].x - Yc * Tw[1], q[1].y - Yc * Tw[2]};
+    const float A[3] = {Tv[1] * Tw[2] - Tv[2] * Tw[1], Tv[2] * Tw[0] - Tv[0] * Tw[2], Tv[0] * Tw[1] - Tv[1] * Tw[0]};
+    const float B[3] = {Tw[1] * Tu[2] - Tw[2] * Tu[1], Tw[2] * Tu[0] - Tw[0] * Tu[2], Tw[0] * Tu[1] - Tw[1] * Tu[0]};
+    const float C[3] = {Tu[1] * Tv[2] - Tu[2] * Tv[1], Tu[2] * Tv[0] - Tu[0] * Tv[2], Tu[0] * Tv[1] - Tu[1] * Tv[0]};
+    const float mx = q[2].y - Xc, my = q[2].z - Yc, opacity = q[2].w;
+    s_e[0][slot] = make_float4(A[0], A[1], A[2], B[0]);
+    s_e[1][slot] = make_float4(B[1], B[2], C[0], C[1]);
+    s_e[2][slot] = make_float4(C[2], Tw[0], Tw[1], Tw[2]);
+    s_e[3][slot] = make_float4(mx, my, opacity, 0.f);
+    s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[4].x);
+    s_e[5][slot] = make_float4(q[4].y, q[4].z, 0.f, 0.f);
+    if (kQuads == kBwdQuads) {
+        s_e[6][slot] = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
+        s_e[7][slot] = make_float4(Tv[1], Tv[2], 0.f, 0.f);
     }
-    __builtin_amdgcn_wave_barrier();
-    return count;
+    return cull ? quadrant_mask(Tu, Tv, Tw, mx, my, opacity) : 0xFu;
+}
+
+struct Hit {
+    float sx, sy, dx, dy, depth, G, alpha, pz_inv;
+    bool use3d;
+};
+
+// Ray-splat intersection + alpha at tile-local pixel (xl, yl); branch-free, returns the validity predicate
+// (the chain of `continue`s of Appendix A.4, with the same comparison senses so NaNs behave alike).
+__device__ __forceinline__ bool intersect(float xl, float yl, const float4 e0, const float4 e1, const float4 e2, const float4 e3,
+                                          Hit& h) {
+    const float ppx = fmaf(xl, e0.x, fmaf(yl, e0.w, e1.z));
+    const float ppy = fmaf(xl, e0.y, fmaf(yl, e1.x, e1.w));
+    const float ppz = fmaf(xl, e0.z, fmaf(yl, e1.y, e2.x));
+    h.pz_inv = fast_rcp(ppz);
+    h.sx = ppx * h.pz_inv; h.sy = ppy * h.pz_inv;
+    const float rho3d = h.sx * h.sx + h.sy * h.sy;
+    h.dx = e3.x - xl; h.dy = e3.y - yl;
+    const float rho2d = kFilterInvSquare * (h.dx * h.dx + h.dy * h.dy);
+    h.use3d = rho3d <= rho2d;
+    const float rho = fminf(rho3d, rho2d);
+    h.depth = h.use3d ? (h.sx * e2.y + h.sy * e2.z) + e2.w : e2.w;
+    const float power = -0.5f * rho;
+    h.G = __builtin_amdgcn_exp2f(power * kLog2e);
+    h.alpha = fminf(kAlphaCap, e3.z * h.G);
+    return (ppz != 0.f) & !(h.depth < kNear) & !(power > 0.f) & !(h.alpha < kAlphaFloor);
+}
+
+__device__ __forceinline__ void load_record(const float4* __restrict__ recs, uint32_t gid, float4 (&q)[kRecQuads]) {
+    const float4* r = recs + (size_t)gid * kRecQuads;
+#pragma unroll
+    for (int k = 0; k < kRecQuads; ++k) q[k] = r[k];
 }
 
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
-                                                                 const uint32_t* __restrict__ point_list,
-                                                                 const float4* __restrict__ recs,
-                                                                 float* __restrict__ out_color, float* __restrict__ out_allmap,
-                                                                 float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                                 int cull) {
-    __shared__ float4 s_q[kRecQuads][kBlock];
-    __shared__ uint8_t s_mask[kBlock];
-    __shared__ uint16_t s_list[kBlock / 64][kBlock];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+__global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
+                                                                const uint32_t* __restrict__ point_list,
+                                                                const float4* __restrict__ recs,
+                                                                float* __restrict__ out_color, float* __restrict__ out_allmap,
+                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                                int cull) {
+    __shared__ float4 s_e[kFwdQuads][kWave];
+    const int lane = threadIdx.x;
     const int tile = blockIdx.x;
-    const float Xc = (float)((tile % f.tiles_x) * kTile + 8), Yc = (float)((tile / f.tiles_x) * kTile + 8);
-    int px, py;
-    pixel_of(tile, f.tiles_x, tid, px, py);
-    const bool inside = px < f.W && py < f.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const int tx0 = (tile % f.tiles_x) * kTile, ty0 = (tile / f.tiles_x) * kTile;
+    const float Xc = (float)(tx0 + 8), Yc = (float)(ty0 + 8);
+    const int lx = lane & 7, ly = lane >> 3;
     const uint2 range = ranges[tile];
+    const uint32_t n_total = range.y - range.x;
 
-    bool done = !inside;
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
-    float Dsum = 0.f, M1 = 0.f, M2 = 0.f, distortion = 0.f, median_depth = 0.f;
-    uint32_t last_contributor = 0, median_contributor = 0xFFFFFFFFu;
-
-    for (uint32_t base = range.x; base < range.y; base += kBlock) {
-        if (__syncthreads_and(done)) break;  // also fences the previous round's LDS reads
-        const uint32_t n = min((uint32_t)kBlock, range.y - base);
-        if ((uint32_t)tid < n) {
-            const float4* r = recs + (size_t)point_list[base + tid] * kRecQuads;
-            float4 q[kRecQuads];
+    float xl[4], yl[4];
+    bool done[4];
+    float T[4], C0[4], C1[4], C2[4], N0[4], N1[4], N2[4], Dsum[4], M1[4], M2[4], dist[4], med[4];
+    uint32_t lastc[4], medc[4];
+    uint32_t alive = 0;
 #pragma unroll
-            for (int k = 0; k < kRecQuads; ++k) { q[k] = r[k]; s_q[k][tid] = q[k]; }
-            s_mask[tid] = cull ? (uint8_t)quadrant_mask(q[0], q[1], q[2], Xc, Yc) : (uint8_t)0xF;
-        }
-        __syncthreads();
-        const uint32_t c0 = base - range.x;
-        if (__ballot(!done) == 0) continue;  // this wave is finished (it still takes part in the barriers)
-        const int cnt = build_wave_list(s_mask, s_list, wave, lane, n, n);
-        for (int idx = 0; idx < cnt; ++idx) {
-            const uint32_t j = s_list[wave][idx];
-            if (__ballot(!done) == 0) break;  // whole wave finished
-            Hit h;
-            const float4 q2 = s_q[2][j];
-            const bool valid = !done && intersect(pxf, pyf, s_q[0][j], s_q[1][j], q2, h);
-            if (__ballot(valid) == 0) continue;  // splat misses this wave's 8x8 quadrant entirely
-            if (valid) {
-                const float test_T = T * (1.f - h.alpha);
-                if (test_T < kTStop) {
-                    done = true;  // this entry is NOT blended
-                } else {
-                    const float4 q3 = s_q[3][j], q4 = s_q[4][j];
-                    const float w = h.alpha * T;
-                    const float A = 1.f - T;
-                    const float m = kFar / (kFar - kNear) * (1.f - kNear * fast_rcp(h.depth));
-                    distortion += (m * m * A + M2 - 2.f * m * M1) * w;
-                    Dsum += h.depth * w;
-                    M1 += m * w;
-                    M2 += m * m * w;
-                    if (T > 0.5f) { median_depth = h.depth; median_contributor = c0 + j + 1; }
-                    N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
-                    C0 += q4.x * w; C1 += q4.y * w; C2 += q4.z * w;
-                    T = test_T;
-                    last_contributor = c0 + j + 1;
+    for (int q = 0; q < 4; ++q) {
+        const int px = tx0 + (q & 1) * 8 + lx, py = ty0 + (q >> 1) * 8 + ly;
+        xl[q] = (float)((q & 1) * 8 + lx - 8); yl[q] = (float)((q >> 1) * 8 + ly - 8);
+        done[q] = !(px < f.W && py < f.H);
+        T[q] = 1.f; C0[q] = C1[q] = C2[q] = N0[q] = N1[q] = N2[q] = 0.f;
+        Dsum[q] = M1[q] = M2[q] = dist[q] = med[q] = 0.f;
+        lastc[q] = 0; medc[q] = 0xFFFFFFFFu;
+        if (__ballot(!done[q]) != 0) alive |= 1u << q;
+    }
+
+    float4 nr[kRecQuads];
+    if ((uint32_t)lane < n_total) load_record(recs, point_list[range.x + lane], nr);
+    for (uint32_t base = 0; base < n_total && alive; base += kWave) {
+        const uint32_t n = min((uint32_t)kWave, n_total - base);
+        uint32_t m = 0;
+        if ((uint32_t)lane < n) m = stage_entry<kFwdQuads>(nr, Xc, Yc, cull, s_e, lane);
+        if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
+        unsigned long long bits = __ballot((m & alive) != 0);
+        while (bits) {
+            const int j = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & alive;
+            if (!mj) continue;
+            const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+            const uint32_t contributor = base + (uint32_t)j + 1u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!(mj & (1u << q))) continue;  // wave-uniform
+                Hit h;
+                const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & !done[q];
+                if (__ballot(valid) == 0) continue;
+                const float4 e4 = s_e[4][j], e5 = s_e[5][j];
+                if (valid) {
+                    const float test_T = T[q] * (1.f - h.alpha);
+                    if (test_T < kTStop) {
+                        done[q] = true;  // this entry is NOT blended
+                    } else {
+                        const float w = h.alpha * T[q];
+                        const float A = 1.f - T[q];
+                        const float mm = kFN * (1.f - kNear * fast_rcp(h.depth));
+                        dist[q] += (mm * mm * A + M2[q] - 2.f * mm * M1[q]) * w;
+                        Dsum[q] += h.depth * w;
+                        M1[q] += mm * w;
+                        M2[q] += mm * mm * w;
+                        if (T[q] > 0.5f) { med[q] = h.depth; medc[q] = contributor; }
+                        N0[q] += e4.x * w; N1[q] += e4.y * w; N2[q] += e4.z * w;
+                        C0[q] += e4.w * w; C1[q] += e5.x * w; C2[q] += e5.y * w;
+                        T[q] = test_T;
+                        lastc[q] = contributor;
+                    }
                 }
+                if (__ballot(!done[q]) == 0) alive &= ~(1u << q);
             }
         }
     }
-    if (inside) {
-        const size_t HW = (size_t)f.H * f.W, pix = (size_t)py * f.W + px;
-        final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
-        n_contrib[pix] = last_contributor; n_contrib[HW + pix] = median_contributor;
-        out_color[pix] = C0 + T * f.bg[0];
-        out_color[HW + pix] = C1 + T * f.bg[1];
-        out_color[2 * HW + pix] = C2 + T * f.bg[2];
-        out_allmap[pix] = Dsum;
-        out_allmap[HW + pix] = 1.f - T;
-        out_allmap[2 * HW + pix] = N0; out_allmap[3 * HW + pix] = N1; out_allmap[4 * HW + pix] = N2;
-        out_allmap[5 * HW + pix] = median_depth;
-        out_allmap[6 * HW + pix] = distortion;
+    const size_t HW = (size_t)f.H * f.W;
+    const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px = tx0 + (q & 1) * 8 + lx, py = ty0 + (q >> 1) * 8 + ly;
+        if (px < f.W && py < f.H) {
+            const size_t pix = (size_t)py * f.W + px;
+            final_T[pix] = T[q]; final_T[HW + pix] = M1[q]; final_T[2 * HW + pix] = M2[q];
+            n_contrib[pix] = lastc[q]; n_contrib[HW + pix] = medc[q];
+            out_color[pix] = C0[q] + T[q] * bg0;
+            out_color[HW + pix] = C1[q] + T[q] * bg1;
+            out_color[2 * HW + pix] = C2[q] + T[q] * bg2;
+            out_allmap[pix] = Dsum[q];
+            out_allmap[HW + pix] = 1.f - T[q];
+            out_allmap[2 * HW + pix] = N0[q]; out_allmap[3 * HW + pix] = N1[q]; out_allmap[4 * HW + pix] = N2[q];
+            out_allmap[5 * HW + pix] = med[q];
+            out_allmap[6 * HW + pix] = dist[q];
+        }
     }
 }
 
@@ -248,187 +284,178 @@ __device__ __forceinline__ void wave_reduce20(float (&v)[20]) {
     for (int k = 0; k < 5; ++k) v[k] = row_sum16(v[k]);
 }
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, m));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
 // Output: one 80-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
-// (inst_grads[perm[pos]]), where the records of one Gaussian are contiguous; K8 sums them.  No global atomics: per (wave, splat) the 18 partial
-// sums are wave-reduced, the 4 waves of the tile combine in LDS, and each record is stored exactly once
-// (coalesced, 5 x dwordx4 per thread).  Records of list entries no pixel reached are written as zeros.
-__global__ __launch_bounds__(kBlock) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
-                                                                  const uint32_t* __restrict__ point_list,
-                                                                  const float4* __restrict__ recs,
-                                                                  const float* __restrict__ final_T,
-                                                                  const uint32_t* __restrict__ n_contrib,
-                                                                  const float* __restrict__ dL_dcolor,
-                                                                  const float* __restrict__ dL_dallmap,
-                                                                  const uint32_t* __restrict__ perm,
-                                                                  float4* __restrict__ inst_grads, int cull) {
-    __shared__ float4 s_q[kRecQuads][kBlock];
-    __shared__ __attribute__((aligned(16))) float s_acc[kBlock][kRecFloats];
-    __shared__ uint8_t s_mask[kBlock];
-    __shared__ uint16_t s_list[kBlock / 64][kBlock];
-    __shared__ uint32_t s_max;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// (inst_grads[perm[pos]]), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
+// entries no pixel reached are written as zeros.  Gradient record slots: see common.h.
+__global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
+                                                                 const uint32_t* __restrict__ point_list,
+                                                                 const float4* __restrict__ recs,
+                                                                 const float* __restrict__ final_T,
+                                                                 const uint32_t* __restrict__ n_contrib,
+                                                                 const float* __restrict__ dL_dcolor,
+                                                                 const float* __restrict__ dL_dallmap,
+                                                                 const uint32_t* __restrict__ perm,
+                                                                 float4* __restrict__ inst_grads, int cull) {
+    __shared__ float4 s_e[kBwdQuads][kWave];
+    __shared__ __attribute__((aligned(16))) float s_out[kWave][kRecFloats];
+    const int lane = threadIdx.x;
     const int tile = blockIdx.x;
-    const float Xc = (float)((tile % f.tiles_x) * kTile + 8), Yc = (float)((tile / f.tiles_x) * kTile + 8);
-    int px, py;
-    pixel_of(tile, f.tiles_x, tid, px, py);
-    const bool inside = px < f.W && py < f.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const int tx0 = (tile % f.tiles_x) * kTile, ty0 = (tile / f.tiles_x) * kTile;
+    const float Xc = (float)(tx0 + 8), Yc = (float)(ty0 + 8);
+    const int lx = lane & 7, ly = lane >> 3;
     const uint2 range = ranges[tile];
-    const size_t HW = (size_t)f.H * f.W, pix = inside ? (size_t)py * f.W + px : 0;
-
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const float final_D = inside ? final_T[HW + pix] : 0.f;
-    const float final_D2 = inside ? final_T[2 * HW + pix] : 0.f;
-    const float final_A = 1.f - T_final;
-    const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
-    const uint32_t median_contributor = inside ? n_contrib[HW + pix] : 0u;
-    float gpix[3] = {0, 0, 0}, gN[3] = {0, 0, 0}, g_depth = 0.f, g_accum = 0.f, g_median = 0.f, g_reg = 0.f;
-    if (inside) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { gpix[c] = dL_dcolor[c * HW + pix]; gN[c] = dL_dallmap[(2 + c) * HW + pix]; }
-        g_depth = dL_dallmap[pix]; g_accum = dL_dallmap[HW + pix];
-        g_median = dL_dallmap[5 * HW + pix]; g_reg = dL_dallmap[6 * HW + pix];
-    }
-    const float bg_dot = f.bg[0] * gpix[0] + f.bg[1] * gpix[1] + f.bg[2] * gpix[2];
-
-    if (tid == 0) s_max = 0;
-    {
-        float4* z = reinterpret_cast<float4*>(&s_acc[tid][0]);
-#pragma unroll
-        for (int q = 0; q < kRecQuads; ++q) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    // deepest entry any pixel of this wave / this tile needs
-    uint32_t wave_last = last_contributor;
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, m));
-    if (lane == 0) atomicMax(&s_max, wave_last);
-    __syncthreads();
-    const uint32_t total = s_max;
     const uint32_t count = range.y - range.x;
+    const size_t HW = (size_t)f.H * f.W;
+    const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
 
-    // entries behind the deepest contributor: zero records
+    // per-pixel constants (upstream gradients folded with the forward's final accumulators) and state
+    float xl[4], yl[4], pxf[4], pyf[4];
+    float gr[4], gg[4], gb[4], gn0[4], gn1[4], gn2[4], g_depth[4], g_median[4], Kbg[4], a0[4], a1[4], a2[4];
+    uint32_t lastc[4], medc[4], quad_last[4];
+    float T[4], R[4], X[4];
+    uint32_t total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px = tx0 + (q & 1) * 8 + lx, py = ty0 + (q >> 1) * 8 + ly;
+        xl[q] = (float)((q & 1) * 8 + lx - 8); yl[q] = (float)((q >> 1) * 8 + ly - 8);
+        pxf[q] = (float)px; pyf[q] = (float)py;
+        const bool inside = px < f.W && py < f.H;
+        const size_t pix = inside ? (size_t)py * f.W + px : 0;
+        const float T_final = inside ? final_T[pix] : 0.f;
+        const float fin_D = inside ? final_T[HW + pix] : 0.f, fin_D2 = inside ? final_T[2 * HW + pix] : 0.f;
+        lastc[q] = inside ? n_contrib[pix] : 0u;
+        medc[q] = inside ? n_contrib[HW + pix] : 0u;
+        gr[q] = inside ? dL_dcolor[pix] : 0.f; gg[q] = inside ? dL_dcolor[HW + pix] : 0.f; gb[q] = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+        g_depth[q] = inside ? dL_dallmap[pix] : 0.f;
+        const float g_accum = inside ? dL_dallmap[HW + pix] : 0.f;
+        gn0[q] = inside ? dL_dallmap[2 * HW + pix] : 0.f; gn1[q] = inside ? dL_dallmap[3 * HW + pix] : 0.f; gn2[q] = inside ? dL_dallmap[4 * HW + pix] : 0.f;
+        g_median[q] = inside ? dL_dallmap[5 * HW + pix] : 0.f;
+        const float g_reg = inside ? dL_dallmap[6 * HW + pix] : 0.f;
+        const float bg_dot = bg0 * gr[q] + bg1 * gg[q] + bg2 * gb[q];
+        Kbg[q] = T_final * (g_accum - bg_dot);
+        a0[q] = (1.f - T_final) * g_reg; a1[q] = fin_D * g_reg; a2[q] = fin_D2 * g_reg;
+        T[q] = T_final; R[q] = 0.f; X[q] = 0.f;
+        quad_last[q] = wave_max_u32(lastc[q]);  // deepest entry any pixel of quadrant q needs (uniform)
+        total = max(total, quad_last[q]);
+    }
+
+    // entries behind the deepest contributor of the tile: zero records
     {
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t e = total + tid; e < count; e += kBlock) {
+        for (uint32_t e = total + lane; e < count; e += kWave) {
             float4* o = inst_grads + (size_t)perm[range.x + e] * kRecQuads;
 #pragma unroll
-            for (int q = 0; q < kRecQuads; ++q) o[q] = zero;
+            for (int k = 0; k < kRecQuads; ++k) o[k] = zero;
         }
     }
 
-    float T = T_final;
-    float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
-    float last_depth = 0.f, accum_depth_rec = 0.f, accum_alpha_rec = 0.f;
-    float last_normal[3] = {0, 0, 0}, accum_normal_rec[3] = {0, 0, 0}, last_dL_dT = 0.f;
-
-    const int rounds = (int)((total + kBlock - 1) / kBlock);
+    const int rounds = (int)((total + kWave - 1) / kWave);
+    float4 nr[kRecQuads];
+    if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total)
+        load_record(recs, point_list[range.x + (rounds - 1) * kWave + lane], nr);
     for (int rd = rounds - 1; rd >= 0; --rd) {
-        const uint32_t rbase = (uint32_t)rd * kBlock;
-        const uint32_t n = min((uint32_t)kBlock, total - rbase);
-        if ((uint32_t)tid < n) {
-            const float4* r = recs + (size_t)point_list[range.x + rbase + tid] * kRecQuads;
-            float4 q[kRecQuads];
+        const uint32_t rbase = (uint32_t)rd * kWave;
+        const uint32_t n = min((uint32_t)kWave, total - rbase);
+        uint32_t m = 0;
+        if ((uint32_t)lane < n) {
+            m = stage_entry<kBwdQuads>(nr, Xc, Yc, cull, s_e, lane);
+            uint32_t need = 0;
 #pragma unroll
-            for (int k = 0; k < kRecQuads; ++k) { q[k] = r[k]; s_q[k][tid] = q[k]; }
-            s_mask[tid] = cull ? (uint8_t)quadrant_mask(q[0], q[1], q[2], Xc, Yc) : (uint8_t)0xF;
+            for (int q = 0; q < 4; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
+            m &= need;
         }
-        __syncthreads();
-        if (wave_last > rbase) {
-            // entries of this round that can touch this wave's quadrant and are not behind its deepest contributor
-            const int cnt = build_wave_list(s_mask, s_list, wave, lane, n, wave_last - rbase);
-            for (int idx = cnt - 1; idx >= 0; --idx) {
-                const int j = (int)s_list[wave][idx];
-                const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
+        {
+            float4* z = reinterpret_cast<float4*>(&s_out[lane][0]);
+#pragma unroll
+            for (int k = 0; k < kRecQuads; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (rd > 0) load_record(recs, point_list[range.x + rbase - kWave + lane], nr);  // next round is always full
+        unsigned long long bits = __ballot(m != 0);
+        while (bits) {
+            const int j = 63 - __clzll((long long)bits);
+            bits &= ~(1ull << j);
+            const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
+            const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+            const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
+            float v[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) v[k] = 0.f;
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
-                const float4 q0 = s_q[0][j], q1 = s_q[1][j], q2 = s_q[2][j];
-                const bool valid = (cidx < last_contributor) && intersect(pxf, pyf, q0, q1, q2, h);
+                const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & (cidx < lastc[q]);
                 if (__ballot(valid) == 0) continue;
-                float v[20];
-#pragma unroll
-                for (int k = 0; k < 20; ++k) v[k] = 0.f;
+                any = true;
+                const float4 e4 = s_e[4][j], e5 = s_e[5][j], e6 = s_e[6][j], e7 = s_e[7][j];
                 if (valid) {
-                    const float4 q3 = s_q[3][j], q4 = s_q[4][j];
-                    const float Twx = q1.z, Twy = q1.w;
+                    const float Twx = e2.y, Twy = e2.z, Twz = e2.w;
                     const float one_m_inv = fast_rcp(1.f - h.alpha);
-                    T = T * one_m_inv;
-                    const float w = h.alpha * T;
-                    float dL_dalpha = 0.f;
-                    const float col[3] = {q4.x, q4.y, q4.z}, nrm[3] = {q3.x, q3.y, q3.z};
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        accum_rec[c] = last_alpha * last_color[c] + (1.f - last_alpha) * accum_rec[c];
-                        last_color[c] = col[c];
-                        dL_dalpha += (col[c] - accum_rec[c]) * gpix[c];
-                        v[16 + c] = w * gpix[c];
-                    }
-                    float dL_dz = 0.f;
+                    T[q] *= one_m_inv;                 // transmittance in front of this entry
+                    const float w = h.alpha * T[q];
+                    const float phi = fmaf(e4.w, gr[q], fmaf(e5.x, gg[q], fmaf(e5.y, gb[q], fmaf(h.depth, g_depth[q],
+                                      fmaf(e4.x, gn0[q], fmaf(e4.y, gn1[q], e4.z * gn2[q]))))));
                     const float inv_depth = fast_rcp(h.depth);
-                    const float m_d = kFar / (kFar - kNear) * (1.f - kNear * inv_depth);
-                    const float dmd_dd = (kFar * kNear) / (kFar - kNear) * inv_depth * inv_depth;
-                    if (cidx == median_contributor - 1u) dL_dz += g_median;
-                    const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * g_reg;
-                    dL_dalpha += dL_dweight - last_dL_dT;
-                    last_dL_dT = dL_dweight * h.alpha + (1.f - h.alpha) * last_dL_dT;
-                    const float dL_dmd = 2.f * w * (m_d * final_A - final_D) * g_reg;
-                    dL_dz += dL_dmd * dmd_dd;
-                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                    last_depth = h.depth;
-                    dL_dalpha += (h.depth - accum_depth_rec) * g_depth;
-                    accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
-                    dL_dalpha += (1.f - accum_alpha_rec) * g_accum;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        accum_normal_rec[c] = last_alpha * last_normal[c] + (1.f - last_alpha) * accum_normal_rec[c];
-                        last_normal[c] = nrm[c];
-                        dL_dalpha += (nrm[c] - accum_normal_rec[c]) * gN[c];
-                        v[12 + c] = w * gN[c];
-                    }
-                    dL_dalpha *= T;
-                    last_alpha = h.alpha;
-                    dL_dalpha += (-T_final * one_m_inv) * bg_dot;
-                    const float dL_dG = q2.w * dL_dalpha;
-                    dL_dz += w * g_depth;
+                    const float m_d = kFN * (1.f - kNear * inv_depth);
+                    const float dmd_dd = kFN * kNear * inv_depth * inv_depth;
+                    const float dLw = a2[q] + m_d * (m_d * a0[q] - 2.f * a1[q]);
+                    const float dL_dalpha = T[q] * (phi + dLw - X[q]) - one_m_inv * (R[q] - Kbg[q]);
+                    R[q] = fmaf(w, phi, R[q]);
+                    X[q] = dLw * h.alpha + (1.f - h.alpha) * X[q];
+                    float dL_dz = 2.f * w * (m_d * a0[q] - a1[q]) * dmd_dd + w * g_depth[q];
+                    if (cidx == medc[q] - 1u) dL_dz += g_median[q];
+                    const float dL_dG = e3.z * dL_dalpha;
+                    v[16] += w * gr[q]; v[17] += w * gg[q]; v[18] += w * gb[q];
+                    v[12] += w * gn0[q]; v[13] += w * gn1[q]; v[14] += w * gn2[q];
+                    v[11] += h.G * dL_dalpha;
                     if (h.use3d) {
-                        const float dLdsx = dL_dG * -h.G * h.sx + dL_dz * Twx;
-                        const float dLdsy = dL_dG * -h.G * h.sy + dL_dz * Twy;
-                        const float ax = dLdsx * h.pz_inv, ay = dLdsy * h.pz_inv;
+                        const float gG = -dL_dG * h.G;
+                        const float ax = (gG * h.sx + dL_dz * Twx) * h.pz_inv, ay = (gG * h.sy + dL_dz * Twy) * h.pz_inv;
                         const float dpx = ax, dpy = ay, dpz = -(ax * h.sx + ay * h.sy);
+                        const float kx = xl[q] * Twx - e6.x, ky = xl[q] * Twy - e6.y, kz = xl[q] * Twz - e6.z;
+                        const float lx_ = yl[q] * Twx - e6.w, ly_ = yl[q] * Twy - e7.x, lz_ = yl[q] * Twz - e7.y;
                         // dL_dk = l x dp ; dL_dl = dp x k
-                        const float dkx = h.ly * dpz - h.lz * dpy, dky = h.lz * dpx - h.lx * dpz, dkz = h.lx * dpy - h.ly * dpx;
-                        const float dlx = dpy * h.kz - dpz * h.ky, dly = dpz * h.kx - dpx * h.kz, dlz = dpx * h.ky - dpy * h.kx;
-                        v[0] = -dkx; v[1] = -dky; v[2] = -dkz;
-                        v[3] = -dlx; v[4] = -dly; v[5] = -dlz;
-                        v[6] = pxf * dkx + pyf * dlx + dL_dz * h.sx;
-                        v[7] = pxf * dky + pyf * dly + dL_dz * h.sy;
-                        v[8] = pxf * dkz + pyf * dlz + dL_dz;
+                        const float dkx = ly_ * dpz - lz_ * dpy, dky = lz_ * dpx - lx_ * dpz, dkz = lx_ * dpy - ly_ * dpx;
+                        const float dlx = dpy * kz - dpz * ky, dly = dpz * kx - dpx * kz, dlz = dpx * ky - dpy * kx;
+                        v[0] -= dkx; v[1] -= dky; v[2] -= dkz;
+                        v[3] -= dlx; v[4] -= dly; v[5] -= dlz;
+                        v[6] += pxf[q] * dkx + pyf[q] * dlx + dL_dz * h.sx;
+                        v[7] += pxf[q] * dky + pyf[q] * dly + dL_dz * h.sy;
+                        v[8] += pxf[q] * dkz + pyf[q] * dlz + dL_dz;
                     } else {
-                        v[9] = dL_dG * (-h.G * kFilterInvSquare * h.dx);
-                        v[10] = dL_dG * (-h.G * kFilterInvSquare * h.dy);
-                        v[8] = dL_dz;
+                        const float gG = -dL_dG * h.G * kFilterInvSquare;
+                        v[9] += gG * h.dx;
+                        v[10] += gG * h.dy;
+                        v[8] += dL_dz;
                     }
-                    v[11] = h.G * dL_dalpha;
                 }
+            }
+            if (any) {
                 wave_reduce20(v);
                 if ((lane & 15) == 0) {
-                    float* a = &s_acc[j][5 * (lane >> 4)];
+                    float* o = &s_out[j][5 * (lane >> 4)];
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) atomicAdd(a + k, v[k]);  // ds_add_f32: 4 waves combine per splat
+                    for (int k = 0; k < 5; ++k) o[k] = v[k];
                 }
             }
         }
-        __syncthreads();
-        // flush this round's records (one coalesced 80-B store per thread) and re-zero the accumulators
-        if ((uint32_t)tid < n) {
-            float4* acc = reinterpret_cast<float4*>(&s_acc[tid][0]);
-            float4* o = inst_grads + (size_t)perm[range.x + rbase + tid] * kRecQuads;
+        // flush this round's records: one 80-B store per lane (zeros where nothing contributed)
+        if ((uint32_t)lane < n) {
+            const float4* acc = reinterpret_cast<const float4*>(&s_out[lane][0]);
+            float4* o = inst_grads + (size_t)perm[range.x + rbase + lane] * kRecQuads;
 #pragma unroll
-            for (int q = 0; q < kRecQuads; ++q) { o[q] = acc[q]; acc[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            for (int k = 0; k < kRecQuads; ++k) o[k] = acc[k];
         }
-        // (the next round's staging writes s_q rows; all reads of s_q finished at the barrier above)
     }
 }
 
@@ -437,7 +464,7 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
                                  float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(render_forward_kernel, dim3(n_tiles), dim3(kBlock), 0, s, f, ranges, point_list, recs, out_color,
+    hipLaunchKernelGGL(render_forward_kernel, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, out_color,
                        out_allmap, final_T, n_contrib, cull);
     return hipGetLastError();
 }
@@ -447,7 +474,7 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
                                   const float* dL_dallmap, const uint32_t* perm, float4* inst_grads, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(render_backward_kernel, dim3(n_tiles), dim3(kBlock), 0, s, f, ranges, point_list, recs, final_T,
+    hipLaunchKernelGGL(render_backward_kernel, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, final_T,
                        n_contrib, dL_dcolor, dL_dallmap, perm, inst_grads, cull);
     return hipGetLastError();
 }

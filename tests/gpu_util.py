@@ -97,9 +97,14 @@ def assert_close_frac(a, b, atol, rtol, max_bad_frac, hard, name=""):
     assert (err <= hard * max(1.0, np.abs(b).max())).all(), f"{name}: max err {err.max():.3e} exceeds hard bound"
 
 
-def assert_grads_close(got, ref, rel, name=""):
-    """Per-tensor: max |got-ref| <= rel * max|ref| (float atomics reorder sums; fast rcp/exp in the blend)."""
+def assert_grads_close(got, ref, rel, name="", max_bad_frac=1e-3, hard=5e-2):
+    """Per tensor, relative to its largest magnitude: all but `max_bad_frac` of the elements within `rel`, every
+    element within `hard`.  The slack for a few elements is the same threshold-flip effect as in the images: one
+    (pixel, splat) pair crossing alpha = 1/255 or T = 1e-4 because exp()/rcp() differ by an ulp moves that
+    Gaussian's gradient by a finite amount; everything else differs only by float summation order."""
     got = np.asarray(got, np.float64).reshape(np.asarray(ref).shape); ref = np.asarray(ref, np.float64)
     scale = np.abs(ref).max() + 1e-20
-    err = np.abs(got - ref).max()
-    assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e} > {rel})"
+    err = np.abs(got - ref) / scale
+    bad = (err > rel).mean() if err.size else 0.0
+    assert bad <= max_bad_frac, f"{name}: {bad:.2e} of elements off by more than {rel} of scale {scale:.3e} (max rel err {err.max():.2e})"
+    assert err.max() <= hard, f"{name}: max rel err {err.max():.2e} exceeds hard bound {hard}"
