@@ -38,7 +38,8 @@ extern "C" {
 
 #define SR_ABI_VERSION 1
 #define SR_TILE 16            /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
-#define SR_SPLAT_FLOATS 20    /* floats per packed splat record / gradient record (80 B) */
+#define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
+#define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
 
 typedef enum SrStatus {
     SR_OK = 0,
@@ -143,8 +144,8 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
                       float* out_color, float* out_allmap, void* stream);
 
 /* Backward (K7 blend backward + K8 preprocess backward).  dL_dcolor [3,H,W], dL_dallmap [7,H,W].
- * workspace: sr_backward_workspace_bytes(P, num_rendered) bytes (one 80-B gradient record per (tile, Gaussian)
- * duplicate), contents undefined on entry. */
+ * workspace: sr_backward_workspace_bytes(P, num_rendered) bytes (one 96-B gradient record per (tile, Gaussian)
+ * duplicate plus one per Gaussian), contents undefined on entry. */
 int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
                 void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
                 const float* dL_dcolor, const float* dL_dallmap, void* workspace, size_t workspace_bytes,
@@ -158,8 +159,12 @@ int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, co
  * the test that proves the culling is exact).
  *   SR_OPT_QUADRANT_CULL (default 1): drop list entries that provably cannot reach alpha >= 1/255 inside a
  *   wave's 8x8 pixel quadrant before the per-pixel test. */
-typedef enum SrOption { SR_OPT_QUADRANT_CULL = 0 } SrOption;
+typedef enum SrOption { SR_OPT_QUADRANT_CULL = 0, SR_OPT_DEBUG_STATS = 1 } SrOption;
 int sr_set_option(int option, int value);
+/* With SR_OPT_DEBUG_STATS = 1 the forward blend counts (device-wide, since the last reset): [0] list entries staged,
+ * [1] entries kept by the quadrant culling, [2] (entry, quadrant) tests run, [3] tests with >= 1 contributing pixel,
+ * [4] contributing (pixel, entry) pairs.  Synchronises the device.  out8: 8 host uint64. */
+int sr_debug_stats(unsigned long long* out8, int reset);
 
 /* Profiling aid.  sr_set_stage_timing(1) makes every later call from this thread bracket each stage with a
  * pair of HIP events recorded on the caller's stream (no host sync while recording; up to 512 launches per

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsurfel_raster.so")
 
 SR_OPT_QUADRANT_CULL = 0
+SR_OPT_DEBUG_STATS = 1
 SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
                   "preprocess_bwd"]
 
@@ -49,7 +50,7 @@ class SrImageView(C.Structure):
 # every symbol include/surfel_raster.h declares (checked by tests/test_abi.py)
 EXPORTS = ["sr_abi_version", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
            "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan",
-           "sr_forward_render", "sr_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_set_option"]
+           "sr_forward_render", "sr_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_set_option", "sr_debug_stats"]
 
 _lib = None
 
@@ -89,6 +90,7 @@ def load():
     lib.sr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sr_set_stage_timing.argtypes = [C.c_int]
     lib.sr_set_option.argtypes = [C.c_int, C.c_int]
+    lib.sr_debug_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     lib.sr_stage_stats.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     if lib.sr_abi_version() != 1:
         raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 1")

@@ -37,6 +37,7 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                   const float* dL_dallmap, const uint32_t* perm, float4* inst_grads, int cull, hipStream_t s);
+hipError_t read_render_stats(unsigned long long* out8, bool reset);
 }  // namespace sr
 
 using namespace sr;
@@ -209,9 +210,9 @@ size_t sr_geom_bytes(int32_t P) { return geom_layout(P).total; }
 size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t W, int32_t H) { (void)P; return bin_layout(num_rendered, W, H).total; }
 size_t sr_image_bytes(int32_t W, int32_t H) { return img_layout(W, H).total; }
 size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered) {
-    // D per-(tile, Gaussian) gradient records + P reduced per-Gaussian records, 80 B each
-    return align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * kRecFloats * 4, 256) +
-           align_up((size_t)(P > 0 ? P : 1) * kRecFloats * 4, 256);
+    // D per-(tile, Gaussian) gradient records + P reduced per-Gaussian records, 96 B each
+    return align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * kGradFloats * 4, 256) +
+           align_up((size_t)(P > 0 ? P : 1) * kGradFloats * 4, 256);
 }
 
 int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out) {
@@ -346,7 +347,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
     // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous); every one
     // of the D records is written by K7.  Then one reduced record per Gaussian.
     float4* inst_grads = static_cast<float4*>(workspace);
-    float4* grecs = at<float4>(workspace, align_up((size_t)(D > 0 ? D : 1) * kRecFloats * 4, 256));
+    float4* grecs = at<float4>(workspace, align_up((size_t)(D > 0 ? D : 1) * kGradFloats * 4, 256));
     {
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0)
@@ -375,9 +376,17 @@ int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, co
 
 int sr_set_option(int option, int value) {
     switch (option) {
-        case SR_OPT_QUADRANT_CULL: g_opt_cull.store(value ? 1 : 0); return SR_OK;
+        case SR_OPT_QUADRANT_CULL: g_opt_cull.store((g_opt_cull.load() & ~1) | (value ? 1 : 0)); return SR_OK;
+        case SR_OPT_DEBUG_STATS: g_opt_cull.store((g_opt_cull.load() & ~2) | (value ? 2 : 0)); return SR_OK;
         default: return fail(SR_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
+}
+
+int sr_debug_stats(unsigned long long* out8, int reset) {
+    if (!out8) return fail(SR_ERR_INVALID_ARGUMENT, "NULL output");
+    SR_HIP(hipDeviceSynchronize());
+    SR_HIP(read_render_stats(out8, reset != 0));
+    return SR_OK;
 }
 
 void sr_set_stage_timing(int enable) {

@@ -22,10 +22,18 @@ constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
 // Packed per-Gaussian record, 5 x float4 = 80 B, 16-B aligned (one gather = five dwordx4 loads):
 //   q0 = Tu.x Tu.y Tu.z Tv.x | q1 = Tv.y Tv.z Tw.x Tw.y | q2 = Tw.z xy.x xy.y opacity
 //   q3 = n.x n.y n.z depth   | q4 = r g b radius
-// The gradient record written by the blend backward uses the same slots
-// (slot 15 and 19 unused): d/dT[0..8], d/dxy[9,10], d/dopacity[11], d/dnormal[12..14], d/drgb[16..18].
 constexpr int kRecQuads = 5;
 constexpr int kRecFloats = SR_SPLAT_FLOATS;
+
+// Gradient record written by the blend backward (one per (tile, Gaussian) duplicate, then summed per Gaussian),
+// 6 x float4 = 96 B.  The transMat gradient is kept in "moment" form: with dp = dL/dp of the ray-splat cross
+// product p = k x l at a pixel (x, y) (global pixel coordinates),
+//   S0 = sum dp, Sx = sum x dp, Sy = sum y dp, Z = sum dL/ddepth * (s.x, s.y, 1)
+// are linear in the pixels AND in the tiles, so they can be summed first and turned into dL/dT once per
+// Gaussian (K8):  dTu = Tv x S0 - Tw x Sy,  dTv = S0 x Tu - Sx x Tw,  dTw = Tu x Sy - Tv x Sx + Z.
+//   slots  0..2 S0 | 3..5 Sx | 6..8 Sy | 9..11 Z | 12,13 d/dxy | 14 d/dopacity | 15..17 d/dnormal | 18..20 d/drgb
+constexpr int kGradQuads = 6;
+constexpr int kGradFloats = SR_GRAD_FLOATS;
 
 struct FrameDev {
     int W, H, tiles_x, tiles_y;

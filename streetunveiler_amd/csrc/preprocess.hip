@@ -288,18 +288,20 @@ __global__ __launch_bounds__(256) void reduce_instance_grads_kernel(int P, const
     const uint32_t end = sorted_offsets[r];
     const uint32_t begin = r > 0 ? sorted_offsets[r - 1] : 0u;
     if (end == begin) return;  // culled / no tiles: K8b never reads its record
-    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0;
+    float4 g[kGradQuads];
+#pragma unroll
+    for (int k = 0; k < kGradQuads; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (uint32_t e = begin; e < end; ++e) {
-        const float4* gr = inst_grads + (size_t)e * kRecQuads;
-        const float4 a0 = gr[0], a1 = gr[1], a2 = gr[2], a3 = gr[3], a4 = gr[4];
-        g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w;
-        g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
-        g2.x += a2.x; g2.y += a2.y; g2.z += a2.z; g2.w += a2.w;
-        g3.x += a3.x; g3.y += a3.y; g3.z += a3.z; g3.w += a3.w;
-        g4.x += a4.x; g4.y += a4.y; g4.z += a4.z; g4.w += a4.w;
+        const float4* gr = inst_grads + (size_t)e * kGradQuads;
+#pragma unroll
+        for (int k = 0; k < kGradQuads; ++k) {
+            const float4 a = gr[k];
+            g[k].x += a.x; g[k].y += a.y; g[k].z += a.z; g[k].w += a.w;
+        }
     }
-    float4* o = grecs + (size_t)sorted_gid[r] * kRecQuads;
-    o[0] = g0; o[1] = g1; o[2] = g2; o[3] = g3; o[4] = g4;
+    float4* o = grecs + (size_t)sorted_gid[r] * kGradQuads;
+#pragma unroll
+    for (int k = 0; k < kGradQuads; ++k) o[k] = g[k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -327,15 +329,25 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
         float* row = s_sh + tid * kShLdsStride;
         if (vis) {
             const float4* rec = recs + (size_t)i * kRecQuads;
-            const float4* gr = grecs + (size_t)i * kRecQuads;
+            const float4* gr = grecs + (size_t)i * kGradQuads;
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4];
+            const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4], g5 = gr[5];
             const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
-            dT[0] = g0.x; dT[1] = g0.y; dT[2] = g0.z; dT[3] = g0.w; dT[4] = g1.x; dT[5] = g1.y; dT[6] = g1.z; dT[7] = g1.w; dT[8] = g2.x;
-            const float gx2 = g2.y, gy2 = g2.z;
-            g_opa = g2.w;
-            const float gn[3] = {g3.x, g3.y, g3.z};
-            g_col[0] = g4.x; g_col[1] = g4.y; g_col[2] = g4.z;
+            // moments -> dL/dT (see common.h): dTu = Tv x S0 - Tw x Sy, dTv = S0 x Tu - Sx x Tw, dTw = Tu x Sy - Tv x Sx + Z
+            {
+                const float S0[3] = {g0.x, g0.y, g0.z}, Sx[3] = {g0.w, g1.x, g1.y}, Sy[3] = {g1.z, g1.w, g2.x}, Z[3] = {g2.y, g2.z, g2.w};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                    dT[0 + c] = (Tv[c1] * S0[c2] - Tv[c2] * S0[c1]) - (Tw[c1] * Sy[c2] - Tw[c2] * Sy[c1]);
+                    dT[3 + c] = (S0[c1] * Tu[c2] - S0[c2] * Tu[c1]) - (Sx[c1] * Tw[c2] - Sx[c2] * Tw[c1]);
+                    dT[6 + c] = (Tu[c1] * Sy[c2] - Tu[c2] * Sy[c1]) - (Tv[c1] * Sx[c2] - Tv[c2] * Sx[c1]) + Z[c];
+                }
+            }
+            const float gx2 = g3.x, gy2 = g3.y;
+            g_opa = g3.z;
+            const float gn[3] = {g3.w, g4.x, g4.y};
+            g_col[0] = g4.z; g_col[1] = g4.w; g_col[2] = g5.x;
             // densification proxy from the blend-only dL/dT (Appendix A.6, last paragraph)
             g_m2d[0] = dT[2] * Tw[2] * 0.5f * (float)f.W;
             g_m2d[1] = dT[5] * Tw[2] * 0.5f * (float)f.H;

@@ -17,9 +17,11 @@
 // K7 keeps three floats of running state per pixel (T, R, X) instead of the reference's 17: with the
 // per-pixel upstream gradients folded in, the "colour/depth/normal accumulated behind" recurrences collapse
 // into R = sum_{k>i} w_k phi_k, phi_k = rgb_k.g_rgb + depth_k g_depth + n_k.g_n  (algebraically identical to
-// Appendix A.5).  Per entry the 18 partial sums of all touched quadrants are added per lane, reduced across
-// the wave ONCE (v_permlane32/16_swap + DPP: 50 VALU ops), and stored as one 80-B gradient record -- no
-// atomics anywhere, deterministic.
+// Appendix A.5), and the transMat gradient is accumulated as moments of dL/dp (S0, Sx, Sy, Z: see common.h)
+// so the two cross products per (pixel, splat) pair of the textbook form run once per Gaussian in K8 instead.
+// Per entry the 21 partial sums of all touched quadrants are added per lane, reduced across the wave ONCE
+// (v_permlane32/16_swap + DPP: 60 VALU ops), and stored as one 96-B gradient record -- no atomics anywhere,
+// deterministic.
 //
 // Behavioural contract: SURVEY.md Appendix A.4 / A.5; output channel order
 // [REF /root/reference/gaussian_renderer/__init__.py:149-165].
@@ -32,6 +34,10 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kFN = kFar / (kFar - kNear);
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// debug statistics of K6 (enabled by option bit 1): [0] entries staged, [1] entries with a non-zero quadrant mask,
+// [2] quadrant tests executed, [3] quadrant tests with >= 1 valid lane, [4] valid (pixel, entry) pairs, [5] blended pairs
+__device__ unsigned long long g_stats[8];
 
 // ---------------------------------------------------------------------------------------------
 // Quadrant culling.  A list entry can only contribute to a pixel if alpha = min(0.99, opacity*G) >= 1/255,
@@ -188,9 +194,10 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         uint32_t m = 0;
-        if ((uint32_t)lane < n) m = stage_entry<kFwdQuads>(nr, Xc, Yc, cull, s_e, lane);
+        if ((uint32_t)lane < n) m = stage_entry<kFwdQuads>(nr, Xc, Yc, cull & 1, s_e, lane);
         if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
         unsigned long long bits = __ballot((m & alive) != 0);
+        if ((cull & 2) && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
         while (bits) {
             const int j = __ffsll((long long)bits) - 1;
             bits &= bits - 1;
@@ -203,6 +210,10 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                 if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
                 const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & !done[q];
+                if (cull & 2) {
+                    const unsigned long long vb = __ballot(valid);
+                    if (lane == 0) { atomicAdd(&g_stats[2], 1ull); if (vb) atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)__popcll(vb)); }
+                }
                 if (__ballot(valid) == 0) continue;
                 const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                 if (valid) {
@@ -250,11 +261,11 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave-level transpose-reduction of 20 values per lane (gfx950):
-//   fold across the two 32-lane halves with v_permlane32_swap (value k <-> k+10), across row pairs with
-//   v_permlane16_swap (k <-> k+5), then a 4-step DPP row rotation sum.  50 VALU ops for 20 values (a plain
-//   butterfly needs 120 cross-lane ops).  Afterwards every lane of 16-lane row g holds, in v[0..4], the
-//   64-lane totals of values 5g .. 5g+4.
+// wave-level transpose-reduction of 24 values per lane (gfx950):
+//   fold across the two 32-lane halves with v_permlane32_swap (value k <-> k+12), across row pairs with
+//   v_permlane16_swap (k <-> k+6), then a 4-step DPP row rotation sum.  60 VALU ops for 24 values (a plain
+//   butterfly needs 144 cross-lane ops).  Afterwards every lane of 16-lane row g holds, in v[0..5], the
+//   64-lane totals of values 6g .. 6g+5.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fold32(float& a, float& b) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -275,13 +286,13 @@ __device__ __forceinline__ float row_sum16(float x) {
     x += dpp_mov<0x121>(x);  // row_ror:1
     return x;
 }
-__device__ __forceinline__ void wave_reduce20(float (&v)[20]) {
+__device__ __forceinline__ void wave_reduce24(float (&v)[24]) {
 #pragma unroll
-    for (int k = 0; k < 10; ++k) fold32(v[k], v[k + 10]);
+    for (int k = 0; k < 12; ++k) fold32(v[k], v[k + 12]);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) fold16(v[k], v[k + 5]);
+    for (int k = 0; k < 6; ++k) fold16(v[k], v[k + 6]);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = row_sum16(v[k]);
+    for (int k = 0; k < 6; ++k) v[k] = row_sum16(v[k]);
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
@@ -293,7 +304,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 // ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
-// Output: one 80-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
+// Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
 // (inst_grads[perm[pos]]), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
 // entries no pixel reached are written as zeros.  Gradient record slots: see common.h.
 __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
@@ -305,8 +316,8 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                                                                  const float* __restrict__ dL_dallmap,
                                                                  const uint32_t* __restrict__ perm,
                                                                  float4* __restrict__ inst_grads, int cull) {
-    __shared__ float4 s_e[kBwdQuads][kWave];
-    __shared__ __attribute__((aligned(16))) float s_out[kWave][kRecFloats];
+    __shared__ float4 s_e[kFwdQuads][kWave];
+    __shared__ __attribute__((aligned(16))) float s_out[kWave][kGradFloats];
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
     const int tx0 = (tile % f.tiles_x) * kTile, ty0 = (tile / f.tiles_x) * kTile;
@@ -352,9 +363,9 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
     {
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t e = total + lane; e < count; e += kWave) {
-            float4* o = inst_grads + (size_t)perm[range.x + e] * kRecQuads;
+            float4* o = inst_grads + (size_t)perm[range.x + e] * kGradQuads;
 #pragma unroll
-            for (int k = 0; k < kRecQuads; ++k) o[k] = zero;
+            for (int k = 0; k < kGradQuads; ++k) o[k] = zero;
         }
     }
 
@@ -367,7 +378,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         const uint32_t n = min((uint32_t)kWave, total - rbase);
         uint32_t m = 0;
         if ((uint32_t)lane < n) {
-            m = stage_entry<kBwdQuads>(nr, Xc, Yc, cull, s_e, lane);
+            m = stage_entry<kFwdQuads>(nr, Xc, Yc, cull & 1, s_e, lane);
             uint32_t need = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         {
             float4* z = reinterpret_cast<float4*>(&s_out[lane][0]);
 #pragma unroll
-            for (int k = 0; k < kRecQuads; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < kGradQuads; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (rd > 0) load_record(recs, point_list[range.x + rbase - kWave + lane], nr);  // next round is always full
         unsigned long long bits = __ballot(m != 0);
@@ -386,9 +397,9 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
             const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
-            float v[20];
+            float v[24];
 #pragma unroll
-            for (int k = 0; k < 20; ++k) v[k] = 0.f;
+            for (int k = 0; k < 24; ++k) v[k] = 0.f;
             bool any = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -397,9 +408,9 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                 const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & (cidx < lastc[q]);
                 if (__ballot(valid) == 0) continue;
                 any = true;
-                const float4 e4 = s_e[4][j], e5 = s_e[5][j], e6 = s_e[6][j], e7 = s_e[7][j];
+                const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                 if (valid) {
-                    const float Twx = e2.y, Twy = e2.z, Twz = e2.w;
+                    const float Twx = e2.y, Twy = e2.z;
                     const float one_m_inv = fast_rcp(1.f - h.alpha);
                     T[q] *= one_m_inv;                 // transmittance in front of this entry
                     const float w = h.alpha * T[q];
@@ -415,48 +426,52 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                     float dL_dz = 2.f * w * (m_d * a0[q] - a1[q]) * dmd_dd + w * g_depth[q];
                     if (cidx == medc[q] - 1u) dL_dz += g_median[q];
                     const float dL_dG = e3.z * dL_dalpha;
-                    v[16] += w * gr[q]; v[17] += w * gg[q]; v[18] += w * gb[q];
-                    v[12] += w * gn0[q]; v[13] += w * gn1[q]; v[14] += w * gn2[q];
-                    v[11] += h.G * dL_dalpha;
+                    v[18] += w * gr[q]; v[19] += w * gg[q]; v[20] += w * gb[q];
+                    v[15] += w * gn0[q]; v[16] += w * gn1[q]; v[17] += w * gn2[q];
+                    v[14] += h.G * dL_dalpha;
                     if (h.use3d) {
                         const float gG = -dL_dG * h.G;
-                        const float ax = (gG * h.sx + dL_dz * Twx) * h.pz_inv, ay = (gG * h.sy + dL_dz * Twy) * h.pz_inv;
-                        const float dpx = ax, dpy = ay, dpz = -(ax * h.sx + ay * h.sy);
-                        const float kx = xl[q] * Twx - e6.x, ky = xl[q] * Twy - e6.y, kz = xl[q] * Twz - e6.z;
-                        const float lx_ = yl[q] * Twx - e6.w, ly_ = yl[q] * Twy - e7.x, lz_ = yl[q] * Twz - e7.y;
-                        // dL_dk = l x dp ; dL_dl = dp x k
-                        const float dkx = ly_ * dpz - lz_ * dpy, dky = lz_ * dpx - lx_ * dpz, dkz = lx_ * dpy - ly_ * dpx;
-                        const float dlx = dpy * kz - dpz * ky, dly = dpz * kx - dpx * kz, dlz = dpx * ky - dpy * kx;
-                        v[0] -= dkx; v[1] -= dky; v[2] -= dkz;
-                        v[3] -= dlx; v[4] -= dly; v[5] -= dlz;
-                        v[6] += pxf[q] * dkx + pyf[q] * dlx + dL_dz * h.sx;
-                        v[7] += pxf[q] * dky + pyf[q] * dly + dL_dz * h.sy;
-                        v[8] += pxf[q] * dkz + pyf[q] * dlz + dL_dz;
+                        const float dpx = (gG * h.sx + dL_dz * Twx) * h.pz_inv, dpy = (gG * h.sy + dL_dz * Twy) * h.pz_inv;
+                        const float dpz = -(dpx * h.sx + dpy * h.sy);
+                        // moments of dL/dp (global pixel coordinates); the cross products happen once per Gaussian in K8
+                        v[0] += dpx; v[1] += dpy; v[2] += dpz;
+                        v[3] = fmaf(pxf[q], dpx, v[3]); v[4] = fmaf(pxf[q], dpy, v[4]); v[5] = fmaf(pxf[q], dpz, v[5]);
+                        v[6] = fmaf(pyf[q], dpx, v[6]); v[7] = fmaf(pyf[q], dpy, v[7]); v[8] = fmaf(pyf[q], dpz, v[8]);
+                        v[9] = fmaf(dL_dz, h.sx, v[9]); v[10] = fmaf(dL_dz, h.sy, v[10]); v[11] += dL_dz;
                     } else {
                         const float gG = -dL_dG * h.G * kFilterInvSquare;
-                        v[9] += gG * h.dx;
-                        v[10] += gG * h.dy;
-                        v[8] += dL_dz;
+                        v[12] = fmaf(gG, h.dx, v[12]);
+                        v[13] = fmaf(gG, h.dy, v[13]);
+                        v[11] += dL_dz;
                     }
                 }
             }
             if (any) {
-                wave_reduce20(v);
+                wave_reduce24(v);
                 if ((lane & 15) == 0) {
-                    float* o = &s_out[j][5 * (lane >> 4)];
+                    float* o = &s_out[j][6 * (lane >> 4)];
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) o[k] = v[k];
+                    for (int k = 0; k < 6; ++k) o[k] = v[k];
                 }
             }
         }
-        // flush this round's records: one 80-B store per lane (zeros where nothing contributed)
+        // flush this round's records: one 96-B store per lane (zeros where nothing contributed)
         if ((uint32_t)lane < n) {
             const float4* acc = reinterpret_cast<const float4*>(&s_out[lane][0]);
-            float4* o = inst_grads + (size_t)perm[range.x + rbase + lane] * kRecQuads;
+            float4* o = inst_grads + (size_t)perm[range.x + rbase + lane] * kGradQuads;
 #pragma unroll
-            for (int k = 0; k < kRecQuads; ++k) o[k] = acc[k];
+            for (int k = 0; k < kGradQuads; ++k) o[k] = acc[k];
         }
     }
+}
+
+hipError_t read_render_stats(unsigned long long* out8, bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z));
+    }
+    return e;
 }
 
 // launchers ---------------------------------------------------------------------------------------
