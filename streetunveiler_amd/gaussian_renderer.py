@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's render operator.
+
+    render / render_with_mask / render_semantic / render_semantic_with_mask
+
+Same names, argument meaning, returned dict keys and error behaviour as
+/root/reference/gaussian_renderer/__init__.py (render :18-188, render_with_mask :190-325,
+render_semantic :327-460, render_semantic_with_mask :462-598), on top of the drop-in
+`diff_surfel_rasterization` package.  `pc` is anything exposing the GaussianModel getters the reference
+reads (get_xyz, get_opacity, get_scaling, get_rotation, get_features, active_sh_degree, max_sh_degree and,
+for the semantic variants, get_semantics / get_semantics_32bit) -- scene.gaussian_model.GaussianModel and
+scene.mask_gaussian.MaskGaussianModel qualify unchanged; `SurfelModel` below is a minimal stand-in for
+tests and the benchmark.  `pipe` carries convert_SHs_python, compute_cov3D_python, depth_ratio, debug
+[REF /root/reference/arguments/__init__.py:62-68].
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+from .sh import eval_sh
+
+# [REF /root/reference/utils/semantic_utils.py:100-102]
+concerned_classes_list = ["road", "sidewalk", "building", "vegetation", "sky", "vehicle"]
+concerned_classes_ind_map = {cn: i for i, cn in enumerate(concerned_classes_list)}
+# colour of each of the 6 classes (first rows of the reference's semantic colour table, values 0..255)
+_SEMANTIC_COLOR = torch.tensor([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [255, 0, 255], [0, 255, 255]])
+
+
+@dataclass
+class PipelineParams:
+    convert_SHs_python: bool = False
+    compute_cov3D_python: bool = False
+    depth_ratio: float = 0.0
+    debug: bool = False
+
+
+class SurfelModel:
+    """Minimal parameter container with the GaussianModel getter surface (activated values stored directly)."""
+
+    def __init__(self, xyz, scaling, rotation, opacity, features, semantics=None, active_sh_degree=3, max_sh_degree=3):
+        self._xyz, self._scaling, self._rotation, self._opacity, self._features = xyz, scaling, rotation, opacity, features
+        self._semantics = semantics
+        self.active_sh_degree, self.max_sh_degree = active_sh_degree, max_sh_degree
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: s._scaling)
+    get_rotation = property(lambda s: s._rotation)
+    get_opacity = property(lambda s: s._opacity)
+    get_features = property(lambda s: s._features)
+    get_semantics = property(lambda s: s._semantics)
+    get_semantics_32bit = property(lambda s: (1 << s._semantics.to(torch.int32)))
+
+    def get_covariance(self, scaling_modifier=1):
+        # the reference's producer indexes a third scale component and cannot run with 2-component surfel
+        # scales (SURVEY.md 8b "dead inputs"); the operator slot itself takes a [P,9] transMat.
+        raise NotImplementedError("compute_cov3D_python is a dead flag for 2D surfels (2-component scales)")
+
+
+# ---------------------------------------------------------------------------------------------------
+def depths_to_points(view, depthmap):
+    """[REF /root/reference/utils/point_utils.py:9-25] back-projection of a depth map to world points."""
+    dev = depthmap.device
+    c2w = (view.world_view_transform.T).inverse()
+    W, H = view.image_width, view.image_height
+    fx = W / (2 * math.tan(view.FoVx / 2.0))
+    fy = H / (2 * math.tan(view.FoVy / 2.0))
+    intrins = torch.tensor([[fx, 0.0, W / 2.0], [0.0, fy, H / 2.0], [0.0, 0.0, 1.0]]).float().to(dev)
+    grid_x, grid_y = torch.meshgrid(torch.arange(W), torch.arange(H), indexing="xy")
+    points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3).float().to(dev)
+    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3]
+    return depthmap.reshape(-1, 1) * rays_d + rays_o
+
+
+def depth_to_normal(view, depth):
+    """[REF /root/reference/utils/point_utils.py:27-37] finite-difference pseudo-normals of a depth map."""
+    points = depths_to_points(view, depth).reshape(*depth.shape[1:], 3)
+    output = torch.zeros_like(points)
+    dx = points[2:, 1:-1] - points[:-2, 1:-1]
+    dy = points[1:-1, 2:] - points[1:-1, :-2]
+    output[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
+    return output, points
+
+
+def postprocess_allmap(viewpoint_camera, pipe, allmap):
+    """allmap[7,H,W] -> the regularisation maps of the render dict [REF gaussian_renderer/__init__.py:148-186]."""
+    render_alpha = allmap[1:2]
+    render_normal = allmap[2:5]
+    render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
+    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
+    render_dist = allmap[6:7]
+    surf_depth = render_depth_expected * (1 - pipe.depth_ratio) + pipe.depth_ratio * render_depth_median
+    surf_normal, surf_point = depth_to_normal(viewpoint_camera, surf_depth)
+    surf_normal = surf_normal.permute(2, 0, 1) * render_alpha.detach()
+    surf_point = surf_point.permute(2, 0, 1)
+    return {"rend_alpha": render_alpha, "rend_normal": render_normal, "rend_dist": render_dist, "surf_depth": surf_depth,
+            "surf_normal": surf_normal, "surf_point": surf_point}
+
+
+def _settings(viewpoint_camera, pc, pipe, bg, scaling_modifier):
+    return GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+
+
+def _screenspace_points(pc):
+    # zero tensor whose .grad receives the screen-space (densification) gradient [REF :28-33]
+    p = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=pc.get_xyz.device) + 0
+    try:
+        p.retain_grad()
+    except Exception:
+        pass
+    return p
+
+
+def _sel(t, mask):
+    return t if mask is None else t[mask]
+
+
+def _geometry_inputs(pc, pipe, screenspace_points, mask, scaling_modifier):
+    means3D, means2D, opacity = _sel(pc.get_xyz, mask), _sel(screenspace_points, mask), _sel(pc.get_opacity, mask)
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = _sel(pc.get_covariance(scaling_modifier), mask)
+    else:
+        scales, rotations = _sel(pc.get_scaling, mask), _sel(pc.get_rotation, mask)
+    try:
+        means3D.retain_grad()
+    except Exception:
+        pass
+    return means3D, means2D, opacity, scales, rotations, cov3D_precomp
+
+
+def _color_inputs(viewpoint_camera, pc, pipe, mask, override_color):
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
+            colors_precomp = _sel(torch.clamp_min(sh2rgb + 0.5, 0.0), mask)
+        else:
+            shs = _sel(pc.get_features, mask)
+    else:
+        colors_precomp = _sel(override_color, mask)
+    return shs, colors_precomp
+
+
+def _semantic_mask(pc, semantic_filter_bit, reverse_semantic):
+    if semantic_filter_bit is None:
+        return None
+    assert reverse_semantic is not None
+    m = (pc.get_semantics_32bit & int(semantic_filter_bit)) != 0
+    return ~m if reverse_semantic is False else m
+
+
+def _render_impl(viewpoint_camera, pc, pipe, bg_color, mask, scaling_modifier, override_color):
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
+    means3D, means2D, opacity, scales, rotations, cov3D_precomp = _geometry_inputs(pc, pipe, screenspace_points, mask, scaling_modifier)
+    shs, colors_precomp = _color_inputs(viewpoint_camera, pc, pipe, mask, override_color)
+    rendered_image, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
+                                               opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    rets = {"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
+    rets.update(postprocess_allmap(viewpoint_camera, pipe, allmap))
+    return rets
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+           semantic_filter_bit: Optional[int] = None, reverse_semantic: Optional[bool] = None):
+    """[REF gaussian_renderer/__init__.py:18-188]"""
+    mask = _semantic_mask(pc, semantic_filter_bit, reverse_semantic)
+    return _render_impl(viewpoint_camera, pc, pipe, bg_color, mask, scaling_modifier, override_color)
+
+
+def render_with_mask(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mask, scaling_modifier=1.0, override_color=None):
+    """[REF gaussian_renderer/__init__.py:190-325]"""
+    return _render_impl(viewpoint_camera, pc, pipe, bg_color, mask, scaling_modifier, override_color)
+
+
+def _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier):
+    dev = pc.get_xyz.device
+    screenspace_points = _screenspace_points(pc)
+    n_cls = len(concerned_classes_list)
+    bg_prob = [0.0] * n_cls
+    bg_prob[concerned_classes_ind_map["sky"]] = 1.0
+    means3D, means2D, opacity, scales, rotations, cov3D_precomp = _geometry_inputs(pc, pipe, screenspace_points, mask, scaling_modifier)
+    semantics_tag = _sel(pc.get_semantics, mask)
+    output_semantic = []
+    for i in range(0, n_cls, 3):   # 6 one-hot classes as two 3-channel passes [REF :417-444]
+        bg = torch.tensor(bg_prob[i:i + 3], dtype=torch.float32, device=dev)
+        rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg, scaling_modifier))
+        valid = min(3, n_cls - i)
+        semantic_3 = torch.zeros_like(means3D).float()
+        for c in range(valid):
+            semantic_3[semantics_tag == (i + c), c] = 1.0
+        rendered_semantic, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=semantic_3,
+                                                      opacities=opacity, scales=scales, rotations=rotations,
+                                                      cov3D_precomp=cov3D_precomp)
+        output_semantic.append(rendered_semantic[:valid])
+    output_semantic = torch.cat(output_semantic, dim=0)
+    topk_values, _ = torch.topk(output_semantic, k=2, dim=0)
+    uncertainty = 1.0 - (topk_values[0, ...] - topk_values[1, ...])
+    semantic_rgb = _SEMANTIC_COLOR.to(dev)[torch.argmax(output_semantic, dim=0)].permute(2, 0, 1) / 255.0
+    return {"render_semantics": output_semantic, "semantic_rgb": semantic_rgb, "semantic_uncertainty": uncertainty}
+
+
+def render_semantic(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
+                    semantic_filter_bit: Optional[int] = None, reverse_semantic: Optional[bool] = None):
+    """[REF gaussian_renderer/__init__.py:327-460] (bg_color is accepted and, as in the reference, unused)."""
+    return _render_semantic_impl(viewpoint_camera, pc, pipe, _semantic_mask(pc, semantic_filter_bit, reverse_semantic), scaling_modifier)
+
+
+def render_semantic_with_mask(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mask, scaling_modifier=1.0):
+    """[REF gaussian_renderer/__init__.py:462-598]"""
+    return _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier)

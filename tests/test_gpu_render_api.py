@@ -1,0 +1,124 @@
+"""GPU (-m gpu): the reference's operator surface (render / render_with_mask / render_semantic[_with_mask],
+SURVEY 8a rows A1-A4) on top of the HIP rasterizer, end to end against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from streetunveiler_amd.gaussian_renderer import (PipelineParams, SurfelModel, postprocess_allmap, render, render_semantic,
+                                                  render_semantic_with_mask, render_with_mask)
+from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(P, W, H, seed, dev, requires_grad=False):
+    g = synthetic_gaussians(P, W, H, seed=seed, scale_lo=3e-3, scale_hi=5e-2)
+    sem = torch.randint(0, 6, (P,), generator=torch.Generator().manual_seed(seed))
+    t = {k: v.to(dev) for k, v in g.items()}
+    if requires_grad:
+        for v in t.values():
+            v.requires_grad_()
+    return g, sem, SurfelModel(t["means3D"], t["scales"], t["rotations"], t["opacities"], t["shs"], sem.to(dev), 3, 3), t
+
+
+def _oracle(g, cam, bg, deg, idx=None, colors=None):
+    from oracle import surfel_oracle as so
+    sel = (lambda a: a) if idx is None else (lambda a: a[idx])
+    kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
+              campos=cam.camera_center.numpy(), bg=np.asarray(bg, np.float32), image_width=cam.image_width,
+              image_height=cam.image_height, sh_degree=deg)
+    n = lambda k: sel(g[k].numpy())
+    if colors is None:
+        return so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), shs=n("shs"), **kw)
+    return so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), colors_precomp=colors, **kw)
+
+
+def test_render_dict_and_backward_through_regularisers():
+    from oracle import surfel_oracle as so
+    from tests.gpu_util import assert_close_frac, assert_grads_close
+    P, W, H = 6000, 208, 120
+    cam = synthetic_camera(W, H, index=2)
+    g, sem, pc, t = _model(P, W, H, 21, DEV, requires_grad=True)
+    bg = torch.tensor([0.2, 0.3, 0.1])
+    pipe = PipelineParams(depth_ratio=0.0)
+    out = render(cam.to(DEV), pc, pipe, bg.to(DEV))
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "rend_alpha", "rend_normal", "rend_dist",
+                        "surf_depth", "surf_normal", "surf_point"}
+    fwd = _oracle(g, cam, bg.numpy(), 3)
+    np.testing.assert_array_equal(out["radii"].cpu().numpy(), fwd["radii"])
+    np.testing.assert_array_equal(out["visibility_filter"].cpu().numpy(), fwd["radii"] > 0)
+    assert_close_frac(out["render"].detach().cpu().numpy(), fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, "render")
+    # the same post-processing applied to the oracle's allmap (CPU, with autograd for dL/dallmap)
+    am = torch.tensor(fwd["allmap"], requires_grad=True)
+    col = torch.tensor(fwd["color"], requires_grad=True)
+    ref = postprocess_allmap(cam, pipe, am)
+    for k in ["rend_alpha", "rend_normal", "rend_dist", "surf_depth"]:
+        assert_close_frac(out[k].detach().cpu().numpy(), ref[k].detach().numpy(), 1e-4, 1e-4, 1e-3, 5e-2, k)
+
+    def loss_fn(o, image):   # train.py-style: image term + normal consistency + distortion + alpha
+        normal_error = (1 - (o["rend_normal"] * o["surf_normal"]).sum(dim=0))[None]
+        return image.square().mean() + 0.05 * normal_error.mean() + 100.0 * o["rend_dist"].mean() + 0.1 * o["rend_alpha"].mean()
+
+    loss_fn(out, out["render"]).backward()
+    loss_fn(ref, col).backward()
+    bwd = so.rasterize_backward(fwd, col.grad.numpy(), am.grad.numpy())
+    torch.cuda.synchronize()
+    for name, got in [("dL_dmeans3D", t["means3D"].grad), ("dL_dopacity", t["opacities"].grad), ("dL_dscales", t["scales"].grad),
+                      ("dL_drotations", t["rotations"].grad), ("dL_dsh", t["shs"].grad), ("dL_dmeans2D", out["viewspace_points"].grad)]:
+        assert_grads_close(got.cpu().numpy(), bwd[name], 5e-3, name, max_bad_frac=2e-3, hard=0.1)
+
+
+def test_semantic_filter_mask_and_python_sh_path():
+    from tests.gpu_util import assert_close_frac
+    P, W, H = 4000, 160, 96
+    cam = synthetic_camera(W, H)
+    g, sem, pc, t = _model(P, W, H, 5, DEV)
+    bg = torch.zeros(3)
+    pipe = PipelineParams()
+    # semantic_filter_bit keeps classes whose bit is set (reverse_semantic=True) or clear (False)
+    bit = (1 << 1) | (1 << 4)
+    for reverse in (True, False):
+        out = render(cam.to(DEV), pc, pipe, bg.to(DEV), semantic_filter_bit=bit, reverse_semantic=reverse)
+        keep = ((1 << sem.numpy()) & bit) != 0
+        keep = keep if reverse else ~keep
+        fwd = _oracle(g, cam, bg.numpy(), 3, idx=keep)
+        assert out["radii"].shape[0] == int(keep.sum())
+        np.testing.assert_array_equal(out["radii"].cpu().numpy(), fwd["radii"])
+        assert_close_frac(out["render"].detach().cpu().numpy(), fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, "masked render")
+    # explicit boolean mask
+    mask = torch.rand(P, generator=torch.Generator().manual_seed(1)) > 0.4
+    out = render_with_mask(cam.to(DEV), pc, pipe, bg.to(DEV), mask.to(DEV))
+    fwd = _oracle(g, cam, bg.numpy(), 3, idx=mask.numpy())
+    assert_close_frac(out["render"].detach().cpu().numpy(), fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, "render_with_mask")
+    # python SH fallback == native SH path
+    a = render(cam.to(DEV), pc, PipelineParams(convert_SHs_python=False), bg.to(DEV))["render"]
+    b = render(cam.to(DEV), pc, PipelineParams(convert_SHs_python=True), bg.to(DEV))["render"]
+    assert_close_frac(a.detach().cpu().numpy(), b.detach().cpu().numpy(), 1e-5, 1e-5, 1e-4, 1e-2, "convert_SHs_python")
+    with pytest.raises(NotImplementedError):
+        render(cam.to(DEV), pc, PipelineParams(compute_cov3D_python=True), bg.to(DEV))
+
+
+def test_render_semantic_six_classes():
+    from tests.gpu_util import assert_close_frac
+    P, W, H = 4000, 160, 96
+    cam = synthetic_camera(W, H, index=5)
+    g, sem, pc, t = _model(P, W, H, 9, DEV)
+    out = render_semantic(cam.to(DEV), pc, PipelineParams(), torch.zeros(3, device=DEV))
+    assert out["render_semantics"].shape == (6, H, W) and out["semantic_rgb"].shape == (3, H, W) and out["semantic_uncertainty"].shape == (H, W)
+    expect = []
+    for i in (0, 3):
+        onehot = np.zeros((P, 3), np.float32)
+        for c in range(3):
+            onehot[sem.numpy() == i + c, c] = 1.0
+        bg = np.zeros(3, np.float32)
+        if i <= 4 < i + 3:
+            bg[4 - i] = 1.0     # sky is background
+        expect.append(_oracle(g, cam, bg, 3, colors=onehot)["color"])
+    expect = np.concatenate(expect, 0)
+    assert_close_frac(out["render_semantics"].detach().cpu().numpy(), expect, 1e-4, 1e-4, 2e-4, 2e-2, "render_semantics")
+    # class probabilities + background sum to one wherever the sky class absorbs the leftover transmittance
+    np.testing.assert_allclose(out["render_semantics"].detach().sum(0).cpu().numpy(), 1.0, atol=2e-3)
+    m = torch.rand(P, generator=torch.Generator().manual_seed(2)) > 0.5
+    out2 = render_semantic_with_mask(cam.to(DEV), pc, PipelineParams(), torch.zeros(3, device=DEV), m.to(DEV))
+    assert out2["render_semantics"].shape == (6, H, W)

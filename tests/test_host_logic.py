@@ -1,0 +1,97 @@
+"""CPU: host-side logic around the operator -- SH python fallback, allmap post-processing, frame-sharded DP (gloo)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from streetunveiler_amd.gaussian_renderer import PipelineParams, depth_to_normal, postprocess_allmap
+from streetunveiler_amd.sh import RGB2SH, SH2RGB, eval_sh
+from streetunveiler_amd.synthetic import synthetic_camera
+
+
+def test_python_sh_fallback_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "sh_golden.npz"))
+    sh, dirs = torch.tensor(z["sh"]), torch.tensor(z["dirs"])
+    for deg in range(4):
+        np.testing.assert_allclose(eval_sh(deg, sh, dirs).numpy(), z[f"rgb_deg{deg}"], atol=1e-6)
+    rgb = torch.tensor(z["rgb2sh_in"])
+    np.testing.assert_allclose(RGB2SH(rgb).numpy(), z["rgb2sh_out"], atol=1e-6)
+    np.testing.assert_allclose(SH2RGB(RGB2SH(rgb)).numpy(), z["sh2rgb_out"], atol=1e-6)
+
+
+def test_postprocess_allmap_against_direct_numpy():
+    """postprocess_allmap restates gaussian_renderer/__init__.py:148-186 + utils/point_utils.py:9-37."""
+    W, H = 40, 24
+    cam = synthetic_camera(W, H, index=2)
+    g = torch.Generator().manual_seed(0)
+    allmap = torch.rand(7, H, W, generator=g)
+    allmap[1, :3] = 0.0              # alpha == 0 rows -> 0/0 -> nan_to_num -> 0
+    allmap[0] = allmap[0] * 10 + 1
+    for ratio in (0.0, 1.0, 0.3):
+        out = postprocess_allmap(cam, PipelineParams(depth_ratio=ratio), allmap.clone())
+        a = allmap.numpy().astype(np.float64)
+        alpha = a[1:2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            exp = np.nan_to_num(a[0:1] / alpha, nan=0.0, posinf=0.0, neginf=0.0)
+        surf = exp * (1 - ratio) + ratio * a[5:6]
+        np.testing.assert_allclose(out["surf_depth"].numpy(), surf, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out["rend_alpha"].numpy(), alpha)
+        R = cam.world_view_transform.numpy()[:3, :3].astype(np.float64)
+        np.testing.assert_allclose(out["rend_normal"].numpy(), np.einsum("chw,dc->dhw", a[2:5], R), atol=1e-5)
+        # pseudo-normals: back-project, central differences, normalise, zero border, times alpha
+        fx = W / (2 * math.tan(cam.FoVx / 2)); fy = H / (2 * math.tan(cam.FoVy / 2))
+        K = np.array([[fx, 0, W / 2], [0, fy, H / 2], [0, 0, 1]])
+        c2w = np.linalg.inv(cam.world_view_transform.numpy().T.astype(np.float64))
+        xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="xy")
+        pix = np.stack([xs, ys, np.ones_like(xs)], -1).reshape(-1, 3).astype(np.float64)
+        pts = (surf.reshape(-1, 1) * (pix @ np.linalg.inv(K).T @ c2w[:3, :3].T) + c2w[:3, 3]).reshape(H, W, 3)
+        n = np.zeros_like(pts)
+        dx = pts[2:, 1:-1] - pts[:-2, 1:-1]; dy = pts[1:-1, 2:] - pts[1:-1, :-2]
+        cr = np.cross(dx, dy); n[1:-1, 1:-1] = cr / np.maximum(np.linalg.norm(cr, axis=-1, keepdims=True), 1e-12)
+        np.testing.assert_allclose(out["surf_point"].numpy(), pts.transpose(2, 0, 1), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out["surf_normal"].numpy(), n.transpose(2, 0, 1) * alpha, atol=2e-3)
+        assert set(out) == {"rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "surf_point"}
+
+
+def _dp_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from streetunveiler_amd.parallel import allreduce_gradients, frames_for_rank, init_distributed, reduce_densification_stats
+    r, w, _ = init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    P = 1000
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = [torch.randn(P, 3, generator=g), torch.randn(P, 16, 3, generator=g), torch.randn(P, 1, generator=g),
+             torch.randn(P, 2, generator=g), torch.randn(P, 4, generator=g), None]
+    local = [x.clone() if x is not None else None for x in grads]
+    import streetunveiler_amd.parallel as par
+    par._BUCKET_INPLACE_BYTES = 100_000   # exercise both the bucketed and the in-place path
+    allreduce_gradients(grads)
+    # densification statistics of this rank's view
+    vs_grad = torch.randn(P, 3, generator=g); radii = torch.randint(0, 5, (P,), generator=g, dtype=torch.int32)
+    accum, denom, maxr = torch.zeros(P, 1), torch.zeros(P, 1), torch.zeros(P)
+    reduce_densification_stats(vs_grad, radii, accum, denom, maxr)
+    torch.save(dict(local=local, reduced=grads, vs_grad=vs_grad, radii=radii, accum=accum, denom=denom, maxr=maxr,
+                    frames=frames_for_rank(8, rank, world)), os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharded_dp_gloo_world2(tmp_path):
+    """all-reduced gradient == sum of the per-rank gradients; densification stats SUM/SUM/MAX."""
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    for k in range(5):
+        expect = rs[0]["local"][k] + rs[1]["local"][k]
+        for r in rs:
+            torch.testing.assert_close(r["reduced"][k], expect, rtol=1e-6, atol=1e-6)
+    acc = sum(torch.where((r["radii"] > 0)[:, None], r["vs_grad"].norm(dim=-1, keepdim=True), torch.zeros(1)) for r in rs)
+    den = sum((r["radii"] > 0).float()[:, None] for r in rs)
+    mx = torch.maximum(*[torch.where(r["radii"] > 0, r["radii"].float(), torch.zeros(1)) for r in rs])
+    for r in rs:
+        torch.testing.assert_close(r["accum"], acc); torch.testing.assert_close(r["denom"], den); torch.testing.assert_close(r["maxr"], mx)
+    assert rs[0]["frames"] == [0, 2, 4, 6] and rs[1]["frames"] == [1, 3, 5, 7]
