@@ -55,6 +55,24 @@ def algorithmic_bytes(P, V, D, npx, deg):
     }
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json:
+    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md
+    prescribes).  PMC counters cannot be read from inside the timed run, so this is the last profiled value for the
+    default C3 workload; None for any other workload."""
+    if (args.gaussians, args.width, args.height, args.sh_degree, args.no_aux) != (3_000_000, 1920, 1080, 3, False):
+        return None, None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))["kernels"]
+        return d["sr::" + kernel]["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(args, g, cam, dc, da):
     """The CPU oracle (a port: the reference has no CPU rasterizer) timed on a bounded sub-sample of the
     same scene, forward + backward, OpenMP over all host threads."""
@@ -164,6 +182,8 @@ def main():
         blend_ms = group_ms["blend_fwd"] + group_ms["blend_bwd"]
         blend_gbs = (ab["blend_fwd"] + ab["blend_bwd"]) / (blend_ms * 1e-3) / 1e9 if blend_ms else None
         kernels_ms = sum(group_ms.values())
+        dom_kernel = "render_backward_kernel" if dominant == "blend_bwd" else "render_forward_kernel"
+        traffic, traffic_src = pmc_traffic(dom_kernel, args)
         out = {
             "metric": "Msplats/s fwd+bwd @1920x1080, 3M Gaussians", "value": round(value, 3), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -172,11 +192,12 @@ def main():
                                    f"{'colour+alpha' if args.no_aux else 'all 7 aux-map'} gradients live",
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D,
                        "frames_per_step": world, "parallelism": f"frame-sharded dp{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "render_backward_kernel" if dominant == "blend_bwd" else "render_forward_kernel",
+            "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": None if ach is None else round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 5),
                          "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_ms": round(group_ms[dominant], 4),
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "HBM fraction as BASELINE.json defines it; the blend kernels are FP32-VALU-bound (DESIGN.md 4)",
                          "north_star_blend_fwd_bwd": {"algorithmic_bytes": ab["blend_fwd"] + ab["blend_bwd"], "ms": round(blend_ms, 4),
                                                       "achieved": None if blend_gbs is None else round(blend_gbs, 2),
                                                       "frac": None if blend_gbs is None else round(blend_gbs / HBM_PEAK_GBS, 5)},
