@@ -378,6 +378,7 @@ int sr_set_option(int option, int value) {
     switch (option) {
         case SR_OPT_QUADRANT_CULL: g_opt_cull.store((g_opt_cull.load() & ~1) | (value ? 1 : 0)); return SR_OK;
         case SR_OPT_DEBUG_STATS: g_opt_cull.store((g_opt_cull.load() & ~2) | (value ? 2 : 0)); return SR_OK;
+        case 100: g_opt_cull.store((g_opt_cull.load() & 0xF) | ((value & 0xF) << 4)); return SR_OK;  // undocumented: K7 ablation bits (timing experiments only; results are wrong)
         default: return fail(SR_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }

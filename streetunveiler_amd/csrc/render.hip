@@ -45,9 +45,10 @@ __device__ unsigned long long g_stats[8];
 // u^2+v^2 <= thr under the splat's homography -- an ellipse with dual conic C* = Q diag(thr,thr,-1) Q^T --
 // and {rho2d <= thr} is a disc of radius sqrt(thr/2) around means2D.  The staging lane bounds that union by
 // an octagon (support in directions x, y, x+y, x-y from the tangent-line equation l^T C* l = 0) and tests it
-// against the tile's four 8x8 quadrants.  Entries dropped here are entries the per-pixel test would skip
-// anyway (`continue` in Appendix A.4), so results are unchanged; the bound has 0.3 px / 1 % slack for float
-// rounding and keeps the entry whenever anything is degenerate or NaN.  Inputs are tile-local (origin at
+// against the tile's four 8x8 quadrants.  (A second, nearly exact test in the splat's (u,v) plane removes another
+// 9 % of the tests but costs more at staging than it saves -- measured, not kept.)  Entries dropped here are entries the per-pixel test would skip anyway (`continue` in Appendix A.4),
+// so results are unchanged; the bound has 0.3 px / 1 % slack for float rounding and keeps the entry whenever
+// anything is degenerate or NaN.  Inputs are tile-local (origin at
 // the tile centre), which keeps the conic free of cancellation.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my,
@@ -62,18 +63,18 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
     const float c11 = thr * (Tv[0] * Tv[0] + Tv[1] * Tv[1]) - Tv[2] * Tv[2];
     const float c02 = thr * (Tu[0] * Tw[0] + Tu[1] * Tw[1]) - Tu[2] * Tw[2];
     const float c12 = thr * (Tv[0] * Tw[0] + Tv[1] * Tw[1]) - Tv[2] * Tw[2];
-    const float inv = 1.f / c22;
-    const float r = sqrtf(0.5f * thr);
+    const float inv = fast_rcp(c22);
+    const float r = __builtin_amdgcn_sqrtf(0.5f * thr);
     float lo[4], hi[4];
-    const float A[4] = {c00, c11, c00 + 2.f * c01 + c11, c00 - 2.f * c01 + c11};
-    const float B[4] = {c02, c12, c02 + c12, c02 - c12};
+    const float QA[4] = {c00, c11, c00 + 2.f * c01 + c11, c00 - 2.f * c01 + c11};
+    const float QB[4] = {c02, c12, c02 + c12, c02 - c12};
     const float ctr[4] = {mx, my, mx + my, mx - my};
     const float rad[4] = {r, r, r * 1.4142137f, r * 1.4142137f};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const float disc = B[d] * B[d] - A[d] * c22;
-        const float half = sqrtf(fmaxf(disc, 0.f)) * (-inv) * 1.01f;
-        const float dc = B[d] * inv;
+        const float disc = QB[d] * QB[d] - QA[d] * c22;
+        const float half = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) * (-inv) * 1.01f;
+        const float dc = QB[d] * inv;
         lo[d] = fminf(dc - half, ctr[d] - rad[d]);
         hi[d] = fmaxf(dc + half, ctr[d] + rad[d]);
     }
@@ -81,12 +82,12 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
     uint32_t mask = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float x0 = (q & 1) ? 0.f : -8.f, x1 = x0 + 7.f;
-        const float y0 = (q & 2) ? 0.f : -8.f, y1 = y0 + 7.f;
-        const bool out = lo[0] > x1 + m || hi[0] < x0 - m || lo[1] > y1 + m || hi[1] < y0 - m ||
-                         lo[2] > x1 + y1 + 2.f * m || hi[2] < x0 + y0 - 2.f * m ||
-                         lo[3] > x1 - y0 + 2.f * m || hi[3] < x0 - y1 - 2.f * m;
-        if (!out) mask |= 1u << q;
+        const float x0 = ((q & 1) ? 0.f : -8.f) - m, x1 = ((q & 1) ? 7.f : -1.f) + m;
+        const float y0 = ((q & 2) ? 0.f : -8.f) - m, y1 = ((q & 2) ? 7.f : -1.f) + m;
+        const bool out = lo[0] > x1 || hi[0] < x0 || lo[1] > y1 || hi[1] < y0 || lo[2] > x1 + y1 || hi[2] < x0 + y0 ||
+                         lo[3] > x1 - y0 || hi[3] < x0 - y1;
+        if (out) continue;
+        mask |= 1u << q;
     }
     return mask;
 }
@@ -158,6 +159,7 @@ __device__ __forceinline__ void load_record(const float4* __restrict__ recs, uin
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
+template <bool kStats>
 __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ recs,
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
         if ((uint32_t)lane < n) m = stage_entry<kFwdQuads>(nr, Xc, Yc, cull & 1, s_e, lane);
         if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
         unsigned long long bits = __ballot((m & alive) != 0);
-        if ((cull & 2) && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
+        if (kStats && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
         while (bits) {
             const int j = __ffsll((long long)bits) - 1;
             bits &= bits - 1;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                 if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
                 const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & !done[q];
-                if (cull & 2) {
+                if (kStats) {
                     const unsigned long long vb = __ballot(valid);
                     if (lane == 0) { atomicAdd(&g_stats[2], 1ull); if (vb) atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)__popcll(vb)); }
                 }
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                 if (__ballot(valid) == 0) continue;
                 any = true;
                 const float4 e4 = s_e[4][j], e5 = s_e[5][j];
-                if (valid) {
+                if (valid && !(cull & 64)) {
                     const float Twx = e2.y, Twy = e2.z;
                     const float one_m_inv = fast_rcp(1.f - h.alpha);
                     T[q] *= one_m_inv;                 // transmittance in front of this entry
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                     }
                 }
             }
-            if (any) {
+            if (any && !(cull & 32)) {
                 wave_reduce24(v);
                 if ((lane & 15) == 0) {
                     float* o = &s_out[j][6 * (lane >> 4)];
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             }
         }
         // flush this round's records: one 96-B store per lane (zeros where nothing contributed)
-        if ((uint32_t)lane < n) {
+        if ((uint32_t)lane < n && !(cull & 16)) {
             const float4* acc = reinterpret_cast<const float4*>(&s_out[lane][0]);
             float4* o = inst_grads + (size_t)perm[range.x + rbase + lane] * kGradQuads;
 #pragma unroll
@@ -479,8 +481,12 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
                                  float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(render_forward_kernel, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, out_color,
-                       out_allmap, final_T, n_contrib, cull);
+    if (cull & 2)
+        hipLaunchKernelGGL(render_forward_kernel<true>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, out_color,
+                           out_allmap, final_T, n_contrib, cull);
+    else
+        hipLaunchKernelGGL(render_forward_kernel<false>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, out_color,
+                           out_allmap, final_T, n_contrib, cull);
     return hipGetLastError();
 }
 
