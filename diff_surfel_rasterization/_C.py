@@ -111,8 +111,14 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         # the backward never dereferences opacities (it reads the packed record); pass means3D as a non-NULL stand-in
         g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp)
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D = e(P, 3), e(P, 3), e(P, 1), e(P, 3)
-        dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = e(P, 9), e(P, M, 3), e(P, 2), e(P, 4)
+        has = lambda t: t is not None and t.numel() > 0
+        # gradients of inputs that were not provided are not computed (empty tensors, as `None` for autograd)
+        dL_dmeans2D, dL_dopacity, dL_dmeans3D = e(P, 3), e(P, 1), e(P, 3)
+        dL_dcolors = e(P, 3) if has(colors_precomp) else e(0, 3)
+        dL_dtransMat = e(P, 9) if has(transMat_precomp) else e(0, 9)
+        dL_dsh = e(P, M, 3) if has(sh) else e(0, 0, 3)
+        dL_dscales = e(P, 2) if has(scales) else e(0, 2)
+        dL_drotations = e(P, 4) if has(rotations) else e(0, 4)
         ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered)),), dtype=torch.uint8, device=dev)
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),
                               _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations))

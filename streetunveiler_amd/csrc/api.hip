@@ -25,18 +25,17 @@ hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* ti
                            uint32_t* sorted_keys, uint32_t* sorted_gid, uint32_t* tt_sorted, uint32_t* sorted_offsets,
                            void* temp, size_t temp_bytes, hipStream_t s, hipEvent_t ev_sorted);
 hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
-                    const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* slots_unsorted,
+                    const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* inst_begin,
                     hipStream_t s);
-hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* slots_unsorted,
-                         uint32_t* tile_keys, uint32_t* perm, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t run_finalize_lists(uint32_t D, int n_tiles, const uint32_t* tile_keys, const uint32_t* perm,
-                              const uint32_t* vals_unsorted, uint32_t* point_list, uint2* ranges, hipStream_t s);
+hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
+                         uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                  float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, int cull, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint32_t* perm, float4* inst_grads, int cull, hipStream_t s);
+                                  const float* dL_dallmap, const uint32_t* inst_begin, float4* inst_grads, int cull, hipStream_t s);
 hipError_t read_render_stats(unsigned long long* out8, bool reset);
 }  // namespace sr
 
@@ -107,7 +106,7 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
 
 // ---- buffer layouts ------------------------------------------------------------------------------
 struct GeomLayout {
-    size_t recs, depth_keys, tiles_touched, clamped, iota, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, temp, temp_bytes, total;
+    size_t recs, depth_keys, tiles_touched, clamped, iota, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, inst_begin, temp, temp_bytes, total;
 };
 GeomLayout geom_layout(int P) {
     GeomLayout L{};
@@ -123,6 +122,7 @@ GeomLayout geom_layout(int P) {
     L.sorted_gid = take(n * 4);
     L.tt_sorted = take(n * 4);
     L.sorted_offsets = take(n * 4);
+    L.inst_begin = take(n * 4);
     static thread_local int memo_P = -1;
     static thread_local size_t memo_bytes = 0;
     if (memo_P != P) { memo_bytes = depth_sort_temp_bytes(P); memo_P = P; }
@@ -133,7 +133,7 @@ GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t keys_unsorted, vals_unsorted, slots_unsorted, tile_keys, perm, point_list, ranges, temp, temp_bytes, total;
+    size_t keys_unsorted, vals_unsorted, tile_keys, point_list, ranges, temp, temp_bytes, total;
 };
 BinLayout bin_layout(uint32_t D, int W, int H) {
     BinLayout L{};
@@ -143,9 +143,7 @@ BinLayout bin_layout(uint32_t D, int W, int H) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L.keys_unsorted = take(n * 4);
     L.vals_unsorted = take(n * 4);
-    L.slots_unsorted = take(n * 4);
     L.tile_keys = take(n * 4);
-    L.perm = take(n * 4);
     L.point_list = take(n * 4);
     L.ranges = take((size_t)(tiles > 0 ? tiles : 1) * 8);
     static thread_local uint32_t memo_D = 0xFFFFFFFFu;
@@ -300,22 +298,20 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
             StageTimer t(SR_STAGE_EMIT, s);
             SR_HIP(run_emit(P, f.tiles_x, f.tiles_y, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), recs,
                             at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
-                            at<uint32_t>(binning, B.slots_unsorted), s));
+                            at<uint32_t>(geom, L.inst_begin), s));
         }
         if (int rc = debug_sync(frame, s, "emit_duplicates")) return rc;
         {
             StageTimer t(SR_STAGE_TILE_SORT, s);
-            SR_HIP(run_tile_sort(D, n_tiles, at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.slots_unsorted),
-                                 at<uint32_t>(binning, B.tile_keys), at<uint32_t>(binning, B.perm),
+            SR_HIP(run_tile_sort(D, n_tiles, at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
+                                 at<uint32_t>(binning, B.tile_keys), at<uint32_t>(binning, B.point_list),
                                  at<void>(binning, B.temp), B.temp_bytes, s));
         }
         if (int rc = debug_sync(frame, s, "tile_sort")) return rc;
     }
     {
         StageTimer t(SR_STAGE_RANGES, s);
-        SR_HIP(run_finalize_lists((P > 0) ? D : 0, n_tiles, at<uint32_t>(binning, B.tile_keys), at<uint32_t>(binning, B.perm),
-                                  at<uint32_t>(binning, B.vals_unsorted), at<uint32_t>(binning, B.point_list),
-                                  at<uint2>(binning, B.ranges), s));
+        SR_HIP(run_tile_ranges((P > 0) ? D : 0, n_tiles, at<uint32_t>(binning, B.tile_keys), at<uint2>(binning, B.ranges), s));
     }
     if (int rc = debug_sync(frame, s, "tile_ranges")) return rc;
     {
@@ -352,7 +348,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0)
             SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
-                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint32_t>(binning, B.perm), inst_grads, g_opt_cull.load(), s));
+                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint32_t>(geom, L.inst_begin), inst_grads, g_opt_cull.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;
     {

@@ -6,7 +6,9 @@
 // (tile, depth bits, gaussian id).  This build produces the *same list, bit for bit*, with ~1/3 of
 // the HBM traffic by splitting the key:
 //   1. sort the P Gaussians once by their 32-bit depth key (stable => ties keep ascending id);
-//   2. emit duplicates in that order (coalesced, wave-cooperative);
+//   2. emit duplicates in that order (coalesced, wave-cooperative); the duplicates of one Gaussian are
+//      contiguous in this emission order (inst_begin[gid] + (ty - miny) * w + (tx - minx)), which is where
+//      K7 stores the per-duplicate gradient records so that K8 can sum them as one contiguous span;
 //   3. stable-partition the D duplicates by tile id only (ceil(log2(tiles)) bits, 2 radix passes
 //      of 8-byte pairs instead of 6 passes of 12-byte pairs).
 // Stability of both sorts makes (tile, depth, id) the final order.  Integer work only.
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x
                                                               const float4* __restrict__ recs,
                                                               uint32_t* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out,
-                                                              uint32_t* __restrict__ slot_out) {
+                                                              uint32_t* __restrict__ inst_begin) {
     __shared__ uint32_t s_start[4][65];
     __shared__ uint32_t s_gid[4][64];
     __shared__ int s_minx[4][64], s_miny[4][64], s_w[4][64];
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x
         incl = sorted_offsets[P - 1];
     }
     const uint32_t excl = incl - count;
+    if (r < P) inst_begin[gid] = excl;  // emission index of this Gaussian's first duplicate (K7 derives the others)
     s_start[wave][lane] = excl;
     if (lane == 63) s_start[wave][64] = incl;
     s_gid[wave][lane] = gid; s_minx[wave][lane] = minx; s_miny[wave][lane] = miny; s_w[wave][lane] = w;
@@ -82,19 +85,13 @@ __global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x
         const int dy = (int)(local / (uint32_t)ww), dx = (int)(local - (uint32_t)dy * (uint32_t)ww);
         keys_out[slot] = (uint32_t)((s_miny[wave][lo] + dy) * tiles_x + s_minx[wave][lo] + dx);
         vals_out[slot] = s_gid[wave][lo];
-        slot_out[slot] = slot;  // emission index, carried through the tile sort as the value
     }
 }
 
-// K5: tile ranges from the sorted tile keys; also resolves the sorted permutation:
-//   point_list[pos] = gaussian id of the duplicate at sorted position pos  (perm[pos] = its emission index,
-//   kept for K7: gradient records are stored in emission order, where a Gaussian's duplicates are contiguous).
-__global__ void finalize_lists_kernel(uint32_t D, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ perm,
-                                      const uint32_t* __restrict__ vals_unsorted, uint32_t* __restrict__ point_list,
-                                      uint2* __restrict__ ranges) {
+// K5: tile ranges from the sorted tile keys.
+__global__ void tile_ranges_kernel(uint32_t D, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
-    point_list[j] = vals_unsorted[perm[j]];
     const uint32_t t = tile_keys[j];
     if (j == 0) ranges[t].x = 0;
     else {
@@ -153,27 +150,25 @@ hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* ti
 }
 
 hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
-                    const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* slots_unsorted,
+                    const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* inst_begin,
                     hipStream_t s) {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(emit_duplicates_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, tiles_x, tiles_y, sorted_gid,
-                       sorted_offsets, recs, keys_unsorted, vals_unsorted, slots_unsorted);
+                       sorted_offsets, recs, keys_unsorted, vals_unsorted, inst_begin);
     return hipGetLastError();
 }
 
-hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* slots_unsorted,
-                         uint32_t* tile_keys, uint32_t* perm, void* temp, size_t temp_bytes, hipStream_t s) {
+hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
+                         uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s) {
     if (D == 0) return hipSuccess;
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_unsorted, tile_keys, slots_unsorted, perm, D, 0,
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_unsorted, tile_keys, vals_unsorted, point_list, D, 0,
                                               bits_for((uint32_t)n_tiles), s);
 }
 
-hipError_t run_finalize_lists(uint32_t D, int n_tiles, const uint32_t* tile_keys, const uint32_t* perm,
-                              const uint32_t* vals_unsorted, uint32_t* point_list, uint2* ranges, hipStream_t s) {
+hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s) {
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
     if (e != hipSuccess || D == 0) return e;
-    hipLaunchKernelGGL(finalize_lists_kernel, dim3((D + 255) / 256), dim3(256), 0, s, D, tile_keys, perm, vals_unsorted,
-                       point_list, ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((D + 255) / 256), dim3(256), 0, s, D, tile_keys, ranges);
     return hipGetLastError();
 }
 

@@ -150,6 +150,17 @@ __device__ __forceinline__ bool intersect(float xl, float yl, const float4 e0, c
     return (ppz != 0.f) & !(h.depth < kNear) & !(power > 0.f) & !(h.alpha < kAlphaFloor);
 }
 
+// Emission index of the duplicate (tile tx,ty ; Gaussian gid): duplicates are emitted per Gaussian, y-major /
+// x-minor over its tile rectangle (same expressions as K1 / K3 -> same rectangle).
+__device__ __forceinline__ uint32_t emission_index(const float4 (&q)[kRecQuads], uint32_t first, int tx, int ty, int tiles_x, int tiles_y) {
+    const float cx = q[2].y, cy = q[2].z, radius = q[4].w;
+    int minx = (int)((cx - radius) / (float)kTile), miny = (int)((cy - radius) / (float)kTile);
+    int maxx = (int)((cx + radius + (float)(kTile - 1)) / (float)kTile);
+    minx = min(tiles_x, max(0, minx)); maxx = min(tiles_x, max(0, maxx));
+    miny = min(tiles_y, max(0, miny));
+    return first + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+}
+
 __device__ __forceinline__ void load_record(const float4* __restrict__ recs, uint32_t gid, float4 (&q)[kRecQuads]) {
     const float4* r = recs + (size_t)gid * kRecQuads;
 #pragma unroll
@@ -307,7 +318,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 // K7
 // ---------------------------------------------------------------------------------------------
 // Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
-// (inst_grads[perm[pos]]), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
+// (inst_begin[gid] + its index inside the Gaussian's tile rectangle), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
 // entries no pixel reached are written as zeros.  Gradient record slots: see common.h.
 __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                  const uint32_t* __restrict__ point_list,
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                                                                  const uint32_t* __restrict__ n_contrib,
                                                                  const float* __restrict__ dL_dcolor,
                                                                  const float* __restrict__ dL_dallmap,
-                                                                 const uint32_t* __restrict__ perm,
+                                                                 const uint32_t* __restrict__ inst_begin,
                                                                  float4* __restrict__ inst_grads, int cull) {
     __shared__ float4 s_e[kFwdQuads][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGradFloats];
@@ -365,7 +376,10 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
     {
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t e = total + lane; e < count; e += kWave) {
-            float4* o = inst_grads + (size_t)perm[range.x + e] * kGradQuads;
+            const uint32_t gid = point_list[range.x + e];
+            float4 q[kRecQuads];
+            load_record(recs, gid, q);
+            float4* o = inst_grads + (size_t)emission_index(q, inst_begin[gid], tile % f.tiles_x, tile / f.tiles_x, f.tiles_x, f.tiles_y) * kGradQuads;
 #pragma unroll
             for (int k = 0; k < kGradQuads; ++k) o[k] = zero;
         }
@@ -373,14 +387,19 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
 
     const int rounds = (int)((total + kWave - 1) / kWave);
     float4 nr[kRecQuads];
-    if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total)
-        load_record(recs, point_list[range.x + (rounds - 1) * kWave + lane], nr);
+    uint32_t nfirst = 0;
+    if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
+        const uint32_t gid = point_list[range.x + (rounds - 1) * kWave + lane];
+        load_record(recs, gid, nr);
+        nfirst = inst_begin[gid];
+    }
     for (int rd = rounds - 1; rd >= 0; --rd) {
         const uint32_t rbase = (uint32_t)rd * kWave;
         const uint32_t n = min((uint32_t)kWave, total - rbase);
-        uint32_t m = 0;
+        uint32_t m = 0, slot = 0;
         if ((uint32_t)lane < n) {
             m = stage_entry<kFwdQuads>(nr, Xc, Yc, cull & 1, s_e, lane);
+            slot = emission_index(nr, nfirst, tile % f.tiles_x, tile / f.tiles_x, f.tiles_x, f.tiles_y);
             uint32_t need = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
@@ -391,7 +410,11 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
 #pragma unroll
             for (int k = 0; k < kGradQuads; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (rd > 0) load_record(recs, point_list[range.x + rbase - kWave + lane], nr);  // next round is always full
+        if (rd > 0) {  // next round is always full
+            const uint32_t gid = point_list[range.x + rbase - kWave + lane];
+            load_record(recs, gid, nr);
+            nfirst = inst_begin[gid];
+        }
         unsigned long long bits = __ballot(m != 0);
         while (bits) {
             const int j = 63 - __clzll((long long)bits);
@@ -460,7 +483,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         // flush this round's records: one 96-B store per lane (zeros where nothing contributed)
         if ((uint32_t)lane < n && !(cull & 16)) {
             const float4* acc = reinterpret_cast<const float4*>(&s_out[lane][0]);
-            float4* o = inst_grads + (size_t)perm[range.x + rbase + lane] * kGradQuads;
+            float4* o = inst_grads + (size_t)slot * kGradQuads;
 #pragma unroll
             for (int k = 0; k < kGradQuads; ++k) o[k] = acc[k];
         }
@@ -492,11 +515,11 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint32_t* perm, float4* inst_grads, int cull, hipStream_t s) {
+                                  const float* dL_dallmap, const uint32_t* inst_begin, float4* inst_grads, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(render_backward_kernel, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, final_T,
-                       n_contrib, dL_dcolor, dL_dallmap, perm, inst_grads, cull);
+                       n_contrib, dL_dcolor, dL_dallmap, inst_begin, inst_grads, cull);
     return hipGetLastError();
 }
 
