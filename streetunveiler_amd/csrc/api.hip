@@ -32,10 +32,10 @@ hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted,
 hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
-                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, int cull, hipStream_t s);
+                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint8_t* hit_mask, int cull, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint32_t* inst_begin, float4* inst_grads, int cull, hipStream_t s);
+                                  const float* dL_dallmap, const uint32_t* inst_begin, const uint8_t* hit_mask, float4* inst_grads, int cull, hipStream_t s);
 hipError_t read_render_stats(unsigned long long* out8, bool reset);
 }  // namespace sr
 
@@ -133,7 +133,7 @@ GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t keys_unsorted, vals_unsorted, tile_keys, point_list, ranges, temp, temp_bytes, total;
+    size_t keys_unsorted, vals_unsorted, tile_keys, point_list, hit_mask, ranges, temp, temp_bytes, total;
 };
 BinLayout bin_layout(uint32_t D, int W, int H) {
     BinLayout L{};
@@ -145,6 +145,7 @@ BinLayout bin_layout(uint32_t D, int W, int H) {
     L.vals_unsorted = take(n * 4);
     L.tile_keys = take(n * 4);
     L.point_list = take(n * 4);
+    L.hit_mask = take(n);
     L.ranges = take((size_t)(tiles > 0 ? tiles : 1) * 8);
     static thread_local uint32_t memo_D = 0xFFFFFFFFu;
     static thread_local int memo_tiles = -1;
@@ -317,7 +318,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), recs, out_color,
-                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), g_opt_cull.load(), s));
+                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint8_t>(binning, B.hit_mask), g_opt_cull.load(), s));
     }
     return debug_sync(frame, s, "render_forward");
 }
@@ -348,7 +349,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0)
             SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
-                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint32_t>(geom, L.inst_begin), inst_grads, g_opt_cull.load(), s));
+                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint32_t>(geom, L.inst_begin), at<uint8_t>(binning, B.hit_mask), inst_grads, g_opt_cull.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;
     {

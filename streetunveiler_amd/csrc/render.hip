@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                                                                 const float4* __restrict__ recs,
                                                                 float* __restrict__ out_color, float* __restrict__ out_allmap,
                                                                 float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                                int cull) {
+                                                                uint8_t* __restrict__ hit_mask, int cull) {
     __shared__ float4 s_e[kFwdQuads][kWave];
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
         if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
         unsigned long long bits = __ballot((m & alive) != 0);
         if (kStats && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
+        unsigned long long hit[4] = {0ull, 0ull, 0ull, 0ull};  // scalar: bit j of hit[q] = entry j reached a pixel of quadrant q
         while (bits) {
             const int j = __ffsll((long long)bits) - 1;
             bits &= bits - 1;
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                     if (lane == 0) { atomicAdd(&g_stats[2], 1ull); if (vb) atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)__popcll(vb)); }
                 }
                 if (__ballot(valid) == 0) continue;
+                hit[q] |= 1ull << j;
                 const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                 if (valid) {
                     const float test_T = T[q] * (1.f - h.alpha);
@@ -250,6 +252,13 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                 }
                 if (__ballot(!done[q]) == 0) alive &= ~(1u << q);
             }
+        }
+        // exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel here
+        if ((uint32_t)lane < n) {
+            uint32_t hm = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
+            hit_mask[range.x + base + lane] = (uint8_t)hm;
         }
     }
     const size_t HW = (size_t)f.H * f.W;
@@ -328,6 +337,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                                                                  const float* __restrict__ dL_dcolor,
                                                                  const float* __restrict__ dL_dallmap,
                                                                  const uint32_t* __restrict__ inst_begin,
+                                                                 const uint8_t* __restrict__ hit_mask,
                                                                  float4* __restrict__ inst_grads, int cull) {
     __shared__ float4 s_e[kFwdQuads][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGradFloats];
@@ -387,18 +397,21 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
 
     const int rounds = (int)((total + kWave - 1) / kWave);
     float4 nr[kRecQuads];
-    uint32_t nfirst = 0;
+    uint32_t nfirst = 0, nhit = 0;
     if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
-        const uint32_t gid = point_list[range.x + (rounds - 1) * kWave + lane];
+        const uint32_t pos = range.x + (rounds - 1) * kWave + lane;
+        const uint32_t gid = point_list[pos];
         load_record(recs, gid, nr);
         nfirst = inst_begin[gid];
+        nhit = hit_mask[pos];
     }
     for (int rd = rounds - 1; rd >= 0; --rd) {
         const uint32_t rbase = (uint32_t)rd * kWave;
         const uint32_t n = min((uint32_t)kWave, total - rbase);
         uint32_t m = 0, slot = 0;
         if ((uint32_t)lane < n) {
-            m = stage_entry<kFwdQuads>(nr, Xc, Yc, cull & 1, s_e, lane);
+            (void)stage_entry<kFwdQuads>(nr, Xc, Yc, 0, s_e, lane);
+            m = nhit;   // (entry, quadrant) pairs that reached a pixel in the forward: exact, no culling test needed here
             slot = emission_index(nr, nfirst, tile % f.tiles_x, tile / f.tiles_x, f.tiles_x, f.tiles_y);
             uint32_t need = 0;
 #pragma unroll
@@ -411,9 +424,11 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             for (int k = 0; k < kGradQuads; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (rd > 0) {  // next round is always full
-            const uint32_t gid = point_list[range.x + rbase - kWave + lane];
+            const uint32_t pos = range.x + rbase - kWave + lane;
+            const uint32_t gid = point_list[pos];
             load_record(recs, gid, nr);
             nfirst = inst_begin[gid];
+            nhit = hit_mask[pos];
         }
         unsigned long long bits = __ballot(m != 0);
         while (bits) {
@@ -501,25 +516,25 @@ hipError_t read_render_stats(unsigned long long* out8, bool reset) {
 
 // launchers ---------------------------------------------------------------------------------------
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
-                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, int cull, hipStream_t s) {
+                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint8_t* hit_mask, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     if (cull & 2)
         hipLaunchKernelGGL(render_forward_kernel<true>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, out_color,
-                           out_allmap, final_T, n_contrib, cull);
+                           out_allmap, final_T, n_contrib, hit_mask, cull);
     else
         hipLaunchKernelGGL(render_forward_kernel<false>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, out_color,
-                           out_allmap, final_T, n_contrib, cull);
+                           out_allmap, final_T, n_contrib, hit_mask, cull);
     return hipGetLastError();
 }
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint32_t* inst_begin, float4* inst_grads, int cull, hipStream_t s) {
+                                  const float* dL_dallmap, const uint32_t* inst_begin, const uint8_t* hit_mask, float4* inst_grads, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(render_backward_kernel, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, final_T,
-                       n_contrib, dL_dcolor, dL_dallmap, inst_begin, inst_grads, cull);
+                       n_contrib, dL_dcolor, dL_dallmap, inst_begin, hit_mask, inst_grads, cull);
     return hipGetLastError();
 }
 
