@@ -94,7 +94,8 @@ def assert_close_frac(a, b, atol, rtol, max_bad_frac, hard, name=""):
     bad = err > (atol + rtol * np.abs(b))
     frac = bad.mean() if bad.size else 0.0
     assert frac <= max_bad_frac, f"{name}: {frac:.3e} of elements off by more than tol (max err {err.max():.3e})"
-    assert (err <= hard * max(1.0, np.abs(b).max())).all(), f"{name}: max err {err.max():.3e} exceeds hard bound"
+    if hard is not None:
+        assert (err <= hard * max(1.0, np.abs(b).max())).all(), f"{name}: max err {err.max():.3e} exceeds hard bound"
 
 
 def assert_grads_close(got, ref, rel, name="", max_bad_frac=1e-3, hard=5e-2):
@@ -108,3 +109,13 @@ def assert_grads_close(got, ref, rel, name="", max_bad_frac=1e-3, hard=5e-2):
     bad = (err > rel).mean() if err.size else 0.0
     assert bad <= max_bad_frac, f"{name}: {bad:.2e} of elements off by more than {rel} of scale {scale:.3e} (max rel err {err.max():.2e})"
     assert err.max() <= hard, f"{name}: max rel err {err.max():.2e} exceeds hard bound {hard}"
+
+
+def check_allmap(got, ref, tag, max_bad_frac=5e-4):
+    """allmap parity: channels 0-4 and 6 are sums (a flipped contributor moves them by <= 1/255-ish of the scale);
+    channel 5 (median depth) is a SELECTION -- the depth of the last contributor with T > 0.5 -- so a pixel whose T
+    crosses 0.5 within float noise legitimately jumps to another splat's depth: it only gets the fraction criterion."""
+    got = np.asarray(got); ref = np.asarray(ref)
+    keep = [0, 1, 2, 3, 4, 6]
+    assert_close_frac(got[keep], ref[keep], 1e-4, 1e-4, max_bad_frac, 2e-2, tag + " allmap[sums]")
+    assert_close_frac(got[5], ref[5], 1e-4, 1e-4, max_bad_frac, None, tag + " allmap[median depth]")

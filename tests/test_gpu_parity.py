@@ -54,7 +54,8 @@ def _check_images(out, fwd, tag):
     from tests.gpu_util import assert_close_frac
     assert_close_frac(out["color"], fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, tag + " color")
     # allmap: depth-like channels are O(10), use rtol too
-    assert_close_frac(out["allmap"], fwd["allmap"], 1e-4, 1e-4, 5e-4, 2e-2, tag + " allmap")
+    from tests.gpu_util import check_allmap
+    check_allmap(out["allmap"], fwd["allmap"], tag)
 
 
 def _check_grads(out, bwd, names, tag, rel=2e-3):
