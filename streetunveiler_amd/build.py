@@ -22,6 +22,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-a
 SOURCES = [
     ("preprocess.hip", ["-ffp-contract=off"]),  # op order is part of the bit-exact contract with the oracle
     ("binning.hip", []),
+    ("radix_sort.hip", []),
     ("render.hip", []),
     ("api.hip", []),
 ]

@@ -12,22 +12,17 @@
 //   3. stable-partition the D duplicates by tile id only (ceil(log2(tiles)) bits, 2 radix passes
 //      of 8-byte pairs instead of 6 passes of 12-byte pairs).
 // Stability of both sorts makes (tile, depth, id) the final order.  Integer work only.
-#include <hipcub/hipcub.hpp>
-
 #include "common.h"
 
 namespace sr {
 
-__global__ void iota_kernel(int n, uint32_t* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (uint32_t)i;
-}
-
-__global__ void gather_u32_kernel(int n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src,
-                                  uint32_t* __restrict__ dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[idx[i]];
-}
+// radix_sort.hip
+size_t radix_sort_temp_bytes(uint32_t n);
+hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s);
+size_t gather_scan_temp_bytes(uint32_t n);
+hipError_t gather_inclusive_scan(const uint32_t* idx, const uint32_t* src, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes,
+                                 hipStream_t s);
 
 // K3: wave-cooperative duplicate emission.  Each wave owns 64 consecutive depth ranks; the lanes
 // then walk the wave's contiguous output span 64 slots at a time (coalesced 4-B stores), finding the
@@ -107,46 +102,29 @@ static int bits_for(uint32_t n) {  // number of bits needed to represent values 
     return b < 1 ? 1 : b;
 }
 
-// temp-storage sizes ------------------------------------------------------------------------------
+// temp-storage sizes (pure host arithmetic) --------------------------------------------------------
 size_t depth_sort_temp_bytes(int P) {
-    size_t a = 0, b = 0;
-    uint32_t* p = nullptr;
-    hipError_t e1 = hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, P > 0 ? P : 1, 0, 32, (hipStream_t)0);
-    hipError_t e2 = hipcub::DeviceScan::InclusiveSum(nullptr, b, p, p, P > 0 ? P : 1, (hipStream_t)0);
-    if (e1 != hipSuccess || e2 != hipSuccess) {  // no device visible (CPU-only build box): conservative bound
-        (void)hipGetLastError();
-        a = (size_t)(P > 0 ? P : 1) * 16 + (4u << 20);
-        b = 0;
-    }
+    const uint32_t n = (uint32_t)(P > 0 ? P : 1);
+    const size_t a = radix_sort_temp_bytes(n), b = gather_scan_temp_bytes(n);
     return align_up(a > b ? a : b, 256);
 }
 
 size_t tile_sort_temp_bytes(uint32_t D, int n_tiles) {
-    size_t a = 0;
-    uint32_t* p = nullptr;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, D > 0 ? D : 1, 0, bits_for((uint32_t)n_tiles),
-                                                      (hipStream_t)0);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        a = (size_t)(D > 0 ? D : 1) * 16 + (4u << 20);
-    }
-    return align_up(a, 256);
+    (void)n_tiles;
+    return align_up(radix_sort_temp_bytes(D > 0 ? D : 1), 256);
 }
 
 // launchers ---------------------------------------------------------------------------------------
 hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* iota,
                            uint32_t* sorted_keys, uint32_t* sorted_gid, uint32_t* tt_sorted, uint32_t* sorted_offsets,
                            void* temp, size_t temp_bytes, hipStream_t s, hipEvent_t ev_sorted) {
+    (void)iota; (void)tt_sorted;
     if (P == 0) return hipSuccess;
-    const int nb = (P + 255) / 256;
-    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, s, P, iota);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, depth_keys, sorted_keys, iota, sorted_gid, P, 0, 32, s);
+    // stable sort of (depth key, gaussian id): ties keep ascending id; culled Gaussians (key 0xFFFFFFFF) end up last
+    hipError_t e = radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s);
     if (e != hipSuccess) return e;
     if (ev_sorted) (void)hipEventRecord(ev_sorted, s);
-    hipLaunchKernelGGL(gather_u32_kernel, dim3(nb), dim3(256), 0, s, P, sorted_gid, tiles_touched, tt_sorted);
-    e = hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, tt_sorted, sorted_offsets, P, s);
-    if (e != hipSuccess) return e;
-    return hipGetLastError();
+    return gather_inclusive_scan(sorted_gid, tiles_touched, sorted_offsets, (uint32_t)P, temp, temp_bytes, s);
 }
 
 hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
@@ -161,8 +139,7 @@ hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid,
 hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
                          uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s) {
     if (D == 0) return hipSuccess;
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_unsorted, tile_keys, vals_unsorted, point_list, D, 0,
-                                              bits_for((uint32_t)n_tiles), s);
+    return radix_sort_pairs(keys_unsorted, vals_unsorted, tile_keys, point_list, D, bits_for((uint32_t)n_tiles), temp, temp_bytes, s);
 }
 
 hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s) {

@@ -1,0 +1,306 @@
+// radix_sort.hip -- hand-written stable LSD radix sort of (u32 key, u32 value) pairs for gfx950 (wave64).
+//
+// Used twice per frame: (1) order the P Gaussians by their 32-bit depth key (4 passes x 8 bits; the value of
+// the first pass is the implicit index), (2) stable-partition the D duplicates by tile id
+// (ceil(log2 tiles) bits in 2 passes).  Stability is what makes the final list equal to the reference's
+// 64-bit (tile | depth) sort (binning.hip).
+//
+// One pass = histogram -> two tiny scans -> scatter.  A 256-thread block owns 2048 consecutive items; each
+// wave owns 512 of them and ranks them 64 at a time with the wave64 match-any idiom: `bits` ballots build,
+// for every lane, the mask of lanes holding the same digit; rank = popcount(mask & lanes_below), the run
+// base lives in LDS per (wave, digit).  No atomics on global memory, integer work only, no MFMA.
+#include "common.h"
+
+namespace sr {
+
+constexpr int kRsThreads = 256;
+constexpr int kRsItems = 8;                       // per thread
+constexpr int kRsTile = kRsThreads * kRsItems;    // 2048 items per block
+constexpr int kRsMaxBins = 256;
+
+__global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, int bits,
+                                                             uint32_t* __restrict__ hist, int nblocks) {
+    __shared__ uint32_t s_h[kRsMaxBins];
+    const int tid = threadIdx.x, bins = 1 << bits;
+    const uint32_t mask = (uint32_t)bins - 1u;
+    if (tid < bins) s_h[tid] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)kRsTile;
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+        const uint32_t idx = base + (uint32_t)(i * kRsThreads + tid);
+        if (idx < n) atomicAdd(&s_h[(keys[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    if (tid < bins) hist[(size_t)tid * nblocks + blockIdx.x] = s_h[tid];   // bin-major: row b = per-block counts of digit b
+}
+
+// Exclusive scan of every row (one block per digit), row totals out.
+__global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __restrict__ hist, int nblocks, uint32_t* __restrict__ row_total) {
+    __shared__ uint32_t s_w[kRsThreads / 64];
+    __shared__ uint32_t s_carry;
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int c = 0; c < nblocks; c += kRsThreads) {
+        const int i = c + tid;
+        const uint32_t x = i < nblocks ? row[i] : 0u;
+        uint32_t incl = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int k = 0; k < w; ++k) wbase += s_w[k];
+        const uint32_t carry = s_carry;
+        if (i < nblocks) row[i] = carry + wbase + incl - x;
+        __syncthreads();
+        if (tid == kRsThreads - 1) s_carry = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (tid == 0) row_total[blockIdx.x] = s_carry;
+}
+
+// Exclusive scan of the (<= 256) row totals -> first output position of every digit.
+__global__ __launch_bounds__(kRsMaxBins) void rs_scan_bins_kernel(const uint32_t* __restrict__ row_total, int bins, uint32_t* __restrict__ bin_base) {
+    __shared__ uint32_t s[kRsMaxBins];
+    const int tid = threadIdx.x;
+    s[tid] = tid < bins ? row_total[tid] : 0u;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < bins; ++b) { const uint32_t c = s[b]; s[b] = run; run += c; }
+    }
+    __syncthreads();
+    if (tid < bins) bin_base[tid] = s[tid];
+}
+
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                uint32_t n, int shift, int bits, const uint32_t* __restrict__ hist,
+                                                                const uint32_t* __restrict__ bin_base, int nblocks) {
+    __shared__ uint32_t s_count[kRsThreads / 64][kRsMaxBins];  // items of digit b held by wave w
+    __shared__ uint32_t s_run[kRsThreads / 64][kRsMaxBins];    // next block-local slot for (wave, digit)
+    __shared__ uint32_t s_lstart[kRsMaxBins];                  // block-local start of digit b
+    __shared__ uint32_t s_gbase[kRsMaxBins];                   // global position of the block's first item of digit b
+    __shared__ uint32_t s_wsum[kRsThreads / 64];
+    __shared__ uint32_t s_key[kRsTile], s_val[kRsTile];        // the tile, stably reordered by digit
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, bins = 1 << bits;
+    const uint32_t mask = (uint32_t)bins - 1u;
+    for (int b = tid; b < (kRsThreads / 64) * kRsMaxBins; b += kRsThreads) (&s_count[0][0])[b] = 0;
+    __syncthreads();
+    // wave w owns items [wbase, wbase + 512), 64 at a time in order -> stable
+    const uint32_t tile_base = blockIdx.x * (uint32_t)kRsTile;
+    const uint32_t wbase = tile_base + (uint32_t)w * (64 * kRsItems);
+    uint32_t key[kRsItems], val[kRsItems];
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+        const uint32_t idx = wbase + (uint32_t)(i * 64 + lane);
+        key[i] = 0; val[i] = 0;
+        if (idx < n) {
+            key[i] = keys_in[idx];
+            val[i] = vals_in ? vals_in[idx] : idx;   // first pass of an index sort: the value is the position itself
+            atomicAdd(&s_count[w][(key[i] >> shift) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    // block-local exclusive scan over digits (thread t <-> digit t), then per-wave run starts
+    {
+        uint32_t tot = 0;
+        if (tid < bins) {
+#pragma unroll
+            for (int k = 0; k < kRsThreads / 64; ++k) tot += s_count[k][tid];
+        }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) s_wsum[w] = incl;
+        __syncthreads();
+        uint32_t off = incl - tot;
+        for (int k = 0; k < w; ++k) off += s_wsum[k];
+        if (tid < bins) {
+            s_lstart[tid] = off;
+            s_gbase[tid] = bin_base[tid] + hist[(size_t)tid * nblocks + blockIdx.x];
+            uint32_t run = off;
+#pragma unroll
+            for (int k = 0; k < kRsThreads / 64; ++k) { s_run[k][tid] = run; run += s_count[k][tid]; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+        const uint32_t idx = wbase + (uint32_t)(i * 64 + lane);
+        const bool live = idx < n;
+        const uint32_t d = (key[i] >> shift) & mask;
+        unsigned long long same = __ballot(live);        // lanes holding the same digit as this lane
+        for (int b = 0; b < bits; ++b) {
+            const unsigned long long vote = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? vote : ~vote;
+        }
+        const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        uint32_t pos = 0;
+        if (live) pos = s_run[w][d] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (live && rank == 0) s_run[w][d] += (uint32_t)__popcll(same);  // one leader per digit advances the run
+        __builtin_amdgcn_wave_barrier();
+        if (live) { s_key[pos] = key[i]; s_val[pos] = val[i]; }
+    }
+    __syncthreads();
+    // coalesced write-out: consecutive local slots of one digit are consecutive in global memory
+    const uint32_t count = min((uint32_t)kRsTile, n - tile_base);
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+        const uint32_t li = (uint32_t)(i * kRsThreads + tid);
+        if (li < count) {
+            const uint32_t k = s_key[li];
+            const uint32_t d = (k >> shift) & mask;
+            const uint32_t g = s_gbase[d] + (li - s_lstart[d]);
+            keys_out[g] = k; vals_out[g] = s_val[li];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inclusive scan of gathered values: out[i] = sum_{j<=i} src[idx[j]]  (tile counts in depth order, K2).
+// Three small kernels: per-block scan (2048 items) + block totals, scan of the totals, add-back.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src,
+                                                                 uint32_t n, uint32_t* __restrict__ out, uint32_t* __restrict__ block_total) {
+    __shared__ uint32_t s_w[kRsThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t base = blockIdx.x * (uint32_t)kRsTile + (uint32_t)tid * kRsItems;   // 8 consecutive items per thread
+    uint32_t v[kRsItems], sum = 0;
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+        const uint32_t j = base + i;
+        v[i] = j < n ? src[idx[j]] : 0u;
+        sum += v[i];
+        v[i] = sum;   // inclusive within the thread
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    uint32_t off = incl - sum;
+    for (int k = 0; k < w; ++k) off += s_w[k];
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+        const uint32_t j = base + i;
+        if (j < n) out[j] = off + v[i];
+    }
+    if (tid == kRsThreads - 1) block_total[blockIdx.x] = off + sum;
+}
+
+__global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __restrict__ block_total, int nblocks) {
+    // exclusive scan in place, one block, sequential over chunks of 256
+    __shared__ uint32_t s_w[kRsThreads / 64];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int c = 0; c < nblocks; c += kRsThreads) {
+        const int i = c + tid;
+        const uint32_t x = i < nblocks ? block_total[i] : 0u;
+        uint32_t incl = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t wb = 0;
+        for (int k = 0; k < w; ++k) wb += s_w[k];
+        const uint32_t carry = s_carry;
+        if (i < nblocks) block_total[i] = carry + wb + incl - x;
+        __syncthreads();
+        if (tid == kRsThreads - 1) s_carry = carry + wb + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kRsThreads) void scan_add_kernel(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ block_base) {
+    const uint32_t b = block_base[blockIdx.x];
+    const uint32_t base = blockIdx.x * (uint32_t)kRsTile;
+    if (b == 0) return;
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+        const uint32_t j = base + (uint32_t)(i * kRsThreads + threadIdx.x);
+        if (j < n) out[j] += b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline int rs_blocks(uint32_t n) { return (int)((n + kRsTile - 1) / kRsTile); }
+
+// scratch: ping-pong (keys, vals) + histogram table + row totals + digit bases
+size_t radix_sort_temp_bytes(uint32_t n) {
+    const size_t nb = (size_t)rs_blocks(n > 0 ? n : 1);
+    return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 2 + align_up(nb * kRsMaxBins * 4, 256) + align_up(kRsMaxBins * 4, 256) * 2;
+}
+
+// Sorts by key bits [0, total_bits) in passes of <= 8 bits (as even as possible); stable; result in keys_out/vals_out.
+// vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.
+hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (temp_bytes < radix_sort_temp_bytes(n)) return hipErrorInvalidValue;
+    int passes = (total_bits + 7) / 8;
+    if (passes < 1) passes = 1;
+    if (passes & 1) ++passes;   // even pass count: the ping-pong ends in keys_out/vals_out (an extra pass on zero bits is a stable copy)
+    const int nb = rs_blocks(n);
+    char* t = static_cast<char*>(temp);
+    uint32_t* tk = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)n * 4, 256);
+    uint32_t* tv = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)n * 4, 256);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)nb * kRsMaxBins * 4, 256);
+    uint32_t* row_total = reinterpret_cast<uint32_t*>(t); t += align_up(kRsMaxBins * 4, 256);
+    uint32_t* bin_base = reinterpret_cast<uint32_t*>(t);
+    const uint32_t* ki = keys_in; const uint32_t* vi = vals_in;
+    int shift = 0, left = total_bits;
+    for (int p = 0; p < passes; ++p) {
+        const int remaining_passes = passes - p;
+        int bits = left > 0 ? (left + remaining_passes - 1) / remaining_passes : 1;
+        if (bits > 8) bits = 8;
+        if (bits < 1) bits = 1;
+        uint32_t* ko = (p & 1) ? keys_out : tk;
+        uint32_t* vo = (p & 1) ? vals_out : tv;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
+        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
+        hipLaunchKernelGGL(rs_scan_bins_kernel, dim3(1), dim3(kRsMaxBins), 0, s, row_total, 1 << bits, bin_base);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, bin_base, nb);
+        ki = ko; vi = vo;
+        shift += bits; left -= bits;
+    }
+    return hipGetLastError();
+}
+
+size_t gather_scan_temp_bytes(uint32_t n) { return align_up((size_t)rs_blocks(n > 0 ? n : 1) * 4, 256); }
+
+hipError_t gather_inclusive_scan(const uint32_t* idx, const uint32_t* src, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes,
+                                 hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (temp_bytes < gather_scan_temp_bytes(n)) return hipErrorInvalidValue;
+    const int nb = rs_blocks(n);
+    uint32_t* totals = static_cast<uint32_t*>(temp);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(kRsThreads), 0, s, idx, src, n, out, totals);
+    if (nb > 1) {
+        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kRsThreads), 0, s, totals, nb);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(kRsThreads), 0, s, out, n, totals);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace sr
