@@ -19,7 +19,7 @@ namespace sr {
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s);
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint32_t* aux_src, uint32_t* aux_out);
 size_t gather_scan_temp_bytes(uint32_t n);
 hipError_t gather_inclusive_scan(const uint32_t* idx, const uint32_t* src, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes,
                                  hipStream_t s);
@@ -118,13 +118,15 @@ size_t tile_sort_temp_bytes(uint32_t D, int n_tiles) {
 hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* iota,
                            uint32_t* sorted_keys, uint32_t* sorted_gid, uint32_t* tt_sorted, uint32_t* sorted_offsets,
                            void* temp, size_t temp_bytes, hipStream_t s, hipEvent_t ev_sorted) {
-    (void)iota; (void)tt_sorted;
+    (void)iota;
     if (P == 0) return hipSuccess;
-    // stable sort of (depth key, gaussian id): ties keep ascending id; culled Gaussians (key 0xFFFFFFFF) end up last
-    hipError_t e = radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s);
+    // stable sort of (depth key, gaussian id): ties keep ascending id; culled Gaussians (key 0xFFFFFFFF) end up last.
+    // The last pass also gathers tiles_touched into depth order, so the scan below reads sequentially.
+    hipError_t e = radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, tiles_touched,
+                                    tt_sorted);
     if (e != hipSuccess) return e;
     if (ev_sorted) (void)hipEventRecord(ev_sorted, s);
-    return gather_inclusive_scan(sorted_gid, tiles_touched, sorted_offsets, (uint32_t)P, temp, temp_bytes, s);
+    return gather_inclusive_scan(nullptr, tt_sorted, sorted_offsets, (uint32_t)P, temp, temp_bytes, s);
 }
 
 hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
@@ -139,7 +141,8 @@ hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid,
 hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
                          uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s) {
     if (D == 0) return hipSuccess;
-    return radix_sort_pairs(keys_unsorted, vals_unsorted, tile_keys, point_list, D, bits_for((uint32_t)n_tiles), temp, temp_bytes, s);
+    return radix_sort_pairs(keys_unsorted, vals_unsorted, tile_keys, point_list, D, bits_for((uint32_t)n_tiles), temp, temp_bytes, s, nullptr,
+                            nullptr);
 }
 
 hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s) {

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(kRsMaxBins) void rs_scan_bins_kernel(const uint32_t
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                 uint32_t n, int shift, int bits, const uint32_t* __restrict__ hist,
-                                                                const uint32_t* __restrict__ bin_base, int nblocks) {
+                                                                const uint32_t* __restrict__ bin_base, int nblocks,
+                                                                const uint32_t* __restrict__ aux_src, uint32_t* __restrict__ aux_out) {
     __shared__ uint32_t s_count[kRsThreads / 64][kRsMaxBins];  // items of digit b held by wave w
     __shared__ uint32_t s_run[kRsThreads / 64][kRsMaxBins];    // next block-local slot for (wave, digit)
     __shared__ uint32_t s_lstart[kRsMaxBins];                  // block-local start of digit b
@@ -162,7 +163,9 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
             const uint32_t k = s_key[li];
             const uint32_t d = (k >> shift) & mask;
             const uint32_t g = s_gbase[d] + (li - s_lstart[d]);
-            keys_out[g] = k; vals_out[g] = s_val[li];
+            const uint32_t v = s_val[li];
+            keys_out[g] = k; vals_out[g] = v;
+            if (aux_out) aux_out[g] = aux_src[v];   // last pass: payload gathered in sorted order (aux_out[i] = aux_src[vals_out[i]])
         }
     }
 }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t*
 #pragma unroll
     for (int i = 0; i < kRsItems; ++i) {
         const uint32_t j = base + i;
-        v[i] = j < n ? src[idx[j]] : 0u;
+        v[i] = j < n ? (idx ? src[idx[j]] : src[j]) : 0u;
         sum += v[i];
         v[i] = sum;   // inclusive within the thread
     }
@@ -253,9 +256,10 @@ size_t radix_sort_temp_bytes(uint32_t n) {
 }
 
 // Sorts by key bits [0, total_bits) in passes of <= 8 bits (as even as possible); stable; result in keys_out/vals_out.
-// vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.
+// vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.  If aux_out != nullptr the last pass also
+// writes aux_out[i] = aux_src[vals_out[i]] (a payload gathered in sorted order, for free).
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s) {
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint32_t* aux_src, uint32_t* aux_out) {
     if (n == 0) return hipSuccess;
     if (temp_bytes < radix_sort_temp_bytes(n)) return hipErrorInvalidValue;
     int passes = (total_bits + 7) / 8;
@@ -280,7 +284,9 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
         hipLaunchKernelGGL(rs_scan_bins_kernel, dim3(1), dim3(kRsMaxBins), 0, s, row_total, 1 << bits, bin_base);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, bin_base, nb);
+        const bool last = p == passes - 1;
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, bin_base, nb,
+                           last ? aux_src : nullptr, last ? aux_out : nullptr);
         ki = ko; vi = vo;
         shift += bits; left -= bits;
     }
