@@ -106,7 +106,7 @@ def main():
     rank, world, local_rank = init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())  # (the modulo only matters for the gloo smoke test)
     torch.cuda.set_device(dev)
 
     from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C

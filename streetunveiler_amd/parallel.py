@@ -28,10 +28,13 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SURFEL_DIST_BACKEND=gloo lets the N>1 path be exercised on a box with fewer GPUs than ranks
+            backend = os.environ.get("SURFEL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
+            if local_rank >= torch.cuda.device_count():
+                raise RuntimeError(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs visible (one process per GPU)")
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
