@@ -16,7 +16,7 @@ hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussian
                                       const uint8_t* clamped, const float4* recs, const float4* grecs,
                                       const SrGradients& out, hipStream_t s);
 hipError_t launch_reduce_instance_grads(int P, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
-                                        const float4* inst_grads, float4* grecs, hipStream_t s);
+                                        const float4* inst_grads, float4* grecs, uint32_t tag_lo, uint32_t tag_hi, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 // binning.hip
 size_t depth_sort_temp_bytes(int P);
@@ -25,8 +25,7 @@ hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* ti
                            uint32_t* sorted_keys, uint32_t* sorted_gid, uint32_t* tt_sorted, uint32_t* sorted_offsets,
                            void* temp, size_t temp_bytes, hipStream_t s, hipEvent_t ev_sorted);
 hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
-                    const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* inst_begin,
-                    hipStream_t s);
+                    float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, hipStream_t s);
 hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
                          uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s);
@@ -35,7 +34,7 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
                                  float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint8_t* hit_mask, int cull, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint32_t* inst_begin, const uint8_t* hit_mask, float4* inst_grads, int cull, hipStream_t s);
+                                  const float* dL_dallmap, const uint8_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi, int cull, hipStream_t s);
 hipError_t read_render_stats(unsigned long long* out8, bool reset);
 }  // namespace sr
 
@@ -106,7 +105,7 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
 
 // ---- buffer layouts ------------------------------------------------------------------------------
 struct GeomLayout {
-    size_t recs, depth_keys, tiles_touched, clamped, iota, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, inst_begin, temp, temp_bytes, total;
+    size_t recs, depth_keys, tiles_touched, clamped, iota, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, temp, temp_bytes, total;
 };
 GeomLayout geom_layout(int P) {
     GeomLayout L{};
@@ -122,7 +121,6 @@ GeomLayout geom_layout(int P) {
     L.sorted_gid = take(n * 4);
     L.tt_sorted = take(n * 4);
     L.sorted_offsets = take(n * 4);
-    L.inst_begin = take(n * 4);
     static thread_local int memo_P = -1;
     static thread_local size_t memo_bytes = 0;
     if (memo_P != P) { memo_bytes = depth_sort_temp_bytes(P); memo_P = P; }
@@ -289,7 +287,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     hipStream_t s = static_cast<hipStream_t>(stream);
     const FrameDev f = make_frame(frame, g);
     const int n_tiles = f.tiles_x * f.tiles_y;
-    const float4* recs = nullptr;
+    float4* recs = nullptr;
     if (P > 0 && D > 0) {
         if (!geom) return fail(SR_ERR_INVALID_ARGUMENT, "geom is NULL");
         const GeomLayout L = geom_layout(P);
@@ -298,8 +296,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
         {
             StageTimer t(SR_STAGE_EMIT, s);
             SR_HIP(run_emit(P, f.tiles_x, f.tiles_y, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), recs,
-                            at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
-                            at<uint32_t>(geom, L.inst_begin), s));
+                            at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted), s));
         }
         if (int rc = debug_sync(frame, s, "emit_duplicates")) return rc;
         {
@@ -345,17 +342,23 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
     // of the D records is written by K7.  Then one reduced record per Gaussian.
     float4* inst_grads = static_cast<float4*>(workspace);
     float4* grecs = at<float4>(workspace, align_up((size_t)(D > 0 ? D : 1) * kGradFloats * 4, 256));
+    // K7 only writes the records of list entries some pixel reached; each written record carries this call's 64-bit
+    // tag in its two padding slots and K8a ignores records without it (stale workspace contents) -- no zero-fill pass.
+    static std::atomic<uint64_t> s_call{0x9E3779B97F4A7C15ull};
+    uint64_t z = s_call.fetch_add(0x9E3779B97F4A7C15ull) ^ (uint64_t)(uintptr_t)workspace;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    const uint32_t tag_lo = (uint32_t)z | 1u, tag_hi = (uint32_t)(z >> 32) | 0x80000000u;
     {
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0)
             SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
-                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint32_t>(geom, L.inst_begin), at<uint8_t>(binning, B.hit_mask), inst_grads, g_opt_cull.load(), s));
+                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint8_t>(binning, B.hit_mask), inst_grads, tag_lo, tag_hi, g_opt_cull.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;
     {
         StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
         SR_HIP(launch_reduce_instance_grads(P, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), inst_grads,
-                                            grecs, s));
+                                            grecs, tag_lo, tag_hi, s));
         SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), grecs, *grads, s));
     }
     return debug_sync(frame, s, "preprocess_backward");

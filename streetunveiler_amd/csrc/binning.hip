@@ -7,7 +7,7 @@
 // the HBM traffic by splitting the key:
 //   1. sort the P Gaussians once by their 32-bit depth key (stable => ties keep ascending id);
 //   2. emit duplicates in that order (coalesced, wave-cooperative); the duplicates of one Gaussian are
-//      contiguous in this emission order (inst_begin[gid] + (ty - miny) * w + (tx - minx)), which is where
+//      contiguous in this emission order (first[gid] + (ty - miny) * w + (tx - minx)), which is where
 //      K7 stores the per-duplicate gradient records so that K8 can sum them as one contiguous span;
 //   3. stable-partition the D duplicates by tile id only (ceil(log2(tiles)) bits, 2 radix passes
 //      of 8-byte pairs instead of 6 passes of 12-byte pairs).
@@ -30,10 +30,9 @@ hipError_t gather_inclusive_scan(const uint32_t* idx, const uint32_t* src, uint3
 __global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x, int tiles_y,
                                                               const uint32_t* __restrict__ sorted_gid,
                                                               const uint32_t* __restrict__ sorted_offsets,
-                                                              const float4* __restrict__ recs,
+                                                              float4* __restrict__ recs,
                                                               uint32_t* __restrict__ keys_out,
-                                                              uint32_t* __restrict__ vals_out,
-                                                              uint32_t* __restrict__ inst_begin) {
+                                                              uint32_t* __restrict__ vals_out) {
     __shared__ uint32_t s_start[4][65];
     __shared__ uint32_t s_gid[4][64];
     __shared__ int s_minx[4][64], s_miny[4][64], s_w[4][64];
@@ -63,7 +62,9 @@ __global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x
         incl = sorted_offsets[P - 1];
     }
     const uint32_t excl = incl - count;
-    if (r < P) inst_begin[gid] = excl;  // emission index of this Gaussian's first duplicate (K7 derives the others)
+    // emission index of this Gaussian's first duplicate, parked in slot 15 of its record (K7 derives the others and gets
+    // it for free with the record gather)
+    if (r < P && count) reinterpret_cast<float*>(recs)[(size_t)gid * kRecFloats + 15] = __uint_as_float(excl);
     s_start[wave][lane] = excl;
     if (lane == 63) s_start[wave][64] = incl;
     s_gid[wave][lane] = gid; s_minx[wave][lane] = minx; s_miny[wave][lane] = miny; s_w[wave][lane] = w;
@@ -130,11 +131,10 @@ hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* ti
 }
 
 hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
-                    const float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* inst_begin,
-                    hipStream_t s) {
+                    float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, hipStream_t s) {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(emit_duplicates_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, tiles_x, tiles_y, sorted_gid,
-                       sorted_offsets, recs, keys_unsorted, vals_unsorted, inst_begin);
+                       sorted_offsets, recs, keys_unsorted, vals_unsorted);
     return hipGetLastError();
 }
 

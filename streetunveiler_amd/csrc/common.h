@@ -21,7 +21,8 @@ constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
 
 // Packed per-Gaussian record, 5 x float4 = 80 B, 16-B aligned (one gather = five dwordx4 loads):
 //   q0 = Tu.x Tu.y Tu.z Tv.x | q1 = Tv.y Tv.z Tw.x Tw.y | q2 = Tw.z xy.x xy.y opacity
-//   q3 = n.x n.y n.z depth   | q4 = r g b radius
+//   q3 = n.x n.y n.z first   | q4 = r g b radius      (first = emission index of the Gaussian's first duplicate, u32 bits,
+//                                                        written by K3; K1 leaves the view-space depth there)
 constexpr int kRecQuads = 5;
 constexpr int kRecFloats = SR_SPLAT_FLOATS;
 

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
 __global__ __launch_bounds__(256) void reduce_instance_grads_kernel(int P, const uint32_t* __restrict__ sorted_gid,
                                                                     const uint32_t* __restrict__ sorted_offsets,
                                                                     const float4* __restrict__ inst_grads,
-                                                                    float4* __restrict__ grecs) {
+                                                                    float4* __restrict__ grecs, uint32_t tag_lo, uint32_t tag_hi) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P) return;
     const uint32_t end = sorted_offsets[r];
@@ -293,11 +293,13 @@ __global__ __launch_bounds__(256) void reduce_instance_grads_kernel(int P, const
     for (int k = 0; k < kGradQuads; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (uint32_t e = begin; e < end; ++e) {
         const float4* gr = inst_grads + (size_t)e * kGradQuads;
+        float4 a[kGradQuads];
 #pragma unroll
-        for (int k = 0; k < kGradQuads; ++k) {
-            const float4 a = gr[k];
-            g[k].x += a.x; g[k].y += a.y; g[k].z += a.z; g[k].w += a.w;
-        }
+        for (int k = 0; k < kGradQuads; ++k) a[k] = gr[k];
+        // records K7 did not write this call (entry behind every pixel's last contributor) carry no / a stale tag
+        if (__float_as_uint(a[5].z) != tag_lo || __float_as_uint(a[5].w) != tag_hi) continue;
+#pragma unroll
+        for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[k].x; g[k].y += a[k].y; g[k].z += a[k].z; g[k].w += a[k].w; }
     }
     float4* o = grecs + (size_t)sorted_gid[r] * kGradQuads;
 #pragma unroll
@@ -473,10 +475,10 @@ hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians
 }
 
 hipError_t launch_reduce_instance_grads(int P, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
-                                        const float4* inst_grads, float4* grecs, hipStream_t s) {
+                                        const float4* inst_grads, float4* grecs, uint32_t tag_lo, uint32_t tag_hi, hipStream_t s) {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(reduce_instance_grads_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, sorted_gid, sorted_offsets,
-                       inst_grads, grecs);
+                       inst_grads, grecs, tag_lo, tag_hi);
     return hipGetLastError();
 }
 

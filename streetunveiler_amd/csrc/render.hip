@@ -347,8 +347,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 // K7
 // ---------------------------------------------------------------------------------------------
 // Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
-// (inst_begin[gid] + its index inside the Gaussian's tile rectangle), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
-// entries no pixel reached are written as zeros.  Gradient record slots: see common.h.
+// (first[gid] + its index inside the Gaussian's tile rectangle; first[gid] rides in slot 15 of the splat record), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
+// entries no pixel reached are not written; written records carry the call's tag.  Gradient record slots: see common.h.
 __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                  const uint32_t* __restrict__ point_list,
                                                                  const float4* __restrict__ recs,
@@ -356,9 +356,9 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                                                                  const uint32_t* __restrict__ n_contrib,
                                                                  const float* __restrict__ dL_dcolor,
                                                                  const float* __restrict__ dL_dallmap,
-                                                                 const uint32_t* __restrict__ inst_begin,
                                                                  const uint8_t* __restrict__ hit_mask,
-                                                                 float4* __restrict__ inst_grads, int cull) {
+                                                                 float4* __restrict__ inst_grads, uint32_t tag_lo, uint32_t tag_hi,
+                                                                 int cull) {
     __shared__ float4 s_e[kFwdQuads][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGradFloats];
     const int lane = threadIdx.x;
@@ -402,27 +402,15 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         total = max(total, quad_last[q]);
     }
 
-    // entries behind the deepest contributor of the tile: zero records
-    {
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t e = total + lane; e < count; e += kWave) {
-            const uint32_t gid = point_list[range.x + e];
-            float4 q[kRecQuads];
-            load_record(recs, gid, q);
-            float4* o = inst_grads + (size_t)emission_index(q, inst_begin[gid], tile % f.tiles_x, tile / f.tiles_x, f.tiles_x, f.tiles_y) * kGradQuads;
-#pragma unroll
-            for (int k = 0; k < kGradQuads; ++k) o[k] = zero;
-        }
-    }
-
+    // entries behind the deepest contributor of the tile get no record at all: K8a recognises the records written in
+    // this call by their tag
     const int rounds = (int)((total + kWave - 1) / kWave);
     float4 nr[kRecQuads];
-    uint32_t nfirst = 0, nhit = 0;
+    uint32_t nhit = 0;
     if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
         const uint32_t pos = range.x + (rounds - 1) * kWave + lane;
         const uint32_t gid = point_list[pos];
         load_record(recs, gid, nr);
-        nfirst = inst_begin[gid];
         nhit = hit_mask[pos];
     }
     for (int rd = rounds - 1; rd >= 0; --rd) {
@@ -432,7 +420,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         if ((uint32_t)lane < n) {
             (void)stage_entry<kFwdQuads>(nr, Xc, Yc, 0, s_e, lane);
             m = nhit;   // (entry, quadrant) pairs that reached a pixel in the forward: exact, no culling test needed here
-            slot = emission_index(nr, nfirst, tile % f.tiles_x, tile / f.tiles_x, f.tiles_x, f.tiles_y);
+            slot = emission_index(nr, __float_as_uint(nr[3].w), tile % f.tiles_x, tile / f.tiles_x, f.tiles_x, f.tiles_y);
             uint32_t need = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
@@ -447,7 +435,6 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             const uint32_t pos = range.x + rbase - kWave + lane;
             const uint32_t gid = point_list[pos];
             load_record(recs, gid, nr);
-            nfirst = inst_begin[gid];
             nhit = hit_mask[pos];
         }
         unsigned long long bits = __ballot(m != 0);
@@ -517,7 +504,9 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             const float4* acc = reinterpret_cast<const float4*>(&s_out[lane][0]);
             float4* o = inst_grads + (size_t)slot * kGradQuads;
 #pragma unroll
-            for (int k = 0; k < kGradQuads; ++k) o[k] = acc[k];
+            for (int k = 0; k < kGradQuads - 1; ++k) o[k] = acc[k];
+            const float4 last = acc[kGradQuads - 1];
+            o[kGradQuads - 1] = make_float4(last.x, last.y, __uint_as_float(tag_lo), __uint_as_float(tag_hi));
         }
     }
 }
@@ -547,11 +536,11 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint32_t* inst_begin, const uint8_t* hit_mask, float4* inst_grads, int cull, hipStream_t s) {
+                                  const float* dL_dallmap, const uint8_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(render_backward_kernel, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, final_T,
-                       n_contrib, dL_dcolor, dL_dallmap, inst_begin, hit_mask, inst_grads, cull);
+                       n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, tag_lo, tag_hi, cull);
     return hipGetLastError();
 }
 
