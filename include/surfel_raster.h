@@ -145,7 +145,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
 
 /* Backward (K7 blend backward + K8 preprocess backward).  dL_dcolor [3,H,W], dL_dallmap [7,H,W].
  * workspace: sr_backward_workspace_bytes(P, num_rendered) bytes (one 96-B gradient record per (tile, Gaussian)
- * duplicate plus one per Gaussian), contents undefined on entry. */
+ * duplicate), contents undefined on entry. */
 int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
                 void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
                 const float* dL_dcolor, const float* dL_dallmap, void* workspace, size_t workspace_bytes,

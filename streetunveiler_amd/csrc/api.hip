@@ -13,10 +13,9 @@ namespace sr {
 hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians& g, float4* recs, uint32_t* depth_keys,
                                      uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii, hipStream_t s);
 hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
-                                      const uint8_t* clamped, const float4* recs, const float4* grecs,
-                                      const SrGradients& out, hipStream_t s);
-hipError_t launch_reduce_instance_grads(int P, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
-                                        const float4* inst_grads, float4* grecs, uint32_t tag_lo, uint32_t tag_hi, hipStream_t s);
+                                      const uint8_t* clamped, const float4* recs, const float4* inst_grads,
+                                      const uint32_t* tiles_touched, uint32_t tag_lo, uint32_t tag_hi, const SrGradients& out,
+                                      hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 // binning.hip
 size_t depth_sort_temp_bytes(int P);
@@ -207,9 +206,8 @@ size_t sr_geom_bytes(int32_t P) { return geom_layout(P).total; }
 size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t W, int32_t H) { (void)P; return bin_layout(num_rendered, W, H).total; }
 size_t sr_image_bytes(int32_t W, int32_t H) { return img_layout(W, H).total; }
 size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered) {
-    // D per-(tile, Gaussian) gradient records + P reduced per-Gaussian records, 96 B each
-    return align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * kGradFloats * 4, 256) +
-           align_up((size_t)(P > 0 ? P : 1) * kGradFloats * 4, 256);
+    (void)P;  // one 96-B gradient record per (tile, Gaussian) duplicate
+    return align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * kGradFloats * 4, 256);
 }
 
 int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out) {
@@ -338,10 +336,8 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
     if (workspace_bytes < sr_backward_workspace_bytes(P, D)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P, D));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const FrameDev f = make_frame(frame, g);
-    // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous); every one
-    // of the D records is written by K7.  Then one reduced record per Gaussian.
+    // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous)
     float4* inst_grads = static_cast<float4*>(workspace);
-    float4* grecs = at<float4>(workspace, align_up((size_t)(D > 0 ? D : 1) * kGradFloats * 4, 256));
     // K7 only writes the records of list entries some pixel reached; each written record carries this call's 64-bit
     // tag in its two padding slots and K8a ignores records without it (stale workspace contents) -- no zero-fill pass.
     static std::atomic<uint64_t> s_call{0x9E3779B97F4A7C15ull};
@@ -357,9 +353,8 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;
     {
         StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
-        SR_HIP(launch_reduce_instance_grads(P, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), inst_grads,
-                                            grecs, tag_lo, tag_hi, s));
-        SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), grecs, *grads, s));
+        SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), inst_grads,
+                                          at<uint32_t>(geom, L.tiles_touched), tag_lo, tag_hi, *grads, s));
     }
     return debug_sync(frame, s, "preprocess_backward");
 }

@@ -275,46 +275,18 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// K8a: sum the per-(tile, Gaussian) gradient records of each Gaussian.  K7 stores them in emission order,
-// where the records of depth-rank r are the contiguous span [offsets[r-1], offsets[r]); consecutive ranks
-// own consecutive spans, so a wave streams one contiguous region.  Ascending order -> deterministic sums.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_instance_grads_kernel(int P, const uint32_t* __restrict__ sorted_gid,
-                                                                    const uint32_t* __restrict__ sorted_offsets,
-                                                                    const float4* __restrict__ inst_grads,
-                                                                    float4* __restrict__ grecs, uint32_t tag_lo, uint32_t tag_hi) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P) return;
-    const uint32_t end = sorted_offsets[r];
-    const uint32_t begin = r > 0 ? sorted_offsets[r - 1] : 0u;
-    if (end == begin) return;  // culled / no tiles: K8b never reads its record
-    float4 g[kGradQuads];
-#pragma unroll
-    for (int k = 0; k < kGradQuads; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t e = begin; e < end; ++e) {
-        const float4* gr = inst_grads + (size_t)e * kGradQuads;
-        float4 a[kGradQuads];
-#pragma unroll
-        for (int k = 0; k < kGradQuads; ++k) a[k] = gr[k];
-        // records K7 did not write this call (entry behind every pixel's last contributor) carry no / a stale tag
-        if (__float_as_uint(a[5].z) != tag_lo || __float_as_uint(a[5].w) != tag_hi) continue;
-#pragma unroll
-        for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[k].x; g[k].y += a[k].y; g[k].z += a[k].z; g[k].w += a[k].w; }
-    }
-    float4* o = grecs + (size_t)sorted_gid[r] * kGradQuads;
-#pragma unroll
-    for (int k = 0; k < kGradQuads; ++k) o[k] = g[k];
-}
-
-// ---------------------------------------------------------------------------------------------
-// K8b: per-Gaussian chain rule (Appendix A.6)
+// K8: per-Gaussian backward (Appendix A.6).  First sums the Gaussian's per-(tile, Gaussian) gradient records: K7 stores
+// them in emission order, where they form the contiguous span [first, first + tiles_touched) (first rides in slot 15 of
+// the splat record); ascending order -> deterministic.  Records without this call's tag were not written by K7 (entry
+// behind every pixel's last contributor) and are skipped.
 // ---------------------------------------------------------------------------------------------
 template <bool kLdsSH>
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float4* __restrict__ recs,
-    const float4* __restrict__ grecs, SrGradients out) {
+    const float4* __restrict__ inst_grads, const uint32_t* __restrict__ tiles_touched, uint32_t tag_lo, uint32_t tag_hi,
+    SrGradients out) {
     __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
     const int tid = threadIdx.x, base = blockIdx.x * 256;
     const int i = base + tid;
@@ -331,9 +303,24 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
         float* row = s_sh + tid * kShLdsStride;
         if (vis) {
             const float4* rec = recs + (size_t)i * kRecQuads;
-            const float4* gr = grecs + (size_t)i * kGradQuads;
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4], g5 = gr[5];
+            float4 g0, g1, g2, g3, g4, g5;
+            {
+                float4 g[kGradQuads];
+#pragma unroll
+                for (int k = 0; k < kGradQuads; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const uint32_t first = __float_as_uint(rec[3].w), cnt = tiles_touched[i];
+                for (uint32_t e = first; e < first + cnt; ++e) {
+                    const float4* gr = inst_grads + (size_t)e * kGradQuads;
+                    float4 a[kGradQuads];
+#pragma unroll
+                    for (int k = 0; k < kGradQuads; ++k) a[k] = gr[k];
+                    if (__float_as_uint(a[5].z) != tag_lo || __float_as_uint(a[5].w) != tag_hi) continue;
+#pragma unroll
+                    for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[k].x; g[k].y += a[k].y; g[k].z += a[k].z; g[k].w += a[k].w; }
+                }
+                g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3]; g4 = g[4]; g5 = g[5];
+            }
             const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
             // moments -> dL/dT (see common.h): dTu = Tv x S0 - Tw x Sy, dTv = S0 x Tu - Sx x Tw, dTw = Tu x Sy - Tv x Sx + Z
             {
@@ -474,25 +461,18 @@ hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_instance_grads(int P, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
-                                        const float4* inst_grads, float4* grecs, uint32_t tag_lo, uint32_t tag_hi, hipStream_t s) {
-    if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(reduce_instance_grads_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, sorted_gid, sorted_offsets,
-                       inst_grads, grecs, tag_lo, tag_hi);
-    return hipGetLastError();
-}
-
 hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
-                                      const uint8_t* clamped, const float4* recs, const float4* grecs,
-                                      const SrGradients& out, hipStream_t s) {
+                                      const uint8_t* clamped, const float4* recs, const float4* inst_grads,
+                                      const uint32_t* tiles_touched, uint32_t tag_lo, uint32_t tag_hi, const SrGradients& out,
+                                      hipStream_t s) {
     if (P == 0) return hipSuccess;
     const dim3 grid((P + 255) / 256), block(256);
     if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs) && (!out.dL_dsh || aligned16(out.dL_dsh)))
         hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
-                           g.transMat_precomp, radii, clamped, recs, grecs, out);
+                           g.transMat_precomp, radii, clamped, recs, inst_grads, tiles_touched, tag_lo, tag_hi, out);
     else
         hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
-                           g.transMat_precomp, radii, clamped, recs, grecs, out);
+                           g.transMat_precomp, radii, clamped, recs, inst_grads, tiles_touched, tag_lo, tag_hi, out);
     return hipGetLastError();
 }
 
