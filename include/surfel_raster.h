@@ -166,6 +166,12 @@ int sr_set_option(int option, int value);
  * [4] contributing (pixel, entry) pairs.  Synchronises the device.  out8: 8 host uint64. */
 int sr_debug_stats(unsigned long long* out8, int reset);
 
+/* Test hook for the library's stable LSD radix sort (binning K2/K4): sorts n (key, value) u32 pairs by key bits
+ * [0, total_bits); vals_in == NULL means value = index.  temp: sr_debug_radix_sort_temp_bytes(n) bytes. */
+size_t sr_debug_radix_sort_temp_bytes(uint32_t n);
+int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
+                        int total_bits, void* temp, size_t temp_bytes, void* stream);
+
 /* Profiling aid.  sr_set_stage_timing(1) makes every later call from this thread bracket each stage with a
  * pair of HIP events recorded on the caller's stream (no host sync while recording; up to 512 launches per
  * stage).  sr_stage_stats() waits for the recorded events and returns the summed duration (ms) and the

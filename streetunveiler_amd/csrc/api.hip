@@ -35,6 +35,10 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
                                   const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                   const float* dL_dallmap, const uint8_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi, int cull, hipStream_t s);
 hipError_t read_render_stats(unsigned long long* out8, bool reset);
+// radix_sort.hip
+size_t radix_sort_temp_bytes(uint32_t n);
+hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint32_t* aux_src, uint32_t* aux_out);
 }  // namespace sr
 
 using namespace sr;
@@ -376,6 +380,17 @@ int sr_set_option(int option, int value) {
         case 100: g_opt_cull.store((g_opt_cull.load() & 0xF) | ((value & 0xF) << 4)); return SR_OK;  // undocumented: K7 ablation bits (timing experiments only; results are wrong)
         default: return fail(SR_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
+}
+
+size_t sr_debug_radix_sort_temp_bytes(uint32_t n) { return radix_sort_temp_bytes(n); }
+
+int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
+                        int total_bits, void* temp, size_t temp_bytes, void* stream) {
+    if (n > 0 && (!keys_in || !keys_out || !vals_out || !temp)) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (total_bits < 1 || total_bits > 32) return fail(SR_ERR_INVALID_ARGUMENT, "total_bits %d not in 1..32", total_bits);
+    if (temp_bytes < radix_sort_temp_bytes(n)) return fail(SR_ERR_BUFFER_TOO_SMALL, "temp %zu < %zu", temp_bytes, radix_sort_temp_bytes(n));
+    SR_HIP(radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, total_bits, temp, temp_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr));
+    return SR_OK;
 }
 
 int sr_debug_stats(unsigned long long* out8, int reset) {

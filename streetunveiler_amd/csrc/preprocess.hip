@@ -313,9 +313,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
                 for (uint32_t e = first; e < first + cnt; ++e) {
                     const float4* gr = inst_grads + (size_t)e * kGradQuads;
                     float4 a[kGradQuads];
-#pragma unroll
-                    for (int k = 0; k < kGradQuads; ++k) a[k] = gr[k];
+                    a[5] = gr[5];   // tag first: 35 % of the records (entries no pixel reached) are never written, skip their other 80 B
                     if (__float_as_uint(a[5].z) != tag_lo || __float_as_uint(a[5].w) != tag_hi) continue;
+#pragma unroll
+                    for (int k = 0; k < kGradQuads - 1; ++k) a[k] = gr[k];
 #pragma unroll
                     for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[k].x; g[k].y += a[k].y; g[k].z += a[k].z; g[k].w += a[k].w; }
                 }
