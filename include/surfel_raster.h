@@ -155,6 +155,19 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
 int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     uint8_t* present, void* stream);
 
+/* Fused post-processing of the operator's allmap == gaussian_renderer/__init__.py:152-177 +
+ * utils/point_utils.py:9-37 of the reference: allmap[7,H,W] -> rend_normal[3,H,W] (world space), surf_depth[1,H,W],
+ * surf_normal[3,H,W] (finite-difference pseudo-normals times alpha, zero border), surf_point[3,H,W].
+ * fovx/fovy in radians, viewmatrix = world_view_transform (device [16]).  Backward: gradient w.r.t. allmap from the
+ * gradients of the four outputs (NULL = zero); scratch6 is [6,H,W] floats of caller-owned scratch; channel 6 of
+ * g_allmap is written as 0 and alpha is treated as detached inside surf_normal, as in the reference. */
+int sr_postprocess_forward(int32_t image_width, int32_t image_height, float fovx, float fovy, float depth_ratio,
+                           const float* viewmatrix, const float* allmap, float* rend_normal, float* surf_depth,
+                           float* surf_normal, float* surf_point, void* stream);
+int sr_postprocess_backward(int32_t image_width, int32_t image_height, float fovx, float fovy, float depth_ratio,
+                            const float* viewmatrix, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,
+                            const float* g_surf_normal, const float* g_surf_point, float* scratch6, float* g_allmap, void* stream);
+
 /* Process-wide tuning switches (results are identical for every setting; they exist for A/B timing and for
  * the test that proves the culling is exact).
  *   SR_OPT_QUADRANT_CULL (default 1): drop list entries that provably cannot reach alpha >= 1/255 inside a

@@ -24,6 +24,7 @@ SOURCES = [
     ("binning.hip", []),
     ("radix_sort.hip", []),
     ("render.hip", []),
+    ("postprocess.hip", []),
     ("api.hip", []),
 ]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "surfel_raster.h")]

@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <atomic>
 #include <mutex>
 
@@ -39,6 +40,13 @@ hipError_t read_render_stats(unsigned long long* out8, bool reset);
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint32_t* aux_src, uint32_t* aux_out);
+// postprocess.hip
+struct PostCam { int W, H; float fx, fy, depth_ratio; const float* view; };
+hipError_t launch_postprocess_forward(const PostCam& cam, const float* allmap, float* rend_normal, float* surf_depth,
+                                      float* surf_normal, float* surf_point, hipStream_t s);
+hipError_t launch_postprocess_backward(const PostCam& cam, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,
+                                       const float* g_surf_normal, const float* g_surf_point, float* scratch6, float* g_allmap,
+                                       hipStream_t s);
 }  // namespace sr
 
 using namespace sr;
@@ -370,6 +378,35 @@ int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, co
     if (P == 0) return SR_OK;
     if (!means3D || !viewmatrix || !present) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     SR_HIP(launch_mark_visible(P, means3D, viewmatrix, present, static_cast<hipStream_t>(stream)));
+    return SR_OK;
+}
+
+static int post_cam(int32_t W, int32_t H, float fovx, float fovy, float depth_ratio, const float* viewmatrix, PostCam* cam) {
+    if (W <= 0 || H <= 0 || !viewmatrix) return fail(SR_ERR_INVALID_ARGUMENT, "bad image size / NULL viewmatrix");
+    cam->W = W; cam->H = H;
+    cam->fx = (float)W / (2.f * tanf(fovx * 0.5f)); cam->fy = (float)H / (2.f * tanf(fovy * 0.5f));
+    cam->depth_ratio = depth_ratio; cam->view = viewmatrix;
+    return SR_OK;
+}
+
+int sr_postprocess_forward(int32_t W, int32_t H, float fovx, float fovy, float depth_ratio, const float* viewmatrix,
+                           const float* allmap, float* rend_normal, float* surf_depth, float* surf_normal, float* surf_point,
+                           void* stream) {
+    PostCam cam;
+    if (int rc = post_cam(W, H, fovx, fovy, depth_ratio, viewmatrix, &cam)) return rc;
+    if (!allmap || !rend_normal || !surf_depth || !surf_normal || !surf_point) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    SR_HIP(launch_postprocess_forward(cam, allmap, rend_normal, surf_depth, surf_normal, surf_point, static_cast<hipStream_t>(stream)));
+    return SR_OK;
+}
+
+int sr_postprocess_backward(int32_t W, int32_t H, float fovx, float fovy, float depth_ratio, const float* viewmatrix,
+                            const float* allmap, const float* g_rend_normal, const float* g_surf_depth, const float* g_surf_normal,
+                            const float* g_surf_point, float* scratch6, float* g_allmap, void* stream) {
+    PostCam cam;
+    if (int rc = post_cam(W, H, fovx, fovy, depth_ratio, viewmatrix, &cam)) return rc;
+    if (!allmap || !scratch6 || !g_allmap) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    SR_HIP(launch_postprocess_backward(cam, allmap, g_rend_normal, g_surf_depth, g_surf_normal, g_surf_point, scratch6, g_allmap,
+                                       static_cast<hipStream_t>(stream)));
     return SR_OK;
 }
 

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle.postprocess_torch import postprocess_allmap as postprocess_allmap_torch
 from streetunveiler_amd.gaussian_renderer import (PipelineParams, SurfelModel, postprocess_allmap, render, render_semantic,
                                                   render_semantic_with_mask, render_with_mask)
 from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians
@@ -52,7 +53,7 @@ def test_render_dict_and_backward_through_regularisers():
     # the same post-processing applied to the oracle's allmap (CPU, with autograd for dL/dallmap)
     am = torch.tensor(fwd["allmap"], requires_grad=True)
     col = torch.tensor(fwd["color"], requires_grad=True)
-    ref = postprocess_allmap(cam, pipe, am)
+    ref = postprocess_allmap_torch(cam, pipe.depth_ratio, am)
     for k in ["rend_alpha", "rend_normal", "rend_dist", "surf_depth"]:
         assert_close_frac(out[k].detach().cpu().numpy(), ref[k].detach().numpy(), 1e-4, 1e-4, 1e-3, 5e-2, k)
 
@@ -122,3 +123,31 @@ def test_render_semantic_six_classes():
     m = torch.rand(P, generator=torch.Generator().manual_seed(2)) > 0.5
     out2 = render_semantic_with_mask(cam.to(DEV), pc, PipelineParams(), torch.zeros(3, device=DEV), m.to(DEV))
     assert out2["render_semantics"].shape == (6, H, W)
+
+
+def test_fused_postprocess_matches_torch_restatement():
+    """csrc/postprocess.hip forward + backward against the plain-torch restatement (float64 on the CPU)."""
+    W, H = 200, 120
+    cam = synthetic_camera(W, H, index=6)
+    g = torch.Generator().manual_seed(4)
+    allmap = torch.rand(7, H, W, generator=g)
+    allmap[0] = allmap[0] * 20 + 1; allmap[5] = allmap[5] * 20 + 1
+    allmap[1] = allmap[1] * 0.98 + 0.01
+    allmap[:, :5, :9] = 0.0                       # empty pixels: alpha == 0, 0/0 -> nan_to_num -> 0
+    grads = {k: torch.randn(c, H, W, generator=g) for k, c in [("rend_normal", 3), ("surf_depth", 1), ("surf_normal", 3), ("surf_point", 3)]}
+    for ratio in (0.0, 1.0, 0.4):
+        a64 = allmap.double().requires_grad_()
+        ref = postprocess_allmap_torch(cam, ratio, a64)
+        sum((ref[k] * grads[k].double()).sum() for k in grads).backward()
+        a_gpu = allmap.to(DEV).requires_grad_()
+        out = postprocess_allmap(cam.to(DEV), PipelineParams(depth_ratio=ratio), a_gpu)
+        sum((out[k] * grads[k].to(DEV)).sum() for k in grads).backward()
+        for k in ["rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "surf_point"]:
+            np.testing.assert_allclose(out[k].detach().cpu().numpy(), ref[k].detach().numpy(), rtol=2e-4, atol=2e-4, err_msg=k)
+        gref = torch.nan_to_num(a64.grad, 0.0, 0.0, 0.0).numpy()   # torch gives NaN (0 * inf) at alpha == 0; the kernel gives 0
+        ggpu = a_gpu.grad.cpu().numpy()
+        assert np.isfinite(ggpu).all()
+        scale = np.abs(gref).max()
+        assert np.abs(ggpu - gref).max() <= 2e-4 * scale, np.abs(ggpu - gref).max() / scale
+    with pytest.raises(Exception, match="no CPU path"):
+        postprocess_allmap(cam, PipelineParams(), allmap)

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from streetunveiler_amd.gaussian_renderer import PipelineParams, depth_to_normal, postprocess_allmap
+from oracle.postprocess_torch import postprocess_allmap
 from streetunveiler_amd.sh import RGB2SH, SH2RGB, eval_sh
 from streetunveiler_amd.synthetic import synthetic_camera
 
@@ -24,7 +24,8 @@ def test_python_sh_fallback_matches_reference(golden_dir):
 
 
 def test_postprocess_allmap_against_direct_numpy():
-    """postprocess_allmap restates gaussian_renderer/__init__.py:148-186 + utils/point_utils.py:9-37."""
+    """oracle.postprocess_torch restates gaussian_renderer/__init__.py:148-186 + utils/point_utils.py:9-37
+    (the checker of the fused HIP post-processing); here it is checked against an independent numpy transcription."""
     W, H = 40, 24
     cam = synthetic_camera(W, H, index=2)
     g = torch.Generator().manual_seed(0)
@@ -32,7 +33,7 @@ def test_postprocess_allmap_against_direct_numpy():
     allmap[1, :3] = 0.0              # alpha == 0 rows -> 0/0 -> nan_to_num -> 0
     allmap[0] = allmap[0] * 10 + 1
     for ratio in (0.0, 1.0, 0.3):
-        out = postprocess_allmap(cam, PipelineParams(depth_ratio=ratio), allmap.clone())
+        out = postprocess_allmap(cam, ratio, allmap.clone())
         a = allmap.numpy().astype(np.float64)
         alpha = a[1:2]
         with np.errstate(divide="ignore", invalid="ignore"):
