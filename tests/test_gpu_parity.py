@@ -222,3 +222,42 @@ def test_radix_sort_stability_and_edges():
             np.testing.assert_array_equal(ko.cpu().numpy().view(np.uint32), keys[order])
             expect_v = order.astype(np.uint32) if vals is None else vals[order]
             np.testing.assert_array_equal(vo.cpu().numpy().view(np.uint32), expect_v)
+
+
+def test_sh_layout_fallbacks_and_scale_modifier():
+    """Paths the bench never takes: SH tensors with M != 16 or a 4-byte-aligned base (no LDS row staging), SH degree 2,
+    and scale_modifier != 1 (forward honours it; the backward keeps upstream's modifier-free scale gradient, A.6)."""
+    import math
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import surfel_oracle as so
+    from tests.gpu_util import DEV, assert_close_frac, assert_grads_close
+    P, W, H = 3000, 160, 96
+    cam, g = _scene(P, W, H, 17, 4e-3, 5e-2, 3)
+    bg = np.array([0.1, 0.0, 0.2], np.float32)
+    dc, da = synthetic_upstream_grads(W, H, seed=9)
+    for (M, deg, misalign, modifier) in [(4, 1, False, 1.0), (9, 2, False, 1.0), (16, 2, True, 1.0), (16, 3, False, 0.7)]:
+        shs_cpu = g["shs"][:, :M].contiguous()
+        fwd = so.rasterize_forward(g["means3D"].numpy(), g["opacities"].numpy(), g["scales"].numpy(), g["rotations"].numpy(), shs=shs_cpu.numpy(),
+                                   viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
+                                   campos=cam.camera_center.numpy(), bg=bg, image_width=W, image_height=H, sh_degree=deg, scale_modifier=modifier)
+        bwd = so.rasterize_backward(fwd, dc.numpy(), da.numpy())
+        if misalign:   # a view that starts 4 bytes into its storage: contiguous but not 16-byte aligned
+            buf = torch.zeros(P * M * 3 + 1, device=DEV)
+            shs = buf[1:].view(P, M, 3)
+            shs.copy_(shs_cpu.to(DEV))
+            assert shs.data_ptr() % 16 != 0
+            shs.requires_grad_()
+        else:
+            shs = shs_cpu.to(DEV).requires_grad_()
+        t = {k: g[k].to(DEV).requires_grad_() for k in ["means3D", "opacities", "scales", "rotations"]}
+        s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.tensor(bg).to(DEV), modifier,
+                                          cam.world_view_transform.to(DEV), cam.full_proj_transform.to(DEV), deg, cam.camera_center.to(DEV), False, False)
+        m2d = torch.zeros(P, 3, device=DEV, requires_grad=True)
+        color, radii, allmap = GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2d, shs=shs, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+        torch.autograd.backward([color, allmap], [dc.to(DEV), da.to(DEV)])
+        tag = f"M{M} deg{deg} misalign{misalign} mod{modifier}"
+        np.testing.assert_array_equal(radii.cpu().numpy(), fwd["radii"], err_msg=tag)
+        assert_close_frac(color.detach().cpu().numpy(), fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, tag)
+        for name, got in [("dL_dmeans3D", t["means3D"].grad), ("dL_dopacity", t["opacities"].grad), ("dL_dscales", t["scales"].grad),
+                          ("dL_drotations", t["rotations"].grad), ("dL_dsh", shs.grad), ("dL_dmeans2D", m2d.grad)]:
+            assert_grads_close(got.cpu().numpy(), bwd[name], 2e-3, tag + " " + name)
