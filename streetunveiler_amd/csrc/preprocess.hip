@@ -310,15 +310,22 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
 #pragma unroll
                 for (int k = 0; k < kGradQuads; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 const uint32_t first = __float_as_uint(rec[3].w), cnt = tiles_touched[i];
-                for (uint32_t e = first; e < first + cnt; ++e) {
-                    const float4* gr = inst_grads + (size_t)e * kGradQuads;
-                    float4 a[kGradQuads];
-                    a[5] = gr[5];   // tag first: 35 % of the records (entries no pixel reached) are never written, skip their other 80 B
-                    if (__float_as_uint(a[5].z) != tag_lo || __float_as_uint(a[5].w) != tag_hi) continue;
+                // two records per trip, all loads issued before any use; untagged records (entries no pixel reached: never
+                // written by K7) are masked out branch-free so the next trip's loads are not held back
+                for (uint32_t e = first; e < first + cnt; e += 2) {
+                    const bool two = e + 1 < first + cnt;
+                    const float4* gr0 = inst_grads + (size_t)e * kGradQuads;
+                    const float4* gr1 = gr0 + (two ? kGradQuads : 0);
+                    float4 a[kGradQuads], b[kGradQuads];
 #pragma unroll
-                    for (int k = 0; k < kGradQuads - 1; ++k) a[k] = gr[k];
+                    for (int k = 0; k < kGradQuads; ++k) { a[k] = gr0[k]; b[k] = gr1[k]; }
+                    const bool oka = __float_as_uint(a[5].z) == tag_lo && __float_as_uint(a[5].w) == tag_hi;
+                    const bool okb = two && __float_as_uint(b[5].z) == tag_lo && __float_as_uint(b[5].w) == tag_hi;
 #pragma unroll
-                    for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[k].x; g[k].y += a[k].y; g[k].z += a[k].z; g[k].w += a[k].w; }
+                    for (int k = 0; k < kGradQuads; ++k) {
+                        if (oka) { g[k].x += a[k].x; g[k].y += a[k].y; g[k].z += a[k].z; g[k].w += a[k].w; }
+                        if (okb) { g[k].x += b[k].x; g[k].y += b[k].y; g[k].z += b[k].z; g[k].w += b[k].w; }
+                    }
                 }
                 g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3]; g4 = g[4]; g5 = g[5];
             }
