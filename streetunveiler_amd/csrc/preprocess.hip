@@ -310,21 +310,26 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
 #pragma unroll
                 for (int k = 0; k < kGradQuads; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 const uint32_t first = __float_as_uint(rec[3].w), cnt = tiles_touched[i];
-                // two records per trip, all loads issued before any use; untagged records (entries no pixel reached: never
+                // four records per trip, all loads issued before any use; untagged records (entries no pixel reached: never
                 // written by K7) are masked out branch-free so the next trip's loads are not held back
-                for (uint32_t e = first; e < first + cnt; e += 2) {
-                    const bool two = e + 1 < first + cnt;
-                    const float4* gr0 = inst_grads + (size_t)e * kGradQuads;
-                    const float4* gr1 = gr0 + (two ? kGradQuads : 0);
-                    float4 a[kGradQuads], b[kGradQuads];
+                constexpr int kTrip = 4;
+                for (uint32_t e = first; e < first + cnt; e += kTrip) {
+                    float4 a[kTrip][kGradQuads];
+                    bool ok[kTrip];
 #pragma unroll
-                    for (int k = 0; k < kGradQuads; ++k) { a[k] = gr0[k]; b[k] = gr1[k]; }
-                    const bool oka = __float_as_uint(a[5].z) == tag_lo && __float_as_uint(a[5].w) == tag_hi;
-                    const bool okb = two && __float_as_uint(b[5].z) == tag_lo && __float_as_uint(b[5].w) == tag_hi;
+                    for (int t = 0; t < kTrip; ++t) {
+                        const bool in = e + t < first + cnt;
+                        const float4* gr = inst_grads + (size_t)(in ? e + t : e) * kGradQuads;
 #pragma unroll
-                    for (int k = 0; k < kGradQuads; ++k) {
-                        if (oka) { g[k].x += a[k].x; g[k].y += a[k].y; g[k].z += a[k].z; g[k].w += a[k].w; }
-                        if (okb) { g[k].x += b[k].x; g[k].y += b[k].y; g[k].z += b[k].z; g[k].w += b[k].w; }
+                        for (int k = 0; k < kGradQuads; ++k) a[t][k] = gr[k];
+                        ok[t] = in;
+                    }
+#pragma unroll
+                    for (int t = 0; t < kTrip; ++t) {
+                        if (ok[t] && __float_as_uint(a[t][5].z) == tag_lo && __float_as_uint(a[t][5].w) == tag_hi) {
+#pragma unroll
+                            for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[t][k].x; g[k].y += a[t][k].y; g[k].z += a[t][k].z; g[k].w += a[t][k].w; }
+                        }
                     }
                 }
                 g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3]; g4 = g[4]; g5 = g[5];
