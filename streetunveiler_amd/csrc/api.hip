@@ -21,9 +21,9 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* view, u
 // binning.hip
 size_t depth_sort_temp_bytes(int P);
 size_t tile_sort_temp_bytes(uint32_t D, int n_tiles);
-hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* iota,
-                           uint32_t* sorted_keys, uint32_t* sorted_gid, uint32_t* tt_sorted, uint32_t* sorted_offsets,
-                           void* temp, size_t temp_bytes, hipStream_t s, hipEvent_t ev_sorted);
+hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* sorted_keys,
+                          uint32_t* sorted_gid, uint32_t* tt_sorted, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t run_tile_count_scan(int P, const uint32_t* tt_sorted, uint32_t* sorted_offsets, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
                     float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, hipStream_t s);
 hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
@@ -56,7 +56,8 @@ namespace {
 thread_local char g_err[512] = "";
 // timing state is process-wide: autograd runs the backward on its own thread
 std::atomic<int> g_timing{0};
-std::atomic<int> g_opt_cull{1};  // SR_OPT_QUADRANT_CULL
+// bit 0 SR_OPT_QUADRANT_CULL, bit 1 SR_OPT_DEBUG_STATS, bits 4..7 K7 ablation switches (option 100, timing experiments only)
+std::atomic<int> g_options{1};
 std::mutex g_ring_mu;
 
 int fail(int code, const char* fmt, ...) {
@@ -116,7 +117,7 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
 
 // ---- buffer layouts ------------------------------------------------------------------------------
 struct GeomLayout {
-    size_t recs, depth_keys, tiles_touched, clamped, iota, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, temp, temp_bytes, total;
+    size_t recs, depth_keys, tiles_touched, clamped, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, temp, temp_bytes, total;
 };
 GeomLayout geom_layout(int P) {
     GeomLayout L{};
@@ -127,7 +128,6 @@ GeomLayout geom_layout(int P) {
     L.depth_keys = take(n * 4);
     L.tiles_touched = take(n * 4);
     L.clamped = take(n);
-    L.iota = take(n * 4);
     L.sorted_keys = take(n * 4);
     L.sorted_gid = take(n * 4);
     L.tt_sorted = take(n * 4);
@@ -269,12 +269,14 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     }
     if (int rc = debug_sync(frame, s, "preprocess_forward")) return rc;
     {
-        // depth sort + scan are timed together as DEPTH_SORT; SCAN marks the gather+scan tail
         StageTimer t(SR_STAGE_DEPTH_SORT, s);
-        SR_HIP(run_depth_order(P, at<uint32_t>(geom, L.depth_keys), at<uint32_t>(geom, L.tiles_touched),
-                               at<uint32_t>(geom, L.iota), at<uint32_t>(geom, L.sorted_keys), at<uint32_t>(geom, L.sorted_gid),
-                               at<uint32_t>(geom, L.tt_sorted), at<uint32_t>(geom, L.sorted_offsets), at<void>(geom, L.temp),
-                               L.temp_bytes, s, nullptr));
+        SR_HIP(run_depth_sort(P, at<uint32_t>(geom, L.depth_keys), at<uint32_t>(geom, L.tiles_touched), at<uint32_t>(geom, L.sorted_keys),
+                              at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.tt_sorted), at<void>(geom, L.temp), L.temp_bytes, s));
+    }
+    {
+        StageTimer t(SR_STAGE_SCAN, s);
+        SR_HIP(run_tile_count_scan(P, at<uint32_t>(geom, L.tt_sorted), at<uint32_t>(geom, L.sorted_offsets), at<void>(geom, L.temp),
+                                   L.temp_bytes, s));
     }
     if (int rc = debug_sync(frame, s, "depth_order")) return rc;
     // the one host read-back of the forward (the reference does the same between scan and duplicateWithKeys)
@@ -325,7 +327,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), recs, out_color,
-                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint8_t>(binning, B.hit_mask), g_opt_cull.load(), s));
+                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint8_t>(binning, B.hit_mask), g_options.load(), s));
     }
     return debug_sync(frame, s, "render_forward");
 }
@@ -360,7 +362,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0)
             SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
-                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint8_t>(binning, B.hit_mask), inst_grads, tag_lo, tag_hi, g_opt_cull.load(), s));
+                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint8_t>(binning, B.hit_mask), inst_grads, tag_lo, tag_hi, g_options.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;
     {
@@ -412,9 +414,9 @@ int sr_postprocess_backward(int32_t W, int32_t H, float fovx, float fovy, float 
 
 int sr_set_option(int option, int value) {
     switch (option) {
-        case SR_OPT_QUADRANT_CULL: g_opt_cull.store((g_opt_cull.load() & ~1) | (value ? 1 : 0)); return SR_OK;
-        case SR_OPT_DEBUG_STATS: g_opt_cull.store((g_opt_cull.load() & ~2) | (value ? 2 : 0)); return SR_OK;
-        case 100: g_opt_cull.store((g_opt_cull.load() & 0xF) | ((value & 0xF) << 4)); return SR_OK;  // undocumented: K7 ablation bits (timing experiments only; results are wrong)
+        case SR_OPT_QUADRANT_CULL: g_options.store((g_options.load() & ~1) | (value ? 1 : 0)); return SR_OK;
+        case SR_OPT_DEBUG_STATS: g_options.store((g_options.load() & ~2) | (value ? 2 : 0)); return SR_OK;
+        case 100: g_options.store((g_options.load() & 0xF) | ((value & 0xF) << 4)); return SR_OK;  // undocumented: K7 ablation bits (timing experiments only; results are wrong)
         default: return fail(SR_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }

@@ -116,17 +116,17 @@ size_t tile_sort_temp_bytes(uint32_t D, int n_tiles) {
 }
 
 // launchers ---------------------------------------------------------------------------------------
-hipError_t run_depth_order(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* iota,
-                           uint32_t* sorted_keys, uint32_t* sorted_gid, uint32_t* tt_sorted, uint32_t* sorted_offsets,
-                           void* temp, size_t temp_bytes, hipStream_t s, hipEvent_t ev_sorted) {
-    (void)iota;
+// K2: stable sort of (depth key, gaussian id) -- ties keep ascending id, culled Gaussians (key 0xFFFFFFFF) end up last.
+hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* sorted_keys,
+                          uint32_t* sorted_gid, uint32_t* tt_sorted, void* temp, size_t temp_bytes, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    // stable sort of (depth key, gaussian id): ties keep ascending id; culled Gaussians (key 0xFFFFFFFF) end up last.
-    // The last pass also gathers tiles_touched into depth order, so the scan below reads sequentially.
-    hipError_t e = radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, tiles_touched,
-                                    tt_sorted);
-    if (e != hipSuccess) return e;
-    if (ev_sorted) (void)hipEventRecord(ev_sorted, s);
+    // the last pass also gathers tiles_touched into depth order, so the scan reads sequentially
+    return radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, tiles_touched, tt_sorted);
+}
+
+// K2: inclusive scan of the tile counts in depth order -> where each Gaussian's duplicates end in emission order.
+hipError_t run_tile_count_scan(int P, const uint32_t* tt_sorted, uint32_t* sorted_offsets, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (P == 0) return hipSuccess;
     return gather_inclusive_scan(nullptr, tt_sorted, sorted_offsets, (uint32_t)P, temp, temp_bytes, s);
 }
 
