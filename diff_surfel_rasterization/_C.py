@@ -112,13 +112,23 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp)
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         has = lambda t: t is not None and t.numel() > 0
-        # gradients of inputs that were not provided are not computed (empty tensors, as `None` for autograd)
-        dL_dmeans2D, dL_dopacity, dL_dmeans3D = e(P, 3), e(P, 1), e(P, 3)
+        # Gradients of inputs that were not provided are not computed (empty tensors, `None` for autograd).  The parameter
+        # gradients are carved out of ONE flat allocation (means3D | sh | opacity | scales | rotations, 58 floats per
+        # Gaussian with SH degree 3) so that a data-parallel step can all-reduce them with a single collective
+        # (streetunveiler_amd.parallel.allreduce_gradients recognises the shared storage).
+        sizes = [("means3D", (P, 3)), ("sh", (P, M, 3) if has(sh) else (0, 0, 3)), ("opacity", (P, 1)),
+                 ("scales", (P, 2) if has(scales) else (0, 2)), ("rotations", (P, 4) if has(rotations) else (0, 4))]
+        numel = lambda shp: int(torch.Size(shp).numel())
+        flat = torch.empty(sum(numel(shp) for _, shp in sizes), dtype=torch.float32, device=dev)
+        views, off = {}, 0
+        for name, shp in sizes:
+            n = numel(shp)
+            views[name] = flat[off:off + n].view(shp)
+            off += n
+        dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations = (views[k] for k in ("means3D", "sh", "opacity", "scales", "rotations"))
+        dL_dmeans2D = e(P, 3)
         dL_dcolors = e(P, 3) if has(colors_precomp) else e(0, 3)
         dL_dtransMat = e(P, 9) if has(transMat_precomp) else e(0, 9)
-        dL_dsh = e(P, M, 3) if has(sh) else e(0, 0, 3)
-        dL_dscales = e(P, 2) if has(scales) else e(0, 2)
-        dL_drotations = e(P, 4) if has(rotations) else e(0, 4)
         ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered)),), dtype=torch.uint8, device=dev)
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),
                               _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations))

@@ -47,15 +47,39 @@ def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
     return [k for k in range(n_frames) if k % world == rank]
 
 
+def _storage_groups(grads: Sequence[torch.Tensor]):
+    """Group tensors that are contiguous views of one storage and together cover one contiguous span of it."""
+    by_storage = {}
+    for g in grads:
+        by_storage.setdefault(g.untyped_storage().data_ptr(), []).append(g)
+    groups, singles = [], []
+    for members in by_storage.values():
+        members.sort(key=lambda t: t.storage_offset())
+        covered = all(m.is_contiguous() for m in members) and all(
+            members[i].storage_offset() + members[i].numel() == members[i + 1].storage_offset() for i in range(len(members) - 1))
+        if len(members) > 1 and covered and len({m.dtype for m in members}) == 1:
+            first = members[0]
+            total = sum(m.numel() for m in members)
+            groups.append(torch.empty(0, dtype=first.dtype, device=first.device).set_(first.untyped_storage(), first.storage_offset(), (total,)))
+        else:
+            singles.extend(members)
+    return groups, singles
+
+
 def allreduce_gradients(grads: Sequence[torch.Tensor], group=None, average: bool = False) -> None:
-    """In-place SUM (or mean) all-reduce of a list of gradient tensors across the frame-parallel ranks."""
+    """In-place SUM (or mean) all-reduce of a list of gradient tensors across the frame-parallel ranks.
+
+    Gradients that the rasterizer's backward carved out of one flat buffer (diff_surfel_rasterization._C) are reduced
+    with ONE collective over that buffer; anything else: large tensors in place, small ones through one bucket."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)
-    small = [g for g in grads if g is not None and g.numel() * g.element_size() < _BUCKET_INPLACE_BYTES]
-    large = [g for g in grads if g is not None and g.numel() * g.element_size() >= _BUCKET_INPLACE_BYTES]
+    grads = [g for g in grads if g is not None and g.numel() > 0]
+    flat_groups, rest = _storage_groups(grads)
+    small = [g for g in rest if g.numel() * g.element_size() < _BUCKET_INPLACE_BYTES]
+    large = flat_groups + [g for g in rest if g.numel() * g.element_size() >= _BUCKET_INPLACE_BYTES]
     handles = []
-    for g in large:  # largest first so the long transfer starts immediately
+    for g in sorted(large, key=lambda t: -t.numel()):  # largest first so the long transfer starts immediately
         handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
     if small:
         flat = torch.cat([g.reshape(-1) for g in small])
@@ -69,8 +93,7 @@ def allreduce_gradients(grads: Sequence[torch.Tensor], group=None, average: bool
         h.wait()
     if average:
         for g in grads:
-            if g is not None:
-                g.div_(world)
+            g.div_(world)
 
 
 def reduce_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, xyz_gradient_accum: torch.Tensor,

@@ -71,11 +71,16 @@ def _dp_worker(rank, world, port, tmp):
     import streetunveiler_amd.parallel as par
     par._BUCKET_INPLACE_BYTES = 100_000   # exercise both the bucketed and the in-place path
     allreduce_gradients(grads)
+    # gradients carved out of one flat buffer (what the rasterizer's backward returns) take the single-collective path
+    flat = torch.randn(P * 10, generator=g)
+    fviews = [flat[:P * 3].view(P, 3), flat[P * 3:P * 9].view(P, 2, 3), flat[P * 9:].view(P, 1)]
+    flocal = flat.clone()
+    allreduce_gradients(fviews + [None])
     # densification statistics of this rank's view
     vs_grad = torch.randn(P, 3, generator=g); radii = torch.randint(0, 5, (P,), generator=g, dtype=torch.int32)
     accum, denom, maxr = torch.zeros(P, 1), torch.zeros(P, 1), torch.zeros(P)
     reduce_densification_stats(vs_grad, radii, accum, denom, maxr)
-    torch.save(dict(local=local, reduced=grads, vs_grad=vs_grad, radii=radii, accum=accum, denom=denom, maxr=maxr,
+    torch.save(dict(local=local, reduced=grads, flocal=flocal, freduced=flat, vs_grad=vs_grad, radii=radii, accum=accum, denom=denom, maxr=maxr,
                     frames=frames_for_rank(8, rank, world)), os.path.join(tmp, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -90,6 +95,8 @@ def test_frame_sharded_dp_gloo_world2(tmp_path):
         expect = rs[0]["local"][k] + rs[1]["local"][k]
         for r in rs:
             torch.testing.assert_close(r["reduced"][k], expect, rtol=1e-6, atol=1e-6)
+    for r in rs:
+        torch.testing.assert_close(r["freduced"], rs[0]["flocal"] + rs[1]["flocal"], rtol=1e-6, atol=1e-6)
     acc = sum(torch.where((r["radii"] > 0)[:, None], r["vs_grad"].norm(dim=-1, keepdim=True), torch.zeros(1)) for r in rs)
     den = sum((r["radii"] > 0).float()[:, None] for r in rs)
     mx = torch.maximum(*[torch.where(r["radii"] > 0, r["radii"].float(), torch.zeros(1)) for r in rs])
