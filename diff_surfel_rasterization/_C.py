@@ -51,10 +51,21 @@ def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W,
     return fr, keep
 
 
+def _channels(colors_precomp):
+    """3 as in the reference, or 6: two 3-channel passes over the same geometry folded into one."""
+    if colors_precomp is None or colors_precomp.numel() == 0:
+        return 3
+    nc = int(colors_precomp.shape[-1])
+    if colors_precomp.ndim != 2 or nc not in (3, 6):
+        raise L.SurfelRasterError("colors_precomp must have dimensions (num_points, 3) or (num_points, 6)")
+    return nc
+
+
 def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp):
     P = int(means3D.shape[0])
     M = int(sh.shape[1]) if sh is not None and sh.numel() else 0
-    g = L.SrGaussians(P, M, _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(sh),
+    NC = _channels(colors_precomp)
+    g = L.SrGaussians(P, M, NC, 0, _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(sh),
                       _ptr(colors_precomp), _ptr(transMat_precomp))
     return g
 
@@ -74,7 +85,9 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
     with torch.cuda.device(dev):
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug)
         g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp)
-        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        if keep[0].numel() != g.color_channels:
+            raise L.SurfelRasterError(f"bg must have {g.color_channels} entries, one per colour channel")
+        color = torch.empty((g.color_channels, H, W), dtype=torch.float32, device=dev)
         allmap = torch.empty((7, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         geom = torch.empty((lib.sr_geom_bytes(P),), dtype=torch.uint8, device=dev)
@@ -127,9 +140,12 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
             off += n
         dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations = (views[k] for k in ("means3D", "sh", "opacity", "scales", "rotations"))
         dL_dmeans2D = e(P, 3)
-        dL_dcolors = e(P, 3) if has(colors_precomp) else e(0, 3)
+        NC = g.color_channels
+        if int(dL_dcolor.shape[0]) != NC or keep[0].numel() != NC:
+            raise L.SurfelRasterError(f"dL_dcolor / bg must have {NC} channels")
+        dL_dcolors = e(P, NC) if has(colors_precomp) else e(0, 3)
         dL_dtransMat = e(P, 9) if has(transMat_precomp) else e(0, 9)
-        ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered)),), dtype=torch.uint8, device=dev)
+        ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered), NC),), dtype=torch.uint8, device=dev)
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),
                               _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations))
         L.check(lib.sr_backward(C.byref(fr), C.byref(g), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(),

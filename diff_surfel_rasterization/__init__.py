@@ -77,7 +77,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = ctx.saved_tensors
         if grad_out_color is None:
-            grad_out_color = torch.zeros((3, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
+            grad_out_color = torch.zeros((int(s.bg.numel()), s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
         if grad_allmap is None:
             grad_allmap = torch.zeros((7, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
         args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,

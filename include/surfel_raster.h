@@ -22,8 +22,10 @@
  *   - return value: 0 on success, negative SrStatus on failure; sr_last_error() gives the text of
  *     the last failure on the calling thread.  No exceptions cross the ABI.
  *   - tensor layouts are the operator's: float32, contiguous; means3D[P,3], opacities[P,1],
- *     scales[P,2], rotations[P,4] (r,x,y,z), shs[P,M,3] (coefficient-major), colors_precomp[P,3],
- *     transMat_precomp[P,9]; images are planar [C,H,W]
+ *     scales[P,2], rotations[P,4] (r,x,y,z), shs[P,M,3] (coefficient-major), colors_precomp[P,NC],
+ *     transMat_precomp[P,9]; images are planar [C,H,W].  NC = SrGaussians.color_channels: 3 as in the reference, or 6
+ *     (precomputed colours only) = two 3-channel passes over the same geometry folded into one -- what the reference's
+ *     render_semantic does with two rasterizer calls (/root/reference/gaussian_renderer/__init__.py:386-431)
  *     (/root/reference/gaussian_renderer/__init__.py:56-138; allmap channel order :149-165).
  */
 #ifndef SURFEL_RASTER_H
@@ -36,10 +38,10 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 1
+#define SR_ABI_VERSION 2
 #define SR_TILE 16            /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
-#define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
+#define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B; 28 = 112 B with 6 colour channels) */
 
 typedef enum SrStatus {
     SR_OK = 0,
@@ -60,7 +62,7 @@ typedef struct SrFrame {
     int32_t sh_degree;     /* active degree (0..3) */
     int32_t prefiltered;   /* always 0 at the reference's call sites; accepted, ignored */
     int32_t debug;         /* 1: synchronise + check after every kernel */
-    const float* bg;          /* device [3] */
+    const float* bg;          /* device [NC] (3, or 6 with SrGaussians.color_channels == 6) */
     const float* viewmatrix;  /* device [16] = world_view_transform (W2C^T), row-major */
     const float* projmatrix;  /* device [16] = full_proj_transform ((P*W2C)^T), row-major */
     const float* campos;      /* device [3] */
@@ -72,6 +74,8 @@ typedef struct SrFrame {
 typedef struct SrGaussians {
     int32_t P;          /* number of Gaussians */
     int32_t sh_coeffs;  /* M = shs.size(1) (16 for max degree 3); 0 with colors_precomp */
+    int32_t color_channels; /* NC: 0 or 3 = rgb; 6 = six precomputed channels (shs must be NULL) */
+    int32_t reserved;       /* 0 */
     const float* means3D;
     const float* opacities;
     const float* scales;
@@ -122,7 +126,7 @@ const char* sr_last_error(void);
 size_t sr_geom_bytes(int32_t P);
 size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t image_width, int32_t image_height);
 size_t sr_image_bytes(int32_t image_width, int32_t image_height);
-size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered);
+size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered, int32_t color_channels);
 
 int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out);
 int sr_binning_view(void* binning, size_t binning_bytes, int32_t P, uint32_t num_rendered, int32_t image_width,
@@ -137,15 +141,15 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
                     uint32_t* num_rendered_host, void* stream);
 
 /* Forward, phase 2 (K3 duplicate emission, K4 tile sort, K5 ranges, K6 blend).
- * out_color [3,H,W], out_allmap [7,H,W] (0 sum w*depth, 1 alpha, 2-4 sum w*normal (view space),
+ * out_color [NC,H,W], out_allmap [7,H,W] (0 sum w*depth, 1 alpha, 2-4 sum w*normal (view space),
  * 5 median depth, 6 distortion). */
 int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning,
                       size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
                       float* out_color, float* out_allmap, void* stream);
 
-/* Backward (K7 blend backward + K8 preprocess backward).  dL_dcolor [3,H,W], dL_dallmap [7,H,W].
- * workspace: sr_backward_workspace_bytes(P, num_rendered) bytes (one 96-B gradient record per (tile, Gaussian)
- * duplicate), contents undefined on entry. */
+/* Backward (K7 blend backward + K8 preprocess backward).  dL_dcolor [NC,H,W], dL_dallmap [7,H,W].
+ * workspace: sr_backward_workspace_bytes(P, num_rendered, NC) bytes (one 96-B -- 112-B for NC = 6 -- gradient record
+ * per (tile, Gaussian) duplicate), contents undefined on entry. */
 int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
                 void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
                 const float* dL_dcolor, const float* dL_dallmap, void* workspace, size_t workspace_bytes,

@@ -23,7 +23,8 @@ class SrFrame(C.Structure):
 
 
 class SrGaussians(C.Structure):
-    _fields_ = [("P", C.c_int32), ("sh_coeffs", C.c_int32), ("means3D", C.c_void_p), ("opacities", C.c_void_p),
+    _fields_ = [("P", C.c_int32), ("sh_coeffs", C.c_int32), ("color_channels", C.c_int32), ("reserved", C.c_int32),
+                ("means3D", C.c_void_p), ("opacities", C.c_void_p),
                 ("scales", C.c_void_p), ("rotations", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
                 ("transMat_precomp", C.c_void_p)]
 
@@ -77,7 +78,7 @@ def load():
     lib.sr_geom_bytes.argtypes = [C.c_int32]
     lib.sr_binning_bytes.argtypes = [C.c_int32, C.c_uint32, C.c_int32, C.c_int32]
     lib.sr_image_bytes.argtypes = [C.c_int32, C.c_int32]
-    lib.sr_backward_workspace_bytes.argtypes = [C.c_int32, C.c_uint32]
+    lib.sr_backward_workspace_bytes.argtypes = [C.c_int32, C.c_uint32, C.c_int32]
     lib.sr_geom_view.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(SrGeomView)]
     lib.sr_binning_view.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(SrBinningView)]
     lib.sr_image_view.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(SrImageView)]
@@ -98,8 +99,8 @@ def load():
     lib.sr_debug_radix_sort_temp_bytes.restype = C.c_size_t
     lib.sr_debug_radix_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sr_stage_stats.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    if lib.sr_abi_version() != 1:
-        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 1")
+    if lib.sr_abi_version() != 2:
+        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 2")
     _lib = lib
     return lib
 

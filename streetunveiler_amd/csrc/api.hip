@@ -31,9 +31,9 @@ hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted,
 hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
-                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint8_t* hit_mask, int cull, hipStream_t s);
+                                 const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint8_t* hit_mask, int cull, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
-                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                                  const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                   const float* dL_dallmap, const uint8_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi, int cull, hipStream_t s);
 hipError_t read_render_stats(unsigned long long* out8, bool reset);
 // radix_sort.hip
@@ -184,6 +184,8 @@ int check_common(const SrFrame* frame, const SrGaussians* g) {
     if (g->P > 0) {
         if (!g->means3D || !g->opacities) return fail(SR_ERR_INVALID_ARGUMENT, "means3D / opacities is NULL");
         if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return fail(SR_ERR_INVALID_ARGUMENT, "Please provide exactly one of either SHs or precomputed colors!");
+        if (g->color_channels != 0 && g->color_channels != 3 && g->color_channels != 6) return fail(SR_ERR_UNSUPPORTED, "color_channels %d not in {3, 6}", g->color_channels);
+        if (g->color_channels == 6 && g->shs) return fail(SR_ERR_INVALID_ARGUMENT, "6 colour channels need precomputed colors, not SHs");
         const bool sr_pair = g->scales != nullptr && g->rotations != nullptr;
         if ((g->scales != nullptr) != (g->rotations != nullptr) || sr_pair == (g->transMat_precomp != nullptr))
             return fail(SR_ERR_INVALID_ARGUMENT, "Please provide exactly one of either scale/rotation pair or precomputed transMat!");
@@ -200,6 +202,7 @@ FrameDev make_frame(const SrFrame* frame, const SrGaussians* g) {
     f.W = frame->image_width; f.H = frame->image_height;
     f.tiles_x = (f.W + kTile - 1) / kTile; f.tiles_y = (f.H + kTile - 1) / kTile;
     f.sh_degree = frame->sh_degree; f.sh_coeffs = g->sh_coeffs;
+    f.colors = g->color_channels == 6 ? 6 : 3;
     f.scale_modifier = frame->scale_modifier;
     f.bg = frame->bg; f.view = frame->viewmatrix; f.proj = frame->projmatrix; f.campos = frame->campos;
     return f;
@@ -217,9 +220,10 @@ const char* sr_last_error(void) { return g_err; }
 size_t sr_geom_bytes(int32_t P) { return geom_layout(P).total; }
 size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t W, int32_t H) { (void)P; return bin_layout(num_rendered, W, H).total; }
 size_t sr_image_bytes(int32_t W, int32_t H) { return img_layout(W, H).total; }
-size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered) {
-    (void)P;  // one 96-B gradient record per (tile, Gaussian) duplicate
-    return align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * kGradFloats * 4, 256);
+size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered, int32_t color_channels) {
+    (void)P;  // one gradient record per (tile, Gaussian) duplicate: 96 B, or 112 B with 6 colour channels
+    const size_t rec = (size_t)(color_channels == 6 ? kGradFloats + 4 : kGradFloats) * 4;
+    return align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * rec, 256);
 }
 
 int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out) {
@@ -326,7 +330,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     if (int rc = debug_sync(frame, s, "tile_ranges")) return rc;
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
-        SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), recs, out_color,
+        SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
                                      out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint8_t>(binning, B.hit_mask), g_options.load(), s));
     }
     return debug_sync(frame, s, "render_forward");
@@ -347,7 +351,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
     if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
     if (binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, B.total);
     if (image_bytes < I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, I.total);
-    if (workspace_bytes < sr_backward_workspace_bytes(P, D)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P, D));
+    if (workspace_bytes < sr_backward_workspace_bytes(P, D, g->color_channels)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P, D, g->color_channels));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const FrameDev f = make_frame(frame, g);
     // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous)
@@ -361,7 +365,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
     {
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0)
-            SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
+            SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs), g->colors_precomp,
                                           at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint8_t>(binning, B.hit_mask), inst_grads, tag_lo, tag_hi, g_options.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;

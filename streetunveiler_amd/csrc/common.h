@@ -39,6 +39,7 @@ constexpr int kGradFloats = SR_GRAD_FLOATS;
 struct FrameDev {
     int W, H, tiles_x, tiles_y;
     int sh_degree, sh_coeffs;
+    int colors;   // colour channels blended per pixel: 3, or 6 (precomputed colours only)
     float scale_modifier;
     const float* bg;
     const float* view;

@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
             if (area > 0) {
                 float rgb[3];
                 if (colors_precomp) {
-                    rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1]; rgb[2] = colors_precomp[3 * (size_t)i + 2];
+                    const float* c = colors_precomp + (size_t)f.colors * i;   // channels 3..5 (if any) are read by the blend kernels
+                    rgb[0] = c[0]; rgb[1] = c[1]; rgb[2] = c[2];
                 } else {
                     float dx = px - f.campos[0], dy = py - f.campos[1], dz = pz - f.campos[2];
                     const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
 // the splat record); ascending order -> deterministic.  Records without this call's tag were not written by K7 (entry
 // behind every pixel's last contributor) and are skipped.
 // ---------------------------------------------------------------------------------------------
-template <bool kLdsSH>
+template <bool kLdsSH, int NC>
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
@@ -291,13 +292,14 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     const int tid = threadIdx.x, base = blockIdx.x * 256;
     const int i = base + tid;
     const int M = f.sh_coeffs;
+    constexpr int kGQ = NC == 6 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record; the tag sits in the last one
     if (kLdsSH) {
         sh_rows_to_lds(shs, base, P, s_sh, tid);
         __syncthreads();
     }
     if (i < P) {
         float g_means3D[3] = {0, 0, 0}, g_scales[2] = {0, 0}, g_rot[4] = {0, 0, 0, 0}, g_m2d[2] = {0, 0};
-        float dT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dTr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_col[3] = {0, 0, 0}, g_opa = 0.f;
+        float dT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dTr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_col[6] = {0, 0, 0, 0, 0, 0}, g_opa = 0.f;
         const bool vis = radii[i] > 0;
         float* dsh_g = (!kLdsSH && out.dL_dsh) ? out.dL_dsh + (size_t)i * M * 3 : nullptr;
         float* row = s_sh + tid * kShLdsStride;
@@ -314,19 +316,19 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
                 // written by K7) are masked out branch-free so the next trip's loads are not held back
                 constexpr int kTrip = 4;
                 for (uint32_t e = first; e < first + cnt; e += kTrip) {
-                    float4 a[kTrip][kGradQuads];
+                    float4 a[kTrip][kGQ];
                     bool ok[kTrip];
 #pragma unroll
                     for (int t = 0; t < kTrip; ++t) {
                         const bool in = e + t < first + cnt;
-                        const float4* gr = inst_grads + (size_t)(in ? e + t : e) * kGradQuads;
+                        const float4* gr = inst_grads + (size_t)(in ? e + t : e) * kGQ;
 #pragma unroll
-                        for (int k = 0; k < kGradQuads; ++k) a[t][k] = gr[k];
+                        for (int k = 0; k < kGQ; ++k) a[t][k] = gr[k];
                         ok[t] = in;
                     }
 #pragma unroll
                     for (int t = 0; t < kTrip; ++t) {
-                        if (ok[t] && __float_as_uint(a[t][5].z) == tag_lo && __float_as_uint(a[t][5].w) == tag_hi) {
+                        if (ok[t] && __float_as_uint(a[t][kGQ - 1].z) == tag_lo && __float_as_uint(a[t][kGQ - 1].w) == tag_hi) {
 #pragma unroll
                             for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[t][k].x; g[k].y += a[t][k].y; g[k].z += a[t][k].z; g[k].w += a[t][k].w; }
                         }
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
             g_opa = g3.z;
             const float gn[3] = {g3.w, g4.x, g4.y};
             g_col[0] = g4.z; g_col[1] = g4.w; g_col[2] = g5.x;
+            if (NC == 6) { g_col[3] = g5.y; g_col[4] = g5.z; g_col[5] = g5.w; }
             // densification proxy from the blend-only dL/dT (Appendix A.6, last paragraph)
             g_m2d[0] = dT[2] * Tw[2] * 0.5f * (float)f.W;
             g_m2d[1] = dT[5] * Tw[2] * 0.5f * (float)f.H;
@@ -434,7 +437,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
         if (out.dL_dscales) { out.dL_dscales[2 * (size_t)i] = g_scales[0]; out.dL_dscales[2 * (size_t)i + 1] = g_scales[1]; }
         if (out.dL_drotations) { reinterpret_cast<float4*>(out.dL_drotations)[i] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]); }
         if (out.dL_dopacity) out.dL_dopacity[i] = g_opa;
-        if (out.dL_dcolors) { out.dL_dcolors[3 * (size_t)i] = g_col[0]; out.dL_dcolors[3 * (size_t)i + 1] = g_col[1]; out.dL_dcolors[3 * (size_t)i + 2] = g_col[2]; }
+        if (out.dL_dcolors) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) out.dL_dcolors[NC * (size_t)i + c] = g_col[c];
+        }
         if (out.dL_dtransMat) {
             // upstream writes the AABB-centre-augmented dL/dT back only when transMat is an input (A.6)
 #pragma unroll
@@ -480,11 +486,14 @@ hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussian
                                       hipStream_t s) {
     if (P == 0) return hipSuccess;
     const dim3 grid((P + 255) / 256), block(256);
-    if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs) && (!out.dL_dsh || aligned16(out.dL_dsh)))
-        hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
+    if (f.colors == 6)
+        hipLaunchKernelGGL((preprocess_backward_kernel<false, 6>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
+                           g.transMat_precomp, radii, clamped, recs, inst_grads, tiles_touched, tag_lo, tag_hi, out);
+    else if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs) && (!out.dL_dsh || aligned16(out.dL_dsh)))
+        hipLaunchKernelGGL((preprocess_backward_kernel<true, 3>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
                            g.transMat_precomp, radii, clamped, recs, inst_grads, tiles_touched, tag_lo, tag_hi, out);
     else
-        hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
+        hipLaunchKernelGGL((preprocess_backward_kernel<false, 3>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
                            g.transMat_precomp, radii, clamped, recs, inst_grads, tiles_touched, tag_lo, tag_hi, out);
     return hipGetLastError();
 }

@@ -94,15 +94,20 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
 
 // ---------------------------------------------------------------------------------------------
 // Staged entry layout in LDS (struct-of-quads, s_e[quad][slot]):
-//   e0 = A.xyz B.x | e1 = B.yz C.xy | e2 = C.z Tw.xyz | e3 = xy'.x xy'.y opacity -
-//   e4 = n.xyz r   | e5 = g b - -    | (K7 only) e6 = Tu'.xyz Tv'.x | e7 = Tv'.yz - -
-// with A = Tv' x Tw, B = Tw x Tu', C = Tu' x Tv' and ' = relative to the tile centre (Xc, Yc).
+//   e0 = A.xyz B.x | e1 = B.yz C.xy | e2 = C.z Tw.xyz | e3 = xy'.x xy'.y opacity c5
+//   e4 = n.xyz c0  | e5 = c1 c2 c3 c4
+// with A = Tv' x Tw, B = Tw x Tu', C = Tu' x Tv' and ' = relative to the tile centre (Xc, Yc); c0..c2 = rgb, c3..c5 only
+// in the 6-channel variant (the two 3-channel one-hot passes of render_semantic as ONE pass).
 // ---------------------------------------------------------------------------------------------
 constexpr int kFwdQuads = 6;
-constexpr int kBwdQuads = 8;
 
-template <int kQuads>
-__device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], float Xc, float Yc, int cull,
+// channels 3..5 of a 6-channel precomputed colour row, straight from the caller's [P,6] array
+__device__ __forceinline__ float4 load_extra(const float* __restrict__ colors6, uint32_t gid) {
+    const float* c = colors6 + 6 * (size_t)gid + 3;
+    return make_float4(c[0], c[1], c[2], 0.f);
+}
+
+__device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], const float4 ex, float Xc, float Yc, int cull,
                                                 float4 (*s_e)[kWave], int slot) {
     const float Tw[3] = {q[1].z, q[1].w, q[2].x};
     const float Tu[3] = {q[0].x - Xc * Tw[0], q[0].y - Xc * Tw[1], q[0].z - Xc * Tw[2]};
@@ -114,13 +119,9 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], fl
     s_e[0][slot] = make_float4(A[0], A[1], A[2], B[0]);
     s_e[1][slot] = make_float4(B[1], B[2], C[0], C[1]);
     s_e[2][slot] = make_float4(C[2], Tw[0], Tw[1], Tw[2]);
-    s_e[3][slot] = make_float4(mx, my, opacity, 0.f);
+    s_e[3][slot] = make_float4(mx, my, opacity, ex.z);
     s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[4].x);
-    s_e[5][slot] = make_float4(q[4].y, q[4].z, 0.f, 0.f);
-    if (kQuads == kBwdQuads) {
-        s_e[6][slot] = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
-        s_e[7][slot] = make_float4(Tv[1], Tv[2], 0.f, 0.f);
-    }
+    s_e[5][slot] = make_float4(q[4].y, q[4].z, ex.x, ex.y);
     return cull ? quadrant_mask(Tu, Tv, Tw, mx, my, opacity) : 0xFu;
 }
 
@@ -170,10 +171,11 @@ __device__ __forceinline__ void load_record(const float4* __restrict__ recs, uin
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
-template <bool kStats>
+template <bool kStats, int NC>
 __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ recs,
+                                                                const float* __restrict__ extra,
                                                                 float* __restrict__ out_color, float* __restrict__ out_allmap,
                                                                 float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                                 uint8_t* __restrict__ hit_mask, int cull) {
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     float xl[4], yl[4];
     bool done[4];
     float T[4], C0[4], C1[4], C2[4], N0[4], N1[4], N2[4], Dsum[4], M1[4], M2[4], dist[4], med[4];
+    float C3[4], C4[4], C5[4];   // only live in the 6-channel variant
     uint32_t lastc[4], medc[4];
     uint32_t alive = 0;
 #pragma unroll
@@ -197,18 +200,27 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
         xl[q] = (float)((q & 1) * 8 + lx - 8); yl[q] = (float)((q >> 1) * 8 + ly - 8);
         done[q] = !(px < f.W && py < f.H);
         T[q] = 1.f; C0[q] = C1[q] = C2[q] = N0[q] = N1[q] = N2[q] = 0.f;
+        C3[q] = C4[q] = C5[q] = 0.f;
         Dsum[q] = M1[q] = M2[q] = dist[q] = med[q] = 0.f;
         lastc[q] = 0; medc[q] = 0xFFFFFFFFu;
         if (__ballot(!done[q]) != 0) alive |= 1u << q;
     }
 
-    float4 nr[kRecQuads];
-    if ((uint32_t)lane < n_total) load_record(recs, point_list[range.x + lane], nr);
+    float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((uint32_t)lane < n_total) {
+        const uint32_t gid = point_list[range.x + lane];
+        load_record(recs, gid, nr);
+        if (NC == 6) nx = load_extra(extra, gid);
+    }
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         uint32_t m = 0;
-        if ((uint32_t)lane < n) m = stage_entry<kFwdQuads>(nr, Xc, Yc, cull & 1, s_e, lane);
-        if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
+        if ((uint32_t)lane < n) m = stage_entry(nr, nx, Xc, Yc, cull & 1, s_e, lane);
+        if (base + kWave + lane < n_total) {
+            const uint32_t gid = point_list[range.x + base + kWave + lane];
+            load_record(recs, gid, nr);
+            if (NC == 6) nx = load_extra(extra, gid);
+        }
         unsigned long long bits = __ballot((m & alive) != 0);
         if (kStats && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
         unsigned long long hit[4] = {0ull, 0ull, 0ull, 0ull};  // scalar: bit j of hit[q] = entry j reached a pixel of quadrant q
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                         if (T[q] > 0.5f) { med[q] = h.depth; medc[q] = contributor; }
                         N0[q] += e4.x * w; N1[q] += e4.y * w; N2[q] += e4.z * w;
                         C0[q] += e4.w * w; C1[q] += e5.x * w; C2[q] += e5.y * w;
+                        if (NC == 6) { C3[q] += e5.z * w; C4[q] += e5.w * w; C5[q] += e3.w * w; }
                         T[q] = test_T;
                         lastc[q] = contributor;
                     }
@@ -273,6 +286,11 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
             out_color[pix] = C0[q] + T[q] * bg0;
             out_color[HW + pix] = C1[q] + T[q] * bg1;
             out_color[2 * HW + pix] = C2[q] + T[q] * bg2;
+            if (NC == 6) {
+                out_color[3 * HW + pix] = C3[q] + T[q] * f.bg[3];
+                out_color[4 * HW + pix] = C4[q] + T[q] * f.bg[4];
+                out_color[5 * HW + pix] = C5[q] + T[q] * f.bg[5];
+            }
             out_allmap[pix] = Dsum[q];
             out_allmap[HW + pix] = 1.f - T[q];
             out_allmap[2 * HW + pix] = N0[q]; out_allmap[3 * HW + pix] = N1[q]; out_allmap[4 * HW + pix] = N2[q];
@@ -349,9 +367,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 // Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
 // (first[gid] + its index inside the Gaussian's tile rectangle; first[gid] rides in slot 15 of the splat record), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
 // entries no pixel reached are not written; written records carry the call's tag.  Gradient record slots: see common.h.
+template <int NC>
 __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                  const uint32_t* __restrict__ point_list,
                                                                  const float4* __restrict__ recs,
+                                                                 const float* __restrict__ extra,
                                                                  const float* __restrict__ final_T,
                                                                  const uint32_t* __restrict__ n_contrib,
                                                                  const float* __restrict__ dL_dcolor,
@@ -374,6 +394,8 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
     // per-pixel constants (upstream gradients folded with the forward's final accumulators) and state
     float xl[4], yl[4], pxf[4], pyf[4];
     float gr[4], gg[4], gb[4], gn0[4], gn1[4], gn2[4], g_depth[4], g_median[4], Kbg[4], a0[4], a1[4], a2[4];
+    float gc3[4], gc4[4], gc5[4];   // only live in the 6-channel variant
+    constexpr int kGQ = NC == 6 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record
     uint32_t lastc[4], medc[4], quad_last[4];
     float T[4], R[4], X[4];
     uint32_t total = 0;
@@ -394,7 +416,12 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         gn0[q] = inside ? dL_dallmap[2 * HW + pix] : 0.f; gn1[q] = inside ? dL_dallmap[3 * HW + pix] : 0.f; gn2[q] = inside ? dL_dallmap[4 * HW + pix] : 0.f;
         g_median[q] = inside ? dL_dallmap[5 * HW + pix] : 0.f;
         const float g_reg = inside ? dL_dallmap[6 * HW + pix] : 0.f;
-        const float bg_dot = bg0 * gr[q] + bg1 * gg[q] + bg2 * gb[q];
+        float bg_dot = bg0 * gr[q] + bg1 * gg[q] + bg2 * gb[q];
+        gc3[q] = gc4[q] = gc5[q] = 0.f;
+        if (NC == 6) {
+            gc3[q] = inside ? dL_dcolor[3 * HW + pix] : 0.f; gc4[q] = inside ? dL_dcolor[4 * HW + pix] : 0.f; gc5[q] = inside ? dL_dcolor[5 * HW + pix] : 0.f;
+            bg_dot += f.bg[3] * gc3[q] + f.bg[4] * gc4[q] + f.bg[5] * gc5[q];
+        }
         Kbg[q] = T_final * (g_accum - bg_dot);
         a0[q] = (1.f - T_final) * g_reg; a1[q] = fin_D * g_reg; a2[q] = fin_D2 * g_reg;
         T[q] = T_final; R[q] = 0.f; X[q] = 0.f;
@@ -405,12 +432,13 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
     // entries behind the deepest contributor of the tile get no record at all: K8a recognises the records written in
     // this call by their tag
     const int rounds = (int)((total + kWave - 1) / kWave);
-    float4 nr[kRecQuads];
+    float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t nhit = 0;
     if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
         const uint32_t pos = range.x + (rounds - 1) * kWave + lane;
         const uint32_t gid = point_list[pos];
         load_record(recs, gid, nr);
+        if (NC == 6) nx = load_extra(extra, gid);
         nhit = hit_mask[pos];
     }
     for (int rd = rounds - 1; rd >= 0; --rd) {
@@ -418,7 +446,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         const uint32_t n = min((uint32_t)kWave, total - rbase);
         uint32_t m = 0, slot = 0;
         if ((uint32_t)lane < n) {
-            (void)stage_entry<kFwdQuads>(nr, Xc, Yc, 0, s_e, lane);
+            (void)stage_entry(nr, nx, Xc, Yc, 0, s_e, lane);
             m = nhit;   // (entry, quadrant) pairs that reached a pixel in the forward: exact, no culling test needed here
             slot = emission_index(nr, __float_as_uint(nr[3].w), tile % f.tiles_x, tile / f.tiles_x, f.tiles_x, f.tiles_y);
             uint32_t need = 0;
@@ -435,6 +463,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             const uint32_t pos = range.x + rbase - kWave + lane;
             const uint32_t gid = point_list[pos];
             load_record(recs, gid, nr);
+            if (NC == 6) nx = load_extra(extra, gid);
             nhit = hit_mask[pos];
         }
         unsigned long long bits = __ballot(m != 0);
@@ -461,8 +490,9 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                     const float one_m_inv = fast_rcp(1.f - h.alpha);
                     T[q] *= one_m_inv;                 // transmittance in front of this entry
                     const float w = h.alpha * T[q];
-                    const float phi = fmaf(e4.w, gr[q], fmaf(e5.x, gg[q], fmaf(e5.y, gb[q], fmaf(h.depth, g_depth[q],
-                                      fmaf(e4.x, gn0[q], fmaf(e4.y, gn1[q], e4.z * gn2[q]))))));
+                    float phi = fmaf(e4.w, gr[q], fmaf(e5.x, gg[q], fmaf(e5.y, gb[q], fmaf(h.depth, g_depth[q],
+                                fmaf(e4.x, gn0[q], fmaf(e4.y, gn1[q], e4.z * gn2[q]))))));
+                    if (NC == 6) phi = fmaf(e5.z, gc3[q], fmaf(e5.w, gc4[q], fmaf(e3.w, gc5[q], phi)));
                     const float inv_depth = fast_rcp(h.depth);
                     const float m_d = kFN * (1.f - kNear * inv_depth);
                     const float dmd_dd = kFN * kNear * inv_depth * inv_depth;
@@ -474,6 +504,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                     if (cidx == medc[q] - 1u) dL_dz += g_median[q];
                     const float dL_dG = e3.z * dL_dalpha;
                     v[18] += w * gr[q]; v[19] += w * gg[q]; v[20] += w * gb[q];
+                    if (NC == 6) { v[21] += w * gc3[q]; v[22] += w * gc4[q]; v[23] += w * gc5[q]; }
                     v[15] += w * gn0[q]; v[16] += w * gn1[q]; v[17] += w * gn2[q];
                     v[14] += h.G * dL_dalpha;
                     if (h.use3d) {
@@ -502,11 +533,16 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         // flush this round's records: one 96-B store per lane (zeros where nothing contributed)
         if ((uint32_t)lane < n && !(cull & 16)) {
             const float4* acc = reinterpret_cast<const float4*>(&s_out[lane][0]);
-            float4* o = inst_grads + (size_t)slot * kGradQuads;
+            float4* o = inst_grads + (size_t)slot * kGQ;
 #pragma unroll
             for (int k = 0; k < kGradQuads - 1; ++k) o[k] = acc[k];
             const float4 last = acc[kGradQuads - 1];
-            o[kGradQuads - 1] = make_float4(last.x, last.y, __uint_as_float(tag_lo), __uint_as_float(tag_hi));
+            if (NC == 6) {   // all 24 slots carry values; the tag gets a 7th quad
+                o[kGradQuads - 1] = last;
+                o[kGradQuads] = make_float4(0.f, 0.f, __uint_as_float(tag_lo), __uint_as_float(tag_hi));
+            } else {
+                o[kGradQuads - 1] = make_float4(last.x, last.y, __uint_as_float(tag_lo), __uint_as_float(tag_hi));
+            }
         }
     }
 }
@@ -522,25 +558,32 @@ hipError_t read_render_stats(unsigned long long* out8, bool reset) {
 
 // launchers ---------------------------------------------------------------------------------------
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
-                                 float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint8_t* hit_mask, int cull, hipStream_t s) {
+                                 const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib,
+                                 uint8_t* hit_mask, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    if (cull & 2)
-        hipLaunchKernelGGL(render_forward_kernel<true>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, out_color,
-                           out_allmap, final_T, n_contrib, hit_mask, cull);
-    else
-        hipLaunchKernelGGL(render_forward_kernel<false>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, out_color,
-                           out_allmap, final_T, n_contrib, hit_mask, cull);
+    const dim3 grid(n_tiles), block(kWave);
+#define SR_LAUNCH_FWD(STATS, NCH)                                                                                            \
+    hipLaunchKernelGGL((render_forward_kernel<STATS, NCH>), grid, block, 0, s, f, ranges, point_list, recs, extra, out_color, \
+                       out_allmap, final_T, n_contrib, hit_mask, cull)
+    if (f.colors == 6) { if (cull & 2) SR_LAUNCH_FWD(true, 6); else SR_LAUNCH_FWD(false, 6); }
+    else               { if (cull & 2) SR_LAUNCH_FWD(true, 3); else SR_LAUNCH_FWD(false, 3); }
+#undef SR_LAUNCH_FWD
     return hipGetLastError();
 }
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
-                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint8_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi, int cull, hipStream_t s) {
+                                  const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                                  const float* dL_dallmap, const uint8_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi,
+                                  int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(render_backward_kernel, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, final_T,
-                       n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, tag_lo, tag_hi, cull);
+    if (f.colors == 6)
+        hipLaunchKernelGGL(render_backward_kernel<6>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, extra, final_T,
+                           n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, tag_lo, tag_hi, cull);
+    else
+        hipLaunchKernelGGL(render_backward_kernel<3>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, extra, final_T,
+                           n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, tag_lo, tag_hi, cull);
     return hipGetLastError();
 }
 

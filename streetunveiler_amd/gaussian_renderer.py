@@ -165,19 +165,16 @@ def _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier):
     bg_prob[concerned_classes_ind_map["sky"]] = 1.0
     means3D, means2D, opacity, scales, rotations, cov3D_precomp = _geometry_inputs(pc, pipe, screenspace_points, mask, scaling_modifier)
     semantics_tag = _sel(pc.get_semantics, mask)
-    output_semantic = []
-    for i in range(0, n_cls, 3):   # 6 one-hot classes as two 3-channel passes [REF :417-444]
-        bg = torch.tensor(bg_prob[i:i + 3], dtype=torch.float32, device=dev)
-        rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg, scaling_modifier))
-        valid = min(3, n_cls - i)
-        semantic_3 = torch.zeros_like(means3D).float()
-        for c in range(valid):
-            semantic_3[semantics_tag == (i + c), c] = 1.0
-        rendered_semantic, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=semantic_3,
-                                                      opacities=opacity, scales=scales, rotations=rotations,
-                                                      cov3D_precomp=cov3D_precomp)
-        output_semantic.append(rendered_semantic[:valid])
-    output_semantic = torch.cat(output_semantic, dim=0)
+    # The reference renders the 6 one-hot class channels as two 3-channel passes over identical geometry [REF :417-444];
+    # here the operator blends 6 precomputed channels in ONE pass (preprocess, binning, sort and the
+    # per-pixel alpha chain are shared), which gives bit-identical channel values.
+    assert n_cls == 6, "the single-pass semantic render is built for the reference's 6 classes"
+    bg = torch.tensor(bg_prob, dtype=torch.float32, device=dev)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg, scaling_modifier))
+    semantic_6 = (semantics_tag.view(-1, 1) == torch.arange(n_cls, device=dev).view(1, -1)).float()
+    output_semantic, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=semantic_6,
+                                                opacities=opacity, scales=scales, rotations=rotations,
+                                                cov3D_precomp=cov3D_precomp)
     topk_values, _ = torch.topk(output_semantic, k=2, dim=0)
     uncertainty = 1.0 - (topk_values[0, ...] - topk_values[1, ...])
     semantic_rgb = _SEMANTIC_COLOR.to(dev)[torch.argmax(output_semantic, dim=0)].permute(2, 0, 1) / 255.0

@@ -261,3 +261,40 @@ def test_sh_layout_fallbacks_and_scale_modifier():
         for name, got in [("dL_dmeans3D", t["means3D"].grad), ("dL_dopacity", t["opacities"].grad), ("dL_dscales", t["scales"].grad),
                           ("dL_drotations", t["rotations"].grad), ("dL_dsh", shs.grad), ("dL_dmeans2D", m2d.grad)]:
             assert_grads_close(got.cpu().numpy(), bwd[name], 2e-3, tag + " " + name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_tpre", [False, True])
+def test_six_colour_channels_equal_two_three_channel_passes(use_tpre):
+    """one 6-channel pass == the reference's two 3-channel passes over the same geometry
+    (/root/reference/gaussian_renderer/__init__.py:417-444).  Oracle pass A carries colours 0..2 and the allmap
+    gradient, pass B colours 3..5 with a zero allmap gradient; parameter gradients add, colour gradients concatenate."""
+    from tests.gpu_util import assert_close_frac, run_hip, run_oracle
+    P, W, H = 3000, 208, 120
+    cam, g = _scene(P, W, H, 21, 5e-3, 6e-2, 4)
+    rng = np.random.default_rng(5)
+    colors = rng.random((P, 6)).astype(np.float32)
+    bg = np.array([0.0, 0.25, 0.0, 0.0, 1.0, 0.5], np.float32)
+    dcA, da = synthetic_upstream_grads(W, H, seed=6)
+    dcB, _ = synthetic_upstream_grads(W, H, seed=7)
+    dc = torch.cat([dcA, dcB], 0)
+    Tpre = None
+    if use_tpre:
+        f0, _ = run_oracle(g, cam, bg[:3], 0, colors=colors[:, :3].copy())
+        Tpre = f0["transMat"].copy()
+        Tpre[f0["radii"] == 0] = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], np.float32)
+    fA, bA = run_oracle(g, cam, bg[:3], 0, dcA, da, colors=colors[:, :3].copy(), Tpre=Tpre)
+    fB, bB = run_oracle(g, cam, bg[3:], 0, dcB, torch.zeros_like(da), colors=colors[:, 3:].copy(), Tpre=Tpre)
+    out = run_hip(g, cam, bg, 0, dc, da, colors=colors, Tpre=Tpre)
+    assert out["color"].shape == (6, H, W)
+    np.testing.assert_array_equal(out["radii"], fA["radii"])
+    fwd = dict(color=np.concatenate([fA["color"], fB["color"]], 0), allmap=fA["allmap"])
+    _check_images(out, fwd, "six channels")
+    names = ["dL_dmeans3D", "dL_dopacity", "dL_dmeans2D"] + (["dL_dtransMat"] if use_tpre else ["dL_dscales", "dL_drotations"])
+    bwd = {k: bA[k] + bB[k] for k in names}
+    bwd["dL_dcolors"] = np.concatenate([bA["dL_dcolors"], bB["dL_dcolors"]], 1)
+    _check_grads(out, bwd, names + ["dL_dcolors"], "six channels")
+    # the first three channels and the allmap are bit-identical to a plain 3-channel call on the same inputs
+    out3 = run_hip(g, cam, bg[:3], 0, colors=colors[:, :3].copy(), Tpre=Tpre)
+    np.testing.assert_array_equal(out["color"][:3], out3["color"])
+    np.testing.assert_array_equal(out["allmap"], out3["allmap"])
