@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-aux", action="store_true", help="C2 variant: only colour + alpha gradients live")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["factored", "allreduce"], default="factored",
+                    help="N > 1 gradient exchange: factored = all-gather 12-B colour gradients + local SH expansion + all-reduce of "
+                         "the other 40 B/Gaussian; allreduce = plain all-reduce of all 232 B/Gaussian")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-oracle work for the cpu_baseline leg")
     return ap.parse_args()
 
@@ -102,7 +105,7 @@ def cpu_baseline(args, g, cam, dc, da):
 
 def main():
     args = parse()
-    from streetunveiler_amd.parallel import allreduce_gradients, init_distributed
+    from streetunveiler_amd.parallel import allreduce_gradients, factored_sh_exchange, init_distributed
     rank, world, local_rank = init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -124,6 +127,8 @@ def main():
                                              1.0, cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), deg,
                                              cam.camera_center.to(dev), False, False)
     rasterizer = GaussianRasterizer(settings)
+    # the camera list is replicated: every rank knows every rank's camera position
+    all_campos = torch.stack([synthetic_camera(W, H, index=r, n_cams=world).camera_center for r in range(world)]).to(dev) if world > 1 else None
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     leaves = [params["means3D"], params["shs"], params["opacities"], params["scales"], params["rotations"], means2D]
 
@@ -132,9 +137,15 @@ def main():
             t.grad = None
         color, radii, allmap = rasterizer(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
                                           opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
-        torch.autograd.backward([color, allmap], [dc, da])
-        if world > 1:
-            allreduce_gradients([t.grad for t in leaves[:5]])
+        if world > 1 and args.exchange == "factored":
+            # SH gradient: all-gather of the 12-B colour gradients + local expansion; the other 40 B/Gaussian: one
+            # all-reduce, queued behind it inside backward -- every gradient leaves backward summed over the ranks
+            with factored_sh_exchange(all_campos=all_campos, reduce_all=True):
+                torch.autograd.backward([color, allmap], [dc, da])
+        else:
+            torch.autograd.backward([color, allmap], [dc, da])
+            if world > 1:
+                allreduce_gradients([t.grad for t in leaves[:5]])   # 232 B/Gaussian, one collective over the flat buffer
         return radii
 
     # scene statistics (outside the timed region)
@@ -191,7 +202,9 @@ def main():
             "config": {"workload": f"C3: {P} synthetic Gaussians, {W}x{H}, SH degree {deg}, fwd+bwd, "
                                    f"{'colour+alpha' if args.no_aux else 'all 7 aux-map'} gradients live",
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D,
-                       "frames_per_step": world, "parallelism": f"frame-sharded dp{world}" if world > 1 else "single GPU"},
+                       "frames_per_step": world, "parallelism": f"frame-sharded dp{world}" if world > 1 else "single GPU",
+                       **({"gradient_exchange": ("all-gather of 12-B colour gradients + local SH expansion + all-reduce of 40 B/Gaussian"
+                                                 if args.exchange == "factored" else "all-reduce of 232 B/Gaussian")} if world > 1 else {})},
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": None if ach is None else round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 5),

@@ -107,8 +107,12 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
 
 def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap, sh, degree, campos,
-                                 geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None):
-    """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry."""
+                                 geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None, defer_sh=False):
+    """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry.
+
+    `defer_sh=True` (frame-parallel ranks, streetunveiler_amd.parallel): with SHs as the colour source, dL_dsh is NOT
+    expanded (empty tensor returned) and dL_dcolors carries the clamp-masked dL/drgb [P,3] to be all-gathered and expanded
+    with `sh_gradient_expand`."""
     lib = L.load()
     means3D = _f32c(means3D, "means3D")
     colors_precomp = _f32c(colors_precomp, "colors_precomp"); scales = _f32c(scales, "scales")
@@ -129,7 +133,8 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         # gradients are carved out of ONE flat allocation (means3D | sh | opacity | scales | rotations, 58 floats per
         # Gaussian with SH degree 3) so that a data-parallel step can all-reduce them with a single collective
         # (streetunveiler_amd.parallel.allreduce_gradients recognises the shared storage).
-        sizes = [("means3D", (P, 3)), ("sh", (P, M, 3) if has(sh) else (0, 0, 3)), ("opacity", (P, 1)),
+        defer_sh = bool(defer_sh) and has(sh)
+        sizes = [("means3D", (P, 3)), ("sh", (P, M, 3) if has(sh) and not defer_sh else (0, 0, 3)), ("opacity", (P, 1)),
                  ("scales", (P, 2) if has(scales) else (0, 2)), ("rotations", (P, 4) if has(rotations) else (0, 4))]
         numel = lambda shp: int(torch.Size(shp).numel())
         flat = torch.empty(sum(numel(shp) for _, shp in sizes), dtype=torch.float32, device=dev)
@@ -143,7 +148,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         NC = g.color_channels
         if int(dL_dcolor.shape[0]) != NC or keep[0].numel() != NC:
             raise L.SurfelRasterError(f"dL_dcolor / bg must have {NC} channels")
-        dL_dcolors = e(P, NC) if has(colors_precomp) else e(0, 3)
+        dL_dcolors = e(P, NC) if has(colors_precomp) or defer_sh else e(0, 3)
         dL_dtransMat = e(P, 9) if has(transMat_precomp) else e(0, 9)
         ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered), NC),), dtype=torch.uint8, device=dev)
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),
@@ -154,6 +159,20 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
                                 C.byref(grads), _stream(dev)), "sr_backward")
     del keep
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+
+
+def sh_gradient_expand(means3D, campos, dL_dcolors, sh_coeffs, degree):
+    """dL_dsh [P,M,3] = sum over views v of the SH adjoint of dL_dcolors[v] seen from campos[v] (include/surfel_raster.h)."""
+    lib = L.load()
+    means3D = _f32c(means3D, "means3D"); campos = _f32c(campos, "campos").reshape(-1, 3); dL_dcolors = _f32c(dL_dcolors, "dL_dcolors")
+    P, V = int(means3D.shape[0]), int(campos.shape[0])
+    if dL_dcolors.numel() != V * P * 3:
+        raise L.SurfelRasterError(f"dL_dcolors must have {V} x {P} x 3 elements")
+    out = torch.empty((P, int(sh_coeffs), 3), dtype=torch.float32, device=means3D.device)
+    with torch.cuda.device(means3D.device):
+        L.check(lib.sr_sh_gradient_expand(P, int(sh_coeffs), int(degree), V, _ptr(means3D), _ptr(campos), _ptr(dL_dcolors),
+                                          _ptr(out), _stream(means3D.device)), "sr_sh_gradient_expand")
+    return out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

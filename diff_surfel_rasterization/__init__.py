@@ -83,17 +83,24 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, grad_allmap, sh, s.sh_degree, s.campos, geomBuffer,
                 ctx.num_rendered, binningBuffer, imgBuffer, s.debug)
+        # frame-parallel ranks may exchange the SH gradient in factored form (streetunveiler_amd.parallel)
+        from streetunveiler_amd.parallel import active_sh_exchange
+        exchange = active_sh_exchange() if sh.numel() else None
+        kwargs = {"defer_sh": True} if exchange is not None else {}
         if s.debug:
             snapshot = _cpu_snapshot(args)
             try:
-                out = _C.rasterize_gaussians_backward(*args)
+                out = _C.rasterize_gaussians_backward(*args, **kwargs)
             except Exception:
                 torch.save(snapshot, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
         else:
-            out = _C.rasterize_gaussians_backward(*args)
+            out = _C.rasterize_gaussians_backward(*args, **kwargs)
         grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations = out
+        if exchange is not None:   # grad_colors_precomp holds the clamp-masked dL/drgb; dL_dsh comes back summed over ranks
+            rest = [grad_means3D, grad_opacities, grad_scales, grad_rotations] if exchange.reduce_all else []
+            grad_sh = exchange.run(grad_colors_precomp, means3D, s.campos, int(sh.shape[1]), s.sh_degree, also_reduce=rest)
         none_if_empty = lambda g, ref: g if ref.numel() else None
         return (grad_means3D, grad_means2D, none_if_empty(grad_sh, sh), none_if_empty(grad_colors_precomp, colors_precomp),
                 grad_opacities, none_if_empty(grad_scales, scales), none_if_empty(grad_rotations, rotations),

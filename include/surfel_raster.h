@@ -89,11 +89,11 @@ typedef struct SrGaussians {
  * Every non-NULL pointer is fully written (zeros for invisible Gaussians); NULL = not wanted. */
 typedef struct SrGradients {
     float* dL_dmeans2D;    /* [P,3] densification proxy (x, y, 0) -- what viewspace_points.grad receives */
-    float* dL_dcolors;     /* [P,3] */
+    float* dL_dcolors;     /* [P,NC] w.r.t. colors_precomp; with shs as the colour source: [P,3] clamp-masked dL/drgb (the SH adjoint's input, see sr_sh_gradient_expand) */
     float* dL_dopacity;    /* [P,1] */
     float* dL_dmeans3D;    /* [P,3] */
     float* dL_dtransMat;   /* [P,9] */
-    float* dL_dsh;         /* [P,M,3] */
+    float* dL_dsh;         /* [P,M,3]; may be NULL with shs given (frame-parallel ranks ship dL_dcolors instead) */
     float* dL_dscales;     /* [P,2] */
     float* dL_drotations;  /* [P,4] */
 } SrGradients;
@@ -154,6 +154,15 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
                 void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
                 const float* dL_dcolor, const float* dL_dallmap, void* workspace, size_t workspace_bytes,
                 const SrGradients* grads, void* stream);
+
+/* Frame-parallel SH gradient (no reference counterpart -- the reference is single-GPU).  The SH adjoint is
+ * linear in the clamp-masked colour gradient and its only other per-view input is the camera position, so ranks that
+ * rendered n_views frames of the SAME Gaussians all-gather dL_dcolors (12 B/Gaussian) instead of all-reducing dL_dsh
+ * (192 B/Gaussian) and each expands the sum:  dL_dsh[i][k][c] = sum_v basis_k(dir(means3D[i], campos[v])) * dL_dcolors[v][i][c].
+ * campos [n_views,3], dL_dcolors [n_views,P,3], dL_dsh [P,M,3] (fully written), all device pointers.  n_views = 1
+ * reproduces sr_backward's dL_dsh bit for bit. */
+int sr_sh_gradient_expand(int32_t P, int32_t sh_coeffs, int32_t sh_degree, int32_t n_views, const float* means3D,
+                          const float* campos, const float* dL_dcolors, float* dL_dsh, void* stream);
 
 /* K9: present[i] = (view-space z of means3D[i] > 0.2).  present is uint8 (torch.bool storage). */
 int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -18,6 +18,8 @@ hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussian
                                       const uint32_t* tiles_touched, uint32_t tag_lo, uint32_t tag_hi, const SrGradients& out,
                                       hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+hipError_t launch_sh_gradient_expand(int P, int M, int deg, int V, const float* means3D, const float* campos, const float* gc,
+                                     float* dL_dsh, hipStream_t s);
 // binning.hip
 size_t depth_sort_temp_bytes(int P);
 size_t tile_sort_temp_bytes(uint32_t D, int n_tiles);
@@ -375,6 +377,17 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
                                           at<uint32_t>(geom, L.tiles_touched), tag_lo, tag_hi, *grads, s));
     }
     return debug_sync(frame, s, "preprocess_backward");
+}
+
+int sr_sh_gradient_expand(int32_t P, int32_t sh_coeffs, int32_t sh_degree, int32_t n_views, const float* means3D,
+                          const float* campos, const float* dL_dcolors, float* dL_dsh, void* stream) {
+    if (P < 0 || n_views < 1) return fail(SR_ERR_INVALID_ARGUMENT, "P < 0 or n_views < 1");
+    if (sh_degree < 0 || sh_degree > 3) return fail(SR_ERR_UNSUPPORTED, "sh_degree %d not in 0..3", sh_degree);
+    if (sh_coeffs < (sh_degree + 1) * (sh_degree + 1)) return fail(SR_ERR_INVALID_ARGUMENT, "shs has %d coefficients, degree %d needs %d", sh_coeffs, sh_degree, (sh_degree + 1) * (sh_degree + 1));
+    if (P == 0) return SR_OK;
+    if (!means3D || !campos || !dL_dcolors || !dL_dsh) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    SR_HIP(launch_sh_gradient_expand(P, sh_coeffs, sh_degree, n_views, means3D, campos, dL_dcolors, dL_dsh, static_cast<hipStream_t>(stream)));
+    return SR_OK;
 }
 
 int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -416,6 +416,9 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
                 const float x = ox / len, y = oy / len, z = oz / len;
                 const uint8_t cl = clamped[i];
                 const float gc[3] = {(cl & 1) ? 0.f : g_col[0], (cl & 2) ? 0.f : g_col[1], (cl & 4) ? 0.f : g_col[2]};
+                // with SHs as the colour source dL_dcolors (optional) carries the clamp-masked dL/drgb: the one per-view
+                // input of the SH adjoint, which is all a frame-parallel rank has to ship (sh_gradient_expand_kernel)
+                g_col[0] = gc[0]; g_col[1] = gc[1]; g_col[2] = gc[2];
                 float ddir[3];
                 if (kLdsSH) sh_backward(f.sh_degree, M, row, row, out.dL_dsh != nullptr, x, y, z, gc, ddir);
                 else sh_backward(f.sh_degree, M, shs + (size_t)i * M * 3, dsh_g, dsh_g != nullptr, x, y, z, gc, ddir);
@@ -450,6 +453,74 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     if (kLdsSH && out.dL_dsh) {
         __syncthreads();
         sh_rows_from_lds(out.dL_dsh, base, P, s_sh, tid);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SH gradient of V frames of the same Gaussians from their clamp-masked colour gradients:
+//   dL_dsh[i][k][c] = sum_v basis_k(dir(p_i, campos_v)) * gc[v][i][c]
+// The SH adjoint is linear in gc and its only other per-view input is the camera position, so frame-parallel ranks
+// all-gather 12 B per Gaussian instead of all-reducing the 192-B dL_dsh rows and every rank expands the sum locally.
+// b[k] * g is evaluated exactly as sh_backward does, so V = 1 reproduces K8's dL_dsh bit for bit.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float b[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b[k] = 0.f;
+    b[0] = kSH_C0;
+    if (deg > 0) {
+        b[1] = -kSH_C1 * y; b[2] = kSH_C1 * z; b[3] = -kSH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = kSH_C2[0] * xy; b[5] = kSH_C2[1] * yz; b[6] = kSH_C2[2] * (2.f * zz - xx - yy);
+            b[7] = kSH_C2[3] * xz; b[8] = kSH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                b[9] = kSH_C3[0] * y * (3.f * xx - yy);
+                b[10] = kSH_C3[1] * xy * z;
+                b[11] = kSH_C3[2] * y * (4.f * zz - xx - yy);
+                b[12] = kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                b[13] = kSH_C3[4] * x * (4.f * zz - xx - yy);
+                b[14] = kSH_C3[5] * z * (xx - yy);
+                b[15] = kSH_C3[6] * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+template <bool kLdsSH>
+__global__ __launch_bounds__(256) void sh_gradient_expand_kernel(int P, int M, int deg, int V, const float* __restrict__ means3D,
+                                                                  const float* __restrict__ campos, const float* __restrict__ gc,
+                                                                  float* __restrict__ dL_dsh) {
+    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
+    const int tid = threadIdx.x, base = blockIdx.x * 256;
+    const int i = base + tid;
+    if (i < P) {
+        float acc[48];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+        const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+        for (int v = 0; v < V; ++v) {
+            const float* g = gc + ((size_t)v * P + i) * 3;
+            const float g0 = g[0], g1 = g[1], g2 = g[2];
+            if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;   // not visible in this view (or fully clamped): adds +0
+            const float ox = px - campos[3 * v], oy = py - campos[3 * v + 1], oz = pz - campos[3 * v + 2];
+            const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
+            float b[16];
+            sh_basis(deg, ox / len, oy / len, oz / len, b);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { acc[3 * k] += b[k] * g0; acc[3 * k + 1] += b[k] * g1; acc[3 * k + 2] += b[k] * g2; }
+        }
+        if (kLdsSH) {
+            float4* row = reinterpret_cast<float4*>(s_sh + tid * kShLdsStride);
+#pragma unroll
+            for (int k = 0; k < kShRowFloats / 4; ++k) row[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+        } else {
+            float* row = dL_dsh + (size_t)i * M * 3;
+            for (int k = 0; k < M * 3; ++k) row[k] = k < 48 ? acc[k] : 0.f;
+        }
+    }
+    if (kLdsSH) {
+        __syncthreads();
+        sh_rows_from_lds(dL_dsh, base, P, s_sh, tid);
     }
 }
 
@@ -495,6 +566,17 @@ hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussian
     else
         hipLaunchKernelGGL((preprocess_backward_kernel<false, 3>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
                            g.transMat_precomp, radii, clamped, recs, inst_grads, tiles_touched, tag_lo, tag_hi, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sh_gradient_expand(int P, int M, int deg, int V, const float* means3D, const float* campos, const float* gc,
+                                     float* dL_dsh, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    const dim3 grid((P + 255) / 256), block(256);
+    if (M == 16 && aligned16(dL_dsh))
+        hipLaunchKernelGGL(sh_gradient_expand_kernel<true>, grid, block, 0, s, P, M, deg, V, means3D, campos, gc, dL_dsh);
+    else
+        hipLaunchKernelGGL(sh_gradient_expand_kernel<false>, grid, block, 0, s, P, M, deg, V, means3D, campos, gc, dL_dsh);
     return hipGetLastError();
 }
 

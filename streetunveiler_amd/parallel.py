@@ -6,14 +6,20 @@ collective), and the ranks meet once per optimisation step:
   * densification statistics, which are per-view norms and therefore cannot be derived from the summed
     gradient: SUM of xyz_gradient_accum / denom, MAX of max_radii2D
     [REF /root/reference/scene/gaussian_model.py:555-557; /root/reference/train.py:166-169].
+  * the SH part of that gradient (192 of the 232 B per Gaussian) can be exchanged in factored form instead
+    (`factored_sh_exchange`): the SH adjoint is linear in the clamp-masked colour gradient (12 B per Gaussian) and
+    its only other per-view input is the camera position, so ranks ALL-GATHER the colour gradients and every rank
+    expands sum_v basis(dir_v) (x) g_v locally (csrc/preprocess.hip sh_gradient_expand_kernel).  The result is the
+    same all-reduced dL_dsh (float summation order aside) for 8x (2 ranks) .. 2.3x (8 ranks) fewer bytes over xGMI.
 One process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI on ROCm); "gloo" for the CPU tests.
 xGMI is point-to-point, so few large messages beat many small ones: small tensors are packed into one
 bucket, large ones (the SH gradient is 83 % of the bytes) are reduced in place without a staging copy.
 """
 from __future__ import annotations
 
+import contextlib
 import os
-from typing import Iterable, List, Optional, Sequence, Tuple
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -94,6 +100,81 @@ def allreduce_gradients(grads: Sequence[torch.Tensor], group=None, average: bool
     if average:
         for g in grads:
             g.div_(world)
+
+
+class ShExchange:
+    """State of an active factored SH-gradient exchange (see `factored_sh_exchange`)."""
+
+    def __init__(self, group=None, expand: Optional[Callable] = None, all_campos: Optional[torch.Tensor] = None,
+                 reduce_all: bool = False):
+        self.group, self.expand, self.all_campos, self.reduce_all = group, expand, all_campos, reduce_all
+        self.calls = 0          # exchanges run (tests / diagnostics)
+        self.bytes_sent = 0     # payload bytes this rank contributed to the all-gathers
+
+    def run(self, gc: torch.Tensor, means3D: torch.Tensor, campos: torch.Tensor, sh_coeffs: int, degree: int,
+            also_reduce: Sequence[torch.Tensor] = ()) -> torch.Tensor:
+        """gc: this rank's clamp-masked dL/drgb [P,3] -> dL_dsh [P,M,3] summed over all ranks' frames.
+
+        `also_reduce`: further gradient tensors to SUM all-reduce in place; their collective is queued right behind the
+        all-gather, so it runs on the communication stream while the expansion kernel runs on the compute stream."""
+        world = dist.get_world_size(self.group)
+        gc = gc.contiguous()
+        flat = torch.empty(world * gc.numel(), dtype=gc.dtype, device=gc.device)   # 1-D in/out: accepted by RCCL and gloo alike
+        h = dist.all_gather_into_tensor(flat, gc.reshape(-1), group=self.group, async_op=True)
+        gathered = flat.view((world,) + tuple(gc.shape))
+        if self.all_campos is not None:      # every rank knows the camera list: nothing to exchange
+            cams = self.all_campos.to(device=gc.device, dtype=torch.float32).reshape(world, 3)
+        else:
+            mine = campos.detach().to(device=gc.device, dtype=torch.float32).reshape(3).contiguous()
+            cams = torch.empty(world * 3, dtype=torch.float32, device=gc.device)
+            dist.all_gather_into_tensor(cams, mine, group=self.group)
+            cams = cams.view(world, 3)
+        pending = []
+        groups, singles = _storage_groups([t for t in also_reduce if t is not None and t.numel() > 0])
+        for t in groups + singles:
+            pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        h.wait()
+        self.calls += 1
+        self.bytes_sent += gc.numel() * gc.element_size()
+        expand = self.expand
+        if expand is None:
+            from diff_surfel_rasterization import _C   # the HIP kernel; no CPU path
+            expand = _C.sh_gradient_expand
+        out = expand(means3D.detach(), cams, gathered, sh_coeffs, degree)
+        for w in pending:
+            w.wait()
+        return out
+
+
+_ACTIVE_SH_EXCHANGE: Optional[ShExchange] = None
+
+
+@contextlib.contextmanager
+def factored_sh_exchange(group=None, expand: Optional[Callable] = None, all_campos: Optional[torch.Tensor] = None,
+                         reduce_all: bool = False):
+    """Within this context the rasterizer's backward returns dL_dsh ALREADY SUMMED over the frame-parallel ranks.
+
+    Each rank's backward all-gathers its clamp-masked colour gradient (12 B/Gaussian; plus the 12-B camera position
+    unless `all_campos` [world,3] is given) and expands the SH adjoint of all `world` frames locally, instead of
+    all-reducing the 192-B/Gaussian dL_dsh afterwards.  Requirements: every rank runs the same sequence of backward
+    calls on the same Gaussians (same P, same subset) -- the collective sits inside backward, as in DDP.  Gradients of
+    everything else (means3D, opacity, scales, rotations) stay local: pass those, and NOT the SH parameters'
+    gradients, to `allreduce_gradients`.  With `reduce_all=True` the backward also all-reduces those four (one collective
+    over the flat buffer they are carved from, overlapped with the expansion kernel) and EVERY parameter gradient of the
+    operator leaves backward already summed -- then nothing of it may be all-reduced again.
+    No-op when torch.distributed is not initialised or the group has one rank."""
+    global _ACTIVE_SH_EXCHANGE
+    prev = _ACTIVE_SH_EXCHANGE
+    ex = ShExchange(group, expand, all_campos, reduce_all) if dist.is_initialized() and dist.get_world_size(group) > 1 else None
+    _ACTIVE_SH_EXCHANGE = ex
+    try:
+        yield ex
+    finally:
+        _ACTIVE_SH_EXCHANGE = prev
+
+
+def active_sh_exchange() -> Optional[ShExchange]:
+    return _ACTIVE_SH_EXCHANGE
 
 
 def reduce_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, xyz_gradient_accum: torch.Tensor,

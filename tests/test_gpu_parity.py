@@ -298,3 +298,58 @@ def test_six_colour_channels_equal_two_three_channel_passes(use_tpre):
     out3 = run_hip(g, cam, bg[:3], 0, colors=colors[:, :3].copy(), Tpre=Tpre)
     np.testing.assert_array_equal(out["color"][:3], out3["color"])
     np.testing.assert_array_equal(out["allmap"], out3["allmap"])
+
+
+def test_sh_gradient_expand_matches_backward():
+    """Frame-parallel SH gradient: K8 with a deferred SH expansion + sr_sh_gradient_expand == K8's own dL_dsh
+    (bit for bit with one view), and the expansion of two views == the sum of their dL_dsh."""
+    from diff_surfel_rasterization import _C
+    from tests.gpu_util import DEV, settings_for
+    P, W, H = 5000, 192, 112
+    _, g = _scene(P, W, H, 31, 5e-3, 6e-2, 0)
+    dc, da = synthetic_upstream_grads(W, H, seed=9)
+    e = torch.empty(0, device=DEV)
+    d = {k: v.to(DEV) for k, v in g.items()}
+    per_view = []
+    for index in (1, 6):
+        cam = synthetic_camera(W, H, index=index)
+        for deg in ((3, 1) if index == 1 else (3,)):
+            s = settings_for(cam, np.zeros(3, np.float32), deg)
+            D, color, allmap, radii, geom, binning, img = _C.rasterize_gaussians(
+                s.bg, d["means3D"], e, d["opacities"], d["scales"], d["rotations"], 1.0, e, s.viewmatrix, s.projmatrix,
+                s.tanfovx, s.tanfovy, H, W, d["shs"], deg, s.campos, False, False)
+            args = (s.bg, d["means3D"], radii, e, d["scales"], d["rotations"], 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx,
+                    s.tanfovy, dc.to(DEV), da.to(DEV), d["shs"], deg, s.campos, geom, D, binning, img, False)
+            full = _C.rasterize_gaussians_backward(*args)
+            lean = _C.rasterize_gaussians_backward(*args, defer_sh=True)
+            assert lean[5].numel() == 0 and tuple(lean[1].shape) == (P, 3) and full[1].numel() == 0
+            for k in (0, 2, 3, 6, 7):   # every other gradient is untouched by the deferral
+                assert torch.equal(full[k], lean[k])
+            one = _C.sh_gradient_expand(d["means3D"], s.campos, lean[1], 16, deg)
+            assert float(full[5].abs().max()) > 0
+            assert torch.equal(one, full[5]), f"deg {deg}: max diff {float((one - full[5]).abs().max())}"
+            assert not one[(radii == 0)].any()
+            if deg == 3:
+                per_view.append((s.campos.clone(), lean[1].clone(), full[5].clone()))
+    both = _C.sh_gradient_expand(d["means3D"], torch.stack([v[0] for v in per_view]), torch.stack([v[1] for v in per_view]), 16, 3)
+    torch.testing.assert_close(both, per_view[0][2] + per_view[1][2], rtol=1e-5, atol=1e-6)
+    # general-layout path (M = 9 rows, degree 2)
+    sh9 = d["shs"][:, :9].contiguous()
+    nine = _C.sh_gradient_expand(d["means3D"], per_view[0][0], per_view[0][1], 9, 2)
+    ref = _C.sh_gradient_expand(d["means3D"], per_view[0][0], per_view[0][1], 16, 2)
+    assert torch.equal(nine, ref[:, :9]) and sh9.shape[1] == 9
+
+
+def test_factored_sh_exchange_two_ranks_one_gpu():
+    """The N > 1 exchange end to end (autograd hook, all-gather, HIP expansion, all-reduce of the rest) with two ranks
+    sharing this box's one GPU over gloo; tools/check_factored_exchange.py compares against locally summed gradients."""
+    import socket, subprocess, sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SURFEL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "check_factored_exchange.py")],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "factored exchange OK" in r.stdout

@@ -103,3 +103,49 @@ def test_frame_sharded_dp_gloo_world2(tmp_path):
     for r in rs:
         torch.testing.assert_close(r["accum"], acc); torch.testing.assert_close(r["denom"], den); torch.testing.assert_close(r["maxr"], mx)
     assert rs[0]["frames"] == [0, 2, 4, 6] and rs[1]["frames"] == [1, 3, 5, 7]
+
+
+def _sh_adjoint_torch(means3D, cams, gathered, sh_coeffs, degree):
+    """Test-side stand-in for the HIP expand kernel: autograd of the python SH evaluation (linear in sh)."""
+    P = means3D.shape[0]
+    sh = torch.zeros(P, sh_coeffs, 3, dtype=torch.float64, requires_grad=True)
+    total = 0.0
+    for v in range(cams.shape[0]):
+        d = means3D.double() - cams[v].double()
+        d = d / d.norm(dim=1, keepdim=True)
+        total = total + (eval_sh(degree, sh.transpose(1, 2), d) * gathered[v].double()).sum()
+    return torch.autograd.grad(total, sh)[0].float()
+
+
+def _sh_exchange_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from streetunveiler_amd.parallel import active_sh_exchange, factored_sh_exchange, init_distributed
+    init_distributed(backend="gloo")
+    P = 500
+    means3D = torch.randn(P, 3, generator=torch.Generator().manual_seed(7)) * 3      # same Gaussians on every rank
+    g = torch.Generator().manual_seed(200 + rank)
+    gc = torch.randn(P, 3, generator=g)
+    gc[torch.rand(P, generator=g) < 0.3] = 0.0                                       # invisible in this rank's frame
+    campos = torch.randn(3, generator=g) * 10
+    assert active_sh_exchange() is None
+    with factored_sh_exchange(expand=_sh_adjoint_torch) as ex:
+        assert active_sh_exchange() is ex
+        summed = ex.run(gc, means3D, campos, 16, 3)
+    with factored_sh_exchange(expand=_sh_adjoint_torch, all_campos=torch.stack([torch.randn(3, generator=torch.Generator().manual_seed(200 + r)) for r in range(world)])) as ex2:
+        ex2.run(gc, means3D, campos, 16, 2)
+        assert ex2.calls == 1 and ex2.bytes_sent == P * 12
+    assert active_sh_exchange() is None
+    torch.save(dict(gc=gc, campos=campos, means3D=means3D, summed=summed), os.path.join(tmp, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_factored_sh_exchange_gloo_world2(tmp_path):
+    """all-gather of 12-B colour gradients + local expansion == sum of the per-rank dL_dsh."""
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_sh_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, f"s{r}.pt")) for r in range(world)]
+    expect = sum(_sh_adjoint_torch(r["means3D"], r["campos"][None], r["gc"][None], 16, 3) for r in rs)
+    assert expect.abs().max() > 0.1
+    for r in rs:
+        torch.testing.assert_close(r["summed"], expect, rtol=1e-5, atol=1e-6)
