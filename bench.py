@@ -24,6 +24,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak (packed FMA; 78.6 with plain v_fma_f32) -- MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 FP32_VALU_PEAK_TFLOPS = 157.3
 
@@ -158,20 +159,42 @@ def main():
         V = int((radii0 > 0).sum().item())
     del radii0
 
+    # what the blend kernels execute on this scene (device counters of one forward, outside the timed region)
+    import ctypes
+    st = (ctypes.c_ulonglong * 8)()
+    lib.sr_set_option(_lib.SR_OPT_DEBUG_STATS, 1); lib.sr_debug_stats(st, 1)
+    with torch.no_grad():
+        rasterizer(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
+                   scales=params["scales"], rotations=params["rotations"])
+    torch.cuda.synchronize()
+    lib.sr_debug_stats(st, 1); lib.sr_set_option(_lib.SR_OPT_DEBUG_STATS, 0)
+    blend_counts = {"staged_entries_D_eff": int(st[0]), "entries_after_quadrant_cull": int(st[1]), "quadrant_tests": int(st[2]),
+                    "quadrant_tests_with_a_hit": int(st[3]), "contributing_pairs": int(st[4])}
+
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:   # bring the communicator up before anything is timed, whatever --warmup says
+        w = torch.zeros(1024, device=dev); wg = torch.empty(1024 * world, device=dev)
+        dist.all_reduce(w); dist.all_gather_into_tensor(wg, w)
+        sync()
+
     for _ in range(args.warmup):
         step()
     sync()
     lib.sr_set_stage_timing(1)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         step()
+        marks[k + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4)
     stats = _lib.stage_stats()
     lib.sr_set_stage_timing(0)
     if world > 1:
@@ -195,13 +218,26 @@ def main():
         kernels_ms = sum(group_ms.values())
         dom_kernel = "render_backward_kernel" if dominant == "blend_bwd" else "render_forward_kernel"
         traffic, traffic_src = pmc_traffic(dom_kernel, args)
+        # FP32-VALU view of the same two kernels (SURVEY 8d "algorithmic flops": 60 fwd + 200 bwd per tested pair).  K7 walks
+        # exactly the (entry, quadrant) pairs K6 recorded, so one set of counters serves both.
+        lane_tests = blend_counts["quadrant_tests"] * 64
+        useful = blend_counts["contributing_pairs"] * 260 / (blend_ms * 1e-3) / 1e12 if blend_ms else None
+        issued = lane_tests * 260 / (blend_ms * 1e-3) / 1e12 if blend_ms else None
+        valu = {"peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_pair": 260, **blend_counts, "lane_tests": lane_tests,
+                "lane_utilisation": round(blend_counts["contributing_pairs"] / lane_tests, 4) if lane_tests else None,
+                "issued": None if issued is None else round(issued, 2), "issued_frac": None if issued is None else round(issued / FP32_VALU_PEAK_TFLOPS, 4),
+                "useful": None if useful is None else round(useful, 2), "useful_frac": None if useful is None else round(useful / FP32_VALU_PEAK_TFLOPS, 4),
+                "note": "issued = 64 lanes x quadrant tests, useful = pairs that contribute; SQ_ACTIVE_INST_VALU covers 92-95 % of both "
+                        "kernels' time (profiles/r01_sq_counters.json): instruction-issue-bound, see DESIGN.md 4",
+                "D_eff_blend_bytes": blend_counts["staged_entries_D_eff"] * 296 + npx * 160}
         out = {
             "metric": "Msplats/s fwd+bwd @1920x1080, 3M Gaussians", "value": round(value, 3), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "step_ms_percentiles": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C3: {P} synthetic Gaussians, {W}x{H}, SH degree {deg}, fwd+bwd, "
                                    f"{'colour+alpha' if args.no_aux else 'all 7 aux-map'} gradients live",
-                       "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D,
+                       "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D, "visible_per_P": round(V / P, 4), "D_per_P": round(D / P, 3),
                        "frames_per_step": world, "parallelism": f"frame-sharded dp{world}" if world > 1 else "single GPU",
                        **({"gradient_exchange": ("all-gather of 12-B colour gradients + local SH expansion + all-reduce of 40 B/Gaussian"
                                                  if args.exchange == "factored" else "all-reduce of 232 B/Gaussian")} if world > 1 else {})},
@@ -214,6 +250,7 @@ def main():
                          "north_star_blend_fwd_bwd": {"algorithmic_bytes": ab["blend_fwd"] + ab["blend_bwd"], "ms": round(blend_ms, 4),
                                                       "achieved": None if blend_gbs is None else round(blend_gbs, 2),
                                                       "frac": None if blend_gbs is None else round(blend_gbs / HBM_PEAK_GBS, 5)},
+                         "valu": valu,
                          "whole_op": {"algorithmic_bytes": sum(ab.values()), "kernel_ms": round(kernels_ms, 4),
                                       "frac": round(sum(ab.values()) / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kernels_ms else None}},
             "stage_ms": {k: (None if v is None else round(v, 4)) for k, v in stage_ms.items()},
