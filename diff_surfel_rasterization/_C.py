@@ -61,18 +61,18 @@ def _channels(colors_precomp):
     return nc
 
 
-def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp):
+def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations=0):
     P = int(means3D.shape[0])
     M = int(sh.shape[1]) if sh is not None and sh.numel() else 0
     NC = _channels(colors_precomp)
-    g = L.SrGaussians(P, M, NC, 0, _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(sh),
+    g = L.SrGaussians(P, M, NC, int(activations), _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(sh),
                       _ptr(colors_precomp), _ptr(transMat_precomp))
     return g
 
 
 def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
+                        prefiltered, debug, activations=0):
     lib = L.load()
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise L.SurfelRasterError("means3D must have dimensions (num_points, 3)")
@@ -84,7 +84,7 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
     P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
     with torch.cuda.device(dev):
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug)
-        g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp)
+        g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations)
         if keep[0].numel() != g.color_channels:
             raise L.SurfelRasterError(f"bg must have {g.color_channels} entries, one per colour channel")
         color = torch.empty((g.color_channels, H, W), dtype=torch.float32, device=dev)
@@ -107,7 +107,8 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
 
 def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap, sh, degree, campos,
-                                 geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None, defer_sh=False):
+                                 geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None, defer_sh=False,
+                                 activations=0):
     """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry.
 
     `defer_sh=True` (frame-parallel ranks, streetunveiler_amd.parallel): with SHs as the colour source, dL_dsh is NOT
@@ -126,7 +127,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
     with torch.cuda.device(dev):
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, False, debug)
         # the backward never dereferences opacities (it reads the packed record); pass means3D as a non-NULL stand-in
-        g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp)
+        g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp, activations)
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         has = lambda t: t is not None and t.numel() > 0
         # Gradients of inputs that were not provided are not computed (empty tensors, `None` for autograd).  The parameter

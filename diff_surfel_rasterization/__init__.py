@@ -42,28 +42,32 @@ def _cpu_snapshot(args):
     return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        activations=0):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+                                     raster_settings, activations)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                activations=0):
         s = raster_settings
+        ctx.activations = int(activations)
+        fused = {"activations": ctx.activations} if ctx.activations else {}
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
                 s.debug)
         if s.debug:
             snapshot = _cpu_snapshot(args)  # taken before the call so a crashing kernel cannot corrupt it
             try:
-                out = _C.rasterize_gaussians(*args)
+                out = _C.rasterize_gaussians(*args, **fused)
             except Exception:
                 torch.save(snapshot, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
         else:
-            out = _C.rasterize_gaussians(*args)
+            out = _C.rasterize_gaussians(*args, **fused)
         num_rendered, color, allmap, radii, geomBuffer, binningBuffer, imgBuffer = out
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
@@ -87,6 +91,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         from streetunveiler_amd.parallel import active_sh_exchange
         exchange = active_sh_exchange() if sh.numel() else None
         kwargs = {"defer_sh": True} if exchange is not None else {}
+        if ctx.activations:
+            kwargs["activations"] = ctx.activations
         if s.debug:
             snapshot = _cpu_snapshot(args)
             try:
@@ -104,13 +110,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         none_if_empty = lambda g, ref: g if ref.numel() else None
         return (grad_means3D, grad_means2D, none_if_empty(grad_sh, sh), none_if_empty(grad_colors_precomp, colors_precomp),
                 grad_opacities, none_if_empty(grad_scales, scales), none_if_empty(grad_rotations, rotations),
-                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None)
+                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False):
+        """`fused_activations=True` (extension): `opacities`, `scales`, `rotations` are the RAW parameters
+        (`_opacity`, `_scaling`, `_rotation` of the reference's GaussianModel); sigmoid / exp / normalize run inside the
+        preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values."""
         super().__init__()
         self.raster_settings = raster_settings
+        self.activations = 7 if fused_activations else 0
 
     def markVisible(self, positions):
         with torch.no_grad():
@@ -131,4 +141,5 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s,
+                                   self.activations)

@@ -43,6 +43,12 @@ extern "C" {
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
 #define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B; 28 = 112 B with 6 colour channels) */
 
+/* SrGaussians.activations == the GaussianModel activations
+ * (/root/reference/scene/gaussian_model.py:63-75, getters :101-123) */
+#define SR_ACT_EXP_SCALES 1          /* scales = exp(raw) */
+#define SR_ACT_SIGMOID_OPACITY 2     /* opacities = sigmoid(raw) */
+#define SR_ACT_NORMALIZE_ROTATIONS 4 /* rotations = raw / max(|raw|, 1e-12) */
+
 typedef enum SrStatus {
     SR_OK = 0,
     SR_ERR_INVALID_ARGUMENT = -1, /* NULL where a pointer is required, bad sizes, both/neither of an exclusive pair */
@@ -75,7 +81,8 @@ typedef struct SrGaussians {
     int32_t P;          /* number of Gaussians */
     int32_t sh_coeffs;  /* M = shs.size(1) (16 for max degree 3); 0 with colors_precomp */
     int32_t color_channels; /* NC: 0 or 3 = rgb; 6 = six precomputed channels (shs must be NULL) */
-    int32_t reserved;       /* 0 */
+    int32_t activations;    /* SR_ACT_* bits: the given arrays are the reference's RAW parameters and the activation is fused
+                             * into K1 (and its adjoint into K8: raw gradients out); 0 = activated inputs as in the reference */
     const float* means3D;
     const float* opacities;
     const float* scales;

@@ -10,6 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsurfel_raster.so")
 
+SR_ACT_EXP_SCALES, SR_ACT_SIGMOID_OPACITY, SR_ACT_NORMALIZE_ROTATIONS = 1, 2, 4
 SR_OPT_QUADRANT_CULL = 0
 SR_OPT_DEBUG_STATS = 1
 SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
@@ -23,7 +24,7 @@ class SrFrame(C.Structure):
 
 
 class SrGaussians(C.Structure):
-    _fields_ = [("P", C.c_int32), ("sh_coeffs", C.c_int32), ("color_channels", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("P", C.c_int32), ("sh_coeffs", C.c_int32), ("color_channels", C.c_int32), ("activations", C.c_int32),
                 ("means3D", C.c_void_p), ("opacities", C.c_void_p),
                 ("scales", C.c_void_p), ("rotations", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
                 ("transMat_precomp", C.c_void_p)]

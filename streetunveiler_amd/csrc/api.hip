@@ -187,6 +187,7 @@ int check_common(const SrFrame* frame, const SrGaussians* g) {
         if (!g->means3D || !g->opacities) return fail(SR_ERR_INVALID_ARGUMENT, "means3D / opacities is NULL");
         if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return fail(SR_ERR_INVALID_ARGUMENT, "Please provide exactly one of either SHs or precomputed colors!");
         if (g->color_channels != 0 && g->color_channels != 3 && g->color_channels != 6) return fail(SR_ERR_UNSUPPORTED, "color_channels %d not in {3, 6}", g->color_channels);
+        if (g->activations & ~(SR_ACT_EXP_SCALES | SR_ACT_SIGMOID_OPACITY | SR_ACT_NORMALIZE_ROTATIONS)) return fail(SR_ERR_UNSUPPORTED, "unknown activation bits 0x%x", g->activations);
         if (g->color_channels == 6 && g->shs) return fail(SR_ERR_INVALID_ARGUMENT, "6 colour channels need precomputed colors, not SHs");
         const bool sr_pair = g->scales != nullptr && g->rotations != nullptr;
         if ((g->scales != nullptr) != (g->rotations != nullptr) || sr_pair == (g->transMat_precomp != nullptr))
@@ -205,6 +206,7 @@ FrameDev make_frame(const SrFrame* frame, const SrGaussians* g) {
     f.tiles_x = (f.W + kTile - 1) / kTile; f.tiles_y = (f.H + kTile - 1) / kTile;
     f.sh_degree = frame->sh_degree; f.sh_coeffs = g->sh_coeffs;
     f.colors = g->color_channels == 6 ? 6 : 3;
+    f.activations = g->activations;
     f.scale_modifier = frame->scale_modifier;
     f.bg = frame->bg; f.view = frame->viewmatrix; f.proj = frame->projmatrix; f.campos = frame->campos;
     return f;

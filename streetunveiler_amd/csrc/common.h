@@ -40,6 +40,7 @@ struct FrameDev {
     int W, H, tiles_x, tiles_y;
     int sh_degree, sh_coeffs;
     int colors;   // colour channels blended per pixel: 3, or 6 (precomputed colours only)
+    int activations;   // SR_ACT_* bits: inputs are the raw (pre-activation) parameters
     float scale_modifier;
     const float* bg;
     const float* view;

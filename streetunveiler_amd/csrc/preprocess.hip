@@ -28,6 +28,24 @@ __device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
     R[6] = 2.f * (x * z - r * y);       R[7] = 2.f * (y * z + r * x);       R[8] = 1.f - 2.f * (x * x + y * y);
 }
 
+// Parameter activations of the reference's GaussianModel, fused into K1 / K8 on request
+// [REF scene/gaussian_model.py:63-75: scaling exp, opacity sigmoid, rotation torch.nn.functional.normalize].
+__device__ __forceinline__ float2 load_scales(const float* __restrict__ scales, int i, int act) {
+    float2 s = reinterpret_cast<const float2*>(scales)[i];
+    if (act & SR_ACT_EXP_SCALES) { s.x = expf(s.x); s.y = expf(s.y); }
+    return s;
+}
+__device__ __forceinline__ float4 load_rotation(const float* __restrict__ rotations, int i, int act, float& norm) {
+    float4 q = reinterpret_cast<const float4*>(rotations)[i];
+    norm = 1.f;
+    if (act & SR_ACT_NORMALIZE_ROTATIONS) {
+        norm = fmaxf(sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w), 1e-12f);
+        q.x /= norm; q.y /= norm; q.z /= norm; q.w /= norm;
+    }
+    return q;
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
 // B = viewport^T * full_projection (3x4): rows map a world point to (px*w, py*w, w).
 __device__ __forceinline__ void build_B(const float* __restrict__ proj, int W, int H, float B[12]) {
     const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
@@ -201,8 +219,9 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
         } else {
             float B[12], R[9];
             build_B(f.proj, f.W, f.H, B);
-            quat_to_R(reinterpret_cast<const float4*>(rotations)[i], R);
-            const float2 s = reinterpret_cast<const float2*>(scales)[i];
+            float qn;
+            quat_to_R(load_rotation(rotations, i, f.activations, qn), R);
+            const float2 s = load_scales(scales, i, f.activations);
             const float su = f.scale_modifier * s.x, sv = f.scale_modifier * s.y;
             const float L0[3] = {R[0] * su, R[3] * su, R[6] * su};
             const float L1[3] = {R[1] * sv, R[4] * sv, R[7] * sv};
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
                 out_key = __float_as_uint(vz);
                 q0 = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
                 q1 = make_float4(Tv[1], Tv[2], Tw[0], Tw[1]);
-                q2 = make_float4(Tw[2], cx, cy, opacities[i]);
+                q2 = make_float4(Tw[2], cx, cy, (f.activations & SR_ACT_SIGMOID_OPACITY) ? sigmoidf(opacities[i]) : opacities[i]);
                 q3 = make_float4(nrm[0], nrm[1], nrm[2], vz);
                 q4 = make_float4(rgb[0], rgb[1], rgb[2], radius);
             }
@@ -350,6 +369,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
             }
             const float gx2 = g3.x, gy2 = g3.y;
             g_opa = g3.z;
+            if (f.activations & SR_ACT_SIGMOID_OPACITY) { const float o = r2.w; g_opa *= o * (1.f - o); }
             const float gn[3] = {g3.w, g4.x, g4.y};
             g_col[0] = g4.z; g_col[1] = g4.w; g_col[2] = g5.x;
             if (NC == 6) { g_col[3] = g5.y; g_col[4] = g5.z; g_col[5] = g5.w; }
@@ -376,9 +396,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
             if (!transMat_precomp) {
                 float B[12], R[9];
                 build_B(f.proj, f.W, f.H, B);
-                const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+                float qn;
+                const float4 q = load_rotation(rotations, i, f.activations, qn);
                 quat_to_R(q, R);
-                const float2 sc = reinterpret_cast<const float2*>(scales)[i];  // modifier 1.0 (upstream quirk, A.6)
+                const float2 sc = load_scales(scales, i, f.activations);  // modifier 1.0 (upstream quirk, A.6)
                 float dL0[3], dL1[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -409,6 +430,13 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
                 g_rot[1] = 2.f * (y * G[1] + z * G[2] + y * G[3] - 2.f * x * G[4] - r * G[5] + z * G[6] + r * G[7] - 2.f * x * G[8]);
                 g_rot[2] = 2.f * (-2.f * y * G[0] + x * G[1] + r * G[2] + x * G[3] + z * G[5] - r * G[6] + z * G[7] - 2.f * y * G[8]);
                 g_rot[3] = 2.f * (-2.f * z * G[0] - r * G[1] + x * G[2] + r * G[3] - 2.f * z * G[4] + y * G[5] + x * G[6] + y * G[7]);
+                // adjoints of the fused activations (raw parameters in, raw gradients out)
+                if (f.activations & SR_ACT_EXP_SCALES) { g_scales[0] *= sc.x; g_scales[1] *= sc.y; }
+                if (f.activations & SR_ACT_NORMALIZE_ROTATIONS) {
+                    const float qg = ((q.x * g_rot[0] + q.y * g_rot[1]) + q.z * g_rot[2]) + q.w * g_rot[3];
+                    g_rot[0] = (g_rot[0] - q.x * qg) / qn; g_rot[1] = (g_rot[1] - q.y * qg) / qn;
+                    g_rot[2] = (g_rot[2] - q.z * qg) / qn; g_rot[3] = (g_rot[3] - q.w * qg) / qn;
+                }
             }
             if (shs) {
                 const float ox = px - f.campos[0], oy = py - f.campos[1], oz = pz - f.campos[2];

@@ -37,20 +37,45 @@ class PipelineParams:
     compute_cov3D_python: bool = False
     depth_ratio: float = 0.0
     debug: bool = False
+    # extension: hand the operator the RAW _opacity / _scaling / _rotation and let K1 / K8 apply the
+    # sigmoid / exp / normalize activations and their adjoints (3 elementwise passes + their backward less per call)
+    fused_activations: bool = False
 
 
 class SurfelModel:
-    """Minimal parameter container with the GaussianModel getter surface (activated values stored directly)."""
+    """Minimal parameter container with the GaussianModel getter surface.  `raw=False`: activated values are stored
+    directly; `raw=True`: `_scaling` / `_opacity` / `_rotation` are the reference's pre-activation parameters and the
+    getters apply exp / sigmoid / normalize [REF scene/gaussian_model.py:63-75, 101-123] -- what a PLY checkpoint holds."""
 
-    def __init__(self, xyz, scaling, rotation, opacity, features, semantics=None, active_sh_degree=3, max_sh_degree=3):
+    def __init__(self, xyz, scaling, rotation, opacity, features, semantics=None, active_sh_degree=3, max_sh_degree=3, raw=False):
         self._xyz, self._scaling, self._rotation, self._opacity, self._features = xyz, scaling, rotation, opacity, features
         self._semantics = semantics
         self.active_sh_degree, self.max_sh_degree = active_sh_degree, max_sh_degree
+        self.raw = bool(raw)
+
+    @classmethod
+    def from_ply(cls, path, device="cuda", max_sh_degree=3):
+        """Load a checkpoint in the reference's PLY layout [REF scene/gaussian_model.py:338-382] (raw parameters)."""
+        from .ply import load_ply
+        d = load_ply(path, max_sh_degree)
+        t = lambda a: torch.tensor(a, dtype=torch.float32, device=device).requires_grad_(True)
+        features = torch.cat([t(d["features_dc"]), t(d["features_rest"])], dim=1)
+        return cls(t(d["xyz"]), t(d["scaling"]), t(d["rotation"]), t(d["opacity"]), features,
+                   semantics=torch.tensor(d["semantics"], dtype=torch.int32, device=device), active_sh_degree=max_sh_degree,
+                   max_sh_degree=max_sh_degree, raw=True)
+
+    def save_ply(self, path):
+        from .ply import save_ply
+        n = lambda x: x.detach().cpu().numpy()
+        sem = self._semantics if self._semantics is not None else torch.zeros(self._xyz.shape[0], dtype=torch.int32)
+        assert self.raw, "PLY checkpoints hold the raw (pre-activation) parameters"
+        save_ply(path, n(self._xyz), n(self._features[:, :1]), n(self._features[:, 1:]), n(self._opacity), n(self._scaling),
+                 n(self._rotation), n(sem))
 
     get_xyz = property(lambda s: s._xyz)
-    get_scaling = property(lambda s: s._scaling)
-    get_rotation = property(lambda s: s._rotation)
-    get_opacity = property(lambda s: s._opacity)
+    get_scaling = property(lambda s: torch.exp(s._scaling) if s.raw else s._scaling)
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation) if s.raw else s._rotation)
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity) if s.raw else s._opacity)
     get_features = property(lambda s: s._features)
     get_semantics = property(lambda s: s._semantics)
     get_semantics_32bit = property(lambda s: (1 << s._semantics.to(torch.int32)))
@@ -95,11 +120,22 @@ def _sel(t, mask):
     return t if mask is None else t[mask]
 
 
+def _fused_activations(pc, pipe):
+    """Raw parameters go straight to the operator when asked for and available (a reference GaussianModel always holds
+    them; a SurfelModel only with raw=True)."""
+    return (getattr(pipe, "fused_activations", False) and not pipe.compute_cov3D_python and getattr(pc, "raw", True)
+            and all(hasattr(pc, a) for a in ("_opacity", "_scaling", "_rotation")))
+
+
 def _geometry_inputs(pc, pipe, screenspace_points, mask, scaling_modifier):
-    means3D, means2D, opacity = _sel(pc.get_xyz, mask), _sel(screenspace_points, mask), _sel(pc.get_opacity, mask)
+    fused = _fused_activations(pc, pipe)
+    means3D, means2D = _sel(pc.get_xyz, mask), _sel(screenspace_points, mask)
+    opacity = _sel(pc._opacity if fused else pc.get_opacity, mask)
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:
         cov3D_precomp = _sel(pc.get_covariance(scaling_modifier), mask)
+    elif fused:
+        scales, rotations = _sel(pc._scaling, mask), _sel(pc._rotation, mask)
     else:
         scales, rotations = _sel(pc.get_scaling, mask), _sel(pc.get_rotation, mask)
     try:
@@ -135,7 +171,8 @@ def _semantic_mask(pc, semantic_filter_bit, reverse_semantic):
 
 def _render_impl(viewpoint_camera, pc, pipe, bg_color, mask, scaling_modifier, override_color):
     screenspace_points = _screenspace_points(pc)
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier),
+                                    fused_activations=_fused_activations(pc, pipe))
     means3D, means2D, opacity, scales, rotations, cov3D_precomp = _geometry_inputs(pc, pipe, screenspace_points, mask, scaling_modifier)
     shs, colors_precomp = _color_inputs(viewpoint_camera, pc, pipe, mask, override_color)
     rendered_image, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
@@ -170,7 +207,8 @@ def _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier):
     # per-pixel alpha chain are shared), which gives bit-identical channel values.
     assert n_cls == 6, "the single-pass semantic render is built for the reference's 6 classes"
     bg = torch.tensor(bg_prob, dtype=torch.float32, device=dev)
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg, scaling_modifier))
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg, scaling_modifier),
+                                    fused_activations=_fused_activations(pc, pipe))
     semantic_6 = (semantics_tag.view(-1, 1) == torch.arange(n_cls, device=dev).view(1, -1)).float()
     output_semantic, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=semantic_6,
                                                 opacities=opacity, scales=scales, rotations=rotations,

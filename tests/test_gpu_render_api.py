@@ -1,5 +1,7 @@
 """GPU (-m gpu): the reference's operator surface (render / render_with_mask / render_semantic[_with_mask],
 SURVEY 8a rows A1-A4) on top of the HIP rasterizer, end to end against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -151,3 +153,43 @@ def test_fused_postprocess_matches_torch_restatement():
         assert np.abs(ggpu - gref).max() <= 2e-4 * scale, np.abs(ggpu - gref).max() / scale
     with pytest.raises(Exception, match="no CPU path"):
         postprocess_allmap(cam, PipelineParams(), allmap)
+
+
+def test_fused_activations_and_ply_checkpoint(tmp_path):
+    """raw _opacity/_scaling/_rotation straight into the operator (sigmoid/exp/normalize fused into K1, adjoints
+    into K8) == the reference's torch activations in front of it; and a PLY checkpoint drives the same render."""
+    from tests.gpu_util import assert_close_frac, assert_grads_close, check_allmap
+    P, W, H = 6000, 224, 128
+    cam = synthetic_camera(W, H, index=3).to(DEV)
+    g = synthetic_gaussians(P, W, H, seed=12, scale_lo=3e-3, scale_hi=5e-2)
+    gen = torch.Generator().manual_seed(5)
+    raw = dict(scaling=torch.log(g["scales"]), opacity=torch.logit(g["opacities"].clamp(1e-4, 1 - 1e-4)),
+               rotation=g["rotations"] * (0.25 + 3 * torch.rand(P, 1, generator=gen)))
+    sem = torch.randint(0, 6, (P,), generator=gen)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=DEV)
+    results = {}
+    for fused in (False, True):
+        leaves = {k: v.to(DEV).requires_grad_() for k, v in dict(xyz=g["means3D"], features=g["shs"], **raw).items()}
+        pc = SurfelModel(leaves["xyz"], leaves["scaling"], leaves["rotation"], leaves["opacity"], leaves["features"], sem.to(DEV), 3, 3, raw=True)
+        out = render(cam, pc, PipelineParams(fused_activations=fused, depth_ratio=0.3), bg)
+        loss = (out["render"] * torch.linspace(0.5, 1.5, W, device=DEV)).sum() + out["rend_alpha"].sum() + out["rend_dist"].sum() * 10 \
+            + (out["rend_normal"] * out["surf_normal"]).sum() + out["surf_depth"].mean()
+        loss.backward()
+        results[fused] = (out, {k: v.grad.detach().cpu().numpy() for k, v in leaves.items()}, pc)
+    a, b = results[False], results[True]
+    assert float((a[0]["radii"] != b[0]["radii"]).float().mean()) < 1e-3      # an ulp of exp() may move a ceil()
+    assert_close_frac(b[0]["render"].detach().cpu().numpy(), a[0]["render"].detach().cpu().numpy(), 1e-4, 1e-4, 2e-4, 2e-2, "fused render")
+    for k in ("rend_alpha", "rend_dist", "surf_depth", "rend_normal"):
+        assert_close_frac(b[0][k].detach().cpu().numpy(), a[0][k].detach().cpu().numpy(), 1e-4, 1e-4, 5e-4, None, "fused " + k)
+    for k in a[1]:
+        assert np.abs(a[1][k]).max() > 0, k
+        assert_grads_close(b[1][k], a[1][k], 2e-3, "fused d" + k)
+    # PLY round trip of the raw checkpoint, then the same (fused) render from the file
+    path = os.path.join(tmp_path, "point_cloud.ply")
+    b[2].save_ply(path)
+    pc2 = SurfelModel.from_ply(path, device=DEV)
+    for name in ("_xyz", "_scaling", "_rotation", "_opacity", "_features"):
+        assert torch.equal(getattr(pc2, name).detach(), getattr(b[2], name).detach()), name
+    assert torch.equal(pc2.get_semantics.cpu(), sem.to(torch.int32))
+    out2 = render(cam, pc2, PipelineParams(fused_activations=True, depth_ratio=0.3), bg)
+    assert torch.equal(out2["render"], b[0]["render"]) and torch.equal(out2["radii"], b[0]["radii"])

@@ -149,3 +149,45 @@ def test_factored_sh_exchange_gloo_world2(tmp_path):
     assert expect.abs().max() > 0.1
     for r in rs:
         torch.testing.assert_close(r["summed"], expect, rtol=1e-5, atol=1e-6)
+
+
+def test_ply_checkpoint_layout_and_round_trip(tmp_path):
+    """Reference PLY layout [REF scene/gaussian_model.py:226-259, 338-382]: property names/order, channel-major SH
+    features, int32 semantics; binary and ASCII, any property order."""
+    from streetunveiler_amd.ply import attribute_names, load_ply, save_ply
+    rng = np.random.default_rng(0)
+    P = 37
+    d = dict(xyz=rng.normal(size=(P, 3)), features_dc=rng.normal(size=(P, 1, 3)), features_rest=rng.normal(size=(P, 15, 3)),
+             opacity=rng.normal(size=(P, 1)), scaling=rng.normal(size=(P, 2)), rotation=rng.normal(size=(P, 4)))
+    d = {k: v.astype(np.float32) for k, v in d.items()}
+    sem = rng.integers(0, 6, size=(P, 1))
+    path = os.path.join(tmp_path, "pc.ply")
+    save_ply(path, d["xyz"], d["features_dc"], d["features_rest"], d["opacity"], d["scaling"], d["rotation"], sem)
+    raw = open(path, "rb").read()
+    names = attribute_names()
+    assert names[:9] == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] and names[9] == "f_rest_0" and names[53] == "f_rest_44"
+    assert names[54:] == ["opacity", "scale_0", "scale_1", "rot_0", "rot_1", "rot_2", "rot_3"]
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex 37\n" + "".join(f"property float {n}\n" for n in names) + "property int semantics\nend_header\n"
+    assert raw.startswith(header.encode()) and len(raw) == len(header) + P * (61 * 4 + 4)
+    row0 = np.frombuffer(raw[len(header):len(header) + 62 * 4], "<f4")
+    np.testing.assert_array_equal(row0[:3], d["xyz"][0]); np.testing.assert_array_equal(row0[3:6], 0)
+    np.testing.assert_array_equal(row0[6:9], d["features_dc"][0, 0])                 # f_dc_c = channel c
+    np.testing.assert_array_equal(row0[9:24], d["features_rest"][0, :, 0])            # f_rest_0..14 = channel 0, coefficients 1..15
+    np.testing.assert_array_equal(row0[24:39], d["features_rest"][0, :, 1])
+    back = load_ply(path)
+    for k, v in d.items():
+        np.testing.assert_array_equal(back[k], v)
+    np.testing.assert_array_equal(back["semantics"], sem[:, 0])
+    # ASCII, shuffled property order, an extra property: still loads by name
+    order = list(rng.permutation(len(names)))
+    cols = np.frombuffer(raw[len(header):], np.dtype([(n, "<f4") for n in names] + [("semantics", "<i4")]))
+    with open(os.path.join(tmp_path, "a.ply"), "w") as fh:
+        fh.write("ply\nformat ascii 1.0\ncomment shuffled\nelement vertex 37\nproperty int semantics\nproperty float extra\n")
+        fh.write("".join(f"property float {names[k]}\n" for k in order) + "end_header\n")
+        for r in cols:
+            fh.write(" ".join([str(int(r["semantics"])), "1.5"] + [repr(float(r[names[k]])) for k in order]) + "\n")
+    back2 = load_ply(os.path.join(tmp_path, "a.ply"))
+    for k, v in d.items():
+        np.testing.assert_array_equal(back2[k], v)
+    with pytest.raises(ValueError):
+        load_ply(path, max_sh_degree=2)
