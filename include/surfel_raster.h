@@ -171,6 +171,16 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
 int sr_sh_gradient_expand(int32_t P, int32_t sh_coeffs, int32_t sh_degree, int32_t n_views, const float* means3D,
                           const float* campos, const float* dL_dcolors, float* dL_dsh, void* stream);
 
+/* K-nearest-neighbour mean squared distance == simple_knn._C.dist3knn / dist10knn (K = 3 / 10; scale
+ * initialisation, /root/reference/scene/gaussian_model.py:16,151) and meanDistFromReferencePcd (distance of every point of
+ * one cloud to another cloud, /root/reference/inpainting_pipeline/2_condition_preparation/2_generate_inpainted_mask.py:27,71-73).
+ * out[i] = (sum of the K smallest squared distances from query i to the reference points) / K; with query == NULL every
+ * reference point is searched against the OTHER reference points (n_query ignored, out [n_reference]).  Exact search.
+ * points are [n,3] float32 device arrays; workspace: sr_knn_workspace_bytes(n_query or 0, n_reference) bytes. */
+size_t sr_knn_workspace_bytes(int32_t n_query, int32_t n_reference);
+int sr_knn_mean_dist2(int32_t n_query, const float* query, int32_t n_reference, const float* reference, int32_t K,
+                      int32_t take_sqrt, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* K9: present[i] = (view-space z of means3D[i] > 0.2).  present is uint8 (torch.bool storage). */
 int sr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     uint8_t* present, void* stream);

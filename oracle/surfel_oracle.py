@@ -29,8 +29,8 @@ TILE = 16
 
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (idempotent)."""
-    src = os.path.join(_HERE, "surfel_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "surfel_oracle.c"), os.path.join(_HERE, "knn_oracle.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libsurfel_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 

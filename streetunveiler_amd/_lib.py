@@ -51,7 +51,7 @@ class SrImageView(C.Structure):
 
 # every symbol include/surfel_raster.h declares (checked by tests/test_abi.py)
 EXPORTS = ["sr_abi_version", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
-           "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan", "sr_sh_gradient_expand",
+           "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan", "sr_sh_gradient_expand", "sr_knn_workspace_bytes", "sr_knn_mean_dist2",
            "sr_forward_render", "sr_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_set_option", "sr_debug_stats", "sr_debug_radix_sort", "sr_debug_radix_sort_temp_bytes", "sr_postprocess_forward",
            "sr_postprocess_backward"]
 
@@ -91,6 +91,10 @@ def load():
                                 C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_size_t, C.POINTER(SrGradients), C.c_void_p]
     lib.sr_sh_gradient_expand.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5
+    lib.sr_knn_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.sr_knn_workspace_bytes.restype = C.c_size_t
+    lib.sr_knn_mean_dist2.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]
     lib.sr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sr_set_stage_timing.argtypes = [C.c_int]
     lib.sr_set_option.argtypes = [C.c_int, C.c_int]

@@ -25,6 +25,7 @@ SOURCES = [
     ("radix_sort.hip", []),
     ("render.hip", []),
     ("postprocess.hip", []),
+    ("knn.hip", ["-ffp-contract=off"]),         # squared distances bit-identical to the brute-force oracle
     ("api.hip", []),
 ]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "surfel_raster.h")]

@@ -42,6 +42,10 @@ hipError_t read_render_stats(unsigned long long* out8, bool reset);
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint32_t* aux_src, uint32_t* aux_out);
+// knn.hip
+size_t knn_workspace_bytes(int nq, int nr);
+hipError_t knn_mean_dist2(int nq, const float* query, int nr, const float* reference, int K, int take_sqrt, float* out, void* ws,
+                          size_t ws_bytes, hipStream_t s);
 // postprocess.hip
 struct PostCam { int W, H; float fx, fy, depth_ratio; const float* view; };
 hipError_t launch_postprocess_forward(const PostCam& cam, const float* allmap, float* rend_normal, float* surf_depth,
@@ -389,6 +393,23 @@ int sr_sh_gradient_expand(int32_t P, int32_t sh_coeffs, int32_t sh_degree, int32
     if (P == 0) return SR_OK;
     if (!means3D || !campos || !dL_dcolors || !dL_dsh) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     SR_HIP(launch_sh_gradient_expand(P, sh_coeffs, sh_degree, n_views, means3D, campos, dL_dcolors, dL_dsh, static_cast<hipStream_t>(stream)));
+    return SR_OK;
+}
+
+size_t sr_knn_workspace_bytes(int32_t n_query, int32_t n_reference) {
+    return knn_workspace_bytes(n_query > 0 ? n_query : 0, n_reference > 0 ? n_reference : 0);
+}
+
+int sr_knn_mean_dist2(int32_t n_query, const float* query, int32_t n_reference, const float* reference, int32_t K,
+                      int32_t take_sqrt, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (K != 3 && K != 10) return fail(SR_ERR_UNSUPPORTED, "K = %d, supported: 3 and 10", K);
+    if (n_reference < 0 || (query && n_query < 0)) return fail(SR_ERR_INVALID_ARGUMENT, "negative point count");
+    const int nq = query ? n_query : 0;
+    if ((query ? nq : n_reference) == 0) return SR_OK;
+    if (n_reference == 0) return fail(SR_ERR_INVALID_ARGUMENT, "empty reference cloud");
+    if (!reference || !out || !workspace) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (workspace_bytes < knn_workspace_bytes(nq, n_reference)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, knn_workspace_bytes(nq, n_reference));
+    SR_HIP(knn_mean_dist2(nq, query, n_reference, reference, K, take_sqrt, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream)));
     return SR_OK;
 }
 

@@ -144,3 +144,18 @@ def test_mark_visible_and_empty_inputs():
     assert fwd["num_rendered"] == 0 and (fwd["radii"] == 0).all()
     np.testing.assert_allclose(fwd["color"], np.broadcast_to(bg[:, None, None], (3, 32, 32)))
     assert (fwd["allmap"] == 0).all()
+
+
+def test_knn_oracle_against_kdtree():
+    """oracle/knn_oracle.c (brute force, float32) against an independent implementation: scipy's KD-tree in float64."""
+    from scipy.spatial import cKDTree
+    from oracle.knn_oracle import knn_mean_dist2
+    rng = np.random.default_rng(3)
+    pts = (rng.normal(size=(3000, 3)) * [10, 2, 10]).astype(np.float32)
+    ref = (rng.normal(size=(2000, 3)) * [10, 2, 10]).astype(np.float32)
+    for K in (3, 10):
+        d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=K + 1)
+        np.testing.assert_allclose(knn_mean_dist2(pts, K), (d[:, 1:] ** 2).mean(axis=1), rtol=1e-5)
+    d, _ = cKDTree(ref.astype(np.float64)).query(pts.astype(np.float64), k=3)
+    np.testing.assert_allclose(knn_mean_dist2(pts, 3, reference=ref), (d ** 2).mean(axis=1), rtol=1e-5)
+    np.testing.assert_allclose(knn_mean_dist2(pts, 3, reference=ref, take_sqrt=True), np.sqrt((d ** 2).mean(axis=1)), rtol=1e-5)
