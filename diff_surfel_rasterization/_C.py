@@ -44,10 +44,11 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug):
+def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile=None):
     keep = [_f32c(bg, "bg"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")]
     fr = L.SrFrame(int(H), int(W), float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree),
-                   int(bool(prefiltered)), int(bool(debug)), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]))
+                   int(bool(prefiltered)), int(bool(debug)), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
+                   int(tile[0]) if tile else 0, int(tile[1]) if tile else 0)
     return fr, keep
 
 
@@ -72,7 +73,9 @@ def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transM
 
 def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, activations=0):
+                        prefiltered, debug, activations=0, tile=None):
+    """`tile` = (width, height) of the binning tile, default the reference's 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
+    16x16, 32x8, 32x16); the backward must be given the same shape."""
     lib = L.load()
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise L.SurfelRasterError("means3D must have dimensions (num_points, 3)")
@@ -83,7 +86,7 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
     dev = means3D.device
     P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
     with torch.cuda.device(dev):
-        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug)
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile)
         g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations)
         if keep[0].numel() != g.color_channels:
             raise L.SurfelRasterError(f"bg must have {g.color_channels} entries, one per colour channel")
@@ -108,7 +111,7 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
 def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap, sh, degree, campos,
                                  geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None, defer_sh=False,
-                                 activations=0):
+                                 activations=0, tile=None):
     """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry.
 
     `defer_sh=True` (frame-parallel ranks, streetunveiler_amd.parallel): with SHs as the colour source, dL_dsh is NOT
@@ -125,7 +128,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
     H, W = int(dL_dcolor.shape[1]), int(dL_dcolor.shape[2])
     M = int(sh.shape[1]) if sh is not None and sh.numel() else 0
     with torch.cuda.device(dev):
-        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, False, debug)
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, False, debug, tile)
         # the backward never dereferences opacities (it reads the packed record); pass means3D as a non-NULL stand-in
         g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp, activations)
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -202,10 +205,10 @@ def geom_view(geom: torch.Tensor, P: int):
                 sorted_offsets=_view(geom, v.sorted_offsets, P * 4, torch.int32))
 
 
-def binning_view(binning: torch.Tensor, P: int, D: int, W: int, H: int):
+def binning_view(binning: torch.Tensor, P: int, D: int, W: int, H: int, tile=(16, 16)):
     v = L.SrBinningView()
     L.check(L.load().sr_binning_view(_ptr(binning), binning.numel(), P, D, W, H, C.byref(v)), "sr_binning_view")
-    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    tiles = ((W + tile[0] - 1) // tile[0]) * ((H + tile[1] - 1) // tile[1])
     return dict(tile_keys=_view(binning, v.tile_keys, D * 4, torch.int32), point_list=_view(binning, v.point_list, D * 4, torch.int32),
                 ranges=_view(binning, v.ranges, tiles * 8, torch.int32).view(tiles, 2))
 

@@ -43,18 +43,21 @@ def _cpu_snapshot(args):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        activations=0):
+                        activations=0, tile=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, activations)
+                                     raster_settings, activations, tile)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                activations=0):
+                activations=0, tile=None):
         s = raster_settings
         ctx.activations = int(activations)
+        ctx.tile = tuple(int(t) for t in tile) if tile else None
         fused = {"activations": ctx.activations} if ctx.activations else {}
+        if ctx.tile:
+            fused["tile"] = ctx.tile
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
                 s.debug)
@@ -93,6 +96,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         kwargs = {"defer_sh": True} if exchange is not None else {}
         if ctx.activations:
             kwargs["activations"] = ctx.activations
+        if ctx.tile:
+            kwargs["tile"] = ctx.tile
         if s.debug:
             snapshot = _cpu_snapshot(args)
             try:
@@ -110,17 +115,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         none_if_empty = lambda g, ref: g if ref.numel() else None
         return (grad_means3D, grad_means2D, none_if_empty(grad_sh, sh), none_if_empty(grad_colors_precomp, colors_precomp),
                 grad_opacities, none_if_empty(grad_scales, scales), none_if_empty(grad_rotations, rotations),
-                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None)
+                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False, tile=None):
         """`fused_activations=True` (extension): `opacities`, `scales`, `rotations` are the RAW parameters
         (`_opacity`, `_scaling`, `_rotation` of the reference's GaussianModel); sigmoid / exp / normalize run inside the
-        preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values."""
+        preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values.
+        `tile=(w, h)`: binning tile shape, default the reference's compile-time 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
+        16x16, 32x8, 32x16); images and gradients do not depend on it beyond float summation order."""
         super().__init__()
         self.raster_settings = raster_settings
         self.activations = 7 if fused_activations else 0
+        self.tile = tile
 
     def markVisible(self, positions):
         with torch.no_grad():
@@ -142,4 +150,4 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s,
-                                   self.activations)
+                                   self.activations, self.tile)

@@ -38,8 +38,8 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 2
-#define SR_TILE 16            /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
+#define SR_ABI_VERSION 3
+#define SR_TILE 16            /* default 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y); see SrFrame.tile_width */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
 #define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B; 28 = 112 B with 6 colour channels) */
 
@@ -72,6 +72,8 @@ typedef struct SrFrame {
     const float* viewmatrix;  /* device [16] = world_view_transform (W2C^T), row-major */
     const float* projmatrix;  /* device [16] = full_proj_transform ((P*W2C)^T), row-major */
     const float* campos;      /* device [3] */
+    int32_t tile_width;       /* 0 = 16 (the reference's BLOCK_X); BASELINE config 5 sweeps 8x8, 16x8, 16x16, 32x8, 32x16 */
+    int32_t tile_height;      /* 0 = 16 (BLOCK_Y).  Same shape in every call that shares the state buffers */
 } SrFrame;
 
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward

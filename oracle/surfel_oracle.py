@@ -65,9 +65,10 @@ def _p(a, ty=C.c_float):
 def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None, colors_precomp=None,
                       transMat_precomp=None, *, viewmatrix, projmatrix, campos, bg, image_width: int,
                       image_height: int, sh_degree: int = 0, scale_modifier: float = 1.0,
-                      stages: bool = True) -> Dict[str, np.ndarray]:
-    """K1..K6. Returns every stage's outputs (dict of numpy arrays)."""
+                      stages: bool = True, tile=(16, 16)) -> Dict[str, np.ndarray]:
+    """K1..K6. Returns every stage's outputs (dict of numpy arrays).  `tile` = (BLOCK_X, BLOCK_Y), 16x16 in the reference."""
     L = lib()
+    L.so_set_tile(int(tile[0]), int(tile[1]))
     means3D = _f32(means3D); P = means3D.shape[0]
     opacities = _f32(opacities).reshape(P)
     scales = _f32(scales); rotations = _f32(rotations); shs = _f32(shs)
@@ -89,7 +90,7 @@ def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None,
                             _p(o["transMat"]), _p(o["normal_opacity"]), _p(o["rgb"]), _p(o["clamped"], C.c_uint8),
                             _p(o["tiles_touched"], C.c_uint32), _p(o["rect"], C.c_int32))
     D = int(L.so_count_duplicates(P, _p(o["tiles_touched"], C.c_uint32)))
-    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    gx, gy = (W + int(tile[0]) - 1) // int(tile[0]), (H + int(tile[1]) - 1) // int(tile[1])
     o["num_rendered"] = D
     o["keys"] = np.zeros(max(D, 1), np.uint64)[:D]
     o["point_list"] = np.zeros(max(D, 1), np.uint32)[:D]
@@ -110,7 +111,7 @@ def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None,
     o["_inputs"] = dict(means3D=means3D, opacities=opacities, scales=scales, rotations=rotations, shs=shs,
                         colors_precomp=colors_precomp, transMat_precomp=transMat_precomp, view=view, proj=proj,
                         cam=cam, bg=bgc, W=W, H=H, deg=int(sh_degree), M=M, scale_modifier=float(scale_modifier),
-                        vals_buf=vals_buf)
+                        vals_buf=vals_buf, tile=(int(tile[0]), int(tile[1])))
     return o
 
 
@@ -118,6 +119,7 @@ def rasterize_backward(fwd: Dict[str, np.ndarray], dL_dcolor, dL_dallmap) -> Dic
     """K7 + K8 on the state returned by rasterize_forward."""
     L = lib()
     i = fwd["_inputs"]; P = i["means3D"].shape[0]; W, H, M = i["W"], i["H"], i["M"]
+    L.so_set_tile(*i["tile"])
     dL_dcolor = _f32(dL_dcolor).reshape(3, H, W); dL_dallmap = _f32(dL_dallmap).reshape(7, H, W)
     g = dict(dL_dcolors=np.zeros((P, 3), np.float32), dL_dnormal3D=np.zeros((P, 3), np.float32),
              dL_dtransMat=np.zeros((P, 9), np.float32), dL_dmean2D_raw=np.zeros((P, 2), np.float32),

@@ -20,7 +20,8 @@ SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "rang
 class SrFrame(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("scale_modifier", C.c_float), ("sh_degree", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
-                ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+                ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+                ("tile_width", C.c_int32), ("tile_height", C.c_int32)]
 
 
 class SrGaussians(C.Structure):
@@ -105,8 +106,8 @@ def load():
     lib.sr_debug_radix_sort_temp_bytes.restype = C.c_size_t
     lib.sr_debug_radix_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sr_stage_stats.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    if lib.sr_abi_version() != 2:
-        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 2")
+    if lib.sr_abi_version() != 3:
+        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 3")
     _lib = lib
     return lib
 

@@ -26,7 +26,7 @@ size_t tile_sort_temp_bytes(uint32_t D, int n_tiles);
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* sorted_keys,
                           uint32_t* sorted_gid, uint32_t* tt_sorted, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t run_tile_count_scan(int P, const uint32_t* tt_sorted, uint32_t* sorted_offsets, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t run_emit(int P, int tiles_x, int tiles_y, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
+hipError_t run_emit(int P, int tiles_x, int tiles_y, int tile_w, int tile_h, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
                     float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, hipStream_t s);
 hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
                          uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s);
@@ -153,7 +153,7 @@ struct BinLayout {
 BinLayout bin_layout(uint32_t D, int W, int H) {
     BinLayout L{};
     const size_t n = (size_t)(D > 0 ? D : 1);
-    const int tiles = ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    const int tiles = ((W + 7) / 8) * ((H + 7) / 8);   // sized for the smallest tile shape (8x8); the reference's 16x16 uses a quarter
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L.keys_unsorted = take(n * 4);
@@ -186,6 +186,12 @@ int check_common(const SrFrame* frame, const SrGaussians* g) {
     if (!frame || !g) return fail(SR_ERR_INVALID_ARGUMENT, "frame / gaussians is NULL");
     if (frame->image_width <= 0 || frame->image_height <= 0) return fail(SR_ERR_INVALID_ARGUMENT, "bad image size %dx%d", frame->image_width, frame->image_height);
     if (g->P < 0) return fail(SR_ERR_INVALID_ARGUMENT, "P < 0");
+    {
+        const int tw = frame->tile_width > 0 ? frame->tile_width : kTile, th = frame->tile_height > 0 ? frame->tile_height : kTile;
+        const bool known = (tw == 16 && th == 16) || (tw == 8 && th == 8) || (tw == 16 && th == 8) || (tw == 32 && th == 8) || (tw == 32 && th == 16);
+        if (!known) return fail(SR_ERR_UNSUPPORTED, "tile shape %dx%d not in {8x8, 16x8, 16x16, 32x8, 32x16}", tw, th);
+        if (!(tw == 16 && th == 16) && g->color_channels == 6) return fail(SR_ERR_UNSUPPORTED, "6 colour channels are built for the 16x16 tile only");
+    }
     if (!frame->bg || !frame->viewmatrix || !frame->projmatrix || !frame->campos) return fail(SR_ERR_INVALID_ARGUMENT, "bg / viewmatrix / projmatrix / campos must be non-NULL device pointers");
     if (g->P > 0) {
         if (!g->means3D || !g->opacities) return fail(SR_ERR_INVALID_ARGUMENT, "means3D / opacities is NULL");
@@ -207,7 +213,9 @@ int check_common(const SrFrame* frame, const SrGaussians* g) {
 FrameDev make_frame(const SrFrame* frame, const SrGaussians* g) {
     FrameDev f{};
     f.W = frame->image_width; f.H = frame->image_height;
-    f.tiles_x = (f.W + kTile - 1) / kTile; f.tiles_y = (f.H + kTile - 1) / kTile;
+    f.tile_w = frame->tile_width > 0 ? frame->tile_width : kTile; f.tile_h = frame->tile_height > 0 ? frame->tile_height : kTile;
+    f.inv_tile_w = 1.f / (float)f.tile_w; f.inv_tile_h = 1.f / (float)f.tile_h;
+    f.tiles_x = (f.W + f.tile_w - 1) / f.tile_w; f.tiles_y = (f.H + f.tile_h - 1) / f.tile_h;
     f.sh_degree = frame->sh_degree; f.sh_coeffs = g->sh_coeffs;
     f.colors = g->color_channels == 6 ? 6 : 3;
     f.activations = g->activations;
@@ -319,7 +327,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
         recs = at<float4>(geom, L.recs);
         {
             StageTimer t(SR_STAGE_EMIT, s);
-            SR_HIP(run_emit(P, f.tiles_x, f.tiles_y, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), recs,
+            SR_HIP(run_emit(P, f.tiles_x, f.tiles_y, f.tile_w, f.tile_h, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), recs,
                             at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted), s));
         }
         if (int rc = debug_sync(frame, s, "emit_duplicates")) return rc;

@@ -38,6 +38,8 @@ constexpr int kGradFloats = SR_GRAD_FLOATS;
 
 struct FrameDev {
     int W, H, tiles_x, tiles_y;
+    int tile_w, tile_h;           // pixels per tile: powers of two, multiples of 8 (8x8 quadrant = 1 pixel per lane)
+    float inv_tile_w, inv_tile_h; // exact reciprocals
     int sh_degree, sh_coeffs;
     int colors;   // colour channels blended per pixel: 3, or 6 (precomputed colours only)
     int activations;   // SR_ACT_* bits: inputs are the raw (pre-activation) parameters

@@ -257,9 +257,10 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
             const float hx = cx * cx - tx, hy = cy * cy - ty;
             const float ex = sqrtf(fmaxf(1e-4f, hx)), ey = sqrtf(fmaxf(1e-4f, hy));
             const float radius = ceilf(fmaxf(fmaxf(ex, ey), kCutoff * kFilterSize));
-            int minx = (int)((cx - radius) / (float)kTile), miny = (int)((cy - radius) / (float)kTile);
-            int maxx = (int)((cx + radius + (float)(kTile - 1)) / (float)kTile);
-            int maxy = (int)((cy + radius + (float)(kTile - 1)) / (float)kTile);
+            // tile sizes are powers of two: multiplying by the exact reciprocal == the reference's division
+            int minx = (int)((cx - radius) * f.inv_tile_w), miny = (int)((cy - radius) * f.inv_tile_h);
+            int maxx = (int)((cx + radius + (float)(f.tile_w - 1)) * f.inv_tile_w);
+            int maxy = (int)((cy + radius + (float)(f.tile_h - 1)) * f.inv_tile_h);
             minx = min(f.tiles_x, max(0, minx)); maxx = min(f.tiles_x, max(0, maxx));
             miny = min(f.tiles_y, max(0, miny)); maxy = min(f.tiles_y, max(0, maxy));
             const int area = (maxx - minx) * (maxy - miny);

@@ -45,19 +45,21 @@ __device__ unsigned long long g_stats[8];
 // u^2+v^2 <= thr under the splat's homography -- an ellipse with dual conic C* = Q diag(thr,thr,-1) Q^T --
 // and {rho2d <= thr} is a disc of radius sqrt(thr/2) around means2D.  The staging lane bounds that union by
 // an octagon (support in directions x, y, x+y, x-y from the tangent-line equation l^T C* l = 0) and tests it
-// against the tile's four 8x8 quadrants.  (A second, nearly exact test in the splat's (u,v) plane removes another
+// against the tile's 8x8 quadrants (QX x QY of them; 2 x 2 for the reference's 16x16 tile).  (A second, nearly exact test in the splat's (u,v) plane removes another
 // 9 % of the tests but costs more at staging than it saves -- measured, not kept.)  Entries dropped here are entries the per-pixel test would skip anyway (`continue` in Appendix A.4),
 // so results are unchanged; the bound has 0.3 px / 1 % slack for float rounding and keeps the entry whenever
 // anything is degenerate or NaN.  Inputs are tile-local (origin at
 // the tile centre), which keeps the conic free of cancellation.
 // ---------------------------------------------------------------------------------------------
+template <int QX, int QY>
 __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my,
                                                   float opacity) {
+    constexpr uint32_t kAll = (1u << (QX * QY)) - 1u;
     float thr = 2.f * __logf(255.f * opacity);
     thr = thr * 1.01f + 0.01f;
     if (thr <= 0.f) return 0u;
     const float c22 = thr * (Tw[0] * Tw[0] + Tw[1] * Tw[1]) - Tw[2] * Tw[2];
-    if (!(c22 < 0.f)) return 0xFu;  // the cutoff disc reaches the camera plane: unbounded footprint
+    if (!(c22 < 0.f)) return kAll;  // the cutoff disc reaches the camera plane: unbounded footprint
     const float c00 = thr * (Tu[0] * Tu[0] + Tu[1] * Tu[1]) - Tu[2] * Tu[2];
     const float c01 = thr * (Tu[0] * Tv[0] + Tu[1] * Tv[1]) - Tu[2] * Tv[2];
     const float c11 = thr * (Tv[0] * Tv[0] + Tv[1] * Tv[1]) - Tv[2] * Tv[2];
@@ -81,9 +83,9 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
     const float m = 0.3f;
     uint32_t mask = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float x0 = ((q & 1) ? 0.f : -8.f) - m, x1 = ((q & 1) ? 7.f : -1.f) + m;
-        const float y0 = ((q & 2) ? 0.f : -8.f) - m, y1 = ((q & 2) ? 7.f : -1.f) + m;
+    for (int q = 0; q < QX * QY; ++q) {   // quadrant (q % QX, q / QX) of the tile, coordinates relative to the tile centre
+        const float x0 = (float)((q % QX) * 8 - QX * 4) - m, x1 = (float)((q % QX) * 8 - QX * 4 + 7) + m;
+        const float y0 = (float)((q / QX) * 8 - QY * 4) - m, y1 = (float)((q / QX) * 8 - QY * 4 + 7) + m;
         const bool out = lo[0] > x1 || hi[0] < x0 || lo[1] > y1 || hi[1] < y0 || lo[2] > x1 + y1 || hi[2] < x0 + y0 ||
                          lo[3] > x1 - y0 || hi[3] < x0 - y1;
         if (out) continue;
@@ -107,6 +109,7 @@ __device__ __forceinline__ float4 load_extra(const float* __restrict__ colors6, 
     return make_float4(c[0], c[1], c[2], 0.f);
 }
 
+template <int QX, int QY>
 __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], const float4 ex, float Xc, float Yc, int cull,
                                                 float4 (*s_e)[kWave], int slot) {
     const float Tw[3] = {q[1].z, q[1].w, q[2].x};
@@ -122,7 +125,7 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], co
     s_e[3][slot] = make_float4(mx, my, opacity, ex.z);
     s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[4].x);
     s_e[5][slot] = make_float4(q[4].y, q[4].z, ex.x, ex.y);
-    return cull ? quadrant_mask(Tu, Tv, Tw, mx, my, opacity) : 0xFu;
+    return cull ? quadrant_mask<QX, QY>(Tu, Tv, Tw, mx, my, opacity) : (1u << (QX * QY)) - 1u;
 }
 
 struct Hit {
@@ -153,12 +156,12 @@ __device__ __forceinline__ bool intersect(float xl, float yl, const float4 e0, c
 
 // Emission index of the duplicate (tile tx,ty ; Gaussian gid): duplicates are emitted per Gaussian, y-major /
 // x-minor over its tile rectangle (same expressions as K1 / K3 -> same rectangle).
-__device__ __forceinline__ uint32_t emission_index(const float4 (&q)[kRecQuads], uint32_t first, int tx, int ty, int tiles_x, int tiles_y) {
+__device__ __forceinline__ uint32_t emission_index(const float4 (&q)[kRecQuads], uint32_t first, int tx, int ty, const FrameDev& f) {
     const float cx = q[2].y, cy = q[2].z, radius = q[4].w;
-    int minx = (int)((cx - radius) / (float)kTile), miny = (int)((cy - radius) / (float)kTile);
-    int maxx = (int)((cx + radius + (float)(kTile - 1)) / (float)kTile);
-    minx = min(tiles_x, max(0, minx)); maxx = min(tiles_x, max(0, maxx));
-    miny = min(tiles_y, max(0, miny));
+    int minx = (int)((cx - radius) * f.inv_tile_w), miny = (int)((cy - radius) * f.inv_tile_h);
+    int maxx = (int)((cx + radius + (float)(f.tile_w - 1)) * f.inv_tile_w);
+    minx = min(f.tiles_x, max(0, minx)); maxx = min(f.tiles_x, max(0, maxx));
+    miny = min(f.tiles_y, max(0, miny));
     return first + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
 }
 
@@ -171,7 +174,7 @@ __device__ __forceinline__ void load_record(const float4* __restrict__ recs, uin
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
-template <bool kStats, int NC>
+template <bool kStats, int NC, int QX, int QY>
 __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ recs,
@@ -182,22 +185,23 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     __shared__ float4 s_e[kFwdQuads][kWave];
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
-    const int tx0 = (tile % f.tiles_x) * kTile, ty0 = (tile / f.tiles_x) * kTile;
-    const float Xc = (float)(tx0 + 8), Yc = (float)(ty0 + 8);
+    constexpr int NQ = QX * QY;   // 8x8 quadrants per tile = pixels per lane
+    const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8);
+    const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
     const int lx = lane & 7, ly = lane >> 3;
     const uint2 range = ranges[tile];
     const uint32_t n_total = range.y - range.x;
 
-    float xl[4], yl[4];
-    bool done[4];
-    float T[4], C0[4], C1[4], C2[4], N0[4], N1[4], N2[4], Dsum[4], M1[4], M2[4], dist[4], med[4];
-    float C3[4], C4[4], C5[4];   // only live in the 6-channel variant
-    uint32_t lastc[4], medc[4];
+    float xl[NQ], yl[NQ];
+    bool done[NQ];
+    float T[NQ], C0[NQ], C1[NQ], C2[NQ], N0[NQ], N1[NQ], N2[NQ], Dsum[NQ], M1[NQ], M2[NQ], dist[NQ], med[NQ];
+    float C3[NQ], C4[NQ], C5[NQ];   // only live in the 6-channel variant
+    uint32_t lastc[NQ], medc[NQ];
     uint32_t alive = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = tx0 + (q & 1) * 8 + lx, py = ty0 + (q >> 1) * 8 + ly;
-        xl[q] = (float)((q & 1) * 8 + lx - 8); yl[q] = (float)((q >> 1) * 8 + ly - 8);
+    for (int q = 0; q < NQ; ++q) {
+        const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
+        xl[q] = (float)((q % QX) * 8 + lx - QX * 4); yl[q] = (float)((q / QX) * 8 + ly - QY * 4);
         done[q] = !(px < f.W && py < f.H);
         T[q] = 1.f; C0[q] = C1[q] = C2[q] = N0[q] = N1[q] = N2[q] = 0.f;
         C3[q] = C4[q] = C5[q] = 0.f;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         uint32_t m = 0;
-        if ((uint32_t)lane < n) m = stage_entry(nr, nx, Xc, Yc, cull & 1, s_e, lane);
+        if ((uint32_t)lane < n) m = stage_entry<QX, QY>(nr, nx, Xc, Yc, cull & 1, s_e, lane);
         if (base + kWave + lane < n_total) {
             const uint32_t gid = point_list[range.x + base + kWave + lane];
             load_record(recs, gid, nr);
@@ -223,7 +227,9 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
         }
         unsigned long long bits = __ballot((m & alive) != 0);
         if (kStats && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
-        unsigned long long hit[4] = {0ull, 0ull, 0ull, 0ull};  // scalar: bit j of hit[q] = entry j reached a pixel of quadrant q
+        unsigned long long hit[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) hit[q] = 0ull;  // scalar: bit j of hit[q] = entry j reached a pixel of quadrant q
         while (bits) {
             const int j = __ffsll((long long)bits) - 1;
             bits &= bits - 1;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
             const uint32_t contributor = base + (uint32_t)j + 1u;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
                 const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & !done[q];
@@ -270,15 +276,15 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
         if ((uint32_t)lane < n) {
             uint32_t hm = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
+            for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
             hit_mask[range.x + base + lane] = (uint8_t)hm;
         }
     }
     const size_t HW = (size_t)f.H * f.W;
     const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = tx0 + (q & 1) * 8 + lx, py = ty0 + (q >> 1) * 8 + ly;
+    for (int q = 0; q < NQ; ++q) {
+        const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
         if (px < f.W && py < f.H) {
             const size_t pix = (size_t)py * f.W + px;
             final_T[pix] = T[q]; final_T[HW + pix] = M1[q]; final_T[2 * HW + pix] = M2[q];
@@ -367,7 +373,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 // Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
 // (first[gid] + its index inside the Gaussian's tile rectangle; first[gid] rides in slot 15 of the splat record), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
 // entries no pixel reached are not written; written records carry the call's tag.  Gradient record slots: see common.h.
-template <int NC>
+template <int NC, int QX, int QY>
 __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                  const uint32_t* __restrict__ point_list,
                                                                  const float4* __restrict__ recs,
@@ -383,8 +389,9 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGradFloats];
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
-    const int tx0 = (tile % f.tiles_x) * kTile, ty0 = (tile / f.tiles_x) * kTile;
-    const float Xc = (float)(tx0 + 8), Yc = (float)(ty0 + 8);
+    constexpr int NQ = QX * QY;   // 8x8 quadrants per tile = pixels per lane
+    const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8);
+    const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
     const int lx = lane & 7, ly = lane >> 3;
     const uint2 range = ranges[tile];
     const uint32_t count = range.y - range.x;
@@ -392,17 +399,17 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
     const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
 
     // per-pixel constants (upstream gradients folded with the forward's final accumulators) and state
-    float xl[4], yl[4], pxf[4], pyf[4];
-    float gr[4], gg[4], gb[4], gn0[4], gn1[4], gn2[4], g_depth[4], g_median[4], Kbg[4], a0[4], a1[4], a2[4];
-    float gc3[4], gc4[4], gc5[4];   // only live in the 6-channel variant
+    float xl[NQ], yl[NQ], pxf[NQ], pyf[NQ];
+    float gr[NQ], gg[NQ], gb[NQ], gn0[NQ], gn1[NQ], gn2[NQ], g_depth[NQ], g_median[NQ], Kbg[NQ], a0[NQ], a1[NQ], a2[NQ];
+    float gc3[NQ], gc4[NQ], gc5[NQ];   // only live in the 6-channel variant
     constexpr int kGQ = NC == 6 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record
-    uint32_t lastc[4], medc[4], quad_last[4];
-    float T[4], R[4], X[4];
+    uint32_t lastc[NQ], medc[NQ], quad_last[NQ];
+    float T[NQ], R[NQ], X[NQ];
     uint32_t total = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = tx0 + (q & 1) * 8 + lx, py = ty0 + (q >> 1) * 8 + ly;
-        xl[q] = (float)((q & 1) * 8 + lx - 8); yl[q] = (float)((q >> 1) * 8 + ly - 8);
+    for (int q = 0; q < NQ; ++q) {
+        const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
+        xl[q] = (float)((q % QX) * 8 + lx - QX * 4); yl[q] = (float)((q / QX) * 8 + ly - QY * 4);
         pxf[q] = (float)px; pyf[q] = (float)py;
         const bool inside = px < f.W && py < f.H;
         const size_t pix = inside ? (size_t)py * f.W + px : 0;
@@ -446,12 +453,12 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         const uint32_t n = min((uint32_t)kWave, total - rbase);
         uint32_t m = 0, slot = 0;
         if ((uint32_t)lane < n) {
-            (void)stage_entry(nr, nx, Xc, Yc, 0, s_e, lane);
+            (void)stage_entry<QX, QY>(nr, nx, Xc, Yc, 0, s_e, lane);
             m = nhit;   // (entry, quadrant) pairs that reached a pixel in the forward: exact, no culling test needed here
-            slot = emission_index(nr, __float_as_uint(nr[3].w), tile % f.tiles_x, tile / f.tiles_x, f.tiles_x, f.tiles_y);
+            slot = emission_index(nr, __float_as_uint(nr[3].w), tile % f.tiles_x, tile / f.tiles_x, f);
             uint32_t need = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
+            for (int q = 0; q < NQ; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
             m &= need;
         }
         {
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             for (int k = 0; k < 24; ++k) v[k] = 0.f;
             bool any = false;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
                 const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & (cidx < lastc[q]);
@@ -557,17 +564,34 @@ hipError_t read_render_stats(unsigned long long* out8, bool reset) {
 }
 
 // launchers ---------------------------------------------------------------------------------------
+// Tile shapes (BASELINE config 5's sweep): the reference's 16x16 plus 8x8, 16x8, 32x8, 32x16 = QX x QY quadrants of 8x8
+// pixels, i.e. 1 / 2 / 4 / 8 pixels per lane.  Only the reference shape carries the 6-channel and counter variants.
+#define SR_FOR_TILE_SHAPE(F)                                                    \
+    if (f.tile_w == 16 && f.tile_h == 16) { F(2, 2); }                          \
+    else if (f.tile_w == 8 && f.tile_h == 8) { F(1, 1); }                       \
+    else if (f.tile_w == 16 && f.tile_h == 8) { F(2, 1); }                      \
+    else if (f.tile_w == 32 && f.tile_h == 8) { F(4, 1); }                      \
+    else if (f.tile_w == 32 && f.tile_h == 16) { F(4, 2); }                     \
+    else return hipErrorInvalidValue;
+
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib,
                                  uint8_t* hit_mask, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     const dim3 grid(n_tiles), block(kWave);
-#define SR_LAUNCH_FWD(STATS, NCH)                                                                                            \
-    hipLaunchKernelGGL((render_forward_kernel<STATS, NCH>), grid, block, 0, s, f, ranges, point_list, recs, extra, out_color, \
+#define SR_LAUNCH_FWD(STATS, NCH, QX, QY)                                                                                            \
+    hipLaunchKernelGGL((render_forward_kernel<STATS, NCH, QX, QY>), grid, block, 0, s, f, ranges, point_list, recs, extra, out_color, \
                        out_allmap, final_T, n_contrib, hit_mask, cull)
-    if (f.colors == 6) { if (cull & 2) SR_LAUNCH_FWD(true, 6); else SR_LAUNCH_FWD(false, 6); }
-    else               { if (cull & 2) SR_LAUNCH_FWD(true, 3); else SR_LAUNCH_FWD(false, 3); }
+    if (f.tile_w == 16 && f.tile_h == 16) {
+        if (f.colors == 6) { if (cull & 2) SR_LAUNCH_FWD(true, 6, 2, 2); else SR_LAUNCH_FWD(false, 6, 2, 2); }
+        else               { if (cull & 2) SR_LAUNCH_FWD(true, 3, 2, 2); else SR_LAUNCH_FWD(false, 3, 2, 2); }
+    } else {
+        if (f.colors != 3) return hipErrorInvalidValue;
+#define SR_FWD_SHAPE(QX, QY) SR_LAUNCH_FWD(false, 3, QX, QY)
+        SR_FOR_TILE_SHAPE(SR_FWD_SHAPE)
+#undef SR_FWD_SHAPE
+    }
 #undef SR_LAUNCH_FWD
     return hipGetLastError();
 }
@@ -578,12 +602,18 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
                                   int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    if (f.colors == 6)
-        hipLaunchKernelGGL(render_backward_kernel<6>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, extra, final_T,
-                           n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, tag_lo, tag_hi, cull);
-    else
-        hipLaunchKernelGGL(render_backward_kernel<3>, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, extra, final_T,
-                           n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, tag_lo, tag_hi, cull);
+#define SR_LAUNCH_BWD(NCH, QX, QY)                                                                                                          \
+    hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, extra, final_T, \
+                       n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, tag_lo, tag_hi, cull)
+    if (f.tile_w == 16 && f.tile_h == 16) {
+        if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
+    } else {
+        if (f.colors != 3) return hipErrorInvalidValue;
+#define SR_BWD_SHAPE(QX, QY) SR_LAUNCH_BWD(3, QX, QY)
+        SR_FOR_TILE_SHAPE(SR_BWD_SHAPE)
+#undef SR_BWD_SHAPE
+    }
+#undef SR_LAUNCH_BWD
     return hipGetLastError();
 }
 

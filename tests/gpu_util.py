@@ -17,10 +17,10 @@ def settings_for(cam, bg, deg, debug=False, dev=DEV):
                                          cam.full_proj_transform.to(dev), deg, cam.camera_center.to(dev), False, debug)
 
 
-def run_oracle(g, cam, bg, deg, dc=None, da=None, mode="sh", colors=None, Tpre=None):
+def run_oracle(g, cam, bg, deg, dc=None, da=None, mode="sh", colors=None, Tpre=None, tile=(16, 16)):
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
               campos=cam.camera_center.numpy(), bg=np.asarray(bg, np.float32), image_width=cam.image_width,
-              image_height=cam.image_height, sh_degree=deg)
+              image_height=cam.image_height, sh_degree=deg, tile=tile)
     n = lambda k: g[k].numpy()
     if Tpre is not None:
         fwd = so.rasterize_forward(n("means3D"), n("opacities"), shs=n("shs") if colors is None else None,
@@ -33,7 +33,7 @@ def run_oracle(g, cam, bg, deg, dc=None, da=None, mode="sh", colors=None, Tpre=N
     return fwd, bwd
 
 
-def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=False):
+def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=False, tile=None):
     """Returns dict with outputs, internal state views and (if dc given) input gradients, all numpy."""
     dev = DEV
     s = settings_for(cam, bg, deg, debug)
@@ -49,7 +49,7 @@ def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=Fal
         t["Tpre"] = torch.as_tensor(Tpre).to(dev).requires_grad_(); kw["cov3D_precomp"] = t["Tpre"]
     else:
         kw["scales"] = t["scales"]; kw["rotations"] = t["rotations"]
-    color, radii, allmap = GaussianRasterizer(s)(**kw)
+    color, radii, allmap = GaussianRasterizer(s, tile=tile)(**kw)
     out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), allmap=allmap.detach().cpu().numpy())
     if dc is not None:
         ((color * dc.to(dev)).sum() + (allmap * da.to(dev)).sum()).backward()
@@ -63,7 +63,7 @@ def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=Fal
     return out
 
 
-def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None):
+def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None, tile=None):
     """Calls _C.rasterize_gaussians directly and returns the state-buffer views as numpy (for bit-exact checks)."""
     dev = DEV
     s = settings_for(cam, bg, deg)
@@ -76,11 +76,11 @@ def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None):
     tp = e if Tpre is None else torch.as_tensor(Tpre).to(dev)
     D, color, allmap, radii, geom, binning, img = _C.rasterize_gaussians(
         s.bg, d("means3D"), col, d("opacities"), sc, ro, 1.0, tp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
-        s.image_height, s.image_width, sh, deg, s.campos, False, False)
+        s.image_height, s.image_width, sh, deg, s.campos, False, False, tile=tile)
     torch.cuda.synchronize()
     W, H = cam.image_width, cam.image_height
     gv = {k: v.cpu().numpy() for k, v in _C.geom_view(geom, P).items()} if P else {}
-    bv = {k: v.cpu().numpy() for k, v in _C.binning_view(binning, P, D, W, H).items()}
+    bv = {k: v.cpu().numpy() for k, v in _C.binning_view(binning, P, D, W, H, tile or (16, 16)).items()}
     iv = {k: v.cpu().numpy() for k, v in _C.image_view(img, W, H).items()}
     return dict(D=D, color=color.cpu().numpy(), allmap=allmap.cpu().numpy(), radii=radii.cpu().numpy(), geom=gv, bin=bv, img=iv)
 

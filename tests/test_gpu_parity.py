@@ -353,3 +353,33 @@ def test_factored_sh_exchange_two_ranks_one_gpu():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "factored exchange OK" in r.stdout
+
+
+@pytest.mark.parametrize("tile", [(8, 8), (16, 8), (32, 8), (32, 16)])
+def test_tile_shape_sweep(tile):
+    """BASELINE config 5's tile-size sweep: every shape bins bit-exactly like the oracle run with the same BLOCK_X x BLOCK_Y,
+    renders/differentiates within the usual bars.  (Images are NOT identical across shapes, here or in the reference: alpha
+    >= 1/255 reaches out to 3.33 sigma for opaque splats while the tile rectangle is cut at 3 sigma, so the fringe is clipped
+    at tile granularity.)"""
+    from tests.gpu_util import run_hip, run_hip_raw, run_oracle
+    P, W, H = 4000, 203, 117          # not a multiple of any tile size
+    cam, g = _scene(P, W, H, 17, 4e-3, 8e-2, 2)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    dc, da = synthetic_upstream_grads(W, H, seed=8)
+    fwd, bwd = run_oracle(g, cam, bg, 3, dc, da, tile=tile)
+    gx, gy = (W + tile[0] - 1) // tile[0], (H + tile[1] - 1) // tile[1]
+    assert fwd["ranges"].shape[0] == gx * gy
+    raw = run_hip_raw(g, cam, bg, 3, tile=tile)
+    _check_binning(raw, fwd)
+    out = run_hip(g, cam, bg, 3, dc, da, tile=tile)
+    _check_images(out, fwd, f"tile {tile}")
+    _check_grads(out, bwd, ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"], f"tile {tile}")
+    ref = run_hip(g, cam, bg, 3, dc, da)
+    both = (out["radii"] > 0) & (ref["radii"] > 0)   # (an off-screen splat's clamped tile rectangle can be empty for one shape only)
+    np.testing.assert_array_equal(out["radii"][both], ref["radii"][both])
+    assert (out["radii"] > 0).sum() >= 0.99 * (ref["radii"] > 0).sum()
+    assert np.abs(out["color"] - ref["color"]).mean() < 1e-3   # same picture up to the clipped fringe
+    # unsupported shapes are refused, not silently replaced
+    from streetunveiler_amd._lib import SurfelRasterError
+    with pytest.raises(SurfelRasterError):
+        run_hip(g, cam, bg, 3, tile=(24, 16))
