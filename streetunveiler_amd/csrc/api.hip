@@ -33,10 +33,10 @@ hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted,
 hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
-                                 const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint8_t* hit_mask, int cull, hipStream_t s);
+                                 const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint16_t* hit_mask, int cull, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint8_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi, int cull, hipStream_t s);
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi, int cull, hipStream_t s);
 hipError_t read_render_stats(unsigned long long* out8, bool reset);
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
@@ -160,7 +160,7 @@ BinLayout bin_layout(uint32_t D, int W, int H) {
     L.vals_unsorted = take(n * 4);
     L.tile_keys = take(n * 4);
     L.point_list = take(n * 4);
-    L.hit_mask = take(n);
+    L.hit_mask = take(n * 2);
     L.ranges = take((size_t)(tiles > 0 ? tiles : 1) * 8);
     static thread_local uint32_t memo_D = 0xFFFFFFFFu;
     static thread_local int memo_tiles = -1;
@@ -347,7 +347,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
-                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint8_t>(binning, B.hit_mask), g_options.load(), s));
+                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint16_t>(binning, B.hit_mask), g_options.load(), s));
     }
     return debug_sync(frame, s, "render_forward");
 }
@@ -382,7 +382,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0)
             SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs), g->colors_precomp,
-                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint8_t>(binning, B.hit_mask), inst_grads, tag_lo, tag_hi, g_options.load(), s));
+                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, B.hit_mask), inst_grads, tag_lo, tag_hi, g_options.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;
     {
@@ -464,7 +464,8 @@ int sr_set_option(int option, int value) {
     switch (option) {
         case SR_OPT_QUADRANT_CULL: g_options.store((g_options.load() & ~1) | (value ? 1 : 0)); return SR_OK;
         case SR_OPT_DEBUG_STATS: g_options.store((g_options.load() & ~2) | (value ? 2 : 0)); return SR_OK;
-        case 100: g_options.store((g_options.load() & 0xF) | ((value & 0xF) << 4)); return SR_OK;  // undocumented: K7 ablation bits (timing experiments only; results are wrong)
+        case 101: g_options.store((g_options.load() & 0xFFF) | ((value & 0xFF) << 12)); return SR_OK;  // undocumented: KiB of dynamic LDS per blend wave (occupancy experiments)
+        case 100: g_options.store((g_options.load() & ~0xFF0) | ((value & 0xFF) << 4)); return SR_OK;  // undocumented: K7 ablation bits (timing experiments only; results are wrong)
         default: return fail(SR_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }

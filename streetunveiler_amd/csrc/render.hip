@@ -174,19 +174,22 @@ __device__ __forceinline__ void load_record(const float4* __restrict__ recs, uin
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
-template <bool kStats, int NC, int QX, int QY>
+// SPLIT > 1: the parent tile (QX*8 wide, QY*8*SPLIT high -- the binning tile) is cut into SPLIT horizontal bands, one wave
+// each, all walking the parent's list: fewer pixels per lane -> fewer registers -> more waves per SIMD, which is what these
+// latency-bound loops want, at the price of staging every entry SPLIT times.
+template <bool kStats, int NC, int QX, int QY, int SPLIT>
 __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ recs,
                                                                 const float* __restrict__ extra,
                                                                 float* __restrict__ out_color, float* __restrict__ out_allmap,
                                                                 float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                                uint8_t* __restrict__ hit_mask, int cull) {
+                                                                uint16_t* __restrict__ hit_mask, int cull) {
     __shared__ float4 s_e[kFwdQuads][kWave];
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
-    constexpr int NQ = QX * QY;   // 8x8 quadrants per tile = pixels per lane
-    const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8);
+    const int tile = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
+    constexpr int NQ = QX * QY;   // 8x8 quadrants per wave = pixels per lane
+    const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8 * SPLIT) + part * (QY * 8);
     const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
     const int lx = lane & 7, ly = lane >> 3;
     const uint2 range = ranges[tile];
@@ -277,7 +280,10 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
             uint32_t hm = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
-            hit_mask[range.x + base + lane] = (uint8_t)hm;
+            // 16 bits per list entry; for the 16x16 tile: low byte = quadrants of the upper 16x8 band, high byte = lower band
+            if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base + lane) + part] = (uint8_t)hm;
+            else if (QX == 2 && QY == 2) hit_mask[range.x + base + lane] = (uint16_t)((hm & 3u) | ((hm >> 2) << 8));
+            else hit_mask[range.x + base + lane] = (uint16_t)hm;
         }
     }
     const size_t HW = (size_t)f.H * f.W;
@@ -367,6 +373,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
 }
 
+template <int QX, int QY>
+__device__ __forceinline__ uint32_t decode_hits(uint16_t h) {   // see the hit_mask store in K6
+    return (QX == 2 && QY == 2) ? (((uint32_t)h & 3u) | (((uint32_t)h >> 6) & 0xCu)) : (uint32_t)h;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                                                                  const uint32_t* __restrict__ n_contrib,
                                                                  const float* __restrict__ dL_dcolor,
                                                                  const float* __restrict__ dL_dallmap,
-                                                                 const uint8_t* __restrict__ hit_mask,
+                                                                 const uint16_t* __restrict__ hit_mask,
                                                                  float4* __restrict__ inst_grads, uint32_t tag_lo, uint32_t tag_hi,
                                                                  int cull) {
     __shared__ float4 s_e[kFwdQuads][kWave];
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         const uint32_t gid = point_list[pos];
         load_record(recs, gid, nr);
         if (NC == 6) nx = load_extra(extra, gid);
-        nhit = hit_mask[pos];
+        nhit = decode_hits<QX, QY>(hit_mask[pos]);
     }
     for (int rd = rounds - 1; rd >= 0; --rd) {
         const uint32_t rbase = (uint32_t)rd * kWave;
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             const uint32_t gid = point_list[pos];
             load_record(recs, gid, nr);
             if (NC == 6) nx = load_extra(extra, gid);
-            nhit = hit_mask[pos];
+            nhit = decode_hits<QX, QY>(hit_mask[pos]);
         }
         unsigned long long bits = __ballot(m != 0);
         while (bits) {
@@ -576,19 +587,22 @@ hipError_t read_render_stats(unsigned long long* out8, bool reset) {
 
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib,
-                                 uint8_t* hit_mask, int cull, hipStream_t s) {
+                                 uint16_t* hit_mask, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    const dim3 grid(n_tiles), block(kWave);
-#define SR_LAUNCH_FWD(STATS, NCH, QX, QY)                                                                                            \
-    hipLaunchKernelGGL((render_forward_kernel<STATS, NCH, QX, QY>), grid, block, 0, s, f, ranges, point_list, recs, extra, out_color, \
-                       out_allmap, final_T, n_contrib, hit_mask, cull)
+    const dim3 block(kWave);
+#define SR_LAUNCH_FWD(STATS, NCH, QX, QY, SPLIT)                                                                                  \
+    hipLaunchKernelGGL((render_forward_kernel<STATS, NCH, QX, QY, SPLIT>), dim3(n_tiles * SPLIT), block, (cull >> 12) * 1024, s, f, \
+                       ranges, point_list, recs, extra, out_color, out_allmap, final_T, n_contrib, hit_mask, cull)
     if (f.tile_w == 16 && f.tile_h == 16) {
-        if (f.colors == 6) { if (cull & 2) SR_LAUNCH_FWD(true, 6, 2, 2); else SR_LAUNCH_FWD(false, 6, 2, 2); }
-        else               { if (cull & 2) SR_LAUNCH_FWD(true, 3, 2, 2); else SR_LAUNCH_FWD(false, 3, 2, 2); }
+        // the reference's tile: two 16x8 band waves per tile (the counter variant stays whole so that it counts each entry once)
+        if (f.colors == 6) { if (cull & 2) SR_LAUNCH_FWD(true, 6, 2, 2, 1); else SR_LAUNCH_FWD(false, 6, 2, 1, 2); }
+        else if (cull & 2)      SR_LAUNCH_FWD(true, 3, 2, 2, 1);
+        else if (cull & 0x800)  SR_LAUNCH_FWD(false, 3, 2, 2, 1);   // A/B switch (option 100, bit 7): one wave per tile
+        else                    SR_LAUNCH_FWD(false, 3, 2, 1, 2);
     } else {
         if (f.colors != 3) return hipErrorInvalidValue;
-#define SR_FWD_SHAPE(QX, QY) SR_LAUNCH_FWD(false, 3, QX, QY)
+#define SR_FWD_SHAPE(QX, QY) SR_LAUNCH_FWD(false, 3, QX, QY, 1)
         SR_FOR_TILE_SHAPE(SR_FWD_SHAPE)
 #undef SR_FWD_SHAPE
     }
@@ -598,12 +612,12 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint8_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi,
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi,
                                   int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
 #define SR_LAUNCH_BWD(NCH, QX, QY)                                                                                                          \
-    hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, extra, final_T, \
+    hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), (cull >> 12) * 1024, s, f, ranges, point_list, recs, extra, final_T, \
                        n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, tag_lo, tag_hi, cull)
     if (f.tile_w == 16 && f.tile_h == 16) {
         if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);

@@ -19,11 +19,12 @@ def step():
     torch.autograd.backward([c, a], [dc, da])
 for cull in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,0").split(",")]:
     lib.sr_set_option(_lib.SR_OPT_QUADRANT_CULL, cull & 1)
-    lib.sr_set_option(100, cull >> 4)
+    lib.sr_set_option(100, (cull >> 4) & 0xFF)
+    lib.sr_set_option(101, cull >> 12)   # KiB of dynamic LDS per blend wave
     for _ in range(3): step()
     torch.cuda.synchronize(); lib.sr_set_stage_timing(1)
     for _ in range(10): step()
     torch.cuda.synchronize()
     st = _lib.stage_stats(); lib.sr_set_stage_timing(0)
     print(f"cull={cull}", {k: round(ms / n, 4) for k, (ms, n) in st.items() if n})
-lib.sr_set_option(_lib.SR_OPT_QUADRANT_CULL, 1); lib.sr_set_option(100, 0)
+lib.sr_set_option(_lib.SR_OPT_QUADRANT_CULL, 1); lib.sr_set_option(100, 0); lib.sr_set_option(101, 0)

@@ -16,7 +16,9 @@ s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoV
                                   cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 3, cam.camera_center.to(dev), False, False)
 m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
 rows = []
-for tile in ((8, 8), (16, 8), (16, 16), (32, 8), (32, 16)):
+lib.sr_set_option(101, int(os.environ.get("SR_BLEND_LDS_KIB", "0")))   # occupancy experiments: extra dynamic LDS per blend wave
+shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ.get("SR_TILES", "8x8,16x8,16x16,32x8,32x16").split(",")]
+for tile in shapes:
     def step():
         for t in list(g.values()) + [m2d]: t.grad = None
         c, r, a = GaussianRasterizer(s, tile=tile)(means3D=g["means3D"], means2D=m2d, shs=g["shs"], opacities=g["opacities"], scales=g["scales"], rotations=g["rotations"])
