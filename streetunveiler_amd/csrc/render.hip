@@ -30,6 +30,7 @@
 namespace sr {
 
 constexpr int kWave = 64;
+constexpr int kXcds = 8;   // MI355X: 8 accelerator dies, workgroup i runs on XCD i % 8
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kFN = kFar / (kFar - kNear);
 
@@ -187,7 +188,14 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                                                                 uint16_t* __restrict__ hit_mask, int cull) {
     __shared__ float4 s_e[kFwdQuads][kWave];
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: the SPLIT bands of one tile take consecutive
+    // slots of the SAME XCD so that the second band finds the tile's records in that L2 instead of fetching them again.
+    int tile = blockIdx.x, part = 0;
+    if (SPLIT > 1) {
+        const int xcd = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
+        tile = (k / SPLIT) * kXcds + xcd; part = k % SPLIT;
+        if (tile >= f.tiles_x * f.tiles_y) return;
+    }
     constexpr int NQ = QX * QY;   // 8x8 quadrants per wave = pixels per lane
     const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8 * SPLIT) + part * (QY * 8);
     const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
@@ -592,7 +600,8 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
     if (n_tiles == 0) return hipSuccess;
     const dim3 block(kWave);
 #define SR_LAUNCH_FWD(STATS, NCH, QX, QY, SPLIT)                                                                                  \
-    hipLaunchKernelGGL((render_forward_kernel<STATS, NCH, QX, QY, SPLIT>), dim3(n_tiles * SPLIT), block, (cull >> 12) * 1024, s, f, \
+    hipLaunchKernelGGL((render_forward_kernel<STATS, NCH, QX, QY, SPLIT>),                                                          \
+                       dim3(SPLIT > 1 ? (n_tiles + kXcds - 1) / kXcds * kXcds * SPLIT : n_tiles), block, (cull >> 12) * 1024, s, f, \
                        ranges, point_list, recs, extra, out_color, out_allmap, final_T, n_contrib, hit_mask, cull)
     if (f.tile_w == 16 && f.tile_h == 16) {
         // the reference's tile: two 16x8 band waves per tile (the counter variant stays whole so that it counts each entry once)
