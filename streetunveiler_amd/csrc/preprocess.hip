@@ -332,26 +332,38 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
 #pragma unroll
                 for (int k = 0; k < kGradQuads; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 const uint32_t first = __float_as_uint(rec[3].w), cnt = tiles_touched[i];
-                // four records per trip, all loads issued before any use; untagged records (entries no pixel reached: never
-                // written by K7) are masked out branch-free so the next trip's loads are not held back
+                // Four records per trip.  K7 writes (and tags) a record only where some pixel contributed -- about 40 % of a
+                // Gaussian's span -- so the tag quads are fetched first (one 32-B sector each) and the other 80 B of a record
+                // only behind a matching tag.
                 constexpr int kTrip = 4;
-                for (uint32_t e = first; e < first + cnt; e += kTrip) {
-                    float4 a[kTrip][kGQ];
+                const uint32_t end = first + cnt;
+                auto load_tags = [&](uint32_t e, float4 (&tq)[kTrip]) {
+#pragma unroll
+                    for (int t = 0; t < kTrip; ++t) tq[t] = inst_grads[(size_t)(e + t < end ? e + t : first) * kGQ + (kGQ - 1)];
+                };
+                float4 tq[kTrip], tn[kTrip];
+                if (cnt > 0) load_tags(first, tq);
+                for (uint32_t e = first; e < end; e += kTrip) {
+                    if (e + kTrip < end) load_tags(e + kTrip, tn);   // next trip's tags are in flight behind this trip's bodies
                     bool ok[kTrip];
+                    float4 a[kTrip][kGradQuads];
 #pragma unroll
                     for (int t = 0; t < kTrip; ++t) {
-                        const bool in = e + t < first + cnt;
-                        const float4* gr = inst_grads + (size_t)(in ? e + t : e) * kGQ;
+                        ok[t] = e + t < end && __float_as_uint(tq[t].z) == tag_lo && __float_as_uint(tq[t].w) == tag_hi;
+                        const float4* gr = inst_grads + (size_t)(e + t) * kGQ;
 #pragma unroll
-                        for (int k = 0; k < kGQ; ++k) a[t][k] = gr[k];
-                        ok[t] = in;
+                        for (int k = 0; k < kGradQuads; ++k) {
+                            if (k == kGQ - 1) a[t][k] = tq[t];   // 3-channel record: the tag shares the last value quad
+                            else a[t][k] = ok[t] ? gr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
 #pragma unroll
                     for (int t = 0; t < kTrip; ++t) {
-                        if (ok[t] && __float_as_uint(a[t][kGQ - 1].z) == tag_lo && __float_as_uint(a[t][kGQ - 1].w) == tag_hi) {
+                        if (ok[t]) {
 #pragma unroll
                             for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[t][k].x; g[k].y += a[t][k].y; g[k].z += a[t][k].z; g[k].w += a[t][k].w; }
                         }
+                        tq[t] = tn[t];
                     }
                 }
                 g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3]; g4 = g[4]; g5 = g[5];

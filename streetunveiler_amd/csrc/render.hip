@@ -493,6 +493,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             nhit = decode_hits<QX, QY>(hit_mask[pos]);
         }
         unsigned long long bits = __ballot(m != 0);
+        unsigned long long wrote = 0ull;   // scalar: entries of this round that got a contribution (only those get a record)
         while (bits) {
             const int j = 63 - __clzll((long long)bits);
             bits &= ~(1ull << j);
@@ -551,13 +552,14 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                 }
             }
             if (any && !(cull & 32)) {
+                wrote |= 1ull << j;
                 const float tot = wave_reduce24(v, lane);
                 if ((lane & 1) == 0 && (lane & 6) != 6)
                     s_out[j][6 * (lane >> 4) + ((lane & 8) ? 3 : 0) + ((lane & 4) ? 2 : ((lane >> 1) & 1))] = tot;
             }
         }
-        // flush this round's records: one 96-B store per lane (zeros where nothing contributed)
-        if ((uint32_t)lane < n && !(cull & 16)) {
+        // flush this round's records: one 96-B store per lane whose entry got a contribution
+        if (((wrote >> lane) & 1ull) && !(cull & 16)) {
             const float4* acc = reinterpret_cast<const float4*>(&s_out[lane][0]);
             float4* o = inst_grads + (size_t)slot * kGQ;
 #pragma unroll
