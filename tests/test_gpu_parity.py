@@ -383,3 +383,32 @@ def test_tile_shape_sweep(tile):
     from streetunveiler_amd._lib import SurfelRasterError
     with pytest.raises(SurfelRasterError):
         run_hip(g, cam, bg, 3, tile=(24, 16))
+
+
+def test_very_long_tile_lists_and_tiny_images():
+    """One tile with a list far longer than a staging round can see (40 k translucent splats over a 24x20 image: > 600 rounds of
+    64, 16-bit contributor counts exceeded), and images smaller than a tile / a single pixel."""
+    from tests.gpu_util import run_hip, run_hip_raw, run_oracle
+    P, W, H = 40000, 24, 20
+    cam, g = _scene(P, W, H, 41, 2e-2, 2e-1, 0)
+    g["opacities"] = g["opacities"] * 0.02          # nothing saturates: every pixel walks (almost) the whole list
+    bg = np.array([0.3, 0.6, 0.9], np.float32)
+    dc, da = synthetic_upstream_grads(W, H, seed=5)
+    fwd, bwd = run_oracle(g, cam, bg, 2, dc, da)
+    assert (fwd["ranges"][:, 1] - fwd["ranges"][:, 0]).max() > 20000
+    assert fwd["n_contrib"][0].max() > 5000
+    _check_binning(run_hip_raw(g, cam, bg, 2), fwd)
+    out = run_hip(g, cam, bg, 2, dc, da)
+    _check_images(out, fwd, "long lists")
+    _check_grads(out, bwd, ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"], "long lists")
+    for (w, h) in ((5, 3), (1, 1), (17, 1)):
+        cam2, g2 = _scene(300, w, h, 42, 5e-2, 5e-1, 1)
+        dc2, da2 = synthetic_upstream_grads(w, h, seed=6)
+        f2, b2 = run_oracle(g2, cam2, bg, 1, dc2, da2)
+        o2 = run_hip(g2, cam2, bg, 1, dc2, da2)
+        np.testing.assert_array_equal(o2["radii"], f2["radii"])
+        np.testing.assert_allclose(o2["color"], f2["color"], atol=2e-4)
+        np.testing.assert_allclose(o2["allmap"][[0, 1, 2, 3, 4, 6]], f2["allmap"][[0, 1, 2, 3, 4, 6]], atol=2e-3, rtol=2e-3)
+        for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh"):
+            sc = np.abs(b2[k]).max() + 1e-20
+            assert np.abs(o2[k].reshape(b2[k].shape) - b2[k]).max() <= 2e-2 * sc, (w, h, k)
