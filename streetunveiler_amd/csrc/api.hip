@@ -62,7 +62,8 @@ namespace {
 thread_local char g_err[512] = "";
 // timing state is process-wide: autograd runs the backward on its own thread
 std::atomic<int> g_timing{0};
-// bit 0 SR_OPT_QUADRANT_CULL, bit 1 SR_OPT_DEBUG_STATS, bits 4..7 K7 ablation switches (option 100, timing experiments only)
+// bit 0 SR_OPT_QUADRANT_CULL, bit 1 SR_OPT_DEBUG_STATS; measurement switches that do not change results: bit 11 (option 100,
+// value 0x80) one K6 wave per tile instead of two band waves, bits 12..19 (option 101) KiB of dynamic LDS per blend wave
 std::atomic<int> g_options{1};
 std::mutex g_ring_mu;
 
@@ -464,8 +465,8 @@ int sr_set_option(int option, int value) {
     switch (option) {
         case SR_OPT_QUADRANT_CULL: g_options.store((g_options.load() & ~1) | (value ? 1 : 0)); return SR_OK;
         case SR_OPT_DEBUG_STATS: g_options.store((g_options.load() & ~2) | (value ? 2 : 0)); return SR_OK;
-        case 101: g_options.store((g_options.load() & 0xFFF) | ((value & 0xFF) << 12)); return SR_OK;  // undocumented: KiB of dynamic LDS per blend wave (occupancy experiments)
-        case 100: g_options.store((g_options.load() & ~0xFF0) | ((value & 0xFF) << 4)); return SR_OK;  // undocumented: K7 ablation bits (timing experiments only; results are wrong)
+        case 101: g_options.store((g_options.load() & 0xFFF) | ((value & 0xFF) << 12)); return SR_OK;  // occupancy experiments: KiB of dynamic LDS per blend wave
+        case 100: g_options.store((g_options.load() & ~0xFF0) | ((value & 0x80) << 4)); return SR_OK;  // A/B: K6 as one wave per tile
         default: return fail(SR_ERR_INVALID_ARGUMENT, "unknown option %d", option);
     }
 }

@@ -1,16 +1,18 @@
 // render.hip -- K6 (per-tile front-to-back blend) and K7 (per-tile back-to-front backward), gfx950.
 //
-// Mapping: ONE wave64 per 16x16 tile, four pixels per lane -- lane l owns pixel (l&7, l>>3) of each of the
-// tile's four 8x8 quadrants.  A single-wave workgroup needs no barriers; the tile's depth-sorted splat list is
-// staged through LDS 64 entries at a time (each lane gathers one 80-B packed record with five dwordx4 loads,
-// the next round's records are already in flight while the current round is processed), and in the inner
-// loop all 64 lanes read the same LDS address (broadcast ds_read_b128).  One LDS read of an entry now serves
-// up to 256 pixel tests.  No MFMA: there is no dense contraction in this path.
+// Mapping: a wave64 owns QX x QY quadrants of 8x8 pixels, one pixel of each per lane -- lane l is pixel (l&7, l>>3) of every
+// quadrant.  For the reference's 16x16 tile K7 is ONE wave per tile (2 x 2 quadrants, four pixels per lane: the gradient
+// record of a (tile, Gaussian) pair wants one reduction over the whole tile) and K6 is TWO waves per tile (one per 16x8 band:
+// fewer registers, more waves per SIMD -- these loops are latency-bound); other tile shapes: 1 / 2 / 4 / 8 quadrants per wave.
+// A single-wave workgroup needs no barriers; the tile's depth-sorted splat list is staged through LDS 64 entries at a time
+// (each lane gathers one 80-B packed record with five dwordx4 loads, the next round's records are already in flight while
+// the current round is processed), and in the inner loop all 64 lanes read the same LDS address (broadcast ds_read_b128).
+// No MFMA: there is no dense contraction in this path.
 //
 // Staging also rewrites each record into the form the inner loop wants (tile-local coordinates, which also
 // removes the cancellation of the textbook k x l form):
 //     p = k x l,  k = x Tw - Tu,  l = y Tw - Tv   ==   x (Tv x Tw) + y (Tw x Tu) + (Tu x Tv) = x A + y B + C
-// and computes a 4-bit quadrant mask (exact culling, see quadrant_mask).  The wave then walks only the
+// and computes the quadrant mask (exact culling, see quadrant_mask).  The wave then walks only the
 // entries whose mask is non-zero (scalar bit-scan over a ballot), and inside an entry only the quadrants
 // whose bit is set.
 //
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                 if (__ballot(valid) == 0) continue;
                 any = true;
                 const float4 e4 = s_e[4][j], e5 = s_e[5][j];
-                if (valid && !(cull & 64)) {
+                if (valid) {
                     const float Twx = e2.y, Twy = e2.z;
                     const float one_m_inv = fast_rcp(1.f - h.alpha);
                     T[q] *= one_m_inv;                 // transmittance in front of this entry
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                     }
                 }
             }
-            if (any && !(cull & 32)) {
+            if (any) {
                 wrote |= 1ull << j;
                 const float tot = wave_reduce24(v, lane);
                 if ((lane & 1) == 0 && (lane & 6) != 6)
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             }
         }
         // flush this round's records: one 96-B store per lane whose entry got a contribution
-        if (((wrote >> lane) & 1ull) && !(cull & 16)) {
+        if ((wrote >> lane) & 1ull) {
             const float4* acc = reinterpret_cast<const float4*>(&s_out[lane][0]);
             float4* o = inst_grads + (size_t)slot * kGQ;
 #pragma unroll

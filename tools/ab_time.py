@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""A/B stage timing of the C3 step under library options: python tools/ab_time.py [cull=0|1] [steps]"""
+"""A/B stage timing of the C3 step under library options.  python tools/ab_time.py CODE[,CODE...]
+CODE bits: 1 = quadrant culling on; 0x800 = K6 as one wave per tile; CODE >> 12 = KiB of dynamic LDS per blend wave."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
