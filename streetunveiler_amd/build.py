@@ -18,8 +18,11 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -fno-slp-vectorize: packed FP32 (v_pk_fma_f32 ...) is no faster than two scalar ops on gfx950 and costs register-pair moves and
-# registers (K7: 228 -> 196 VGPRs, K6: 102 -> 88) -- measured: K6 -14 %, K7 -7 %
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+# registers (K7: 228 -> 196 VGPRs, K6: 102 -> 88) -- measured: K6 -14 %, K7 -7 %.
+# -disable-promote-alloca-to-vector: keeps the per-lane accumulator arrays as scalars (SROA) instead of 32-register tuples that
+# are copied wholesale at every branch join (K7: 62 -> 10 v_mov_b64 in the loop body)
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize",
+          "-mllvm", "-disable-promote-alloca-to-vector", "-Wall", "-Wno-unused-function"]
 # (source, extra flags)
 SOURCES = [
     ("preprocess.hip", ["-ffp-contract=off"]),  # op order is part of the bit-exact contract with the oracle

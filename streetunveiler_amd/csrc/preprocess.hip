@@ -556,7 +556,9 @@ __global__ __launch_bounds__(256) void sh_gradient_expand_kernel(int P, int M, i
             for (int k = 0; k < kShRowFloats / 4; ++k) row[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
         } else {
             float* row = dL_dsh + (size_t)i * M * 3;
-            for (int k = 0; k < M * 3; ++k) row[k] = k < 48 ? acc[k] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 48; ++k) { if (k < M * 3) row[k] = acc[k]; }   // constant indices: acc stays in registers
+            for (int k = 48; k < M * 3; ++k) row[k] = 0.f;
         }
     }
     if (kLdsSH) {

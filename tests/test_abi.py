@@ -68,3 +68,26 @@ def test_cpu_tensors_are_rejected_loudly():
     with pytest.raises(_lib.SurfelRasterError, match="no CPU path"):
         r(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.ones(4, 1), colors_precomp=torch.zeros(4, 3),
           scales=torch.ones(4, 2), rotations=torch.ones(4, 4))
+
+
+def test_no_kernel_uses_scratch_memory(tmp_path):
+    """Every gfx950 kernel of the library keeps its per-lane state in registers: no private (scratch) segment, no spills.
+    (A private array indexed with a run-time value, or a register budget forced too low, silently turns into scratch traffic.)"""
+    import glob, re, shutil, subprocess
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("ROCm LLVM tools not present")
+    so = shutil.copy(_lib.LIB_PATH, os.path.join(tmp_path, "lib.so"))
+    subprocess.run([objdump, "--offloading", so], check=True, capture_output=True)
+    objs = glob.glob(so + ".*gfx950*")
+    assert objs, "no gfx950 code object found in the library"
+    kernels = 0
+    for co in objs:
+        notes = subprocess.run([readelf, "--notes", co], check=True, capture_output=True, text=True).stdout
+        for block in notes.split(".agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block).group(1)
+            scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
+            spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1))
+            assert scratch == 0 and spills == 0, f"{name}: {scratch} B scratch, {spills} spilled VGPRs"
+            kernels += 1
+    assert kernels >= 40
