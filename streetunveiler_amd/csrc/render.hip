@@ -504,7 +504,10 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
             float v[24];
 #pragma unroll
-            for (int k = 0; k < 24; ++k) v[k] = 0.f;
+            for (int k = 0; k < 24; ++k) {
+                v[k] = 0.f;
+                asm volatile("" : "+v"(v[k]));   // opaque zero: every quadrant block accumulates in place (no phi copies of constants)
+            }
             bool any = false;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
