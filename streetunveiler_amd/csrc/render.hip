@@ -341,6 +341,13 @@ template <int kCtrl>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), kCtrl, 0xf, 0xf, false));
 }
+// value of lane ^ 4, without the LDS crossbar: a row rotation by 12 (= left by 4) into the lanes whose bit 2 is clear (DPP
+// banks 0 and 2) and by 4 into the others (banks 1 and 3); row_ror:n delivers lane (l - n) mod 16
+__device__ __forceinline__ float dpp_xor4(float x) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x12C, 0xf, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, __float_as_int(x), 0x124, 0xf, 0xA, false);
+    return __int_as_float(t);
+}
 __device__ __forceinline__ float row_sum16(float x) {
     x += dpp_mov<0x128>(x);  // row_ror:8
     x += dpp_mov<0x124>(x);  // row_ror:4
@@ -367,14 +374,14 @@ __device__ __forceinline__ float wave_reduce24(float (&v)[24], int lane) {
     {
         const float keep0 = h4 ? v[2] : v[0], send0 = h4 ? v[0] : v[2];
         const float keep1 = h4 ? 0.f : v[1], send1 = h4 ? v[1] : 0.f;
-        v[0] = keep0 + __shfl_xor(send0, 4);
-        v[1] = keep1 + __shfl_xor(send1, 4);
+        v[0] = keep0 + dpp_xor4(send0);
+        v[1] = keep1 + dpp_xor4(send1);
     }
     {
         const float keep = h2 ? v[1] : v[0], send = h2 ? v[0] : v[1];
-        v[0] = keep + __shfl_xor(send, 2);
+        v[0] = keep + dpp_mov<0x4E>(send);   // quad_perm:[2,3,0,1] = lane ^ 2
     }
-    return v[0] + __shfl_xor(v[0], 1);
+    return v[0] + dpp_mov<0xB1>(v[0]);       // quad_perm:[1,0,3,2] = lane ^ 1
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
