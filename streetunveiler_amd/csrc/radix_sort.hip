@@ -79,9 +79,10 @@ __global__ __launch_bounds__(kRsMaxBins) void rs_scan_bins_kernel(const uint32_t
     if (tid < bins) bin_base[tid] = s[tid];
 }
 
+template <int kBits>   // digit width (compile time: the match-any ballots unroll); 0 = run-time width
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                uint32_t n, int shift, int bits, const uint32_t* __restrict__ hist,
+                                                                uint32_t n, int shift, int bits_rt, const uint32_t* __restrict__ hist,
                                                                 const uint32_t* __restrict__ bin_base, int nblocks,
                                                                 const uint32_t* __restrict__ aux_src, uint32_t* __restrict__ aux_out) {
     __shared__ uint32_t s_count[kRsThreads / 64][kRsMaxBins];  // items of digit b held by wave w
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     __shared__ uint32_t s_gbase[kRsMaxBins];                   // global position of the block's first item of digit b
     __shared__ uint32_t s_wsum[kRsThreads / 64];
     __shared__ uint32_t s_key[kRsTile], s_val[kRsTile];        // the tile, stably reordered by digit
+    const int bits = kBits ? kBits : bits_rt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, bins = 1 << bits;
     const uint32_t mask = (uint32_t)bins - 1u;
     for (int b = tid; b < (kRsThreads / 64) * kRsMaxBins; b += kRsThreads) (&s_count[0][0])[b] = 0;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         const bool live = idx < n;
         const uint32_t d = (key[i] >> shift) & mask;
         unsigned long long same = __ballot(live);        // lanes holding the same digit as this lane
+#pragma unroll
         for (int b = 0; b < bits; ++b) {
             const unsigned long long vote = __ballot((d >> b) & 1u);
             same &= ((d >> b) & 1u) ? vote : ~vote;
@@ -285,8 +288,15 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
         hipLaunchKernelGGL(rs_scan_bins_kernel, dim3(1), dim3(kRsMaxBins), 0, s, row_total, 1 << bits, bin_base);
         const bool last = p == passes - 1;
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, bin_base, nb,
-                           last ? aux_src : nullptr, last ? aux_out : nullptr);
+#define SR_SCATTER(B) hipLaunchKernelGGL(rs_scatter_kernel<B>, dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
+                                         bin_base, nb, last ? aux_src : nullptr, last ? aux_out : nullptr)
+        switch (bits) {
+            case 8: SR_SCATTER(8); break;
+            case 7: SR_SCATTER(7); break;
+            case 6: SR_SCATTER(6); break;
+            default: SR_SCATTER(0); break;
+        }
+#undef SR_SCATTER
         ki = ko; vi = vo;
         shift += bits; left -= bits;
     }
