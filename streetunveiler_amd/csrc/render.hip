@@ -401,8 +401,11 @@ __device__ __forceinline__ uint32_t decode_hits(uint16_t h) {   // see the hit_m
 // Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
 // (first[gid] + its index inside the Gaussian's tile rectangle; first[gid] rides in slot 15 of the splat record), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
 // entries no pixel reached are not written; written records carry the call's tag.  Gradient record slots: see common.h.
+// Register budget: three waves per SIMD (<= 168 VGPRs) wherever the per-pixel state allows it -- the loop is latency-bound
+// at two -- i.e. up to four pixels per lane with three colour channels.
 template <int NC, int QX, int QY>
-__global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(QX * QY <= 4 && NC == 3 ? 3 : 1, QX * QY <= 4 && NC == 3 ? 3 : 8)))
+void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                  const uint32_t* __restrict__ point_list,
                                                                  const float4* __restrict__ recs,
                                                                  const float* __restrict__ extra,
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
     const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
 
     // per-pixel constants (upstream gradients folded with the forward's final accumulators) and state
-    float xl[NQ], yl[NQ], pxf[NQ], pyf[NQ];
+    const float xl0 = (float)(lx - QX * 4), yl0 = (float)(ly - QY * 4);   // tile-local pixel of quadrant 0; quadrant q adds 8*(q%QX, q/QX)
     float gr[NQ], gg[NQ], gb[NQ], gn0[NQ], gn1[NQ], gn2[NQ], g_depth[NQ], g_median[NQ], Kbg[NQ], a0[NQ], a1[NQ], a2[NQ];
     float gc3[NQ], gc4[NQ], gc5[NQ];   // only live in the 6-channel variant
     constexpr int kGQ = NC == 6 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record
@@ -437,8 +440,6 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
-        xl[q] = (float)((q % QX) * 8 + lx - QX * 4); yl[q] = (float)((q / QX) * 8 + ly - QY * 4);
-        pxf[q] = (float)px; pyf[q] = (float)py;
         const bool inside = px < f.W && py < f.H;
         const size_t pix = inside ? (size_t)py * f.W + px : 0;
         const float T_final = inside ? final_T[pix] : 0.f;
@@ -520,7 +521,8 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
             for (int q = 0; q < NQ; ++q) {
                 if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
-                const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & (cidx < lastc[q]);
+                const float xq = xl0 + (float)((q % QX) * 8), yq = yl0 + (float)((q / QX) * 8);
+                const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc[q]);
                 if (__ballot(valid) == 0) continue;
                 any = true;
                 const float4 e4 = s_e[4][j], e5 = s_e[5][j];
@@ -550,10 +552,11 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
                         const float gG = -dL_dG * h.G;
                         const float dpx = (gG * h.sx + dL_dz * Twx) * h.pz_inv, dpy = (gG * h.sy + dL_dz * Twy) * h.pz_inv;
                         const float dpz = -(dpx * h.sx + dpy * h.sy);
-                        // moments of dL/dp (global pixel coordinates); the cross products happen once per Gaussian in K8
+                        // moments of dL/dp in tile-local pixel coordinates (shifted to global ones when the record is written);
+                        // the cross products happen once per Gaussian in K8
                         v[0] += dpx; v[1] += dpy; v[2] += dpz;
-                        v[3] = fmaf(pxf[q], dpx, v[3]); v[4] = fmaf(pxf[q], dpy, v[4]); v[5] = fmaf(pxf[q], dpz, v[5]);
-                        v[6] = fmaf(pyf[q], dpx, v[6]); v[7] = fmaf(pyf[q], dpy, v[7]); v[8] = fmaf(pyf[q], dpz, v[8]);
+                        v[3] = fmaf(xq, dpx, v[3]); v[4] = fmaf(xq, dpy, v[4]); v[5] = fmaf(xq, dpz, v[5]);
+                        v[6] = fmaf(yq, dpx, v[6]); v[7] = fmaf(yq, dpy, v[7]); v[8] = fmaf(yq, dpz, v[8]);
                         v[9] = fmaf(dL_dz, h.sx, v[9]); v[10] = fmaf(dL_dz, h.sy, v[10]); v[11] += dL_dz;
                     } else {
                         const float gG = -dL_dG * h.G * kFilterInvSquare;
@@ -572,7 +575,13 @@ __global__ __launch_bounds__(kWave) void render_backward_kernel(FrameDev f, cons
         }
         // flush this round's records: one 96-B store per lane whose entry got a contribution
         if ((wrote >> lane) & 1ull) {
-            const float4* acc = reinterpret_cast<const float4*>(&s_out[lane][0]);
+            const float4* accl = reinterpret_cast<const float4*>(&s_out[lane][0]);
+            float4 acc[kGradQuads];
+#pragma unroll
+            for (int k = 0; k < kGradQuads; ++k) acc[k] = accl[k];
+            // Sx, Sy from tile-local to global pixel coordinates: sum (Xc + xl) dp = Xc S0 + sum xl dp
+            acc[0].w = fmaf(Xc, acc[0].x, acc[0].w); acc[1].x = fmaf(Xc, acc[0].y, acc[1].x); acc[1].y = fmaf(Xc, acc[0].z, acc[1].y);
+            acc[1].z = fmaf(Yc, acc[0].x, acc[1].z); acc[1].w = fmaf(Yc, acc[0].y, acc[1].w); acc[2].x = fmaf(Yc, acc[0].z, acc[2].x);
             float4* o = inst_grads + (size_t)slot * kGQ;
 #pragma unroll
             for (int k = 0; k < kGradQuads - 1; ++k) o[k] = acc[k];
