@@ -290,9 +290,9 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
             uint32_t hm = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
-            // 16 bits per list entry; for the 16x16 tile: low byte = quadrants of the upper 16x8 band, high byte = lower band
+            // 16 bits per list entry; two-band tiles: low byte = quadrants of the upper band, high byte = lower band
             if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base + lane) + part] = (uint8_t)hm;
-            else if (QX == 2 && QY == 2) hit_mask[range.x + base + lane] = (uint16_t)((hm & 3u) | ((hm >> 2) << 8));
+            else if (QY == 2) hit_mask[range.x + base + lane] = (uint16_t)((hm & ((1u << QX) - 1u)) | ((hm >> QX) << 8));
             else hit_mask[range.x + base + lane] = (uint16_t)hm;
         }
     }
@@ -392,7 +392,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 
 template <int QX, int QY>
 __device__ __forceinline__ uint32_t decode_hits(uint16_t h) {   // see the hit_mask store in K6
-    return (QX == 2 && QY == 2) ? (((uint32_t)h & 3u) | (((uint32_t)h >> 6) & 0xCu)) : (uint32_t)h;
+    // two-band tiles (16x16, 32x16): low byte = the QX quadrant bits of the upper band, high byte = those of the lower band
+    return QY == 2 ? (((uint32_t)h & ((1u << QX) - 1u)) | ((((uint32_t)h >> 8) & ((1u << QX) - 1u)) << QX)) : (uint32_t)h;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -634,9 +635,12 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
         else                    SR_LAUNCH_FWD(false, 3, 2, 1, 2);
     } else {
         if (f.colors != 3) return hipErrorInvalidValue;
+        if (f.tile_w == 32 && f.tile_h == 16) { SR_LAUNCH_FWD(false, 3, 4, 1, 2); }   // two 32x8 band waves per tile
+        else {
 #define SR_FWD_SHAPE(QX, QY) SR_LAUNCH_FWD(false, 3, QX, QY, 1)
-        SR_FOR_TILE_SHAPE(SR_FWD_SHAPE)
+            SR_FOR_TILE_SHAPE(SR_FWD_SHAPE)
 #undef SR_FWD_SHAPE
+        }
     }
 #undef SR_LAUNCH_FWD
     return hipGetLastError();
