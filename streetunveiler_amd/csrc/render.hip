@@ -257,7 +257,8 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                 const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & !done[q];
                 if (kStats) {
                     const unsigned long long vb = __ballot(valid);
-                    if (lane == 0) { atomicAdd(&g_stats[2], 1ull); if (vb) atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)__popcll(vb)); }
+                    if (lane == 0) { atomicAdd(&g_stats[2], 1ull); if (vb) atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)__popcll(vb));
+                                     if (vb & 0xFFFFFFFFull) atomicAdd(&g_stats[5], 1ull); if (vb >> 32) atomicAdd(&g_stats[6], 1ull); }
                 }
                 if (__ballot(valid) == 0) continue;
                 hit[q] |= 1ull << j;

@@ -20,5 +20,5 @@ for cull in (1, 0):
     lib.sr_debug_stats(out, 1)
     st = list(out)
     print(f"cull={cull}: staged={st[0]:,} kept={st[1]:,} ({st[1]/max(st[0],1):.1%}) quad_tests={st[2]:,} ({st[2]/max(st[1],1):.2f}/kept) "
-          f"tests_with_valid={st[3]:,} ({st[3]/max(st[2],1):.1%}) valid_pairs={st[4]:,} lanes/valid_test={st[4]/max(st[3],1):.1f} lanes/test={st[4]/max(st[2],1):.1f}")
+          f"tests_with_valid={st[3]:,} ({st[3]/max(st[2],1):.1%}) valid_pairs={st[4]:,} lanes/valid_test={st[4]/max(st[3],1):.1f} lanes/test={st[4]/max(st[2],1):.1f} tests_hitting_rows0-3={st[5]:,} tests_hitting_rows4-7={st[6]:,}")
 lib.sr_set_option(_lib.SR_OPT_QUADRANT_CULL, 1); lib.sr_set_option(_lib.SR_OPT_DEBUG_STATS, 0)
