@@ -41,7 +41,7 @@ extern "C" {
 #define SR_ABI_VERSION 3
 #define SR_TILE 16            /* default 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y); see SrFrame.tile_width */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
-#define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B; 28 = 112 B with 6 colour channels) */
+#define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
 
 /* SrGaussians.activations == the GaussianModel activations
  * (/root/reference/scene/gaussian_model.py:63-75, getters :101-123) */
@@ -157,8 +157,8 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
                       float* out_color, float* out_allmap, void* stream);
 
 /* Backward (K7 blend backward + K8 preprocess backward).  dL_dcolor [NC,H,W], dL_dallmap [7,H,W].
- * workspace: sr_backward_workspace_bytes(P, num_rendered, NC) bytes (one 96-B -- 112-B for NC = 6 -- gradient record
- * per (tile, Gaussian) duplicate), contents undefined on entry. */
+ * workspace: sr_backward_workspace_bytes(P, num_rendered, NC) bytes (one 96-B gradient record + one flag byte per
+ * (tile, Gaussian) duplicate), contents undefined on entry. */
 int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
                 void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
                 const float* dL_dcolor, const float* dL_dallmap, void* workspace, size_t workspace_bytes,

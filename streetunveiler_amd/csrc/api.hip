@@ -14,9 +14,8 @@ namespace sr {
 hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians& g, float4* recs, uint32_t* depth_keys,
                                      uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii, hipStream_t s);
 hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
-                                      const uint8_t* clamped, const float4* recs, const float4* inst_grads,
-                                      const uint32_t* tiles_touched, uint32_t tag_lo, uint32_t tag_hi, const SrGradients& out,
-                                      hipStream_t s);
+                                      const uint8_t* clamped, const float4* recs, const float4* inst_grads, const uint8_t* written,
+                                      const uint32_t* tiles_touched, const SrGradients& out, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 hipError_t launch_sh_gradient_expand(int P, int M, int deg, int V, const float* means3D, const float* campos, const float* gc,
                                      float* dL_dsh, hipStream_t s);
@@ -36,7 +35,7 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint16_t* hit_mask, int cull, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi, int cull, hipStream_t s);
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, int cull, hipStream_t s);
 hipError_t read_render_stats(unsigned long long* out8, bool reset);
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
@@ -238,9 +237,9 @@ size_t sr_geom_bytes(int32_t P) { return geom_layout(P).total; }
 size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t W, int32_t H) { (void)P; return bin_layout(num_rendered, W, H).total; }
 size_t sr_image_bytes(int32_t W, int32_t H) { return img_layout(W, H).total; }
 size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered, int32_t color_channels) {
-    (void)P;  // one gradient record per (tile, Gaussian) duplicate: 96 B, or 112 B with 6 colour channels
-    const size_t rec = (size_t)(color_channels == 6 ? kGradFloats + 4 : kGradFloats) * 4;
-    return align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * rec, 256);
+    (void)P; (void)color_channels;   // one 96-B gradient record + one "written" byte per (tile, Gaussian) duplicate
+    const size_t n = (size_t)(num_rendered > 0 ? num_rendered : 1);
+    return align_up(n * kGradFloats * 4, 256) + align_up(n, 256);
 }
 
 int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out) {
@@ -373,23 +372,21 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
     const FrameDev f = make_frame(frame, g);
     // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous)
     float4* inst_grads = static_cast<float4*>(workspace);
-    // K7 only writes the records of list entries some pixel reached; each written record carries this call's 64-bit
-    // tag in its two padding slots and K8a ignores records without it (stale workspace contents) -- no zero-fill pass.
-    static std::atomic<uint64_t> s_call{0x9E3779B97F4A7C15ull};
-    uint64_t z = s_call.fetch_add(0x9E3779B97F4A7C15ull) ^ (uint64_t)(uintptr_t)workspace;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-    const uint32_t tag_lo = (uint32_t)z | 1u, tag_hi = (uint32_t)(z >> 32) | 0x80000000u;
+    // K7 writes a record -- and sets the slot's byte in `written` -- only where some pixel contributed; K8 looks at the byte
+    // before it touches the record, so neither the records nor anything but these D bytes need clearing.
+    uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * kGradFloats * 4, 256);
     {
         StageTimer t(SR_STAGE_BLEND_BWD, s);
+        if (D > 0) SR_HIP(hipMemsetAsync(written, 0, D, s));
         if (D > 0)
             SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs), g->colors_precomp,
-                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, B.hit_mask), inst_grads, tag_lo, tag_hi, g_options.load(), s));
+                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, B.hit_mask), inst_grads, written, g_options.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;
     {
         StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
-        SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), inst_grads,
-                                          at<uint32_t>(geom, L.tiles_touched), tag_lo, tag_hi, *grads, s));
+        SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), inst_grads, written,
+                                          at<uint32_t>(geom, L.tiles_touched), *grads, s));
     }
     return debug_sync(frame, s, "preprocess_backward");
 }

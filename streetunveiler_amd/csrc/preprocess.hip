@@ -298,21 +298,20 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
 // ---------------------------------------------------------------------------------------------
 // K8: per-Gaussian backward (Appendix A.6).  First sums the Gaussian's per-(tile, Gaussian) gradient records: K7 stores
 // them in emission order, where they form the contiguous span [first, first + tiles_touched) (first rides in slot 15 of
-// the splat record); ascending order -> deterministic.  Records without this call's tag were not written by K7 (entry
-// behind every pixel's last contributor) and are skipped.
+// the splat record); ascending order -> deterministic.  Slots whose `written` flag is clear got no record from K7 (no pixel
+// contributed) and are skipped without being read.
 // ---------------------------------------------------------------------------------------------
 template <bool kLdsSH, int NC>
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float4* __restrict__ recs,
-    const float4* __restrict__ inst_grads, const uint32_t* __restrict__ tiles_touched, uint32_t tag_lo, uint32_t tag_hi,
+    const float4* __restrict__ inst_grads, const uint8_t* __restrict__ written, const uint32_t* __restrict__ tiles_touched,
     SrGradients out) {
     __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
     const int tid = threadIdx.x, base = blockIdx.x * 256;
     const int i = base + tid;
     const int M = f.sh_coeffs;
-    constexpr int kGQ = NC == 6 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record; the tag sits in the last one
     if (kLdsSH) {
         sh_rows_to_lds(shs, base, P, s_sh, tid);
         __syncthreads();
@@ -332,38 +331,32 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
 #pragma unroll
                 for (int k = 0; k < kGradQuads; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 const uint32_t first = __float_as_uint(rec[3].w), cnt = tiles_touched[i];
-                // Four records per trip.  K7 writes (and tags) a record only where some pixel contributed -- about 40 % of a
-                // Gaussian's span -- so the tag quads are fetched first (one 32-B sector each) and the other 80 B of a record
-                // only behind a matching tag.
+                // Four records per trip.  K7 writes a record only where some pixel contributed -- about 40 % of a Gaussian's span --
+                // and sets the slot's byte in `written`; the flags of the next trip are in flight behind this trip's records.
                 constexpr int kTrip = 4;
                 const uint32_t end = first + cnt;
-                auto load_tags = [&](uint32_t e, float4 (&tq)[kTrip]) {
+                auto load_flags = [&](uint32_t e, uint8_t (&fl)[kTrip]) {
 #pragma unroll
-                    for (int t = 0; t < kTrip; ++t) tq[t] = inst_grads[(size_t)(e + t < end ? e + t : first) * kGQ + (kGQ - 1)];
+                    for (int t = 0; t < kTrip; ++t) fl[t] = e + t < end ? written[e + t] : (uint8_t)0;
                 };
-                float4 tq[kTrip], tn[kTrip];
-                if (cnt > 0) load_tags(first, tq);
+                uint8_t fl[kTrip], fn[kTrip] = {0, 0, 0, 0};
+                load_flags(first, fl);
                 for (uint32_t e = first; e < end; e += kTrip) {
-                    if (e + kTrip < end) load_tags(e + kTrip, tn);   // next trip's tags are in flight behind this trip's bodies
-                    bool ok[kTrip];
+                    if (e + kTrip < end) load_flags(e + kTrip, fn);
                     float4 a[kTrip][kGradQuads];
 #pragma unroll
                     for (int t = 0; t < kTrip; ++t) {
-                        ok[t] = e + t < end && __float_as_uint(tq[t].z) == tag_lo && __float_as_uint(tq[t].w) == tag_hi;
-                        const float4* gr = inst_grads + (size_t)(e + t) * kGQ;
+                        const float4* gr = inst_grads + (size_t)(e + t) * kGradQuads;
 #pragma unroll
-                        for (int k = 0; k < kGradQuads; ++k) {
-                            if (k == kGQ - 1) a[t][k] = tq[t];   // 3-channel record: the tag shares the last value quad
-                            else a[t][k] = ok[t] ? gr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
+                        for (int k = 0; k < kGradQuads; ++k) a[t][k] = fl[t] ? gr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
 #pragma unroll
                     for (int t = 0; t < kTrip; ++t) {
-                        if (ok[t]) {
+                        if (fl[t]) {
 #pragma unroll
                             for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[t][k].x; g[k].y += a[t][k].y; g[k].z += a[t][k].z; g[k].w += a[t][k].w; }
                         }
-                        tq[t] = tn[t];
+                        fl[t] = fn[t];
                     }
                 }
                 g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3]; g4 = g[4]; g5 = g[5];
@@ -595,20 +588,19 @@ hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians
 }
 
 hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
-                                      const uint8_t* clamped, const float4* recs, const float4* inst_grads,
-                                      const uint32_t* tiles_touched, uint32_t tag_lo, uint32_t tag_hi, const SrGradients& out,
-                                      hipStream_t s) {
+                                      const uint8_t* clamped, const float4* recs, const float4* inst_grads, const uint8_t* written,
+                                      const uint32_t* tiles_touched, const SrGradients& out, hipStream_t s) {
     if (P == 0) return hipSuccess;
     const dim3 grid((P + 255) / 256), block(256);
     if (f.colors == 6)
         hipLaunchKernelGGL((preprocess_backward_kernel<false, 6>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
-                           g.transMat_precomp, radii, clamped, recs, inst_grads, tiles_touched, tag_lo, tag_hi, out);
+                           g.transMat_precomp, radii, clamped, recs, inst_grads, written, tiles_touched, out);
     else if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs) && (!out.dL_dsh || aligned16(out.dL_dsh)))
         hipLaunchKernelGGL((preprocess_backward_kernel<true, 3>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
-                           g.transMat_precomp, radii, clamped, recs, inst_grads, tiles_touched, tag_lo, tag_hi, out);
+                           g.transMat_precomp, radii, clamped, recs, inst_grads, written, tiles_touched, out);
     else
         hipLaunchKernelGGL((preprocess_backward_kernel<false, 3>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
-                           g.transMat_precomp, radii, clamped, recs, inst_grads, tiles_touched, tag_lo, tag_hi, out);
+                           g.transMat_precomp, radii, clamped, recs, inst_grads, written, tiles_touched, out);
     return hipGetLastError();
 }
 

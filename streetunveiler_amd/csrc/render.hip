@@ -401,8 +401,9 @@ __device__ __forceinline__ uint32_t decode_hits(uint16_t h) {   // see the hit_m
 // K7
 // ---------------------------------------------------------------------------------------------
 // Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
-// (first[gid] + its index inside the Gaussian's tile rectangle; first[gid] rides in slot 15 of the splat record), where the records of one Gaussian are contiguous; K8 sums them.  Records of list
-// entries no pixel reached are not written; written records carry the call's tag.  Gradient record slots: see common.h.
+// (first[gid] + its index inside the Gaussian's tile rectangle; first[gid] rides in slot 15 of the splat record), where the
+// records of one Gaussian are contiguous; K8 sums them.  Only entries with a contributing pixel get a record, and a 1 in
+// `written[]` at the same index (zeroed per call).  Gradient record slots: see common.h.
 // Register budget: three waves per SIMD (<= 168 VGPRs) wherever the per-pixel state allows it -- the loop is latency-bound
 // at two -- i.e. up to four pixels per lane with three colour channels.
 template <int NC, int QX, int QY>
@@ -416,7 +417,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
                                                                  const float* __restrict__ dL_dcolor,
                                                                  const float* __restrict__ dL_dallmap,
                                                                  const uint16_t* __restrict__ hit_mask,
-                                                                 float4* __restrict__ inst_grads, uint32_t tag_lo, uint32_t tag_hi,
+                                                                 float4* __restrict__ inst_grads, uint8_t* __restrict__ written,
                                                                  int cull) {
     __shared__ float4 s_e[kFwdQuads][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGradFloats];
@@ -435,7 +436,6 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
     const float xl0 = (float)(lx - QX * 4), yl0 = (float)(ly - QY * 4);   // tile-local pixel of quadrant 0; quadrant q adds 8*(q%QX, q/QX)
     float gr[NQ], gg[NQ], gb[NQ], gn0[NQ], gn1[NQ], gn2[NQ], g_depth[NQ], g_median[NQ], Kbg[NQ], a0[NQ], a1[NQ], a2[NQ];
     float gc3[NQ], gc4[NQ], gc5[NQ];   // only live in the 6-channel variant
-    constexpr int kGQ = NC == 6 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record
     uint32_t lastc[NQ], medc[NQ], quad_last[NQ];
     float T[NQ], R[NQ], X[NQ];
     uint32_t total = 0;
@@ -584,16 +584,10 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
             // Sx, Sy from tile-local to global pixel coordinates: sum (Xc + xl) dp = Xc S0 + sum xl dp
             acc[0].w = fmaf(Xc, acc[0].x, acc[0].w); acc[1].x = fmaf(Xc, acc[0].y, acc[1].x); acc[1].y = fmaf(Xc, acc[0].z, acc[1].y);
             acc[1].z = fmaf(Yc, acc[0].x, acc[1].z); acc[1].w = fmaf(Yc, acc[0].y, acc[1].w); acc[2].x = fmaf(Yc, acc[0].z, acc[2].x);
-            float4* o = inst_grads + (size_t)slot * kGQ;
+            float4* o = inst_grads + (size_t)slot * kGradQuads;
 #pragma unroll
-            for (int k = 0; k < kGradQuads - 1; ++k) o[k] = acc[k];
-            const float4 last = acc[kGradQuads - 1];
-            if (NC == 6) {   // all 24 slots carry values; the tag gets a 7th quad
-                o[kGradQuads - 1] = last;
-                o[kGradQuads] = make_float4(0.f, 0.f, __uint_as_float(tag_lo), __uint_as_float(tag_hi));
-            } else {
-                o[kGradQuads - 1] = make_float4(last.x, last.y, __uint_as_float(tag_lo), __uint_as_float(tag_hi));
-            }
+            for (int k = 0; k < kGradQuads; ++k) o[k] = acc[k];
+            written[slot] = 1;   // K8 reads this 1-B flag (zeroed per call) before it touches the record
         }
     }
 }
@@ -649,13 +643,13 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint32_t tag_lo, uint32_t tag_hi,
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written,
                                   int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
 #define SR_LAUNCH_BWD(NCH, QX, QY)                                                                                                          \
     hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), (cull >> 12) * 1024, s, f, ranges, point_list, recs, extra, final_T, \
-                       n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, tag_lo, tag_hi, cull)
+                       n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written, cull)
     if (f.tile_w == 16 && f.tile_h == 16) {
         if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
     } else {
