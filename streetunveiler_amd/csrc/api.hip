@@ -30,10 +30,11 @@ hipError_t run_emit(int P, int tiles_x, int tiles_y, int tile_w, int tile_h, con
 hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
                          uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s);
+hipError_t run_tile_order(int n_tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
 // render.hip
-hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
+hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint16_t* hit_mask, int cull, hipStream_t s);
-hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
+hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                   const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, int cull, hipStream_t s);
 hipError_t read_render_stats(unsigned long long* out8, bool reset);
@@ -148,7 +149,7 @@ GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t keys_unsorted, vals_unsorted, tile_keys, point_list, hit_mask, ranges, temp, temp_bytes, total;
+    size_t keys_unsorted, vals_unsorted, tile_keys, point_list, hit_mask, ranges, order, temp, temp_bytes, total;
 };
 BinLayout bin_layout(uint32_t D, int W, int H) {
     BinLayout L{};
@@ -162,6 +163,7 @@ BinLayout bin_layout(uint32_t D, int W, int H) {
     L.point_list = take(n * 4);
     L.hit_mask = take(n * 2);
     L.ranges = take((size_t)(tiles > 0 ? tiles : 1) * 8);
+    L.order = take((size_t)(tiles > 0 ? tiles : 1) * 4);
     static thread_local uint32_t memo_D = 0xFFFFFFFFu;
     static thread_local int memo_tiles = -1;
     static thread_local size_t memo_bytes = 0;
@@ -342,11 +344,12 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     {
         StageTimer t(SR_STAGE_RANGES, s);
         SR_HIP(run_tile_ranges((P > 0) ? D : 0, n_tiles, at<uint32_t>(binning, B.tile_keys), at<uint2>(binning, B.ranges), s));
+        SR_HIP(run_tile_order(n_tiles, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), s));
     }
     if (int rc = debug_sync(frame, s, "tile_ranges")) return rc;
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
-        SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
+        SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
                                      out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint16_t>(binning, B.hit_mask), g_options.load(), s));
     }
     return debug_sync(frame, s, "render_forward");
@@ -379,7 +382,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0) SR_HIP(hipMemsetAsync(written, 0, D, s));
         if (D > 0)
-            SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs), g->colors_precomp,
+            SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs), g->colors_precomp,
                                           at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, B.hit_mask), inst_grads, written, g_options.load(), s));
     }
     if (int rc = debug_sync(frame, s, "render_backward")) return rc;

@@ -97,6 +97,37 @@ __global__ void tile_ranges_kernel(uint32_t D, const uint32_t* __restrict__ tile
     if (j == D - 1) ranges[t].y = D;
 }
 
+// Dispatch order of the blend waves: tiles by descending power-of-two class of their list length, index order inside a class
+// (stable).  One wave per tile makes the longest lists the tail of K6/K7; starting them first shortens it on scenes with
+// heavy-tailed tile loads, and on uniform scenes (one or two classes) the order stays the locality-friendly index order.
+constexpr int kOrderThreads = 512, kOrderClasses = 16;
+__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(int n_tiles, const uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_cnt[kOrderClasses * kOrderThreads];   // [class, longest first][thread]: the linear index IS the output order
+    __shared__ uint32_t s_wsum[kOrderThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int chunk = (n_tiles + kOrderThreads - 1) / kOrderThreads, begin = min(n_tiles, tid * chunk), end = min(n_tiles, begin + chunk);
+    // class 0: 2^20 entries and more, ..., class 14: 64..127, class 15: fewer than 64 (or none)
+    auto row = [](uint2 r) { const uint32_t len = r.y - r.x; return len ? min(kOrderClasses - 1, max(0, (int)__clz(len) - 11)) : kOrderClasses - 1; };
+    for (int k = 0; k < kOrderClasses; ++k) s_cnt[k * kOrderThreads + tid] = 0;
+    for (int t = begin; t < end; ++t) s_cnt[row(ranges[t]) * kOrderThreads + tid] += 1;   // own column: no conflicts
+    __syncthreads();
+    // exclusive scan of the counters in linear order: thread t owns the kOrderClasses consecutive ones starting at kOrderClasses * t
+    uint32_t local[kOrderClasses], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kOrderClasses; ++k) { local[k] = s_cnt[tid * kOrderClasses + k]; sum += local[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    uint32_t off = incl - sum;
+    for (int j = 0; j < w; ++j) off += s_wsum[j];
+#pragma unroll
+    for (int k = 0; k < kOrderClasses; ++k) { s_cnt[tid * kOrderClasses + k] = off; off += local[k]; }
+    __syncthreads();
+    for (int t = begin; t < end; ++t) { const int k = row(ranges[t]); order[s_cnt[k * kOrderThreads + tid]++] = (uint32_t)t; }
+}
+
 static int bits_for(uint32_t n) {  // number of bits needed to represent values in [0, n)
     int b = 0;
     while ((1ull << b) < (unsigned long long)n) ++b;
@@ -150,6 +181,12 @@ hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, u
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
     if (e != hipSuccess || D == 0) return e;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((D + 255) / 256), dim3(256), 0, s, D, tile_keys, ranges);
+    return hipGetLastError();
+}
+
+hipError_t run_tile_order(int n_tiles, const uint2* ranges, uint32_t* order, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, ranges, order);
     return hipGetLastError();
 }
 

@@ -181,7 +181,7 @@ __device__ __forceinline__ void load_record(const float4* __restrict__ recs, uin
 // each, all walking the parent's list: fewer pixels per lane -> fewer registers -> more waves per SIMD, which is what these
 // latency-bound loops want, at the price of staging every entry SPLIT times.
 template <bool kStats, int NC, int QX, int QY, int SPLIT>
-__global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ recs,
                                                                 const float* __restrict__ extra,
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
         tile = (k / SPLIT) * kXcds + xcd; part = k % SPLIT;
         if (tile >= f.tiles_x * f.tiles_y) return;
     }
+    tile = (int)tile_order[tile];   // longest lists first (binning.hip tile_order_kernel)
     constexpr int NQ = QX * QY;   // 8x8 quadrants per wave = pixels per lane
     const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8 * SPLIT) + part * (QY * 8);
     const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
@@ -408,7 +409,7 @@ __device__ __forceinline__ uint32_t decode_hits(uint16_t h) {   // see the hit_m
 // at two -- i.e. up to four pixels per lane with three colour channels.
 template <int NC, int QX, int QY>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(QX * QY <= 4 && NC == 3 ? 3 : 1, QX * QY <= 4 && NC == 3 ? 3 : 8)))
-void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
+void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
                                                                  const uint32_t* __restrict__ point_list,
                                                                  const float4* __restrict__ recs,
                                                                  const float* __restrict__ extra,
@@ -422,7 +423,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges,
     __shared__ float4 s_e[kFwdQuads][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGradFloats];
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];   // longest lists first
     constexpr int NQ = QX * QY;   // 8x8 quadrants per tile = pixels per lane
     const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8);
     const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
@@ -612,7 +613,7 @@ hipError_t read_render_stats(unsigned long long* out8, bool reset) {
     else if (f.tile_w == 32 && f.tile_h == 16) { F(4, 2); }                     \
     else return hipErrorInvalidValue;
 
-hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
+hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib,
                                  uint16_t* hit_mask, int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
@@ -621,7 +622,7 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
 #define SR_LAUNCH_FWD(STATS, NCH, QX, QY, SPLIT)                                                                                  \
     hipLaunchKernelGGL((render_forward_kernel<STATS, NCH, QX, QY, SPLIT>),                                                          \
                        dim3(SPLIT > 1 ? (n_tiles + kXcds - 1) / kXcds * kXcds * SPLIT : n_tiles), block, (cull >> 12) * 1024, s, f, \
-                       ranges, point_list, recs, extra, out_color, out_allmap, final_T, n_contrib, hit_mask, cull)
+                       ranges, tile_order, point_list, recs, extra, out_color, out_allmap, final_T, n_contrib, hit_mask, cull)
     if (f.tile_w == 16 && f.tile_h == 16) {
         // the reference's tile: two 16x8 band waves per tile (the counter variant stays whole so that it counts each entry once)
         if (f.colors == 6) { if (cull & 2) SR_LAUNCH_FWD(true, 6, 2, 2, 1); else SR_LAUNCH_FWD(false, 6, 2, 1, 2); }
@@ -641,14 +642,14 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
     return hipGetLastError();
 }
 
-hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
+hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                   const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written,
                                   int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
 #define SR_LAUNCH_BWD(NCH, QX, QY)                                                                                                          \
-    hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), (cull >> 12) * 1024, s, f, ranges, point_list, recs, extra, final_T, \
+    hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), (cull >> 12) * 1024, s, f, ranges, tile_order, point_list, recs, extra, final_T, \
                        n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written, cull)
     if (f.tile_w == 16 && f.tile_h == 16) {
         if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
