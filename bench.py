@@ -180,6 +180,15 @@ def main():
         w = torch.zeros(1024, device=dev); wg = torch.empty(1024 * world, device=dev)
         dist.all_reduce(w); dist.all_gather_into_tensor(wg, w)
         sync()
+        if args.exchange == "factored":
+            # one untimed trial step of the factored exchange; should it raise (it would on every rank alike: same code, same
+            # arguments), fall back to the plain all-reduce instead of losing the run -- the JSON line says which one ran
+            try:
+                step()
+                sync()
+            except Exception as e:   # noqa: BLE001
+                print(f"[rank {rank}] factored exchange unavailable ({type(e).__name__}: {e}); using all-reduce", file=sys.stderr, flush=True)
+                args.exchange = "allreduce"
 
     for _ in range(args.warmup):
         step()
