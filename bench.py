@@ -19,6 +19,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -26,7 +27,6 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak (packed FMA; 78.6 with plain v_fma_f32) -- MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-FP32_VALU_PEAK_TFLOPS = 157.3
 
 
 def parse():
