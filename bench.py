@@ -25,7 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak (packed FMA; 78.6 with plain v_fma_f32) -- MI355X_MICROARCH.md
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak = 64 FLOP/clk/SIMD (plain v_fma_f32, 2 cycles per wave64) -- MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
@@ -236,8 +236,8 @@ def main():
                 "lane_utilisation": round(blend_counts["contributing_pairs"] / lane_tests, 4) if lane_tests else None,
                 "issued": None if issued is None else round(issued, 2), "issued_frac": None if issued is None else round(issued / FP32_VALU_PEAK_TFLOPS, 4),
                 "useful": None if useful is None else round(useful, 2), "useful_frac": None if useful is None else round(useful / FP32_VALU_PEAK_TFLOPS, 4),
-                "note": "issued = 64 lanes x quadrant tests, useful = pairs that contribute; SQ_ACTIVE_INST_VALU covers 92-95 % of both "
-                        "kernels' time (profiles/r01_sq_counters.json): instruction-issue-bound, see DESIGN.md 4",
+                "note": "issued = 64 lanes x quadrant tests, useful = pairs that contribute; the kernels are bound by VALU issue and latency, "
+                        "not by memory (profiles/r01_sq_counters.json, DESIGN.md 4",
                 "D_eff_blend_bytes": blend_counts["staged_entries_D_eff"] * 296 + npx * 160}
         out = {
             "metric": "Msplats/s fwd+bwd @1920x1080, 3M Gaussians", "value": round(value, 3), "unit": "Msplats/s",
