@@ -77,6 +77,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # no zero tensors for outputs the loss does not touch (backward handles None)
         return color, radii, allmap
 
     @staticmethod

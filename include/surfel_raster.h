@@ -217,10 +217,11 @@ size_t sr_debug_radix_sort_temp_bytes(uint32_t n);
 int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                         int total_bits, void* temp, size_t temp_bytes, void* stream);
 
-/* Profiling aid.  sr_set_stage_timing(1) makes every later call from this thread bracket each stage with a
- * pair of HIP events recorded on the caller's stream (no host sync while recording; up to 512 launches per
- * stage).  sr_stage_stats() waits for the recorded events and returns the summed duration (ms) and the
- * number of launches of one stage since timing was (re-)enabled. */
+/* Profiling aid.  sr_set_stage_timing(1) makes every later call bracket each stage with a pair of HIP events recorded
+ * on the caller's stream (no host sync while recording; up to 512 launches per stage); sr_set_stage_timing(2 * mask),
+ * mask = OR of (1 << SrStage), brackets only the stages in the mask (every event pair costs a few microseconds of
+ * stream time: the full set adds ~1.4 % to a 4.5 ms step).  sr_stage_stats() waits for the recorded events and returns the
+ * summed duration (ms) and the number of launches of one stage since timing was (re-)enabled. */
 typedef enum SrStage {
     SR_STAGE_PREPROCESS = 0, SR_STAGE_DEPTH_SORT = 1, SR_STAGE_SCAN = 2, SR_STAGE_EMIT = 3, SR_STAGE_TILE_SORT = 4,
     SR_STAGE_RANGES = 5, SR_STAGE_BLEND_FWD = 6, SR_STAGE_BLEND_BWD = 7, SR_STAGE_PREPROCESS_BWD = 8, SR_STAGE_COUNT = 9

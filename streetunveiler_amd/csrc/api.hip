@@ -94,7 +94,8 @@ EvRing g_ring[SR_STAGE_COUNT];
 struct StageTimer {
     int stage; hipStream_t s; int slot = -1;
     StageTimer(int st, hipStream_t stream) : stage(st), s(stream) {
-        if (!g_timing.load()) return;
+        const int mode = g_timing.load();   // 0 off, 1 every stage, otherwise a bit mask of stages (bit 1 << stage, shifted by one)
+        if (!mode || (mode != 1 && !((mode >> 1) & (1 << stage)))) return;
         std::lock_guard<std::mutex> lk(g_ring_mu);
         EvRing& r = g_ring[stage];
         if (r.used >= kEvRing) return;  // ring full: stop recording (stats stay valid for the recorded part)
