@@ -303,8 +303,14 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     }
     if (int rc = debug_sync(frame, s, "depth_order")) return rc;
     // the one host read-back of the forward (the reference does the same between scan and duplicateWithKeys)
-    SR_HIP(hipMemcpyAsync(num_rendered_host, at<uint32_t>(geom, L.sorted_offsets) + (P - 1), 4, hipMemcpyDeviceToHost, s));
+    // through a pinned word (one per host thread, the only allocation this library keeps): a DMA copy instead of the
+    // staged pageable path
+    static thread_local uint32_t* pinned = nullptr;
+    if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
+    uint32_t* dst = pinned ? pinned : num_rendered_host;
+    SR_HIP(hipMemcpyAsync(dst, at<uint32_t>(geom, L.sorted_offsets) + (P - 1), 4, hipMemcpyDeviceToHost, s));
     SR_HIP(hipStreamSynchronize(s));
+    if (pinned) *num_rendered_host = *pinned;
     return SR_OK;
 }
 
