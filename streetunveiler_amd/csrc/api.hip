@@ -12,7 +12,7 @@
 namespace sr {
 // preprocess.hip
 hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians& g, float4* recs, uint32_t* depth_keys,
-                                     uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii, hipStream_t s);
+                                     uint32_t* tiles_touched, uint2* rect, uint8_t* clamped, int32_t* radii, hipStream_t s);
 hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussians& g, const int32_t* radii,
                                       const uint8_t* clamped, const float4* recs, const float4* inst_grads, const uint8_t* written,
                                       const uint32_t* tiles_touched, const SrGradients& out, hipStream_t s);
@@ -25,7 +25,7 @@ size_t tile_sort_temp_bytes(uint32_t D, int n_tiles);
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* sorted_keys,
                           uint32_t* sorted_gid, uint32_t* tt_sorted, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t run_tile_count_scan(int P, const uint32_t* tt_sorted, uint32_t* sorted_offsets, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t run_emit(int P, int tiles_x, int tiles_y, int tile_w, int tile_h, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
+hipError_t run_emit(int P, int tiles_x, const uint2* rect, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
                     float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, hipStream_t s);
 hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
                          uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s);
@@ -125,7 +125,7 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
 
 // ---- buffer layouts ------------------------------------------------------------------------------
 struct GeomLayout {
-    size_t recs, depth_keys, tiles_touched, clamped, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, temp, temp_bytes, total;
+    size_t recs, depth_keys, tiles_touched, rect, clamped, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, temp, temp_bytes, total;
 };
 GeomLayout geom_layout(int P) {
     GeomLayout L{};
@@ -135,6 +135,7 @@ GeomLayout geom_layout(int P) {
     L.recs = take(n * kRecFloats * 4);
     L.depth_keys = take(n * 4);
     L.tiles_touched = take(n * 4);
+    L.rect = take(n * 8);
     L.clamped = take(n);
     L.sorted_keys = take(n * 4);
     L.sorted_gid = take(n * 4);
@@ -288,7 +289,7 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     {
         StageTimer t(SR_STAGE_PREPROCESS, s);
         SR_HIP(launch_preprocess_forward(P, f, *g, at<float4>(geom, L.recs), at<uint32_t>(geom, L.depth_keys),
-                                         at<uint32_t>(geom, L.tiles_touched), at<uint8_t>(geom, L.clamped), radii, s));
+                                         at<uint32_t>(geom, L.tiles_touched), at<uint2>(geom, L.rect), at<uint8_t>(geom, L.clamped), radii, s));
     }
     if (int rc = debug_sync(frame, s, "preprocess_forward")) return rc;
     {
@@ -336,7 +337,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
         recs = at<float4>(geom, L.recs);
         {
             StageTimer t(SR_STAGE_EMIT, s);
-            SR_HIP(run_emit(P, f.tiles_x, f.tiles_y, f.tile_w, f.tile_h, at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), recs,
+            SR_HIP(run_emit(P, f.tiles_x, at<uint2>(geom, L.rect), at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), recs,
                             at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted), s));
         }
         if (int rc = debug_sync(frame, s, "emit_duplicates")) return rc;

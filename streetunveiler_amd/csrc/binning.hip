@@ -27,7 +27,7 @@ hipError_t gather_inclusive_scan(const uint32_t* idx, const uint32_t* src, uint3
 // K3: wave-cooperative duplicate emission.  Each wave owns 64 consecutive depth ranks; the lanes
 // then walk the wave's contiguous output span 64 slots at a time (coalesced 4-B stores), finding the
 // owning Gaussian of each slot by a 6-step binary search over the wave's exclusive offsets in LDS.
-__global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x, int tiles_y, int tile_w, int tile_h, float inv_tile_w, float inv_tile_h,
+__global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x, const uint2* __restrict__ rect,
                                                               const uint32_t* __restrict__ sorted_gid,
                                                               const uint32_t* __restrict__ sorted_offsets,
                                                               float4* __restrict__ recs,
@@ -45,17 +45,9 @@ __global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x
         incl = sorted_offsets[r];
         const uint32_t prev = r > 0 ? sorted_offsets[r - 1] : 0u;
         count = incl - prev;
-        if (count) {
-            const float4 q2 = recs[(size_t)gid * kRecQuads + 2];
-            const float radius = recs[(size_t)gid * kRecQuads + 4].w;
-            const float cx = q2.y, cy = q2.z;
-            // same expressions as K1 (and upstream getRect) -> identical rectangle
-            minx = (int)((cx - radius) * inv_tile_w); miny = (int)((cy - radius) * inv_tile_h);
-            int maxx = (int)((cx + radius + (float)(tile_w - 1)) * inv_tile_w);
-            int maxy = (int)((cy + radius + (float)(tile_h - 1)) * inv_tile_h);
-            minx = min(tiles_x, max(0, minx)); maxx = min(tiles_x, max(0, maxx));
-            miny = min(tiles_y, max(0, miny)); maxy = min(tiles_y, max(0, maxy));
-            w = maxx - minx;
+        if (count) {   // K1's tile rectangle, one 8-B gather instead of two record quads
+            const uint2 rc = rect[gid];
+            minx = (int)(rc.x & 0xFFFFu); miny = (int)(rc.x >> 16); w = (int)(rc.y & 0xFFFFu);
         }
     } else {
         // ranks past P: inherit the last inclusive offset so the search stays monotone
@@ -161,11 +153,10 @@ hipError_t run_tile_count_scan(int P, const uint32_t* tt_sorted, uint32_t* sorte
     return gather_inclusive_scan(nullptr, tt_sorted, sorted_offsets, (uint32_t)P, temp, temp_bytes, s);
 }
 
-hipError_t run_emit(int P, int tiles_x, int tiles_y, int tile_w, int tile_h, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
+hipError_t run_emit(int P, int tiles_x, const uint2* rect, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
                     float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_duplicates_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, tiles_x, tiles_y, tile_w, tile_h,
-                       1.f / (float)tile_w, 1.f / (float)tile_h, sorted_gid,
+    hipLaunchKernelGGL(emit_duplicates_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, tiles_x, rect, sorted_gid,
                        sorted_offsets, recs, keys_unsorted, vals_unsorted);
     return hipGetLastError();
 }

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ transMat_precomp,
     float4* __restrict__ recs, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ tiles_touched,
-    uint8_t* __restrict__ clamped, int32_t* __restrict__ radii) {
+    uint2* __restrict__ rect, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii) {
     __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
     const int tid = threadIdx.x, base = blockIdx.x * 256;
     const int i = base + tid;
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
     // defaults for a culled Gaussian
     int32_t out_radius = 0;
     uint32_t out_tiles = 0, out_key = kCulledKey;
+    uint2 out_rect = make_uint2(0u, 0u);   // tile rectangle for the duplicate emission: minx | miny << 16, width | height << 16
     uint8_t out_clamped = 0;
     float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
 
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
                 }
                 out_radius = (int32_t)radius;
                 out_tiles = (uint32_t)area;
+                out_rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
                 out_key = __float_as_uint(vz);
                 q0 = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
                 q1 = make_float4(Tv[1], Tv[2], Tw[0], Tw[1]);
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
     }
     radii[i] = out_radius;
     tiles_touched[i] = out_tiles;
+    rect[i] = out_rect;
     depth_keys[i] = out_key;
     clamped[i] = out_clamped;
     float4* rec = recs + (size_t)i * kRecQuads;
@@ -575,15 +578,15 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians& g, float4* recs, uint32_t* depth_keys,
-                                     uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii, hipStream_t s) {
+                                     uint32_t* tiles_touched, uint2* rect, uint8_t* clamped, int32_t* radii, hipStream_t s) {
     if (P == 0) return hipSuccess;
     const dim3 grid((P + 255) / 256), block(256);
     if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs))
         hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, 0, s, P, f, g.means3D, g.opacities, g.scales,
-                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys, tiles_touched, clamped, radii);
+                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys, tiles_touched, rect, clamped, radii);
     else
         hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, 0, s, P, f, g.means3D, g.opacities, g.scales,
-                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys, tiles_touched, clamped, radii);
+                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys, tiles_touched, rect, clamped, radii);
     return hipGetLastError();
 }
 
