@@ -208,7 +208,8 @@ typedef enum SrOption { SR_OPT_QUADRANT_CULL = 0, SR_OPT_DEBUG_STATS = 1 } SrOpt
 int sr_set_option(int option, int value);
 /* With SR_OPT_DEBUG_STATS = 1 the forward blend counts (device-wide, since the last reset): [0] list entries staged,
  * [1] entries kept by the quadrant culling, [2] (entry, quadrant) tests run, [3] tests with >= 1 contributing pixel,
- * [4] contributing (pixel, entry) pairs.  Synchronises the device.  out8: 8 host uint64. */
+ * [4] contributing (pixel, entry) pairs, [5] / [6] tests with a contributing pixel in rows 0-3 / rows 4-7 of the quadrant.
+ * Synchronises the device.  out8: 8 host uint64. */
 int sr_debug_stats(unsigned long long* out8, int reset);
 
 /* Test hook for the library's stable LSD radix sort (binning K2/K4): sorts n (key, value) u32 pairs by key bits

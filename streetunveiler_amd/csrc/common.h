@@ -32,7 +32,9 @@ constexpr int kRecFloats = SR_SPLAT_FLOATS;
 //   S0 = sum dp, Sx = sum x dp, Sy = sum y dp, Z = sum dL/ddepth * (s.x, s.y, 1)
 // are linear in the pixels AND in the tiles, so they can be summed first and turned into dL/dT once per
 // Gaussian (K8):  dTu = Tv x S0 - Tw x Sy,  dTv = S0 x Tu - Sx x Tw,  dTw = Tu x Sy - Tv x Sx + Z.
-//   slots  0..2 S0 | 3..5 Sx | 6..8 Sy | 9..11 Z | 12,13 d/dxy | 14 d/dopacity | 15..17 d/dnormal | 18..20 d/drgb
+//   slots  0..2 S0 | 3..5 Sx | 6..8 Sy | 9..11 Z | 12,13 d/dxy | 14 d/dopacity | 15..17 d/dnormal | 18..20 d/drgb |
+//          21..23 d/d(colour channels 3..5) in the 6-channel variant, else unused.
+// Next to the records: one `written` byte per slot, zeroed per call, set by K7 where it stored a record.
 constexpr int kGradQuads = 6;
 constexpr int kGradFloats = SR_GRAD_FLOATS;
 
