@@ -412,3 +412,15 @@ def test_very_long_tile_lists_and_tiny_images():
         for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh"):
             sc = np.abs(b2[k]).max() + 1e-20
             assert np.abs(o2[k].reshape(b2[k].shape) - b2[k]).max() <= 2e-2 * sc, (w, h, k)
+
+
+def test_randomised_scenes_short_sweep():
+    """tools/fuzz_parity.py on a dozen random scenes (sizes, SH degree, tile shape, opacity / scale regimes, precomputed
+    colours): bit-exact binning, images within one flipped contributor, at most max(3, 0.1 %) Gaussians with an
+    out-of-tolerance gradient."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "12", "2000"], cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "12/12 scenes within the parity bars" in r.stdout
