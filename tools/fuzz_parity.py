@@ -12,12 +12,13 @@ from tests.test_gpu_parity import _check_binning
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+big = int(os.environ.get("FUZZ_BIG", "1"))   # FUZZ_BIG=4: images up to 4x wider/higher, 16x the Gaussians
 shapes = [(16, 16)] * 4 + [(8, 8), (16, 8), (32, 8), (32, 16)]
 bad = 0
 for k in range(n_scenes):
     rng = np.random.default_rng(seed0 + k)
-    W, H = int(rng.integers(17, 330)), int(rng.integers(9, 200))
-    P = int(rng.integers(1, 9000))
+    W, H = int(rng.integers(17, 330 * big)), int(rng.integers(9, 200 * big))
+    P = int(rng.integers(1, 9000 * big * big))
     lo = float(10 ** rng.uniform(-3.3, -1.5)); hi = lo * float(10 ** rng.uniform(0.3, 1.5))
     deg = int(rng.integers(0, 4))
     tile = shapes[int(rng.integers(0, len(shapes)))]
