@@ -210,7 +210,8 @@ def binning_view(binning: torch.Tensor, P: int, D: int, W: int, H: int, tile=(16
     L.check(L.load().sr_binning_view(_ptr(binning), binning.numel(), P, D, W, H, C.byref(v)), "sr_binning_view")
     tiles = ((W + tile[0] - 1) // tile[0]) * ((H + tile[1] - 1) // tile[1])
     return dict(tile_keys=_view(binning, v.tile_keys, D * 4, torch.int32), point_list=_view(binning, v.point_list, D * 4, torch.int32),
-                ranges=_view(binning, v.ranges, tiles * 8, torch.int32).view(tiles, 2))
+                ranges=_view(binning, v.ranges, tiles * 8, torch.int32).view(tiles, 2),
+                tile_order=_view(binning, v.tile_order, tiles * 4, torch.int32))
 
 
 def image_view(img: torch.Tensor, W: int, H: int):

@@ -121,6 +121,7 @@ typedef struct SrBinningView {
     const uint32_t* tile_keys;   /* [D] tile id of every sorted duplicate */
     const uint32_t* point_list;  /* [D] Gaussian id of every sorted duplicate (tile-major, then depth, then id) */
     const uint32_t* ranges;      /* [tiles,2] (begin, end) into point_list; (0,0) for empty tiles */
+    const uint32_t* tile_order;  /* [tiles] dispatch order of the blend waves: a permutation, longest list classes first */
 } SrBinningView;
 
 typedef struct SrImageView {

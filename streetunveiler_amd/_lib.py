@@ -43,7 +43,7 @@ class SrGeomView(C.Structure):
 
 
 class SrBinningView(C.Structure):
-    _fields_ = [("tile_keys", C.c_void_p), ("point_list", C.c_void_p), ("ranges", C.c_void_p)]
+    _fields_ = [("tile_keys", C.c_void_p), ("point_list", C.c_void_p), ("ranges", C.c_void_p), ("tile_order", C.c_void_p)]
 
 
 class SrImageView(C.Structure):

@@ -262,7 +262,7 @@ int sr_binning_view(void* binning, size_t binning_bytes, int32_t P, uint32_t D, 
     const BinLayout L = bin_layout(D, W, H);
     if (binning_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, L.total);
     out->tile_keys = at<uint32_t>(binning, L.tile_keys); out->point_list = at<uint32_t>(binning, L.point_list);
-    out->ranges = at<uint32_t>(binning, L.ranges);
+    out->ranges = at<uint32_t>(binning, L.ranges); out->tile_order = at<uint32_t>(binning, L.order);
     return SR_OK;
 }
 

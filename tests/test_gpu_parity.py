@@ -48,6 +48,12 @@ def _check_binning(raw, fwd):
     key64 = (raw["bin"]["tile_keys"].view(np.uint32).astype(np.uint64) << np.uint64(32)) | keys[pl].astype(np.uint64)
     np.testing.assert_array_equal(key64, fwd["keys"])
     np.testing.assert_array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])
+    # dispatch order of the blend waves: a permutation of the tiles, power-of-two length classes descending, index order inside
+    order = raw["bin"]["tile_order"].view(np.uint32).astype(np.int64)
+    assert sorted(order.tolist()) == list(range(fwd["ranges"].shape[0]))
+    ln = (fwd["ranges"][:, 1].astype(np.int64) - fwd["ranges"][:, 0])[order]
+    cls = np.where(ln > 0, np.minimum(15, np.maximum(0, 20 - np.floor(np.log2(np.maximum(ln, 1))).astype(np.int64))), 15)
+    assert (np.diff(cls) >= 0).all() and all((np.diff(order[cls == c]) > 0).all() for c in np.unique(cls))
 
 
 def _check_images(out, fwd, tag):
