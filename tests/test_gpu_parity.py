@@ -430,3 +430,26 @@ def test_randomised_scenes_short_sweep():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "12/12 scenes within the parity bars" in r.stdout
+
+
+def test_degenerate_parameters():
+    """Zero / sub-denormal / gigantic scales, zero quaternions, opacity exactly 0 and 1: same radii, no NaN or Inf on either
+    side, images and gradients within the usual bars (scales underflow in training; nothing here may poison a frame)."""
+    from tests.gpu_util import run_hip, run_oracle
+    P, W, H = 6000, 240, 136
+    cam, g = _scene(P, W, H, 77, 3e-3, 5e-2, 2)
+    idx = np.random.default_rng(0).permutation(P)
+    g["scales"][idx[:60], 0] = 0.0; g["scales"][idx[60:120]] = 0.0
+    g["opacities"][idx[120:180]] = 0.0; g["opacities"][idx[180:240]] = 1.0
+    g["rotations"][idx[240:300]] = 0.0
+    g["scales"][idx[300:360]] = 1e-12; g["scales"][idx[360:420]] = 50.0
+    bg = np.zeros(3, np.float32)
+    dc, da = synthetic_upstream_grads(W, H, seed=3)
+    fwd, bwd = run_oracle(g, cam, bg, 3, dc, da)
+    out = run_hip(g, cam, bg, 3, dc, da)
+    np.testing.assert_array_equal(out["radii"], fwd["radii"])
+    names = ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"]
+    for a in [out["color"], out["allmap"], fwd["color"], fwd["allmap"]] + [out[n] for n in names] + [bwd[n] for n in names]:
+        assert np.isfinite(np.asarray(a)).all()
+    _check_images(out, fwd, "degenerate")
+    _check_grads(out, bwd, names, "degenerate")
