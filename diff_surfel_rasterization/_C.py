@@ -52,6 +52,17 @@ def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W,
     return fr, keep
 
 
+def _mask(mask, P, dev):
+    """[P] bool / uint8 tensor or None -> contiguous uint8 storage on `dev` (torch.bool is one byte per element)."""
+    if mask is None:
+        return None
+    if mask.numel() != P or mask.dtype not in (torch.bool, torch.uint8):
+        raise L.SurfelRasterError("mask must be a bool tensor with one entry per Gaussian")
+    if not mask.is_cuda:
+        raise L.SurfelRasterError("mask must be a CUDA (ROCm) tensor")
+    return mask.contiguous().view(torch.uint8)
+
+
 def _channels(colors_precomp):
     """3 as in the reference, or 6: two 3-channel passes over the same geometry folded into one."""
     if colors_precomp is None or colors_precomp.numel() == 0:
@@ -62,18 +73,18 @@ def _channels(colors_precomp):
     return nc
 
 
-def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations=0):
+def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations=0, mask=None):
     P = int(means3D.shape[0])
     M = int(sh.shape[1]) if sh is not None and sh.numel() else 0
     NC = _channels(colors_precomp)
     g = L.SrGaussians(P, M, NC, int(activations), _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(sh),
-                      _ptr(colors_precomp), _ptr(transMat_precomp))
+                      _ptr(colors_precomp), _ptr(transMat_precomp), _ptr(mask))
     return g
 
 
 def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, activations=0, tile=None):
+                        prefiltered, debug, activations=0, tile=None, mask=None):
     """`tile` = (width, height) of the binning tile, default the reference's 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
     16x16, 32x8, 32x16); the backward must be given the same shape."""
     lib = L.load()
@@ -87,7 +98,8 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
     P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
     with torch.cuda.device(dev):
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile)
-        g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations)
+        mask = _mask(mask, P, dev)
+        g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations, mask)
         if keep[0].numel() != g.color_channels:
             raise L.SurfelRasterError(f"bg must have {g.color_channels} entries, one per colour channel")
         color = torch.empty((g.color_channels, H, W), dtype=torch.float32, device=dev)

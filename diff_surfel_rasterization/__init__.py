@@ -43,21 +43,23 @@ def _cpu_snapshot(args):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        activations=0, tile=None):
+                        activations=0, tile=None, mask=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, activations, tile)
+                                     raster_settings, activations, tile, mask)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                activations=0, tile=None):
+                activations=0, tile=None, mask=None):
         s = raster_settings
         ctx.activations = int(activations)
         ctx.tile = tuple(int(t) for t in tile) if tile else None
         fused = {"activations": ctx.activations} if ctx.activations else {}
         if ctx.tile:
             fused["tile"] = ctx.tile
+        if mask is not None:   # only the forward looks at it: masked-out Gaussians get radius 0 and, with that, zero gradients
+            fused["mask"] = mask
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
                 s.debug)
@@ -116,7 +118,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         none_if_empty = lambda g, ref: g if ref.numel() else None
         return (grad_means3D, grad_means2D, none_if_empty(grad_sh, sh), none_if_empty(grad_colors_precomp, colors_precomp),
                 grad_opacities, none_if_empty(grad_scales, scales), none_if_empty(grad_rotations, rotations),
-                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None)
+                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None, None)
 
 
 class GaussianRasterizer(nn.Module):
@@ -137,7 +139,10 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, mask=None):
+        """`mask` (extension): [P] bool; False = leave the Gaussian out, with the same images as boolean-indexing
+        every input first (what the reference's render_with_mask / semantic filters do) but without the copies: `radii` and
+        all gradients stay full-size, zero where masked out."""
         s = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -151,4 +156,4 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s,
-                                   self.activations, self.tile)
+                                   self.activations, self.tile, mask)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 3
+#define SR_ABI_VERSION 4
 #define SR_TILE 16            /* default 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y); see SrFrame.tile_width */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
 #define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
@@ -92,6 +92,10 @@ typedef struct SrGaussians {
     const float* shs;
     const float* colors_precomp;
     const float* transMat_precomp;  /* the reference's `cov3D_precomp` slot carries a [P,9] transMat in 2DGS */
+    const uint8_t* mask;            /* optional [P] (torch.bool storage): 0 = leave this Gaussian out, exactly as if the caller had
+                                     * boolean-indexed every input (render_with_mask / semantic filters,
+                                     * /root/reference/gaussian_renderer/__init__.py:89-105, 190-325) -- without the copies; radii
+                                     * and gradients stay full-size, zero where masked out.  NULL = all */
 } SrGaussians;
 
 /* Gradient outputs of the backward == return tuple of _C.rasterize_gaussians_backward.

@@ -28,7 +28,7 @@ class SrGaussians(C.Structure):
     _fields_ = [("P", C.c_int32), ("sh_coeffs", C.c_int32), ("color_channels", C.c_int32), ("activations", C.c_int32),
                 ("means3D", C.c_void_p), ("opacities", C.c_void_p),
                 ("scales", C.c_void_p), ("rotations", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
-                ("transMat_precomp", C.c_void_p)]
+                ("transMat_precomp", C.c_void_p), ("mask", C.c_void_p)]
 
 
 class SrGradients(C.Structure):
@@ -106,8 +106,8 @@ def load():
     lib.sr_debug_radix_sort_temp_bytes.restype = C.c_size_t
     lib.sr_debug_radix_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sr_stage_stats.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    if lib.sr_abi_version() != 3:
-        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 3")
+    if lib.sr_abi_version() != 4:
+        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 4")
     _lib = lib
     return lib
 

@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
     int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ transMat_precomp,
-    float4* __restrict__ recs, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ tiles_touched,
-    uint2* __restrict__ rect, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii) {
+    const uint8_t* __restrict__ mask, float4* __restrict__ recs, uint32_t* __restrict__ depth_keys,
+    uint32_t* __restrict__ tiles_touched, uint2* __restrict__ rect, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii) {
     __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
     const int tid = threadIdx.x, base = blockIdx.x * 256;
     const int i = base + tid;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
     const float vx = ((v[0] * px + v[4] * py) + v[8] * pz) + v[12];
     const float vy = ((v[1] * px + v[5] * py) + v[9] * pz) + v[13];
     const float vz = ((v[2] * px + v[6] * py) + v[10] * pz) + v[14];
-    bool alive = vz > kNear;
+    bool alive = vz > kNear && (!mask || mask[i]);   // masked out == not there (same as boolean-indexing the inputs)
     if (alive) {
         float Tm[9], nrm[3];
         if (transMat_precomp) {
@@ -583,10 +583,10 @@ hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians
     const dim3 grid((P + 255) / 256), block(256);
     if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs))
         hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, 0, s, P, f, g.means3D, g.opacities, g.scales,
-                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys, tiles_touched, rect, clamped, radii);
+                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, g.mask, recs, depth_keys, tiles_touched, rect, clamped, radii);
     else
         hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, 0, s, P, f, g.means3D, g.opacities, g.scales,
-                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, recs, depth_keys, tiles_touched, rect, clamped, radii);
+                           g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, g.mask, recs, depth_keys, tiles_touched, rect, clamped, radii);
     return hipGetLastError();
 }
 

@@ -40,6 +40,10 @@ class PipelineParams:
     # extension: hand the operator the RAW _opacity / _scaling / _rotation and let K1 / K8 apply the
     # sigmoid / exp / normalize activations and their adjoints (3 elementwise passes + their backward less per call)
     fused_activations: bool = False
+    # extension: masks (render_with_mask, semantic filters) go to the operator as a per-Gaussian bool instead of
+    # boolean-indexing every parameter tensor first.  Same images; `radii`, `visibility_filter` and `viewspace_points` are then
+    # FULL-size (zero / False where masked out) instead of subset-size, which is why it is opt-in.
+    fused_mask: bool = False
 
 
 class SurfelModel:
@@ -170,13 +174,17 @@ def _semantic_mask(pc, semantic_filter_bit, reverse_semantic):
 
 
 def _render_impl(viewpoint_camera, pc, pipe, bg_color, mask, scaling_modifier, override_color):
+    kernel_mask = None
+    if mask is not None and getattr(pipe, "fused_mask", False):
+        kernel_mask, mask = mask, None   # the operator skips masked-out Gaussians itself: no gathered copies
     screenspace_points = _screenspace_points(pc)
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier),
                                     fused_activations=_fused_activations(pc, pipe))
     means3D, means2D, opacity, scales, rotations, cov3D_precomp = _geometry_inputs(pc, pipe, screenspace_points, mask, scaling_modifier)
     shs, colors_precomp = _color_inputs(viewpoint_camera, pc, pipe, mask, override_color)
     rendered_image, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
-                                               opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+                                               opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+                                               mask=kernel_mask)
     rets = {"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
     rets.update(postprocess_allmap(viewpoint_camera, pipe, allmap))
     return rets
@@ -196,6 +204,9 @@ def render_with_mask(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mask, s
 
 def _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier):
     dev = pc.get_xyz.device
+    kernel_mask = None
+    if mask is not None and getattr(pipe, "fused_mask", False):
+        kernel_mask, mask = mask, None
     screenspace_points = _screenspace_points(pc)
     n_cls = len(concerned_classes_list)
     bg_prob = [0.0] * n_cls
@@ -212,7 +223,7 @@ def _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier):
     semantic_6 = (semantics_tag.view(-1, 1) == torch.arange(n_cls, device=dev).view(1, -1)).float()
     output_semantic, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=semantic_6,
                                                 opacities=opacity, scales=scales, rotations=rotations,
-                                                cov3D_precomp=cov3D_precomp)
+                                                cov3D_precomp=cov3D_precomp, mask=kernel_mask)
     topk_values, _ = torch.topk(output_semantic, k=2, dim=0)
     uncertainty = 1.0 - (topk_values[0, ...] - topk_values[1, ...])
     semantic_rgb = _SEMANTIC_COLOR.to(dev)[torch.argmax(output_semantic, dim=0)].permute(2, 0, 1) / 255.0

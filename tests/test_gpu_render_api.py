@@ -193,3 +193,40 @@ def test_fused_activations_and_ply_checkpoint(tmp_path):
     assert torch.equal(pc2.get_semantics.cpu(), sem.to(torch.int32))
     out2 = render(cam, pc2, PipelineParams(fused_activations=True, depth_ratio=0.3), bg)
     assert torch.equal(out2["render"], b[0]["render"]) and torch.equal(out2["radii"], b[0]["radii"])
+
+
+def test_mask_inside_the_operator_equals_boolean_indexing():
+    """SURVEY 8f N1 (class masks without gathered copies): `mask=` on the operator / PipelineParams.fused_mask give the images of
+    the reference's boolean-indexed call bit for bit, with full-size radii and gradients (zero where masked out)."""
+    P, W, H = 9000, 256, 144
+    cam = synthetic_camera(W, H, index=1).to(DEV)
+    g, sem, _, _ = _model(P, W, H, 21, DEV)
+    bg = torch.tensor([0.1, 0.0, 0.2], device=DEV)
+    m = (torch.rand(P, generator=torch.Generator().manual_seed(3)) > 0.4).to(DEV)
+    wgt = torch.linspace(0.2, 1.8, W, device=DEV)
+    res = {}
+    for fused in (False, True):
+        t = {k: v.to(DEV).requires_grad_() for k, v in g.items()}
+        pc = SurfelModel(t["means3D"], t["scales"], t["rotations"], t["opacities"], t["shs"], sem.to(DEV), 3, 3)
+        out = render_with_mask(cam, pc, PipelineParams(fused_mask=fused, depth_ratio=0.5), bg, m)
+        ((out["render"] * wgt).sum() + out["rend_dist"].sum() * 5 + out["rend_alpha"].sum() + out["surf_depth"].mean()).backward()
+        res[fused] = (out, {k: v.grad.clone() for k, v in t.items()})
+    a, b = res[False], res[True]
+    assert torch.equal(a[0]["render"], b[0]["render"]) and torch.equal(a[0]["rend_dist"], b[0]["rend_dist"])
+    assert b[0]["radii"].shape == (P,) and a[0]["radii"].shape == (int(m.sum()),)
+    assert torch.equal(b[0]["radii"][m], a[0]["radii"]) and not b[0]["radii"][~m].any()
+    assert torch.equal(b[0]["visibility_filter"][m], a[0]["visibility_filter"]) and not b[0]["visibility_filter"][~m].any()
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k          # same records, same sums: bit-identical gradients
+        assert not b[1][k][~m].any()
+    # semantic filter path of render(): bit selects classes, kept out when reverse_semantic is False
+    for fused in (False, True):
+        t = {k: v.to(DEV) for k, v in g.items()}
+        pc = SurfelModel(t["means3D"], t["scales"], t["rotations"], t["opacities"], t["shs"], sem.to(DEV), 3, 3)
+        res[fused] = render(cam, pc, PipelineParams(fused_mask=fused), bg, semantic_filter_bit=0b000110, reverse_semantic=False)["render"]
+    assert torch.equal(res[False], res[True])
+    # and the 6-class semantic render with a mask
+    pc = SurfelModel(*(g[k].to(DEV) for k in ("means3D", "scales", "rotations", "opacities", "shs")), sem.to(DEV), 3, 3)
+    s0 = render_semantic_with_mask(cam, pc, PipelineParams(), torch.zeros(3, device=DEV), m)["render_semantics"]
+    s1 = render_semantic_with_mask(cam, pc, PipelineParams(fused_mask=True), torch.zeros(3, device=DEV), m)["render_semantics"]
+    assert torch.equal(s0, s1)
