@@ -77,6 +77,10 @@ def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transM
     P = int(means3D.shape[0])
     M = int(sh.shape[1]) if sh is not None and sh.numel() else 0
     NC = _channels(colors_precomp)
+    if M and NC == 6:
+        NC = 9   # SH colour + six precomputed channels in one pass
+    elif M and colors_precomp is not None and colors_precomp.numel():
+        raise L.SurfelRasterError("Please provide exactly one of either SHs or precomputed colors!")
     g = L.SrGaussians(P, M, NC, int(activations), _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(sh),
                       _ptr(colors_precomp), _ptr(transMat_precomp), _ptr(mask))
     return g
@@ -149,7 +153,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         # gradients are carved out of ONE flat allocation (means3D | sh | opacity | scales | rotations, 58 floats per
         # Gaussian with SH degree 3) so that a data-parallel step can all-reduce them with a single collective
         # (streetunveiler_amd.parallel.allreduce_gradients recognises the shared storage).
-        defer_sh = bool(defer_sh) and has(sh)
+        defer_sh = bool(defer_sh) and has(sh) and not has(colors_precomp)   # (the 9-channel pass keeps its SH gradient local)
         sizes = [("means3D", (P, 3)), ("sh", (P, M, 3) if has(sh) and not defer_sh else (0, 0, 3)), ("opacity", (P, 1)),
                  ("scales", (P, 2) if has(scales) else (0, 2)), ("rotations", (P, 4) if has(rotations) else (0, 4))]
         numel = lambda shp: int(torch.Size(shp).numel())
@@ -164,7 +168,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         NC = g.color_channels
         if int(dL_dcolor.shape[0]) != NC or keep[0].numel() != NC:
             raise L.SurfelRasterError(f"dL_dcolor / bg must have {NC} channels")
-        dL_dcolors = e(P, NC) if has(colors_precomp) or defer_sh else e(0, 3)
+        dL_dcolors = e(P, 6 if NC == 9 else NC) if has(colors_precomp) or defer_sh else e(0, 3)
         dL_dtransMat = e(P, 9) if has(transMat_precomp) else e(0, 9)
         ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered), NC),), dtype=torch.uint8, device=dev)
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),

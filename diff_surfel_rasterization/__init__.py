@@ -139,16 +139,22 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, mask=None):
+                cov3D_precomp=None, mask=None, extra_colors=None):
         """`mask` (extension): [P] bool; False = leave the Gaussian out, with the same images as boolean-indexing
         every input first (what the reference's render_with_mask / semantic filters do) but without the copies: `radii` and
-        all gradients stay full-size, zero where masked out."""
+        all gradients stay full-size, zero where masked out.
+        `extra_colors` (extension): [P,6] precomputed channels blended IN ADDITION to the SH colour in the same
+        pass (render + render_semantic as one rasterization); needs `shs`, a 9-entry `bg`, returns color[9,H,W]."""
         s = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if extra_colors is not None:
+            if shs is None or colors_precomp is not None or extra_colors.ndim != 2 or extra_colors.shape[1] != 6:
+                raise Exception("extra_colors needs SHs as the colour source and must have dimensions (num_points, 6)")
+            colors_precomp = extra_colors
         empty = torch.Tensor([]).to(means3D.device)
         shs = empty if shs is None else shs
         colors_precomp = empty if colors_precomp is None else colors_precomp

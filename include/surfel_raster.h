@@ -23,7 +23,8 @@
  *     the last failure on the calling thread.  No exceptions cross the ABI.
  *   - tensor layouts are the operator's: float32, contiguous; means3D[P,3], opacities[P,1],
  *     scales[P,2], rotations[P,4] (r,x,y,z), shs[P,M,3] (coefficient-major), colors_precomp[P,NC],
- *     transMat_precomp[P,9]; images are planar [C,H,W].  NC = SrGaussians.color_channels: 3 as in the reference, or 6
+ *     transMat_precomp[P,9]; images are planar [C,H,W].  NC = SrGaussians.color_channels: 3 as in the reference, 9 (see the
+ *     struct), or 6
  *     (precomputed colours only) = two 3-channel passes over the same geometry folded into one -- what the reference's
  *     render_semantic does with two rasterizer calls (/root/reference/gaussian_renderer/__init__.py:386-431)
  *     (/root/reference/gaussian_renderer/__init__.py:56-138; allmap channel order :149-165).
@@ -82,7 +83,8 @@ typedef struct SrFrame {
 typedef struct SrGaussians {
     int32_t P;          /* number of Gaussians */
     int32_t sh_coeffs;  /* M = shs.size(1) (16 for max degree 3); 0 with colors_precomp */
-    int32_t color_channels; /* NC: 0 or 3 = rgb; 6 = six precomputed channels (shs must be NULL) */
+    int32_t color_channels; /* NC: 0 or 3 = rgb; 6 = six precomputed channels (shs must be NULL); 9 = rgb from shs PLUS the six
+                             * channels of colors_precomp[P,6] (both non-NULL): render + render_semantic as one pass */
     int32_t activations;    /* SR_ACT_* bits: the given arrays are the reference's RAW parameters and the activation is fused
                              * into K1 (and its adjoint into K8: raw gradients out); 0 = activated inputs as in the reference */
     const float* means3D;
@@ -102,7 +104,7 @@ typedef struct SrGaussians {
  * Every non-NULL pointer is fully written (zeros for invisible Gaussians); NULL = not wanted. */
 typedef struct SrGradients {
     float* dL_dmeans2D;    /* [P,3] densification proxy (x, y, 0) -- what viewspace_points.grad receives */
-    float* dL_dcolors;     /* [P,NC] w.r.t. colors_precomp; with shs as the colour source: [P,3] clamp-masked dL/drgb (the SH adjoint's input, see sr_sh_gradient_expand) */
+    float* dL_dcolors;     /* [P,NC] w.r.t. colors_precomp ([P,6] for NC = 9); with shs as the colour source: [P,3] clamp-masked dL/drgb (the SH adjoint's input, see sr_sh_gradient_expand) */
     float* dL_dopacity;    /* [P,1] */
     float* dL_dmeans3D;    /* [P,3] */
     float* dL_dtransMat;   /* [P,9] */
@@ -162,7 +164,7 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
                       float* out_color, float* out_allmap, void* stream);
 
 /* Backward (K7 blend backward + K8 preprocess backward).  dL_dcolor [NC,H,W], dL_dallmap [7,H,W].
- * workspace: sr_backward_workspace_bytes(P, num_rendered, NC) bytes (one 96-B gradient record + one flag byte per
+ * workspace: sr_backward_workspace_bytes(P, num_rendered, NC) bytes (one 96-B -- 112-B for NC = 9 -- gradient record + one flag byte per
  * (tile, Gaussian) duplicate), contents undefined on entry. */
 int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
                 void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,

@@ -194,13 +194,15 @@ int check_common(const SrFrame* frame, const SrGaussians* g) {
         const int tw = frame->tile_width > 0 ? frame->tile_width : kTile, th = frame->tile_height > 0 ? frame->tile_height : kTile;
         const bool known = (tw == 16 && th == 16) || (tw == 8 && th == 8) || (tw == 16 && th == 8) || (tw == 32 && th == 8) || (tw == 32 && th == 16);
         if (!known) return fail(SR_ERR_UNSUPPORTED, "tile shape %dx%d not in {8x8, 16x8, 16x16, 32x8, 32x16}", tw, th);
-        if (!(tw == 16 && th == 16) && g->color_channels == 6) return fail(SR_ERR_UNSUPPORTED, "6 colour channels are built for the 16x16 tile only");
+        if (!(tw == 16 && th == 16) && (g->color_channels == 6 || g->color_channels == 9)) return fail(SR_ERR_UNSUPPORTED, "6 / 9 colour channels are built for the 16x16 tile only");
     }
     if (!frame->bg || !frame->viewmatrix || !frame->projmatrix || !frame->campos) return fail(SR_ERR_INVALID_ARGUMENT, "bg / viewmatrix / projmatrix / campos must be non-NULL device pointers");
     if (g->P > 0) {
         if (!g->means3D || !g->opacities) return fail(SR_ERR_INVALID_ARGUMENT, "means3D / opacities is NULL");
-        if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return fail(SR_ERR_INVALID_ARGUMENT, "Please provide exactly one of either SHs or precomputed colors!");
-        if (g->color_channels != 0 && g->color_channels != 3 && g->color_channels != 6) return fail(SR_ERR_UNSUPPORTED, "color_channels %d not in {3, 6}", g->color_channels);
+        if (g->color_channels == 9) {   // SH colour + six precomputed channels in one pass
+            if (!g->shs || !g->colors_precomp) return fail(SR_ERR_INVALID_ARGUMENT, "9 colour channels need SHs AND a [P,6] precomputed colour array");
+        } else if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return fail(SR_ERR_INVALID_ARGUMENT, "Please provide exactly one of either SHs or precomputed colors!");
+        if (g->color_channels != 0 && g->color_channels != 3 && g->color_channels != 6 && g->color_channels != 9) return fail(SR_ERR_UNSUPPORTED, "color_channels %d not in {3, 6, 9}", g->color_channels);
         if (g->activations & ~(SR_ACT_EXP_SCALES | SR_ACT_SIGMOID_OPACITY | SR_ACT_NORMALIZE_ROTATIONS)) return fail(SR_ERR_UNSUPPORTED, "unknown activation bits 0x%x", g->activations);
         if (g->color_channels == 6 && g->shs) return fail(SR_ERR_INVALID_ARGUMENT, "6 colour channels need precomputed colors, not SHs");
         const bool sr_pair = g->scales != nullptr && g->rotations != nullptr;
@@ -221,7 +223,7 @@ FrameDev make_frame(const SrFrame* frame, const SrGaussians* g) {
     f.inv_tile_w = 1.f / (float)f.tile_w; f.inv_tile_h = 1.f / (float)f.tile_h;
     f.tiles_x = (f.W + f.tile_w - 1) / f.tile_w; f.tiles_y = (f.H + f.tile_h - 1) / f.tile_h;
     f.sh_degree = frame->sh_degree; f.sh_coeffs = g->sh_coeffs;
-    f.colors = g->color_channels == 6 ? 6 : 3;
+    f.colors = g->color_channels == 6 ? 6 : (g->color_channels == 9 ? 9 : 3);
     f.activations = g->activations;
     f.scale_modifier = frame->scale_modifier;
     f.bg = frame->bg; f.view = frame->viewmatrix; f.proj = frame->projmatrix; f.campos = frame->campos;
@@ -240,10 +242,12 @@ const char* sr_last_error(void) { return g_err; }
 size_t sr_geom_bytes(int32_t P) { return geom_layout(P).total; }
 size_t sr_binning_bytes(int32_t P, uint32_t num_rendered, int32_t W, int32_t H) { (void)P; return bin_layout(num_rendered, W, H).total; }
 size_t sr_image_bytes(int32_t W, int32_t H) { return img_layout(W, H).total; }
+static size_t record_bytes(int color_channels) { return (size_t)(color_channels == 9 ? kGradFloats + 4 : kGradFloats) * 4; }
+
 size_t sr_backward_workspace_bytes(int32_t P, uint32_t num_rendered, int32_t color_channels) {
-    (void)P; (void)color_channels;   // one 96-B gradient record + one "written" byte per (tile, Gaussian) duplicate
+    (void)P;   // one gradient record (96 B; 112 B with 9 colour channels) + one "written" byte per (tile, Gaussian) duplicate
     const size_t n = (size_t)(num_rendered > 0 ? num_rendered : 1);
-    return align_up(n * kGradFloats * 4, 256) + align_up(n, 256);
+    return align_up(n * record_bytes(color_channels), 256) + align_up(n, 256);
 }
 
 int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out) {
@@ -385,7 +389,7 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
     float4* inst_grads = static_cast<float4*>(workspace);
     // K7 writes a record -- and sets the slot's byte in `written` -- only where some pixel contributed; K8 looks at the byte
     // before it touches the record, so neither the records nor anything but these D bytes need clearing.
-    uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * kGradFloats * 4, 256);
+    uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(g->color_channels), 256);
     {
         StageTimer t(SR_STAGE_BLEND_BWD, s);
         if (D > 0) SR_HIP(hipMemsetAsync(written, 0, D, s));

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
             const int area = (maxx - minx) * (maxy - miny);
             if (area > 0) {
                 float rgb[3];
-                if (colors_precomp) {
+                if (colors_precomp && f.colors != 9) {   // 9 channels: rgb from the SHs, the six extra channels go straight to the blend kernels
                     const float* c = colors_precomp + (size_t)f.colors * i;   // channels 3..5 (if any) are read by the blend kernels
                     rgb[0] = c[0]; rgb[1] = c[1]; rgb[2] = c[2];
                 } else {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     }
     if (i < P) {
         float g_means3D[3] = {0, 0, 0}, g_scales[2] = {0, 0}, g_rot[4] = {0, 0, 0, 0}, g_m2d[2] = {0, 0};
-        float dT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dTr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_col[6] = {0, 0, 0, 0, 0, 0}, g_opa = 0.f;
+        float dT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dTr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_col[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_opa = 0.f;
         const bool vis = radii[i] > 0;
         float* dsh_g = (!kLdsSH && out.dL_dsh) ? out.dL_dsh + (size_t)i * M * 3 : nullptr;
         float* row = s_sh + tid * kShLdsStride;
@@ -330,9 +330,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
             float4 g0, g1, g2, g3, g4, g5;
             {
-                float4 g[kGradQuads];
+                constexpr int kGQ = NC == 9 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record
+                float4 g[kGQ];
 #pragma unroll
-                for (int k = 0; k < kGradQuads; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < kGQ; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 const uint32_t first = __float_as_uint(rec[3].w), cnt = tiles_touched[i];
                 // Four records per trip.  K7 writes a record only where some pixel contributed -- about 40 % of a Gaussian's span --
                 // and sets the slot's byte in `written`; the flags of the next trip are in flight behind this trip's records.
@@ -346,23 +347,24 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
                 load_flags(first, fl);
                 for (uint32_t e = first; e < end; e += kTrip) {
                     if (e + kTrip < end) load_flags(e + kTrip, fn);
-                    float4 a[kTrip][kGradQuads];
+                    float4 a[kTrip][kGQ];
 #pragma unroll
                     for (int t = 0; t < kTrip; ++t) {
-                        const float4* gr = inst_grads + (size_t)(e + t) * kGradQuads;
+                        const float4* gr = inst_grads + (size_t)(e + t) * kGQ;
 #pragma unroll
-                        for (int k = 0; k < kGradQuads; ++k) a[t][k] = fl[t] ? gr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int k = 0; k < kGQ; ++k) a[t][k] = fl[t] ? gr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
 #pragma unroll
                     for (int t = 0; t < kTrip; ++t) {
                         if (fl[t]) {
 #pragma unroll
-                            for (int k = 0; k < kGradQuads; ++k) { g[k].x += a[t][k].x; g[k].y += a[t][k].y; g[k].z += a[t][k].z; g[k].w += a[t][k].w; }
+                            for (int k = 0; k < kGQ; ++k) { g[k].x += a[t][k].x; g[k].y += a[t][k].y; g[k].z += a[t][k].z; g[k].w += a[t][k].w; }
                         }
                         fl[t] = fn[t];
                     }
                 }
                 g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3]; g4 = g[4]; g5 = g[5];
+                if (NC == 9) { g_col[6] = g[kGQ - 1].x; g_col[7] = g[kGQ - 1].y; g_col[8] = g[kGQ - 1].z; }
             }
             const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
             // moments -> dL/dT (see common.h): dTu = Tv x S0 - Tw x Sy, dTv = S0 x Tu - Sx x Tw, dTw = Tu x Sy - Tv x Sx + Z
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
             if (f.activations & SR_ACT_SIGMOID_OPACITY) { const float o = r2.w; g_opa *= o * (1.f - o); }
             const float gn[3] = {g3.w, g4.x, g4.y};
             g_col[0] = g4.z; g_col[1] = g4.w; g_col[2] = g5.x;
-            if (NC == 6) { g_col[3] = g5.y; g_col[4] = g5.z; g_col[5] = g5.w; }
+            if (NC >= 6) { g_col[3] = g5.y; g_col[4] = g5.z; g_col[5] = g5.w; }
             // densification proxy from the blend-only dL/dT (Appendix A.6, last paragraph)
             g_m2d[0] = dT[2] * Tw[2] * 0.5f * (float)f.W;
             g_m2d[1] = dT[5] * Tw[2] * 0.5f * (float)f.H;
@@ -478,8 +480,13 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
         if (out.dL_drotations) { reinterpret_cast<float4*>(out.dL_drotations)[i] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]); }
         if (out.dL_dopacity) out.dL_dopacity[i] = g_opa;
         if (out.dL_dcolors) {
+            if (NC == 9) {   // the six precomputed channels; rgb went through the SH adjoint
 #pragma unroll
-            for (int c = 0; c < NC; ++c) out.dL_dcolors[NC * (size_t)i + c] = g_col[c];
+                for (int c = 0; c < 6; ++c) out.dL_dcolors[6 * (size_t)i + c] = g_col[3 + c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) out.dL_dcolors[NC * (size_t)i + c] = g_col[c];
+            }
         }
         if (out.dL_dtransMat) {
             // upstream writes the AABB-centre-augmented dL/dT back only when transMat is an input (A.6)
@@ -595,7 +602,13 @@ hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussian
                                       const uint32_t* tiles_touched, const SrGradients& out, hipStream_t s) {
     if (P == 0) return hipSuccess;
     const dim3 grid((P + 255) / 256), block(256);
-    if (f.colors == 6)
+    if (f.colors == 9 && g.sh_coeffs == 16 && aligned16(g.shs) && (!out.dL_dsh || aligned16(out.dL_dsh)))
+        hipLaunchKernelGGL((preprocess_backward_kernel<true, 9>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
+                           g.transMat_precomp, radii, clamped, recs, inst_grads, written, tiles_touched, out);
+    else if (f.colors == 9)
+        hipLaunchKernelGGL((preprocess_backward_kernel<false, 9>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
+                           g.transMat_precomp, radii, clamped, recs, inst_grads, written, tiles_touched, out);
+    else if (f.colors == 6)
         hipLaunchKernelGGL((preprocess_backward_kernel<false, 6>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
                            g.transMat_precomp, radii, clamped, recs, inst_grads, written, tiles_touched, out);
     else if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs) && (!out.dL_dsh || aligned16(out.dL_dsh)))

@@ -100,20 +100,21 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
 // ---------------------------------------------------------------------------------------------
 // Staged entry layout in LDS (struct-of-quads, s_e[quad][slot]):
 //   e0 = A.xyz B.x | e1 = B.yz C.xy | e2 = C.z Tw.xyz | e3 = xy'.x xy'.y opacity c5
-//   e4 = n.xyz c0  | e5 = c1 c2 c3 c4
-// with A = Tv' x Tw, B = Tw x Tu', C = Tu' x Tv' and ' = relative to the tile centre (Xc, Yc); c0..c2 = rgb, c3..c5 only
-// in the 6-channel variant (the two 3-channel one-hot passes of render_semantic as ONE pass).
+//   e4 = n.xyz c0  | e5 = c1 c2 c3 c4  | (9 channels only) e6 = c6 c7 c8 -
+// with A = Tv' x Tw, B = Tw x Tu', C = Tu' x Tv' and ' = relative to the tile centre (Xc, Yc); c0..c2 = rgb.  SURVEY 8f N1:
+// NC = 6 blends six precomputed channels (the two 3-channel one-hot passes of render_semantic as ONE pass), NC = 9 blends the
+// SH colour AND six precomputed channels (render + render_semantic as one pass).  Channels 3.. come straight from the caller's
+// [P,6] array at staging time: columns 3..5 for NC = 6 (columns 0..2 went through K1 into the record), all six for NC = 9.
 // ---------------------------------------------------------------------------------------------
-constexpr int kFwdQuads = 6;
+template <int NC> constexpr int entry_quads() { return NC == 9 ? 7 : 6; }
 
-// channels 3..5 of a 6-channel precomputed colour row, straight from the caller's [P,6] array
-__device__ __forceinline__ float4 load_extra(const float* __restrict__ colors6, uint32_t gid) {
-    const float* c = colors6 + 6 * (size_t)gid + 3;
+__device__ __forceinline__ float4 load_extra(const float* __restrict__ colors6, uint32_t gid, int first) {
+    const float* c = colors6 + 6 * (size_t)gid + first;
     return make_float4(c[0], c[1], c[2], 0.f);
 }
 
-template <int QX, int QY>
-__device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], const float4 ex, float Xc, float Yc, int cull,
+template <int QX, int QY, int NC>
+__device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], const float4 ex, const float4 ey, float Xc, float Yc, int cull,
                                                 float4 (*s_e)[kWave], int slot) {
     const float Tw[3] = {q[1].z, q[1].w, q[2].x};
     const float Tu[3] = {q[0].x - Xc * Tw[0], q[0].y - Xc * Tw[1], q[0].z - Xc * Tw[2]};
@@ -128,6 +129,7 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], co
     s_e[3][slot] = make_float4(mx, my, opacity, ex.z);
     s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[4].x);
     s_e[5][slot] = make_float4(q[4].y, q[4].z, ex.x, ex.y);
+    if (NC == 9) s_e[6][slot] = make_float4(ey.x, ey.y, ey.z, 0.f);
     return cull ? quadrant_mask<QX, QY>(Tu, Tv, Tw, mx, my, opacity) : (1u << (QX * QY)) - 1u;
 }
 
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                                                                 float* __restrict__ out_color, float* __restrict__ out_allmap,
                                                                 float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                                 uint16_t* __restrict__ hit_mask, int cull) {
-    __shared__ float4 s_e[kFwdQuads][kWave];
+    __shared__ float4 s_e[entry_quads<NC>()][kWave];
     const int lane = threadIdx.x;
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: the SPLIT bands of one tile take consecutive
     // slots of the SAME XCD so that the second band finds the tile's records in that L2 instead of fetching them again.
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     float xl[NQ], yl[NQ];
     bool done[NQ];
     float T[NQ], C0[NQ], C1[NQ], C2[NQ], N0[NQ], N1[NQ], N2[NQ], Dsum[NQ], M1[NQ], M2[NQ], dist[NQ], med[NQ];
-    float C3[NQ], C4[NQ], C5[NQ];   // only live in the 6-channel variant
+    float C3[NQ], C4[NQ], C5[NQ], C6[NQ], C7[NQ], C8[NQ];   // only live in the 6- / 9-channel variants
     uint32_t lastc[NQ], medc[NQ];
     uint32_t alive = 0;
 #pragma unroll
@@ -218,26 +220,28 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
         xl[q] = (float)((q % QX) * 8 + lx - QX * 4); yl[q] = (float)((q / QX) * 8 + ly - QY * 4);
         done[q] = !(px < f.W && py < f.H);
         T[q] = 1.f; C0[q] = C1[q] = C2[q] = N0[q] = N1[q] = N2[q] = 0.f;
-        C3[q] = C4[q] = C5[q] = 0.f;
+        C3[q] = C4[q] = C5[q] = C6[q] = C7[q] = C8[q] = 0.f;
         Dsum[q] = M1[q] = M2[q] = dist[q] = med[q] = 0.f;
         lastc[q] = 0; medc[q] = 0xFFFFFFFFu;
         if (__ballot(!done[q]) != 0) alive |= 1u << q;
     }
 
-    float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f), ny = nx;
     if ((uint32_t)lane < n_total) {
         const uint32_t gid = point_list[range.x + lane];
         load_record(recs, gid, nr);
-        if (NC == 6) nx = load_extra(extra, gid);
+        if (NC == 6) nx = load_extra(extra, gid, 3);
+            if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
     }
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         uint32_t m = 0;
-        if ((uint32_t)lane < n) m = stage_entry<QX, QY>(nr, nx, Xc, Yc, cull & 1, s_e, lane);
+        if ((uint32_t)lane < n) m = stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, cull & 1, s_e, lane);
         if (base + kWave + lane < n_total) {
             const uint32_t gid = point_list[range.x + base + kWave + lane];
             load_record(recs, gid, nr);
-            if (NC == 6) nx = load_extra(extra, gid);
+            if (NC == 6) nx = load_extra(extra, gid, 3);
+            if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
         }
         unsigned long long bits = __ballot((m & alive) != 0);
         if (kStats && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
@@ -279,7 +283,8 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                         if (T[q] > 0.5f) { med[q] = h.depth; medc[q] = contributor; }
                         N0[q] += e4.x * w; N1[q] += e4.y * w; N2[q] += e4.z * w;
                         C0[q] += e4.w * w; C1[q] += e5.x * w; C2[q] += e5.y * w;
-                        if (NC == 6) { C3[q] += e5.z * w; C4[q] += e5.w * w; C5[q] += e3.w * w; }
+                        if (NC >= 6) { C3[q] += e5.z * w; C4[q] += e5.w * w; C5[q] += e3.w * w; }
+                        if (NC == 9) { const float4 e6 = s_e[6][j]; C6[q] += e6.x * w; C7[q] += e6.y * w; C8[q] += e6.z * w; }
                         T[q] = test_T;
                         lastc[q] = contributor;
                     }
@@ -310,10 +315,15 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
             out_color[pix] = C0[q] + T[q] * bg0;
             out_color[HW + pix] = C1[q] + T[q] * bg1;
             out_color[2 * HW + pix] = C2[q] + T[q] * bg2;
-            if (NC == 6) {
+            if (NC >= 6) {
                 out_color[3 * HW + pix] = C3[q] + T[q] * f.bg[3];
                 out_color[4 * HW + pix] = C4[q] + T[q] * f.bg[4];
                 out_color[5 * HW + pix] = C5[q] + T[q] * f.bg[5];
+            }
+            if (NC == 9) {
+                out_color[6 * HW + pix] = C6[q] + T[q] * f.bg[6];
+                out_color[7 * HW + pix] = C7[q] + T[q] * f.bg[7];
+                out_color[8 * HW + pix] = C8[q] + T[q] * f.bg[8];
             }
             out_allmap[pix] = Dsum[q];
             out_allmap[HW + pix] = 1.f - T[q];
@@ -386,6 +396,15 @@ __device__ __forceinline__ float wave_reduce24(float (&v)[24], int lane) {
     return v[0] + dpp_mov<0xB1>(v[0]);       // quad_perm:[1,0,3,2] = lane ^ 1
 }
 
+// 64-lane totals of three more values (the 9-channel variant): afterwards every lane of 16-lane row r holds the total of value r
+// (row 3: zero).  Two half folds, one row-pair fold, one in-row sum.
+__device__ __forceinline__ float wave_reduce3(float a, float b, float c) {
+    float d = 0.f;
+    fold32(a, b); fold32(c, d);   // a: lanes < 32 hold a's half sums, lanes >= 32 b's;  c: c's | zeros
+    fold16(a, c);                 // rows 0..3: a, c, b, zero
+    return row_sum16(a);
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, m));
@@ -420,8 +439,9 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                                                                  const uint16_t* __restrict__ hit_mask,
                                                                  float4* __restrict__ inst_grads, uint8_t* __restrict__ written,
                                                                  int cull) {
-    __shared__ float4 s_e[kFwdQuads][kWave];
-    __shared__ __attribute__((aligned(16))) float s_out[kWave][kGradFloats];
+    constexpr int kGQ = NC == 9 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record (27 values with 9 channels)
+    __shared__ float4 s_e[entry_quads<NC>()][kWave];
+    __shared__ __attribute__((aligned(16))) float s_out[kWave][kGQ * 4];
     const int lane = threadIdx.x;
     const int tile = (int)tile_order[blockIdx.x];   // longest lists first
     constexpr int NQ = QX * QY;   // 8x8 quadrants per tile = pixels per lane
@@ -436,7 +456,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
     // per-pixel constants (upstream gradients folded with the forward's final accumulators) and state
     const float xl0 = (float)(lx - QX * 4), yl0 = (float)(ly - QY * 4);   // tile-local pixel of quadrant 0; quadrant q adds 8*(q%QX, q/QX)
     float gr[NQ], gg[NQ], gb[NQ], gn0[NQ], gn1[NQ], gn2[NQ], g_depth[NQ], g_median[NQ], Kbg[NQ], a0[NQ], a1[NQ], a2[NQ];
-    float gc3[NQ], gc4[NQ], gc5[NQ];   // only live in the 6-channel variant
+    float gc3[NQ], gc4[NQ], gc5[NQ], gc6[NQ], gc7[NQ], gc8[NQ];   // only live in the 6- / 9-channel variants
     uint32_t lastc[NQ], medc[NQ], quad_last[NQ];
     float T[NQ], R[NQ], X[NQ];
     uint32_t total = 0;
@@ -456,10 +476,14 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
         g_median[q] = inside ? dL_dallmap[5 * HW + pix] : 0.f;
         const float g_reg = inside ? dL_dallmap[6 * HW + pix] : 0.f;
         float bg_dot = bg0 * gr[q] + bg1 * gg[q] + bg2 * gb[q];
-        gc3[q] = gc4[q] = gc5[q] = 0.f;
-        if (NC == 6) {
+        gc3[q] = gc4[q] = gc5[q] = gc6[q] = gc7[q] = gc8[q] = 0.f;
+        if (NC >= 6) {
             gc3[q] = inside ? dL_dcolor[3 * HW + pix] : 0.f; gc4[q] = inside ? dL_dcolor[4 * HW + pix] : 0.f; gc5[q] = inside ? dL_dcolor[5 * HW + pix] : 0.f;
             bg_dot += f.bg[3] * gc3[q] + f.bg[4] * gc4[q] + f.bg[5] * gc5[q];
+        }
+        if (NC == 9) {
+            gc6[q] = inside ? dL_dcolor[6 * HW + pix] : 0.f; gc7[q] = inside ? dL_dcolor[7 * HW + pix] : 0.f; gc8[q] = inside ? dL_dcolor[8 * HW + pix] : 0.f;
+            bg_dot += f.bg[6] * gc6[q] + f.bg[7] * gc7[q] + f.bg[8] * gc8[q];
         }
         Kbg[q] = T_final * (g_accum - bg_dot);
         a0[q] = (1.f - T_final) * g_reg; a1[q] = fin_D * g_reg; a2[q] = fin_D2 * g_reg;
@@ -471,13 +495,14 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
     // entries behind the deepest contributor of the tile get no record at all: K8a recognises the records written in
     // this call by their tag
     const int rounds = (int)((total + kWave - 1) / kWave);
-    float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f), ny = nx;
     uint32_t nhit = 0;
     if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
         const uint32_t pos = range.x + (rounds - 1) * kWave + lane;
         const uint32_t gid = point_list[pos];
         load_record(recs, gid, nr);
-        if (NC == 6) nx = load_extra(extra, gid);
+        if (NC == 6) nx = load_extra(extra, gid, 3);
+            if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
         nhit = decode_hits<QX, QY>(hit_mask[pos]);
     }
     for (int rd = rounds - 1; rd >= 0; --rd) {
@@ -485,7 +510,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
         const uint32_t n = min((uint32_t)kWave, total - rbase);
         uint32_t m = 0, slot = 0;
         if ((uint32_t)lane < n) {
-            (void)stage_entry<QX, QY>(nr, nx, Xc, Yc, 0, s_e, lane);
+            (void)stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, 0, s_e, lane);
             m = nhit;   // (entry, quadrant) pairs that reached a pixel in the forward: exact, no culling test needed here
             slot = emission_index(nr, __float_as_uint(nr[3].w), tile % f.tiles_x, tile / f.tiles_x, f);
             uint32_t need = 0;
@@ -496,13 +521,14 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
         {
             float4* z = reinterpret_cast<float4*>(&s_out[lane][0]);
 #pragma unroll
-            for (int k = 0; k < kGradQuads; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < kGQ; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (rd > 0) {  // next round is always full
             const uint32_t pos = range.x + rbase - kWave + lane;
             const uint32_t gid = point_list[pos];
             load_record(recs, gid, nr);
-            if (NC == 6) nx = load_extra(extra, gid);
+            if (NC == 6) nx = load_extra(extra, gid, 3);
+            if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
             nhit = decode_hits<QX, QY>(hit_mask[pos]);
         }
         unsigned long long bits = __ballot(m != 0);
@@ -519,6 +545,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                 v[k] = 0.f;
                 asm volatile("" : "+v"(v[k]));   // opaque zero: every quadrant block accumulates in place (no phi copies of constants)
             }
+            float w6 = 0.f, w7 = 0.f, w8 = 0.f;   // colour channels 6..8 (9-channel variant)
             bool any = false;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -536,7 +563,8 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     const float w = h.alpha * T[q];
                     float phi = fmaf(e4.w, gr[q], fmaf(e5.x, gg[q], fmaf(e5.y, gb[q], fmaf(h.depth, g_depth[q],
                                 fmaf(e4.x, gn0[q], fmaf(e4.y, gn1[q], e4.z * gn2[q]))))));
-                    if (NC == 6) phi = fmaf(e5.z, gc3[q], fmaf(e5.w, gc4[q], fmaf(e3.w, gc5[q], phi)));
+                    if (NC >= 6) phi = fmaf(e5.z, gc3[q], fmaf(e5.w, gc4[q], fmaf(e3.w, gc5[q], phi)));
+                    if (NC == 9) { const float4 e6 = s_e[6][j]; phi = fmaf(e6.x, gc6[q], fmaf(e6.y, gc7[q], fmaf(e6.z, gc8[q], phi))); }
                     const float inv_depth = fast_rcp(h.depth);
                     const float m_d = kFN * (1.f - kNear * inv_depth);
                     const float dmd_dd = kFN * kNear * inv_depth * inv_depth;
@@ -548,7 +576,8 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     if (cidx == medc[q] - 1u) dL_dz += g_median[q];
                     const float dL_dG = e3.z * dL_dalpha;
                     v[18] += w * gr[q]; v[19] += w * gg[q]; v[20] += w * gb[q];
-                    if (NC == 6) { v[21] += w * gc3[q]; v[22] += w * gc4[q]; v[23] += w * gc5[q]; }
+                    if (NC >= 6) { v[21] += w * gc3[q]; v[22] += w * gc4[q]; v[23] += w * gc5[q]; }
+                    if (NC == 9) { w6 += w * gc6[q]; w7 += w * gc7[q]; w8 += w * gc8[q]; }
                     v[15] += w * gn0[q]; v[16] += w * gn1[q]; v[17] += w * gn2[q];
                     v[14] += h.G * dL_dalpha;
                     if (h.use3d) {
@@ -574,20 +603,24 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                 const float tot = wave_reduce24(v, lane);
                 if ((lane & 1) == 0 && (lane & 6) != 6)
                     s_out[j][6 * (lane >> 4) + ((lane & 8) ? 3 : 0) + ((lane & 4) ? 2 : ((lane >> 1) & 1))] = tot;
+                if (NC == 9) {
+                    const float t3 = wave_reduce3(w6, w7, w8);   // row 0: channel 6, row 1: channel 8, row 2: channel 7
+                    if ((lane & 15) == 0 && lane < 48) s_out[j][24 + (lane == 0 ? 0 : (lane == 16 ? 2 : 1))] = t3;
+                }
             }
         }
         // flush this round's records: one 96-B store per lane whose entry got a contribution
         if ((wrote >> lane) & 1ull) {
             const float4* accl = reinterpret_cast<const float4*>(&s_out[lane][0]);
-            float4 acc[kGradQuads];
+            float4 acc[kGQ];
 #pragma unroll
-            for (int k = 0; k < kGradQuads; ++k) acc[k] = accl[k];
+            for (int k = 0; k < kGQ; ++k) acc[k] = accl[k];
             // Sx, Sy from tile-local to global pixel coordinates: sum (Xc + xl) dp = Xc S0 + sum xl dp
             acc[0].w = fmaf(Xc, acc[0].x, acc[0].w); acc[1].x = fmaf(Xc, acc[0].y, acc[1].x); acc[1].y = fmaf(Xc, acc[0].z, acc[1].y);
             acc[1].z = fmaf(Yc, acc[0].x, acc[1].z); acc[1].w = fmaf(Yc, acc[0].y, acc[1].w); acc[2].x = fmaf(Yc, acc[0].z, acc[2].x);
-            float4* o = inst_grads + (size_t)slot * kGradQuads;
+            float4* o = inst_grads + (size_t)slot * kGQ;
 #pragma unroll
-            for (int k = 0; k < kGradQuads; ++k) o[k] = acc[k];
+            for (int k = 0; k < kGQ; ++k) o[k] = acc[k];
             written[slot] = 1;   // K8 reads this 1-B flag (zeroed per call) before it touches the record
         }
     }
@@ -625,7 +658,8 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
                        ranges, tile_order, point_list, recs, extra, out_color, out_allmap, final_T, n_contrib, hit_mask, cull)
     if (f.tile_w == 16 && f.tile_h == 16) {
         // the reference's tile: two 16x8 band waves per tile (the counter variant stays whole so that it counts each entry once)
-        if (f.colors == 6) { if (cull & 2) SR_LAUNCH_FWD(true, 6, 2, 2, 1); else SR_LAUNCH_FWD(false, 6, 2, 1, 2); }
+        if (f.colors == 9) { SR_LAUNCH_FWD(false, 9, 2, 1, 2); }
+        else if (f.colors == 6) { if (cull & 2) SR_LAUNCH_FWD(true, 6, 2, 2, 1); else SR_LAUNCH_FWD(false, 6, 2, 1, 2); }
         else if (cull & 2)      SR_LAUNCH_FWD(true, 3, 2, 2, 1);
         else if (cull & 0x800)  SR_LAUNCH_FWD(false, 3, 2, 2, 1);   // A/B switch (option 100, bit 7): one wave per tile
         else                    SR_LAUNCH_FWD(false, 3, 2, 1, 2);
@@ -652,7 +686,7 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
     hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), (cull >> 12) * 1024, s, f, ranges, tile_order, point_list, recs, extra, final_T, \
                        n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written, cull)
     if (f.tile_w == 16 && f.tile_h == 16) {
-        if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
+        if (f.colors == 9) SR_LAUNCH_BWD(9, 2, 2); else if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
     } else {
         if (f.colors != 3) return hipErrorInvalidValue;
 #define SR_BWD_SHAPE(QX, QY) SR_LAUNCH_BWD(3, QX, QY)

@@ -202,6 +202,16 @@ def render_with_mask(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mask, s
     return _render_impl(viewpoint_camera, pc, pipe, bg_color, mask, scaling_modifier, override_color)
 
 
+def _top2_margin(prob):
+    """1 - (largest - second largest) over the class axis, and the argmax -- what the reference gets from `torch.topk(prob, k=2, dim=0)`
+    and `torch.argmax` [REF gaussian_renderer/__init__.py:448-449, 586-587]; two `max` reductions give the same values (and gradients)
+    and take 0.1 ms instead of topk's 5.4 ms on a [6,1080,1920] map."""
+    top1, best = prob.max(dim=0)
+    classes = torch.arange(prob.shape[0], device=prob.device).view(-1, 1, 1)
+    top2 = prob.masked_fill(classes == best.unsqueeze(0), float("-inf")).max(dim=0).values
+    return 1.0 - (top1 - top2), best
+
+
 def _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier):
     dev = pc.get_xyz.device
     kernel_mask = None
@@ -224,10 +234,41 @@ def _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier):
     output_semantic, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=semantic_6,
                                                 opacities=opacity, scales=scales, rotations=rotations,
                                                 cov3D_precomp=cov3D_precomp, mask=kernel_mask)
-    topk_values, _ = torch.topk(output_semantic, k=2, dim=0)
-    uncertainty = 1.0 - (topk_values[0, ...] - topk_values[1, ...])
-    semantic_rgb = _SEMANTIC_COLOR.to(dev)[torch.argmax(output_semantic, dim=0)].permute(2, 0, 1) / 255.0
+    uncertainty, best = _top2_margin(output_semantic)
+    semantic_rgb = _SEMANTIC_COLOR.to(dev)[best].permute(2, 0, 1) / 255.0
     return {"render_semantics": output_semantic, "semantic_rgb": semantic_rgb, "semantic_uncertainty": uncertainty}
+
+
+def render_and_semantic(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, mask=None):
+    """`render()` and `render_semantic()` of the same view as ONE rasterization (extension; the reference's
+    training iteration calls the two back to back on identical geometry [REF train.py:84-109]): the operator blends the SH colour
+    and the six one-hot class channels together (9 channels).  Returns the union of the two result dicts; `render` is bit-identical
+    to `render()`, `render_semantics` to `render_semantic()`."""
+    assert not pipe.convert_SHs_python, "the 9-channel pass takes the SHs themselves"
+    dev = pc.get_xyz.device
+    kernel_mask = None
+    if mask is not None and getattr(pipe, "fused_mask", False):
+        kernel_mask, mask = mask, None
+    screenspace_points = _screenspace_points(pc)
+    n_cls = len(concerned_classes_list)
+    assert n_cls == 6
+    bg_prob = [0.0] * n_cls
+    bg_prob[concerned_classes_ind_map["sky"]] = 1.0
+    bg9 = torch.cat([bg_color.to(dev).float().reshape(3), torch.tensor(bg_prob, dtype=torch.float32, device=dev)])
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg9, scaling_modifier),
+                                    fused_activations=_fused_activations(pc, pipe))
+    means3D, means2D, opacity, scales, rotations, cov3D_precomp = _geometry_inputs(pc, pipe, screenspace_points, mask, scaling_modifier)
+    semantics_tag = _sel(pc.get_semantics, mask)
+    semantic_6 = (semantics_tag.view(-1, 1) == torch.arange(n_cls, device=dev).view(1, -1)).float()
+    color9, radii, allmap = rasterizer(means3D=means3D, means2D=means2D, shs=_sel(pc.get_features, mask), opacities=opacity, scales=scales,
+                                       rotations=rotations, cov3D_precomp=cov3D_precomp, mask=kernel_mask, extra_colors=semantic_6)
+    rets = {"render": color9[:3], "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
+    rets.update(postprocess_allmap(viewpoint_camera, pipe, allmap))
+    output_semantic = color9[3:]
+    uncertainty, best = _top2_margin(output_semantic)
+    rets.update({"render_semantics": output_semantic, "semantic_uncertainty": uncertainty,
+                 "semantic_rgb": _SEMANTIC_COLOR.to(dev)[best].permute(2, 0, 1) / 255.0})
+    return rets
 
 
 def render_semantic(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,

@@ -230,3 +230,37 @@ def test_mask_inside_the_operator_equals_boolean_indexing():
     s0 = render_semantic_with_mask(cam, pc, PipelineParams(), torch.zeros(3, device=DEV), m)["render_semantics"]
     s1 = render_semantic_with_mask(cam, pc, PipelineParams(fused_mask=True), torch.zeros(3, device=DEV), m)["render_semantics"]
     assert torch.equal(s0, s1)
+
+
+def test_render_and_semantic_in_one_pass():
+    """SH colour + six class channels blended in ONE rasterization (9 channels) == render() and render_semantic()."""
+    from streetunveiler_amd.gaussian_renderer import render_and_semantic
+    P, W, H = 8000, 224, 128
+    cam = synthetic_camera(W, H, index=4).to(DEV)
+    g, sem, _, _ = _model(P, W, H, 31, DEV)
+    bg = torch.tensor([0.3, 0.2, 0.1], device=DEV)
+    wgt = torch.linspace(0.5, 1.5, W, device=DEV)
+    cls_w = torch.tensor([1.0, -0.5, 0.3, 0.8, -1.2, 0.6], device=DEV).view(6, 1, 1)
+
+    def fresh():
+        t = {k: v.to(DEV).requires_grad_() for k, v in g.items()}
+        return t, SurfelModel(t["means3D"], t["scales"], t["rotations"], t["opacities"], t["shs"], sem.to(DEV), 3, 3)
+
+    def loss_rgb(o): return (o["render"] * wgt).sum() + o["rend_dist"].sum() * 3 + o["rend_alpha"].sum()
+    def loss_sem(o): return (o["render_semantics"] * cls_w).sum()
+    t1, pc1 = fresh()
+    o1 = render_and_semantic(cam, pc1, PipelineParams(), bg)
+    (loss_rgb(o1) + loss_sem(o1)).backward()
+    t2, pc2 = fresh()
+    o2a = render(cam, pc2, PipelineParams(), bg)
+    o2b = render_semantic(cam, pc2, PipelineParams(), torch.zeros(3, device=DEV))
+    (loss_rgb(o2a) + loss_sem(o2b)).backward()
+    assert o1["render"].shape == (3, H, W) and o1["render_semantics"].shape == (6, H, W)
+    assert torch.equal(o1["render"], o2a["render"]) and torch.equal(o1["render_semantics"], o2b["render_semantics"])
+    for k in ("rend_alpha", "rend_dist", "surf_depth", "rend_normal"):
+        assert torch.equal(o1[k], o2a[k]), k
+    assert torch.equal(o1["radii"], o2a["radii"])
+    from tests.gpu_util import assert_grads_close
+    for k in t1:
+        assert float(t2[k].grad.abs().max()) > 0
+        assert_grads_close(t1[k].grad.cpu().numpy(), t2[k].grad.cpu().numpy(), 2e-5, "one pass d" + k, max_bad_frac=0.0, hard=2e-5)
