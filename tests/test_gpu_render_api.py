@@ -264,3 +264,30 @@ def test_render_and_semantic_in_one_pass():
     for k in t1:
         assert float(t2[k].grad.abs().max()) > 0
         assert_grads_close(t1[k].grad.cpu().numpy(), t2[k].grad.cpu().numpy(), 2e-5, "one pass d" + k, max_bad_frac=0.0, hard=2e-5)
+
+
+def test_extensions_compose():
+    """9-channel pass + mask inside the operator + fused activations on a raw (checkpoint-style) model == the plain composition
+    of the reference-style calls."""
+    from streetunveiler_amd.gaussian_renderer import render_and_semantic
+    from tests.gpu_util import assert_close_frac
+    P, W, H = 7000, 208, 120
+    cam = synthetic_camera(W, H, index=6).to(DEV)
+    g = synthetic_gaussians(P, W, H, seed=44, scale_lo=3e-3, scale_hi=5e-2)
+    gen = torch.Generator().manual_seed(8)
+    sem = torch.randint(0, 6, (P,), generator=gen)
+    m = (torch.rand(P, generator=gen) > 0.3).to(DEV)
+    raw = dict(xyz=g["means3D"], features=g["shs"], scaling=torch.log(g["scales"]), opacity=torch.logit(g["opacities"].clamp(1e-4, 1 - 1e-4)),
+               rotation=g["rotations"] * 1.7)
+    bg = torch.tensor([0.05, 0.1, 0.15], device=DEV)
+    def model():
+        t = {k: v.to(DEV) for k, v in raw.items()}
+        return SurfelModel(t["xyz"], t["scaling"], t["rotation"], t["opacity"], t["features"], sem.to(DEV), 3, 3, raw=True)
+    plain = PipelineParams()
+    a = render_with_mask(cam, model(), plain, bg, m)
+    s = render_semantic_with_mask(cam, model(), plain, torch.zeros(3, device=DEV), m)
+    o = render_and_semantic(cam, model(), PipelineParams(fused_mask=True, fused_activations=True), bg, mask=m)
+    assert_close_frac(o["render"].detach().cpu().numpy(), a["render"].detach().cpu().numpy(), 1e-4, 1e-4, 2e-4, 2e-2, "composed render")
+    assert_close_frac(o["render_semantics"].detach().cpu().numpy(), s["render_semantics"].detach().cpu().numpy(), 1e-4, 1e-4, 2e-4, 2e-2, "composed semantics")
+    assert o["radii"].shape == (P,) and not o["radii"][~m].any()
+    assert float((o["radii"][m] != a["radii"]).float().mean()) < 1e-3
