@@ -492,8 +492,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
         total = max(total, quad_last[q]);
     }
 
-    // entries behind the deepest contributor of the tile get no record at all: K8a recognises the records written in
-    // this call by their tag
+    // entries behind the deepest contributor of the tile are never looked at: they get no record and keep a clear `written` flag
     const int rounds = (int)((total + kWave - 1) / kWave);
     float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f), ny = nx;
     uint32_t nhit = 0;
