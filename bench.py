@@ -160,14 +160,12 @@ def main():
     del radii0
 
     # what the blend kernels execute on this scene (device counters of one forward, outside the timed region)
-    import ctypes
-    st = (ctypes.c_ulonglong * 8)()
-    lib.sr_set_option(_lib.SR_OPT_DEBUG_STATS, 1); lib.sr_debug_stats(st, 1)
+    counters = torch.zeros(8, dtype=torch.int64, device=dev)
     with torch.no_grad():
-        rasterizer(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
-                   scales=params["scales"], rotations=params["rotations"])
+        GaussianRasterizer(settings, blend_counters=counters)(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                                              opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
     torch.cuda.synchronize()
-    lib.sr_debug_stats(st, 1); lib.sr_set_option(_lib.SR_OPT_DEBUG_STATS, 0)
+    st = counters.tolist()
     blend_counts = {"staged_entries_D_eff": int(st[0]), "entries_after_quadrant_cull": int(st[1]), "quadrant_tests": int(st[2]),
                     "quadrant_tests_with_a_hit": int(st[3]), "contributing_pairs": int(st[4])}
 

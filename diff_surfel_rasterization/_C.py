@@ -44,11 +44,15 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile=None):
-    keep = [_f32c(bg, "bg"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")]
+def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile=None,
+           quadrant_cull=True, blend_counters=None):
+    keep = [_f32c(bg, "bg"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos"), blend_counters]
+    if blend_counters is not None and (blend_counters.dtype != torch.int64 or blend_counters.numel() < 8 or not blend_counters.is_cuda):
+        raise L.SurfelRasterError("blend_counters must be a CUDA (ROCm) int64 tensor with 8 entries")
     fr = L.SrFrame(int(H), int(W), float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree),
                    int(bool(prefiltered)), int(bool(debug)), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
-                   int(tile[0]) if tile else 0, int(tile[1]) if tile else 0)
+                   int(tile[0]) if tile else 0, int(tile[1]) if tile else 0, 0 if quadrant_cull else L.SR_FLAG_NO_QUADRANT_CULL,
+                   _ptr(blend_counters))
     return fr, keep
 
 
@@ -88,9 +92,10 @@ def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transM
 
 def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, activations=0, tile=None, mask=None):
+                        prefiltered, debug, activations=0, tile=None, mask=None, quadrant_cull=True, blend_counters=None):
     """`tile` = (width, height) of the binning tile, default the reference's 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
-    16x16, 32x8, 32x16); the backward must be given the same shape."""
+    16x16, 32x8, 32x16); the backward must be given the same shape.  `quadrant_cull=False` / `blend_counters` (int64[8], device):
+    per-call SrFrame.flags / SrFrame.blend_counters (tests and profiling; results are identical)."""
     lib = L.load()
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise L.SurfelRasterError("means3D must have dimensions (num_points, 3)")
@@ -101,7 +106,8 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
     dev = means3D.device
     P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
     with torch.cuda.device(dev):
-        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile)
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile,
+                          quadrant_cull, blend_counters)
         mask = _mask(mask, P, dev)
         g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations, mask)
         if keep[0].numel() != g.color_channels:
@@ -127,12 +133,14 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
 def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap, sh, degree, campos,
                                  geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None, defer_sh=False,
-                                 activations=0, tile=None):
+                                 activations=0, tile=None, after_blend=None):
     """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry.
 
     `defer_sh=True` (frame-parallel ranks, streetunveiler_amd.parallel): with SHs as the colour source, dL_dsh is NOT
     expanded (empty tensor returned) and dL_dcolors carries the clamp-masked dL/drgb [P,3] to be all-gathered and expanded
-    with `sh_gradient_expand`."""
+    with `sh_gradient_expand`.  `after_blend(dL_dcolors)`: with `defer_sh`, called between the two halves of the backward
+    (sr_backward_blend -> sr_backward_colors -> HERE -> sr_backward_geometry) with the [P,3] colour gradients already final, so that
+    a frame-parallel rank can put its all-gather on the wire while K8 still runs."""
     lib = L.load()
     means3D = _f32c(means3D, "means3D")
     colors_precomp = _f32c(colors_precomp, "colors_precomp"); scales = _f32c(scales, "scales")
@@ -173,12 +181,44 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered), NC),), dtype=torch.uint8, device=dev)
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),
                               _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations))
-        L.check(lib.sr_backward(C.byref(fr), C.byref(g), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(),
-                                _ptr(binningBuffer), binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(),
-                                int(num_rendered), _ptr(dL_dcolor), _ptr(dL_dallmap), _ptr(ws), ws.numel(),
-                                C.byref(grads), _stream(dev)), "sr_backward")
+        if after_blend is not None and defer_sh and NC == 3:
+            L.check(lib.sr_backward_blend(C.byref(fr), C.byref(g), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
+                                          binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(), int(num_rendered), _ptr(dL_dcolor),
+                                          _ptr(dL_dallmap), _ptr(ws), ws.numel(), _stream(dev)), "sr_backward_blend")
+            L.check(lib.sr_backward_colors(C.byref(fr), C.byref(g), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), int(num_rendered),
+                                           _ptr(ws), ws.numel(), _ptr(dL_dcolors), _stream(dev)), "sr_backward_colors")
+            after_blend(dL_dcolors)
+            grads.dL_dcolors = None      # already final; K8 need not write it again
+            L.check(lib.sr_backward_geometry(C.byref(fr), C.byref(g), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
+                                             binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(), int(num_rendered), _ptr(ws),
+                                             ws.numel(), C.byref(grads), _stream(dev)), "sr_backward_geometry")
+        else:
+            L.check(lib.sr_backward(C.byref(fr), C.byref(g), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(),
+                                    _ptr(binningBuffer), binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(),
+                                    int(num_rendered), _ptr(dL_dcolor), _ptr(dL_dallmap), _ptr(ws), ws.numel(),
+                                    C.byref(grads), _stream(dev)), "sr_backward")
     del keep
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+
+
+def pair_decisions(bg, means3D, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, degree, campos,
+                   geomBuffer, num_rendered, binningBuffer, tile=None):
+    """Test hook (sr_debug_pair_decisions): -> (valid[D, nq] int64, use3d[D, nq] int64) ballots per (list entry, 8x8 quadrant)."""
+    lib = L.load()
+    means3D = _f32c(means3D, "means3D")
+    dev = means3D.device
+    tw, th = tile if tile else (16, 16)
+    nq = (tw // 8) * (th // 8)
+    valid = torch.zeros((max(int(num_rendered), 1), nq), dtype=torch.int64, device=dev)
+    use3d = torch.zeros_like(valid)
+    with torch.cuda.device(dev):
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, degree, campos, False, False, tile)
+        g = L.SrGaussians(int(means3D.shape[0]), 0, 3, 0, _ptr(means3D), _ptr(means3D), None, None, None, _ptr(means3D), _ptr(means3D), None)
+        L.check(lib.sr_debug_pair_decisions(C.byref(fr), C.byref(g), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
+                                            binningBuffer.numel(), int(num_rendered), _ptr(valid), _ptr(use3d), _stream(dev)),
+                "sr_debug_pair_decisions")
+    del keep
+    return valid[:int(num_rendered)], use3d[:int(num_rendered)]
 
 
 def sh_gradient_expand(means3D, campos, dL_dcolors, sh_coeffs, degree):

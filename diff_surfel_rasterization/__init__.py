@@ -43,15 +43,15 @@ def _cpu_snapshot(args):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        activations=0, tile=None, mask=None):
+                        activations=0, tile=None, mask=None, probe=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, activations, tile, mask)
+                                     raster_settings, activations, tile, mask, probe)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                activations=0, tile=None, mask=None):
+                activations=0, tile=None, mask=None, probe=None):
         s = raster_settings
         ctx.activations = int(activations)
         ctx.tile = tuple(int(t) for t in tile) if tile else None
@@ -60,6 +60,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             fused["tile"] = ctx.tile
         if mask is not None:   # only the forward looks at it: masked-out Gaussians get radius 0 and, with that, zero gradients
             fused["mask"] = mask
+        if probe:              # tests / profiling: {"quadrant_cull": bool, "blend_counters": int64[8] device tensor}
+            fused.update(probe)
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
                 s.debug)
@@ -95,8 +97,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ctx.num_rendered, binningBuffer, imgBuffer, s.debug)
         # frame-parallel ranks may exchange the SH gradient in factored form (streetunveiler_amd.parallel)
         from streetunveiler_amd.parallel import active_sh_exchange
-        exchange = active_sh_exchange() if sh.numel() else None
+        # (only when the SHs are the sole colour source: the 9-channel pass keeps its SH gradient local, as _C does)
+        exchange = active_sh_exchange() if sh.numel() and not colors_precomp.numel() else None
         kwargs = {"defer_sh": True} if exchange is not None else {}
+        if exchange is not None and hasattr(exchange, "start"):
+            # the 12-B colour gradients are final right after the blend backward: their all-gather goes on the wire while K8 runs
+            kwargs["after_blend"] = exchange.start
         if ctx.activations:
             kwargs["activations"] = ctx.activations
         if ctx.tile:
@@ -118,20 +124,28 @@ class _RasterizeGaussians(torch.autograd.Function):
         none_if_empty = lambda g, ref: g if ref.numel() else None
         return (grad_means3D, grad_means2D, none_if_empty(grad_sh, sh), none_if_empty(grad_colors_precomp, colors_precomp),
                 grad_opacities, none_if_empty(grad_scales, scales), none_if_empty(grad_rotations, rotations),
-                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None, None)
+                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None, None, None)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False, tile=None):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False, tile=None, quadrant_cull: bool = True,
+                 blend_counters=None):
         """`fused_activations=True` (extension): `opacities`, `scales`, `rotations` are the RAW parameters
         (`_opacity`, `_scaling`, `_rotation` of the reference's GaussianModel); sigmoid / exp / normalize run inside the
         preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values.
         `tile=(w, h)`: binning tile shape, default the reference's compile-time 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
-        16x16, 32x8, 32x16); images and gradients do not depend on it beyond float summation order."""
+        16x16, 32x8, 32x16); images and gradients do not depend on it beyond float summation order.
+        `quadrant_cull=False` / `blend_counters` (int64[8] device tensor): this call's SrFrame.flags / SrFrame.blend_counters --
+        test and profiling switches with identical results (include/surfel_raster.h)."""
         super().__init__()
         self.raster_settings = raster_settings
         self.activations = 7 if fused_activations else 0
         self.tile = tile
+        self.probe = {}
+        if not quadrant_cull:
+            self.probe["quadrant_cull"] = False
+        if blend_counters is not None:
+            self.probe["blend_counters"] = blend_counters
 
     def markVisible(self, positions):
         with torch.no_grad():
@@ -162,4 +176,4 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s,
-                                   self.activations, self.tile, mask)
+                                   self.activations, self.tile, mask, self.probe or None)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 4
+#define SR_ABI_VERSION 5
 #define SR_TILE 16            /* default 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y); see SrFrame.tile_width */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
 #define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
@@ -73,9 +73,18 @@ typedef struct SrFrame {
     const float* viewmatrix;  /* device [16] = world_view_transform (W2C^T), row-major */
     const float* projmatrix;  /* device [16] = full_proj_transform ((P*W2C)^T), row-major */
     const float* campos;      /* device [3] */
-    int32_t tile_width;       /* 0 = 16 (the reference's BLOCK_X); BASELINE config 5 sweeps 8x8, 16x8, 16x16, 32x8, 32x16 */
+    int32_t tile_width;       /* 0 = 16 (the reference's BLOCK_X); BASELINE config 5 sweeps 8x8, 16x8, 16x16, 32x8, 32x16.  The 6- and
+                               * 9-channel passes (SrGaussians.color_channels) and the counter variant exist for 16x16 only */
     int32_t tile_height;      /* 0 = 16 (BLOCK_Y).  Same shape in every call that shares the state buffers */
+    uint32_t flags;           /* SR_FLAG_* bits; per call, nothing about a call is process-wide state */
+    uint64_t* blend_counters; /* NULL, or device [8] u64 owned by the caller: selects the COUNTING variant of the forward blend (same
+                               * results, slow), which adds to [0] list entries staged, [1] entries kept by the quadrant culling,
+                               * [2] (entry, quadrant) tests run, [3] tests with >= 1 contributing pixel, [4] contributing (pixel, entry)
+                               * pairs, [5] / [6] tests with a contributing pixel in rows 0-3 / rows 4-7 of the quadrant */
 } SrFrame;
+#define SR_FLAG_NO_QUADRANT_CULL 1u  /* forward blend: run every list entry against every 8x8 quadrant instead of dropping entries that
+                                      * provably cannot reach alpha >= 1/255 there.  Results are bit-identical either way (a test
+                                      * requires it); the switch exists for that test and for A/B timing */
 
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
  * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp
@@ -171,6 +180,22 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
                 const float* dL_dcolor, const float* dL_dallmap, void* workspace, size_t workspace_bytes,
                 const SrGradients* grads, void* stream);
 
+/* The same backward in two halves, for callers that want to start a gradient exchange in between:
+ *   sr_backward_blend     K7: per-(tile, Gaussian) gradient records into `workspace`;
+ *   sr_backward_colors    optional, 3-channel pass: dL_dcolors[P,3] from those records alone (clamp-masked dL/drgb when shs is the
+ *                         colour source = the input of sr_sh_gradient_expand; plain dL/dcolors_precomp otherwise) -- bit-identical
+ *                         to what sr_backward_geometry returns in SrGradients.dL_dcolors;
+ *   sr_backward_geometry  K8: everything else, from the same workspace.
+ * sr_backward == sr_backward_blend + sr_backward_geometry. */
+int sr_backward_blend(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+                      void* image, size_t image_bytes, uint32_t num_rendered, const float* dL_dcolor, const float* dL_dallmap,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int sr_backward_colors(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
+                       uint32_t num_rendered, void* workspace, size_t workspace_bytes, float* dL_dcolors, void* stream);
+int sr_backward_geometry(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
+                         void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered, void* workspace,
+                         size_t workspace_bytes, const SrGradients* grads, void* stream);
+
 /* Frame-parallel SH gradient (no reference counterpart -- the reference is single-GPU).  The SH adjoint is
  * linear in the clamp-masked colour gradient and its only other per-view input is the camera position, so ranks that
  * rendered n_views frames of the SAME Gaussians all-gather dL_dcolors (12 B/Gaussian) instead of all-reducing dL_dsh
@@ -207,17 +232,15 @@ int sr_postprocess_backward(int32_t image_width, int32_t image_height, float fov
                             const float* viewmatrix, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,
                             const float* g_surf_normal, const float* g_surf_point, float* scratch6, float* g_allmap, void* stream);
 
-/* Process-wide tuning switches (results are identical for every setting; they exist for A/B timing and for
- * the test that proves the culling is exact).
- *   SR_OPT_QUADRANT_CULL (default 1): drop list entries that provably cannot reach alpha >= 1/255 inside a
- *   wave's 8x8 pixel quadrant before the per-pixel test. */
-typedef enum SrOption { SR_OPT_QUADRANT_CULL = 0, SR_OPT_DEBUG_STATS = 1 } SrOption;
-int sr_set_option(int option, int value);
-/* With SR_OPT_DEBUG_STATS = 1 the forward blend counts (device-wide, since the last reset): [0] list entries staged,
- * [1] entries kept by the quadrant culling, [2] (entry, quadrant) tests run, [3] tests with >= 1 contributing pixel,
- * [4] contributing (pixel, entry) pairs, [5] / [6] tests with a contributing pixel in rows 0-3 / rows 4-7 of the quadrant.
- * Synchronises the device.  out8: 8 host uint64. */
-int sr_debug_stats(unsigned long long* out8, int reset);
+/* Test hook of the parity bars: the hard decisions the blend kernels take, dumped per (list entry, pixel) pair.  For list position
+ * j (index into SrBinningView.point_list) and 8x8 quadrant q of its tile (q = (y / 8) * (tile_width / 8) + x / 8, bit = (y % 8) * 8 + x % 8
+ * in tile-local pixel coordinates): valid_bits[j * nq + q] = pixels where the entry passes the chain of skips of the forward blend
+ * (p.z != 0, depth >= near, power <= 0, alpha >= 1/255 -- NOT the pixel's saturation state), use3d_bits = pixels where it takes the
+ * ray-splat path (rho3d <= rho2d).  Computed by the same device functions on the same staged values as K6 / K7, i.e. these are the
+ * bits they act on; tests/ hands them to the CPU oracle so that both sides blend the same contributor sets.
+ * Both arrays: device [num_rendered * nq] u64, nq = (tile_width / 8) * (tile_height / 8). */
+int sr_debug_pair_decisions(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning,
+                            size_t binning_bytes, uint32_t num_rendered, uint64_t* valid_bits, uint64_t* use3d_bits, void* stream);
 
 /* Test hook for the library's stable LSD radix sort (binning K2/K4): sorts n (key, value) u32 pairs by key bits
  * [0, total_bits); vals_in == NULL means value = index.  temp: sr_debug_radix_sort_temp_bytes(n) bytes. */
@@ -225,7 +248,8 @@ size_t sr_debug_radix_sort_temp_bytes(uint32_t n);
 int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                         int total_bits, void* temp, size_t temp_bytes, void* stream);
 
-/* Profiling aid.  sr_set_stage_timing(1) makes every later call bracket each stage with a pair of HIP events recorded
+/* Profiling aid -- the one piece of process-wide state in this library (mutex-protected: autograd runs the backward on its own
+ * thread).  sr_set_stage_timing(1) makes every later call bracket each stage with a pair of HIP events recorded
  * on the caller's stream (no host sync while recording; up to 512 launches per stage); sr_set_stage_timing(2 * mask),
  * mask = OR of (1 << SrStage), brackets only the stages in the mask (every event pair costs a few microseconds of
  * stream time: the full set adds ~1.4 % to a 4.5 ms step).  sr_stage_stats() waits for the recorded events and returns the

@@ -29,7 +29,7 @@ TILE = 16
 
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (idempotent)."""
-    srcs = [os.path.join(_HERE, "surfel_oracle.c"), os.path.join(_HERE, "knn_oracle.c")]
+    srcs = [os.path.join(_HERE, "surfel_oracle.c"), os.path.join(_HERE, "surfel_blend.inc"), os.path.join(_HERE, "knn_oracle.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libsurfel_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -65,8 +65,12 @@ def _p(a, ty=C.c_float):
 def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None, colors_precomp=None,
                       transMat_precomp=None, *, viewmatrix, projmatrix, campos, bg, image_width: int,
                       image_height: int, sh_degree: int = 0, scale_modifier: float = 1.0,
-                      stages: bool = True, tile=(16, 16)) -> Dict[str, np.ndarray]:
-    """K1..K6. Returns every stage's outputs (dict of numpy arrays).  `tile` = (BLOCK_X, BLOCK_Y), 16x16 in the reference."""
+                      stages: bool = True, tile=(16, 16), forced=None, f64: bool = False) -> Dict[str, np.ndarray]:
+    """K1..K6. Returns every stage's outputs (dict of numpy arrays).  `tile` = (BLOCK_X, BLOCK_Y), 16x16 in the reference.
+    `forced` = dict(valid=u64[D,nq], use3d=u64[D,nq], n_contrib=u32[2,H,W]): blend with the hard decisions of another
+    implementation (sr_debug_pair_decisions + its n_contrib) -- see so_render_forward; the backward then uses them too.
+    `f64=True`: the blend (K6, and K7 in rasterize_backward) is evaluated in double precision on the same float32 per-Gaussian
+    inputs (surfel_blend.inc compiled with REAL = double): the arbiter of the parity report, not the oracle."""
     L = lib()
     L.so_set_tile(int(tile[0]), int(tile[1]))
     means3D = _f32(means3D); P = means3D.shape[0]
@@ -101,17 +105,25 @@ def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None,
                   _p(vals_buf, C.c_uint32), _p(o["ranges"], C.c_uint32))
     assert rc == 0, f"so_bin failed: {rc}"
     o["keys"] = keys_buf[:D]; o["point_list"] = vals_buf[:D]
-    o["color"] = np.zeros((3, H, W), np.float32); o["allmap"] = np.zeros((7, H, W), np.float32)
-    o["final_T"] = np.zeros((3, H, W), np.float32); o["n_contrib"] = np.zeros((2, H, W), np.uint32)
+    rt, ct = (np.float64, C.c_double) if f64 else (np.float32, C.c_float)
+    o["color"] = np.zeros((3, H, W), rt); o["allmap"] = np.zeros((7, H, W), rt)
+    o["final_T"] = np.zeros((3, H, W), rt); o["n_contrib"] = np.zeros((2, H, W), np.uint32)
     tested = C.c_uint64(0)
-    L.so_render_forward(W, H, _p(o["ranges"], C.c_uint32), _p(vals_buf, C.c_uint32), _p(o["means2D"]),
-                        _p(o["transMat"]), _p(o["normal_opacity"]), _p(o["rgb"]), _p(bgc), _p(o["color"]),
-                        _p(o["allmap"]), _p(o["final_T"]), _p(o["n_contrib"], C.c_uint32), C.byref(tested))
+    fv = fu = fn = None
+    if forced is not None:
+        nq = (int(tile[0]) // 8) * (int(tile[1]) // 8)
+        fv = np.ascontiguousarray(forced["valid"], dtype=np.uint64).reshape(-1); fu = np.ascontiguousarray(forced["use3d"], dtype=np.uint64).reshape(-1)
+        fn = np.ascontiguousarray(forced["n_contrib"], dtype=np.uint32).reshape(2, H, W)
+        assert fv.size == D * nq and fu.size == D * nq, "forced decisions must cover every (list position, quadrant)"
+    (L.so_render_forward_f64 if f64 else L.so_render_forward)(
+        W, H, _p(o["ranges"], C.c_uint32), _p(vals_buf, C.c_uint32), _p(o["means2D"]), _p(o["transMat"]), _p(o["normal_opacity"]),
+        _p(o["rgb"]), _p(bgc), _p(o["color"], ct), _p(o["allmap"], ct), _p(o["final_T"], ct), _p(o["n_contrib"], C.c_uint32),
+        C.byref(tested), _p(fv, C.c_uint64), _p(fu, C.c_uint64), _p(fn, C.c_uint32))
     o["tested_pairs"] = int(tested.value)
     o["_inputs"] = dict(means3D=means3D, opacities=opacities, scales=scales, rotations=rotations, shs=shs,
                         colors_precomp=colors_precomp, transMat_precomp=transMat_precomp, view=view, proj=proj,
                         cam=cam, bg=bgc, W=W, H=H, deg=int(sh_degree), M=M, scale_modifier=float(scale_modifier),
-                        vals_buf=vals_buf, tile=(int(tile[0]), int(tile[1])))
+                        vals_buf=vals_buf, tile=(int(tile[0]), int(tile[1])), forced=(fv, fu), f64=bool(f64))
     return o
 
 
@@ -121,14 +133,19 @@ def rasterize_backward(fwd: Dict[str, np.ndarray], dL_dcolor, dL_dallmap) -> Dic
     i = fwd["_inputs"]; P = i["means3D"].shape[0]; W, H, M = i["W"], i["H"], i["M"]
     L.so_set_tile(*i["tile"])
     dL_dcolor = _f32(dL_dcolor).reshape(3, H, W); dL_dallmap = _f32(dL_dallmap).reshape(7, H, W)
-    g = dict(dL_dcolors=np.zeros((P, 3), np.float32), dL_dnormal3D=np.zeros((P, 3), np.float32),
-             dL_dtransMat=np.zeros((P, 9), np.float32), dL_dmean2D_raw=np.zeros((P, 2), np.float32),
-             dL_dopacity=np.zeros((P, 1), np.float32))
-    L.so_render_backward(W, H, _p(fwd["ranges"], C.c_uint32), _p(i["vals_buf"], C.c_uint32), _p(fwd["means2D"]),
-                         _p(fwd["transMat"]), _p(fwd["normal_opacity"]), _p(fwd["rgb"]), _p(i["bg"]),
-                         _p(fwd["final_T"]), _p(fwd["n_contrib"], C.c_uint32), _p(dL_dcolor), _p(dL_dallmap),
-                         _p(g["dL_dcolors"]), _p(g["dL_dnormal3D"]), _p(g["dL_dtransMat"]), _p(g["dL_dmean2D_raw"]),
-                         _p(g["dL_dopacity"]))
+    f64 = i.get("f64", False)
+    rt, ct = (np.float64, C.c_double) if f64 else (np.float32, C.c_float)
+    g = dict(dL_dcolors=np.zeros((P, 3), rt), dL_dnormal3D=np.zeros((P, 3), rt), dL_dtransMat=np.zeros((P, 9), rt),
+             dL_dmean2D_raw=np.zeros((P, 2), rt), dL_dopacity=np.zeros((P, 1), rt))
+    (L.so_render_backward_f64 if f64 else L.so_render_backward)(
+        W, H, _p(fwd["ranges"], C.c_uint32), _p(i["vals_buf"], C.c_uint32), _p(fwd["means2D"]), _p(fwd["transMat"]),
+        _p(fwd["normal_opacity"]), _p(fwd["rgb"]), _p(i["bg"]), _p(fwd["final_T"], ct), _p(fwd["n_contrib"], C.c_uint32),
+        _p(dL_dcolor), _p(dL_dallmap), _p(g["dL_dcolors"], ct), _p(g["dL_dnormal3D"], ct), _p(g["dL_dtransMat"], ct),
+        _p(g["dL_dmean2D_raw"], ct), _p(g["dL_dopacity"], ct), _p(i["forced"][0], C.c_uint64), _p(i["forced"][1], C.c_uint64))
+    if f64:   # K8 is the float32 per-Gaussian chain in every variant: hand it the double sums rounded once
+        g["dL_dopacity64"] = g["dL_dopacity"].copy()
+        for k in ("dL_dcolors", "dL_dnormal3D", "dL_dtransMat", "dL_dmean2D_raw", "dL_dopacity"):
+            g[k] = np.ascontiguousarray(g[k], dtype=np.float32)
     g["dL_dtransMat_render"] = g["dL_dtransMat"].copy()
     g["dL_dmeans3D"] = np.zeros((P, 3), np.float32); g["dL_dscales"] = np.zeros((P, 2), np.float32)
     g["dL_drotations"] = np.zeros((P, 4), np.float32); g["dL_dmeans2D"] = np.zeros((P, 3), np.float32)
@@ -143,6 +160,24 @@ def rasterize_backward(fwd: Dict[str, np.ndarray], dL_dcolor, dL_dallmap) -> Dic
     if M:
         g["dL_dsh"] = dsh_buf
     return g
+
+
+# noise allowances of the blend's hard decisions (see so_render_margins): float32 rounding of exp / rcp / the ray-splat cross
+# product moves 255*alpha by ~1e-6, T' by ~1e-5 after ~100 factors, rho3d (tile-local vs global pixel coordinates) by ~1e-4
+DEFAULT_EPS = dict(alpha=2e-5, T=1e-4, path=1e-3, near=1e-5, median=2e-5)
+
+
+def render_margins(fwd: Dict[str, np.ndarray], eps: Optional[Dict[str, float]] = None) -> Dict[str, np.ndarray]:
+    """Decision margins of the forward blend (so_render_margins): `pixel`[H,W], `median`[H,W], `gaussian`[P]; > 1 = robust."""
+    L = lib()
+    i = fwd["_inputs"]; P = i["means3D"].shape[0]; W, H = i["W"], i["H"]
+    L.so_set_tile(*i["tile"])
+    e = dict(DEFAULT_EPS); e.update(eps or {})
+    ev = np.array([e["alpha"], e["T"], e["path"], e["near"], e["median"]], np.float32)
+    pm = np.zeros((H, W), np.float32); mm = np.zeros((H, W), np.float32); gm = np.zeros(P, np.float32)
+    L.so_render_margins(P, W, H, _p(fwd["ranges"], C.c_uint32), _p(i["vals_buf"], C.c_uint32), _p(fwd["means2D"]),
+                        _p(fwd["transMat"]), _p(fwd["normal_opacity"]), _p(ev), _p(pm), _p(mm), _p(gm))
+    return dict(pixel=pm, median=mm, gaussian=gm, eps=e)
 
 
 def mark_visible(means3D, viewmatrix) -> np.ndarray:

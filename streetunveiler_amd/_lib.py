@@ -11,8 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsurfel_raster.so")
 
 SR_ACT_EXP_SCALES, SR_ACT_SIGMOID_OPACITY, SR_ACT_NORMALIZE_ROTATIONS = 1, 2, 4
-SR_OPT_QUADRANT_CULL = 0
-SR_OPT_DEBUG_STATS = 1
+SR_FLAG_NO_QUADRANT_CULL = 1
 SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
                   "preprocess_bwd"]
 
@@ -21,7 +20,7 @@ class SrFrame(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("scale_modifier", C.c_float), ("sh_degree", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-                ("tile_width", C.c_int32), ("tile_height", C.c_int32)]
+                ("tile_width", C.c_int32), ("tile_height", C.c_int32), ("flags", C.c_uint32), ("blend_counters", C.c_void_p)]
 
 
 class SrGaussians(C.Structure):
@@ -53,7 +52,7 @@ class SrImageView(C.Structure):
 # every symbol include/surfel_raster.h declares (checked by tests/test_abi.py)
 EXPORTS = ["sr_abi_version", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
            "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan", "sr_sh_gradient_expand", "sr_knn_workspace_bytes", "sr_knn_mean_dist2",
-           "sr_forward_render", "sr_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_set_option", "sr_debug_stats", "sr_debug_radix_sort", "sr_debug_radix_sort_temp_bytes", "sr_postprocess_forward",
+           "sr_forward_render", "sr_backward", "sr_backward_blend", "sr_backward_colors", "sr_backward_geometry", "sr_debug_pair_decisions", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_debug_radix_sort", "sr_debug_radix_sort_temp_bytes", "sr_postprocess_forward",
            "sr_postprocess_backward"]
 
 _lib = None
@@ -91,6 +90,14 @@ def load():
     lib.sr_backward.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                 C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_size_t, C.POINTER(SrGradients), C.c_void_p]
+    lib.sr_backward_blend.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.sr_backward_colors.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                       C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.sr_backward_geometry.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(SrGradients), C.c_void_p]
+    lib.sr_debug_pair_decisions.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sr_sh_gradient_expand.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5
     lib.sr_knn_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.sr_knn_workspace_bytes.restype = C.c_size_t
@@ -98,16 +105,14 @@ def load():
                                       C.c_size_t, C.c_void_p]
     lib.sr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sr_set_stage_timing.argtypes = [C.c_int]
-    lib.sr_set_option.argtypes = [C.c_int, C.c_int]
-    lib.sr_debug_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     lib.sr_postprocess_forward.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 7
     lib.sr_postprocess_backward.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 9
     lib.sr_debug_radix_sort_temp_bytes.argtypes = [C.c_uint32]
     lib.sr_debug_radix_sort_temp_bytes.restype = C.c_size_t
     lib.sr_debug_radix_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sr_stage_stats.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    if lib.sr_abi_version() != 4:
-        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 4")
+    if lib.sr_abi_version() != 5:
+        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 5")
     _lib = lib
     return lib
 

@@ -33,11 +33,15 @@ hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, u
 hipError_t run_tile_order(int n_tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
-                                 const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint16_t* hit_mask, int cull, hipStream_t s);
+                                 const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint16_t* hit_mask, int flags,
+                                 unsigned long long* counters, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, int cull, hipStream_t s);
-hipError_t read_render_stats(unsigned long long* out8, bool reset);
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s);
+hipError_t launch_pair_decisions(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
+                                 unsigned long long* valid_bits, unsigned long long* use3d_bits, hipStream_t s);
+hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii, const uint8_t* clamped, const float4* recs, const float4* inst_grads,
+                                  const uint8_t* written, const uint32_t* tiles_touched, bool mask_clamped, float* dL_dcolors, hipStream_t s);
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
@@ -60,11 +64,9 @@ using namespace sr;
 namespace {
 
 thread_local char g_err[512] = "";
-// timing state is process-wide: autograd runs the backward on its own thread
+// The only process-wide state of the library is this profiling aid (everything that changes what a call does is a field
+// of that call's SrFrame): autograd runs the backward on its own thread, so the rings are shared and mutex-protected.
 std::atomic<int> g_timing{0};
-// bit 0 SR_OPT_QUADRANT_CULL, bit 1 SR_OPT_DEBUG_STATS; measurement switches that do not change results: bit 11 (option 100,
-// value 0x80) one K6 wave per tile instead of two band waves, bits 12..19 (option 101) KiB of dynamic LDS per blend wave
-std::atomic<int> g_options{1};
 std::mutex g_ring_mu;
 
 int fail(int code, const char* fmt, ...) {
@@ -103,15 +105,14 @@ struct StageTimer {
             if (hipEventCreate(&r.ev[r.created][0]) != hipSuccess || hipEventCreate(&r.ev[r.created][1]) != hipSuccess) return;
             ++r.created;
         }
-        slot = r.used;
+        slot = r.used++;   // reserved here: a timer started meanwhile on another thread (autograd's backward) gets the next one
         (void)hipEventRecord(r.ev[slot][0], s);
+        (void)hipEventRecord(r.ev[slot][1], s);   // placeholder end, so that a reader never meets a never-recorded event
     }
     ~StageTimer() {
         if (slot < 0) return;
         std::lock_guard<std::mutex> lk(g_ring_mu);
-        EvRing& r = g_ring[stage];
-        (void)hipEventRecord(r.ev[slot][1], s);
-        r.used = slot + 1;
+        (void)hipEventRecord(g_ring[stage].ev[slot][1], s);
     }
 };
 
@@ -361,49 +362,114 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     if (int rc = debug_sync(frame, s, "tile_ranges")) return rc;
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
+        const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0);
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
-                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint16_t>(binning, B.hit_mask), g_options.load(), s));
+                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint16_t>(binning, B.hit_mask), flags,
+                                     reinterpret_cast<unsigned long long*>(frame->blend_counters), s));
     }
     return debug_sync(frame, s, "render_forward");
+}
+
+namespace {
+struct BackwardCtx {
+    int P; GeomLayout L; BinLayout B; ImgLayout I; FrameDev f; float4* inst_grads; uint8_t* written; hipStream_t s;
+};
+// argument checks and buffer carving shared by the backward entry points
+int backward_ctx(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+                 void* image, size_t image_bytes, uint32_t D, void* workspace, size_t workspace_bytes, void* stream, BackwardCtx* c) {
+    if (int rc = check_common(frame, g)) return rc;
+    c->P = g->P;
+    if (c->P == 0) return SR_OK;
+    if (!geom || !binning || !image || !workspace) return fail(SR_ERR_INVALID_ARGUMENT, "NULL buffer argument");
+    const int W = frame->image_width, H = frame->image_height;
+    c->L = geom_layout(c->P); c->B = bin_layout(D, W, H); c->I = img_layout(W, H);
+    if (geom_bytes < c->L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, c->L.total);
+    if (binning_bytes < c->B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, c->B.total);
+    if (image_bytes < c->I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, c->I.total);
+    if (workspace_bytes < sr_backward_workspace_bytes(c->P, D, g->color_channels)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(c->P, D, g->color_channels));
+    c->s = static_cast<hipStream_t>(stream);
+    c->f = make_frame(frame, g);
+    // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous).  K7 writes a record --
+    // and sets the slot's byte in `written` -- only where some pixel contributed; K8 looks at the byte before it touches the
+    // record, so neither the records nor anything but these D bytes need clearing.
+    c->inst_grads = static_cast<float4*>(workspace);
+    c->written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(g->color_channels), 256);
+    return SR_OK;
+}
+}  // namespace
+
+int sr_backward_blend(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+                      void* image, size_t image_bytes, uint32_t D, const float* dL_dcolor, const float* dL_dallmap, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    BackwardCtx c;
+    if (int rc = backward_ctx(frame, g, geom, geom_bytes, binning, binning_bytes, image, image_bytes, D, workspace, workspace_bytes, stream, &c)) return rc;
+    if (c.P == 0) return SR_OK;
+    if (!dL_dcolor || !dL_dallmap) return fail(SR_ERR_INVALID_ARGUMENT, "dL_dcolor / dL_dallmap is NULL");
+    {
+        StageTimer t(SR_STAGE_BLEND_BWD, c.s);
+        if (D > 0) SR_HIP(hipMemsetAsync(c.written, 0, D, c.s));
+        if (D > 0)
+            SR_HIP(launch_render_backward(c.f, at<uint2>(binning, c.B.ranges), at<uint32_t>(binning, c.B.order), at<uint32_t>(binning, c.B.point_list), at<float4>(geom, c.L.recs), g->colors_precomp,
+                                          at<float>(image, c.I.final_T), at<uint32_t>(image, c.I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, c.B.hit_mask), c.inst_grads, c.written, c.s));
+    }
+    return debug_sync(frame, c.s, "render_backward");
+}
+
+int sr_backward_colors(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes, uint32_t D,
+                       void* workspace, size_t workspace_bytes, float* dL_dcolors, void* stream) {
+    if (int rc = check_common(frame, g)) return rc;
+    const int P = g->P;
+    if (P == 0) return SR_OK;
+    if (g->color_channels == 6 || g->color_channels == 9) return fail(SR_ERR_UNSUPPORTED, "sr_backward_colors serves the 3-channel pass");
+    if (!radii || !geom || !workspace || !dL_dcolors) return fail(SR_ERR_INVALID_ARGUMENT, "NULL buffer argument");
+    const GeomLayout L = geom_layout(P);
+    if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
+    if (workspace_bytes < sr_backward_workspace_bytes(P, D, g->color_channels)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame(frame, g);
+    const uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(g->color_channels), 256);
+    StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
+    SR_HIP(launch_color_gradients(P, f, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), static_cast<const float4*>(workspace), written,
+                                  at<uint32_t>(geom, L.tiles_touched), g->shs != nullptr, dL_dcolors, s));
+    return debug_sync(frame, s, "color_gradients");
+}
+
+int sr_backward_geometry(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
+                         void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t D, void* workspace,
+                         size_t workspace_bytes, const SrGradients* grads, void* stream) {
+    if (!grads) return fail(SR_ERR_INVALID_ARGUMENT, "grads is NULL");
+    BackwardCtx c;
+    if (int rc = backward_ctx(frame, g, geom, geom_bytes, binning, binning_bytes, image, image_bytes, D, workspace, workspace_bytes, stream, &c)) return rc;
+    if (c.P == 0) return SR_OK;
+    if (!radii) return fail(SR_ERR_INVALID_ARGUMENT, "radii is NULL");
+    {
+        StageTimer t(SR_STAGE_PREPROCESS_BWD, c.s);
+        SR_HIP(launch_preprocess_backward(c.P, c.f, *g, radii, at<uint8_t>(geom, c.L.clamped), at<float4>(geom, c.L.recs), c.inst_grads, c.written,
+                                          at<uint32_t>(geom, c.L.tiles_touched), *grads, c.s));
+    }
+    return debug_sync(frame, c.s, "preprocess_backward");
 }
 
 int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes,
                 void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t D, const float* dL_dcolor,
                 const float* dL_dallmap, void* workspace, size_t workspace_bytes, const SrGradients* grads, void* stream) {
-    if (int rc = check_common(frame, g)) return rc;
     if (!grads) return fail(SR_ERR_INVALID_ARGUMENT, "grads is NULL");
-    const int P = g->P;
-    if (P == 0) return SR_OK;
-    if (!radii || !geom || !binning || !image || !dL_dcolor || !dL_dallmap || !workspace) return fail(SR_ERR_INVALID_ARGUMENT, "NULL buffer argument");
-    const int W = frame->image_width, H = frame->image_height;
-    const GeomLayout L = geom_layout(P);
-    const BinLayout B = bin_layout(D, W, H);
-    const ImgLayout I = img_layout(W, H);
-    if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
-    if (binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, B.total);
-    if (image_bytes < I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, I.total);
-    if (workspace_bytes < sr_backward_workspace_bytes(P, D, g->color_channels)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P, D, g->color_channels));
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = sr_backward_blend(frame, g, geom, geom_bytes, binning, binning_bytes, image, image_bytes, D, dL_dcolor, dL_dallmap, workspace, workspace_bytes, stream)) return rc;
+    return sr_backward_geometry(frame, g, radii, geom, geom_bytes, binning, binning_bytes, image, image_bytes, D, workspace, workspace_bytes, grads, stream);
+}
+
+int sr_debug_pair_decisions(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+                            uint32_t D, uint64_t* valid_bits, uint64_t* use3d_bits, void* stream) {
+    if (int rc = check_common(frame, g)) return rc;
+    if (g->P == 0 || D == 0) return SR_OK;
+    if (!geom || !binning || !valid_bits || !use3d_bits) return fail(SR_ERR_INVALID_ARGUMENT, "NULL buffer argument");
+    const GeomLayout L = geom_layout(g->P);
+    const BinLayout B = bin_layout(D, frame->image_width, frame->image_height);
+    if (geom_bytes < L.total || binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "state buffer too small");
     const FrameDev f = make_frame(frame, g);
-    // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous)
-    float4* inst_grads = static_cast<float4*>(workspace);
-    // K7 writes a record -- and sets the slot's byte in `written` -- only where some pixel contributed; K8 looks at the byte
-    // before it touches the record, so neither the records nor anything but these D bytes need clearing.
-    uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(g->color_channels), 256);
-    {
-        StageTimer t(SR_STAGE_BLEND_BWD, s);
-        if (D > 0) SR_HIP(hipMemsetAsync(written, 0, D, s));
-        if (D > 0)
-            SR_HIP(launch_render_backward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs), g->colors_precomp,
-                                          at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, B.hit_mask), inst_grads, written, g_options.load(), s));
-    }
-    if (int rc = debug_sync(frame, s, "render_backward")) return rc;
-    {
-        StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
-        SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), inst_grads, written,
-                                          at<uint32_t>(geom, L.tiles_touched), *grads, s));
-    }
-    return debug_sync(frame, s, "preprocess_backward");
+    SR_HIP(launch_pair_decisions(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
+                                 reinterpret_cast<unsigned long long*>(valid_bits), reinterpret_cast<unsigned long long*>(use3d_bits), static_cast<hipStream_t>(stream)));
+    return SR_OK;
 }
 
 int sr_sh_gradient_expand(int32_t P, int32_t sh_coeffs, int32_t sh_degree, int32_t n_views, const float* means3D,
@@ -473,16 +539,6 @@ int sr_postprocess_backward(int32_t W, int32_t H, float fovx, float fovy, float 
     return SR_OK;
 }
 
-int sr_set_option(int option, int value) {
-    switch (option) {
-        case SR_OPT_QUADRANT_CULL: g_options.store((g_options.load() & ~1) | (value ? 1 : 0)); return SR_OK;
-        case SR_OPT_DEBUG_STATS: g_options.store((g_options.load() & ~2) | (value ? 2 : 0)); return SR_OK;
-        case 101: g_options.store((g_options.load() & 0xFFF) | ((value & 0xFF) << 12)); return SR_OK;  // occupancy experiments: KiB of dynamic LDS per blend wave
-        case 100: g_options.store((g_options.load() & ~0xFF0) | ((value & 0x80) << 4)); return SR_OK;  // A/B: K6 as one wave per tile
-        default: return fail(SR_ERR_INVALID_ARGUMENT, "unknown option %d", option);
-    }
-}
-
 size_t sr_debug_radix_sort_temp_bytes(uint32_t n) { return radix_sort_temp_bytes(n); }
 
 int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
@@ -491,13 +547,6 @@ int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32
     if (total_bits < 1 || total_bits > 32) return fail(SR_ERR_INVALID_ARGUMENT, "total_bits %d not in 1..32", total_bits);
     if (temp_bytes < radix_sort_temp_bytes(n)) return fail(SR_ERR_BUFFER_TOO_SMALL, "temp %zu < %zu", temp_bytes, radix_sort_temp_bytes(n));
     SR_HIP(radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, total_bits, temp, temp_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr));
-    return SR_OK;
-}
-
-int sr_debug_stats(unsigned long long* out8, int reset) {
-    if (!out8) return fail(SR_ERR_INVALID_ARGUMENT, "NULL output");
-    SR_HIP(hipDeviceSynchronize());
-    SR_HIP(read_render_stats(out8, reset != 0));
     return SR_OK;
 }
 

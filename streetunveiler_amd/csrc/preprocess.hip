@@ -501,6 +501,32 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Colour gradients only (sr_backward_colors): sums slots 18..20 of a Gaussian's written gradient records -- the same records,
+// flags and ascending order as K8, so the sums are the ones K8 forms -- and applies the SH clamp mask.  This is all a
+// frame-parallel rank has to ship for the factored SH exchange (12 B per Gaussian), and it is available right after K7: the
+// all-gather can run while K8 does the rest of the backward.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void color_gradient_kernel(int P, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+                                                             const float4* __restrict__ recs, const float4* __restrict__ inst_grads,
+                                                             const uint8_t* __restrict__ written, const uint32_t* __restrict__ tiles_touched,
+                                                             int mask_clamped, float* __restrict__ dL_dcolors) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (radii[i] > 0) {
+        const uint32_t first = __float_as_uint(recs[(size_t)i * kRecQuads + 3].w), end = first + tiles_touched[i];
+        for (uint32_t e = first; e < end; ++e) {
+            if (!written[e]) continue;
+            const float4* gr = inst_grads + (size_t)e * kGradQuads;
+            const float4 g4 = gr[4]; const float g5x = gr[5].x;
+            c0 += g4.z; c1 += g4.w; c2 += g5x;
+        }
+        if (mask_clamped) { const uint8_t cl = clamped[i]; if (cl & 1) c0 = 0.f; if (cl & 2) c1 = 0.f; if (cl & 4) c2 = 0.f; }
+    }
+    dL_dcolors[3 * (size_t)i] = c0; dL_dcolors[3 * (size_t)i + 1] = c1; dL_dcolors[3 * (size_t)i + 2] = c2;
+}
+
+// ---------------------------------------------------------------------------------------------
 // SH gradient of V frames of the same Gaussians from their clamp-masked colour gradients:
 //   dL_dsh[i][k][c] = sum_v basis_k(dir(p_i, campos_v)) * gc[v][i][c]
 // The SH adjoint is linear in gc and its only other per-view input is the camera position, so frame-parallel ranks
@@ -628,6 +654,15 @@ hipError_t launch_sh_gradient_expand(int P, int M, int deg, int V, const float* 
         hipLaunchKernelGGL(sh_gradient_expand_kernel<true>, grid, block, 0, s, P, M, deg, V, means3D, campos, gc, dL_dsh);
     else
         hipLaunchKernelGGL(sh_gradient_expand_kernel<false>, grid, block, 0, s, P, M, deg, V, means3D, campos, gc, dL_dsh);
+    return hipGetLastError();
+}
+
+hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii, const uint8_t* clamped, const float4* recs, const float4* inst_grads,
+                                  const uint8_t* written, const uint32_t* tiles_touched, bool mask_clamped, float* dL_dcolors, hipStream_t s) {
+    (void)f;
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(color_gradient_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, clamped, recs, inst_grads, written, tiles_touched,
+                       mask_clamped ? 1 : 0, dL_dcolors);
     return hipGetLastError();
 }
 

@@ -16,10 +16,12 @@
 // entries whose mask is non-zero (scalar bit-scan over a ballot), and inside an entry only the quadrants
 // whose bit is set.
 //
-// K7 keeps three floats of running state per pixel (T, R, X) instead of the reference's 17: with the
-// per-pixel upstream gradients folded in, the "colour/depth/normal accumulated behind" recurrences collapse
-// into R = sum_{k>i} w_k phi_k, phi_k = rgb_k.g_rgb + depth_k g_depth + n_k.g_n  (algebraically identical to
-// Appendix A.5), and the transMat gradient is accumulated as moments of dL/dp (S0, Sx, Sy, Z: see common.h)
+// K7 keeps TWO floats of running state per pixel (T, Z) instead of the reference's 17: with the per-pixel upstream gradients
+// folded in, the "colour/depth/normal accumulated behind" recurrences AND the distortion weight recurrence
+// (last_dL_dT = dLw alpha + (1 - alpha) last_dL_dT, which equals sum_{k>i} w_k dLw_k / T_{i+1}) collapse into one suffix sum
+//     Z_i = sum_{k>i} w_k psi_k - T_final (g_alpha - bg.g_rgb),   psi_k = rgb_k.g_rgb + depth_k g_depth + n_k.g_n + dLw_k,
+//     dL/dalpha_i = T_i psi_i - Z_i / (1 - alpha_i)
+// (algebraically identical to Appendix A.5), and the transMat gradient is accumulated as moments of dL/dp (S0, Sx, Sy, Z: see common.h)
 // so the two cross products per (pixel, splat) pair of the textbook form run once per Gaussian in K8 instead.
 // Per entry the 21 partial sums of all touched quadrants are added per lane, reduced across the wave ONCE
 // (v_permlane32/16_swap + DPP: 60 VALU ops), and stored as one 96-B gradient record -- no atomics anywhere,
@@ -38,9 +40,9 @@ constexpr float kFN = kFar / (kFar - kNear);
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// debug statistics of K6 (enabled by option bit 1): [0] entries staged, [1] entries with a non-zero quadrant mask,
-// [2] quadrant tests executed, [3] quadrant tests with >= 1 valid lane, [4] valid (pixel, entry) pairs, [5] blended pairs
-__device__ unsigned long long g_stats[8];
+// counters of the K6 counter variant (SrFrame.blend_counters, caller-owned, 8 x u64): [0] entries staged, [1] entries with a
+// non-zero quadrant mask, [2] quadrant tests executed, [3] quadrant tests with >= 1 valid lane, [4] valid (pixel, entry) pairs,
+// [5] / [6] tests with a valid pixel in rows 0-3 / rows 4-7 of the quadrant
 
 // ---------------------------------------------------------------------------------------------
 // Quadrant culling.  A list entry can only contribute to a pixel if alpha = min(0.99, opacity*G) >= 1/255,
@@ -56,7 +58,7 @@ __device__ unsigned long long g_stats[8];
 // ---------------------------------------------------------------------------------------------
 template <int QX, int QY>
 __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my,
-                                                  float opacity) {
+                                                  float opacity, float yshift) {
     constexpr uint32_t kAll = (1u << (QX * QY)) - 1u;
     float thr = 2.f * __logf(255.f * opacity);
     thr = thr * 1.01f + 0.01f;
@@ -83,6 +85,8 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
         lo[d] = fminf(dc - half, ctr[d] - rad[d]);
         hi[d] = fmaxf(dc + half, ctr[d] + rad[d]);
     }
+    // the wave's quadrants sit `yshift` below the local origin: shift the bounds instead of the (compile-time) rectangles
+    lo[1] -= yshift; hi[1] -= yshift; lo[2] -= yshift; hi[2] -= yshift; lo[3] += yshift; hi[3] += yshift;
     const float m = 0.3f;
     uint32_t mask = 0;
 #pragma unroll
@@ -115,7 +119,7 @@ __device__ __forceinline__ float4 load_extra(const float* __restrict__ colors6, 
 
 template <int QX, int QY, int NC>
 __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], const float4 ex, const float4 ey, float Xc, float Yc, int cull,
-                                                float4 (*s_e)[kWave], int slot) {
+                                                float4 (*s_e)[kWave], int slot, float yshift = 0.f) {
     const float Tw[3] = {q[1].z, q[1].w, q[2].x};
     const float Tu[3] = {q[0].x - Xc * Tw[0], q[0].y - Xc * Tw[1], q[0].z - Xc * Tw[2]};
     const float Tv[3] = {q[0].w - Yc * Tw[0], q[1].x - Yc * Tw[1], q[1].y - Yc * Tw[2]};
@@ -130,7 +134,7 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], co
     s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[4].x);
     s_e[5][slot] = make_float4(q[4].y, q[4].z, ex.x, ex.y);
     if (NC == 9) s_e[6][slot] = make_float4(ey.x, ey.y, ey.z, 0.f);
-    return cull ? quadrant_mask<QX, QY>(Tu, Tv, Tw, mx, my, opacity) : (1u << (QX * QY)) - 1u;
+    return cull ? quadrant_mask<QX, QY>(Tu, Tv, Tw, mx, my, opacity, yshift) : (1u << (QX * QY)) - 1u;
 }
 
 struct Hit {
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                                                                 const float* __restrict__ extra,
                                                                 float* __restrict__ out_color, float* __restrict__ out_allmap,
                                                                 float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                                uint16_t* __restrict__ hit_mask, int cull) {
+                                                                uint16_t* __restrict__ hit_mask, int cull, unsigned long long* __restrict__ g_stats) {
     __shared__ float4 s_e[entry_quads<NC>()][kWave];
     const int lane = threadIdx.x;
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: the SPLIT bands of one tile take consecutive
@@ -203,7 +207,9 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     tile = (int)tile_order[tile];   // longest lists first (binning.hip tile_order_kernel)
     constexpr int NQ = QX * QY;   // 8x8 quadrants per wave = pixels per lane
     const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8 * SPLIT) + part * (QY * 8);
-    const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
+    // local origin = centre of the binning tile (shared with K7: identical staged values, identical decisions)
+    const float Xc = (float)(tx0 + QX * 4), Yc = (float)((tile / f.tiles_x) * (QY * 8 * SPLIT) + QY * SPLIT * 4);
+    const float yshift = (float)(part * (QY * 8) - QY * (SPLIT - 1) * 4);   // this band's quadrants relative to that centre
     const int lx = lane & 7, ly = lane >> 3;
     const uint2 range = ranges[tile];
     const uint32_t n_total = range.y - range.x;
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
-        xl[q] = (float)((q % QX) * 8 + lx - QX * 4); yl[q] = (float)((q / QX) * 8 + ly - QY * 4);
+        xl[q] = (float)((q % QX) * 8 + lx - QX * 4); yl[q] = (float)((q / QX) * 8 + ly - QY * 4) + yshift;
         done[q] = !(px < f.W && py < f.H);
         T[q] = 1.f; C0[q] = C1[q] = C2[q] = N0[q] = N1[q] = N2[q] = 0.f;
         C3[q] = C4[q] = C5[q] = C6[q] = C7[q] = C8[q] = 0.f;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         uint32_t m = 0;
-        if ((uint32_t)lane < n) m = stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, cull & 1, s_e, lane);
+        if ((uint32_t)lane < n) m = stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, cull & 1, s_e, lane, yshift);
         if (base + kWave + lane < n_total) {
             const uint32_t gid = point_list[range.x + base + kWave + lane];
             load_record(recs, gid, nr);
@@ -437,8 +443,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                                                                  const float* __restrict__ dL_dcolor,
                                                                  const float* __restrict__ dL_dallmap,
                                                                  const uint16_t* __restrict__ hit_mask,
-                                                                 float4* __restrict__ inst_grads, uint8_t* __restrict__ written,
-                                                                 int cull) {
+                                                                 float4* __restrict__ inst_grads, uint8_t* __restrict__ written) {
     constexpr int kGQ = NC == 9 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record (27 values with 9 channels)
     __shared__ float4 s_e[entry_quads<NC>()][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGQ * 4];
@@ -455,10 +460,10 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
 
     // per-pixel constants (upstream gradients folded with the forward's final accumulators) and state
     const float xl0 = (float)(lx - QX * 4), yl0 = (float)(ly - QY * 4);   // tile-local pixel of quadrant 0; quadrant q adds 8*(q%QX, q/QX)
-    float gr[NQ], gg[NQ], gb[NQ], gn0[NQ], gn1[NQ], gn2[NQ], g_depth[NQ], g_median[NQ], Kbg[NQ], a0[NQ], a1[NQ], a2[NQ];
+    float gr[NQ], gg[NQ], gb[NQ], gn0[NQ], gn1[NQ], gn2[NQ], g_depth[NQ], g_median[NQ], a0[NQ], a1[NQ], a2[NQ];
     float gc3[NQ], gc4[NQ], gc5[NQ], gc6[NQ], gc7[NQ], gc8[NQ];   // only live in the 6- / 9-channel variants
     uint32_t lastc[NQ], medc[NQ], quad_last[NQ];
-    float T[NQ], R[NQ], X[NQ];
+    float T[NQ], Z[NQ];
     uint32_t total = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -485,9 +490,8 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             gc6[q] = inside ? dL_dcolor[6 * HW + pix] : 0.f; gc7[q] = inside ? dL_dcolor[7 * HW + pix] : 0.f; gc8[q] = inside ? dL_dcolor[8 * HW + pix] : 0.f;
             bg_dot += f.bg[6] * gc6[q] + f.bg[7] * gc7[q] + f.bg[8] * gc8[q];
         }
-        Kbg[q] = T_final * (g_accum - bg_dot);
         a0[q] = (1.f - T_final) * g_reg; a1[q] = fin_D * g_reg; a2[q] = fin_D2 * g_reg;
-        T[q] = T_final; R[q] = 0.f; X[q] = 0.f;
+        T[q] = T_final; Z[q] = -T_final * (g_accum - bg_dot);   // the background / alpha term rides in the suffix sum
         quad_last[q] = wave_max_u32(lastc[q]);  // deepest entry any pixel of quadrant q needs (uniform)
         total = max(total, quad_last[q]);
     }
@@ -567,10 +571,9 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     const float inv_depth = fast_rcp(h.depth);
                     const float m_d = kFN * (1.f - kNear * inv_depth);
                     const float dmd_dd = kFN * kNear * inv_depth * inv_depth;
-                    const float dLw = a2[q] + m_d * (m_d * a0[q] - 2.f * a1[q]);
-                    const float dL_dalpha = T[q] * (phi + dLw - X[q]) - one_m_inv * (R[q] - Kbg[q]);
-                    R[q] = fmaf(w, phi, R[q]);
-                    X[q] = dLw * h.alpha + (1.f - h.alpha) * X[q];
+                    const float psi = phi + (a2[q] + m_d * (m_d * a0[q] - 2.f * a1[q]));
+                    const float dL_dalpha = T[q] * psi - one_m_inv * Z[q];
+                    Z[q] = fmaf(w, psi, Z[q]);
                     float dL_dz = 2.f * w * (m_d * a0[q] - a1[q]) * dmd_dd + w * g_depth[q];
                     if (cidx == medc[q] - 1u) dL_dz += g_median[q];
                     const float dL_dG = e3.z * dL_dalpha;
@@ -625,18 +628,49 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
     }
 }
 
-hipError_t read_render_stats(unsigned long long* out8, bool reset) {
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 8);
-    if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z));
+// ---------------------------------------------------------------------------------------------
+// Decision dump (test infrastructure of the parity bars, not part of the operator): for every list entry of every tile and
+// every pixel of the tile, whether the ray-splat test of K6 / K7 accepts the pair (`valid`: the chain of skips of Appendix A.4
+// up to alpha >= 1/255, WITHOUT the pixel's saturation state) and which path it takes (`use3d`: rho3d <= rho2d).  Same staging,
+// same `intersect`, same local origin as the blend kernels => the same bits they act on.  One wave per tile, lane l = pixel
+// (l & 7, l >> 3) of each 8x8 quadrant; out[(list position) * QX*QY + quadrant] = 64-bit ballot.
+// ---------------------------------------------------------------------------------------------
+template <int QX, int QY>
+__global__ __launch_bounds__(kWave) void pair_decisions_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                                                               const float4* __restrict__ recs, unsigned long long* __restrict__ valid_bits,
+                                                               unsigned long long* __restrict__ use3d_bits) {
+    __shared__ float4 s_e[entry_quads<3>()][kWave];
+    constexpr int NQ = QX * QY;
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8);
+    const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
+    const float xl0 = (float)((lane & 7) - QX * 4), yl0 = (float)((lane >> 3) - QY * 4);
+    const uint2 range = ranges[tile];
+    const uint32_t n_total = range.y - range.x;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t base = 0; base < n_total; base += kWave) {
+        const uint32_t n = min((uint32_t)kWave, n_total - base);
+        if ((uint32_t)lane < n) {
+            float4 nr[kRecQuads];
+            load_record(recs, point_list[range.x + base + lane], nr);
+            (void)stage_entry<QX, QY, 3>(nr, zero4, zero4, Xc, Yc, 0, s_e, lane);
+        }
+        for (uint32_t j = 0; j < n; ++j) {
+            const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                Hit h;
+                const bool valid = intersect(xl0 + (float)((q % QX) * 8), yl0 + (float)((q / QX) * 8), e0, e1, e2, e3, h);
+                const unsigned long long vb = __ballot(valid), ub = __ballot(h.use3d);
+                if (lane == 0) { valid_bits[(size_t)(range.x + base + j) * NQ + q] = vb; use3d_bits[(size_t)(range.x + base + j) * NQ + q] = ub; }
+            }
+        }
     }
-    return e;
 }
 
 // launchers ---------------------------------------------------------------------------------------
 // Tile shapes (BASELINE config 5's sweep): the reference's 16x16 plus 8x8, 16x8, 32x8, 32x16 = QX x QY quadrants of 8x8
-// pixels, i.e. 1 / 2 / 4 / 8 pixels per lane.  Only the reference shape carries the 6-channel and counter variants.
+// pixels, i.e. 1 / 2 / 4 / 8 pixels per lane.  Only the reference shape carries the 6- / 9-channel and counter variants.
 #define SR_FOR_TILE_SHAPE(F)                                                    \
     if (f.tile_w == 16 && f.tile_h == 16) { F(2, 2); }                          \
     else if (f.tile_w == 8 && f.tile_h == 8) { F(1, 1); }                       \
@@ -645,22 +679,24 @@ hipError_t read_render_stats(unsigned long long* out8, bool reset) {
     else if (f.tile_w == 32 && f.tile_h == 16) { F(4, 2); }                     \
     else return hipErrorInvalidValue;
 
+// flags: bit 0 = quadrant culling on (SR_FLAG_NO_QUADRANT_CULL clear), bit 1 = counter variant (counters != NULL)
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib,
-                                 uint16_t* hit_mask, int cull, hipStream_t s) {
+                                 uint16_t* hit_mask, int flags, unsigned long long* counters, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     const dim3 block(kWave);
+    const int cull = flags & 1;
+    const bool count = (flags & 2) != 0 && counters != nullptr;
 #define SR_LAUNCH_FWD(STATS, NCH, QX, QY, SPLIT)                                                                                  \
     hipLaunchKernelGGL((render_forward_kernel<STATS, NCH, QX, QY, SPLIT>),                                                          \
-                       dim3(SPLIT > 1 ? (n_tiles + kXcds - 1) / kXcds * kXcds * SPLIT : n_tiles), block, (cull >> 12) * 1024, s, f, \
-                       ranges, tile_order, point_list, recs, extra, out_color, out_allmap, final_T, n_contrib, hit_mask, cull)
+                       dim3(SPLIT > 1 ? (n_tiles + kXcds - 1) / kXcds * kXcds * SPLIT : n_tiles), block, 0, s, f, \
+                       ranges, tile_order, point_list, recs, extra, out_color, out_allmap, final_T, n_contrib, hit_mask, cull, counters)
     if (f.tile_w == 16 && f.tile_h == 16) {
         // the reference's tile: two 16x8 band waves per tile (the counter variant stays whole so that it counts each entry once)
         if (f.colors == 9) { SR_LAUNCH_FWD(false, 9, 2, 1, 2); }
-        else if (f.colors == 6) { if (cull & 2) SR_LAUNCH_FWD(true, 6, 2, 2, 1); else SR_LAUNCH_FWD(false, 6, 2, 1, 2); }
-        else if (cull & 2)      SR_LAUNCH_FWD(true, 3, 2, 2, 1);
-        else if (cull & 0x800)  SR_LAUNCH_FWD(false, 3, 2, 2, 1);   // A/B switch (option 100, bit 7): one wave per tile
+        else if (f.colors == 6) { if (count) SR_LAUNCH_FWD(true, 6, 2, 2, 1); else SR_LAUNCH_FWD(false, 6, 2, 1, 2); }
+        else if (count)         SR_LAUNCH_FWD(true, 3, 2, 2, 1);
         else                    SR_LAUNCH_FWD(false, 3, 2, 1, 2);
     } else {
         if (f.colors != 3) return hipErrorInvalidValue;
@@ -677,13 +713,12 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
 
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written,
-                                  int cull, hipStream_t s) {
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
 #define SR_LAUNCH_BWD(NCH, QX, QY)                                                                                                          \
-    hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), (cull >> 12) * 1024, s, f, ranges, tile_order, point_list, recs, extra, final_T, \
-                       n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written, cull)
+    hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, extra, final_T, \
+                       n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written)
     if (f.tile_w == 16 && f.tile_h == 16) {
         if (f.colors == 9) SR_LAUNCH_BWD(9, 2, 2); else if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
     } else {
@@ -693,6 +728,16 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
 #undef SR_BWD_SHAPE
     }
 #undef SR_LAUNCH_BWD
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_decisions(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
+                                 unsigned long long* valid_bits, unsigned long long* use3d_bits, hipStream_t s) {
+    const int n_tiles = f.tiles_x * f.tiles_y;
+    if (n_tiles == 0) return hipSuccess;
+#define SR_DEC_SHAPE(QX, QY) hipLaunchKernelGGL((pair_decisions_kernel<QX, QY>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, point_list, recs, valid_bits, use3d_bits)
+    SR_FOR_TILE_SHAPE(SR_DEC_SHAPE)
+#undef SR_DEC_SHAPE
     return hipGetLastError();
 }
 

@@ -63,7 +63,9 @@ class SurfelModel:
         from .ply import load_ply
         d = load_ply(path, max_sh_degree)
         t = lambda a: torch.tensor(a, dtype=torch.float32, device=device).requires_grad_(True)
-        features = torch.cat([t(d["features_dc"]), t(d["features_rest"])], dim=1)
+        # one leaf [P,16,3] (the operator's layout) so that `_features.grad` exists after backward
+        features = torch.cat([torch.tensor(d["features_dc"], dtype=torch.float32, device=device),
+                              torch.tensor(d["features_rest"], dtype=torch.float32, device=device)], dim=1).requires_grad_(True)
         return cls(t(d["xyz"]), t(d["scaling"]), t(d["rotation"]), t(d["opacity"]), features,
                    semantics=torch.tensor(d["semantics"], dtype=torch.int32, device=device), active_sh_degree=max_sh_degree,
                    max_sh_degree=max_sh_degree, raw=True)
@@ -124,10 +126,20 @@ def _sel(t, mask):
     return t if mask is None else t[mask]
 
 
+def _plain_getters(pc):
+    """True only for models whose opacity / scaling / rotation getters are exactly sigmoid / exp / normalize of `_opacity` /
+    `_scaling` / `_rotation`: a SurfelModel with raw=True, or the reference's GaussianModel
+    [REF scene/gaussian_model.py:63-75, 101-123].  NOT MaskGaussianModel: its getters activate `_x + _new_x * mask`
+    [REF scene/mask_gaussian.py:140-176], so the raw tensors are not what it renders (and are frozen there)."""
+    if isinstance(pc, SurfelModel):
+        return pc.raw
+    return type(pc).__name__ == "GaussianModel" and getattr(pc, "fused_activations_ok", True)
+
+
 def _fused_activations(pc, pipe):
-    """Raw parameters go straight to the operator when asked for and available (a reference GaussianModel always holds
-    them; a SurfelModel only with raw=True)."""
-    return (getattr(pipe, "fused_activations", False) and not pipe.compute_cov3D_python and getattr(pc, "raw", True)
+    """Raw parameters go straight to the operator when asked for and when the model's getters are the plain activations;
+    any other model (MaskGaussianModel, subclasses with extra terms) silently keeps the getter path."""
+    return (getattr(pipe, "fused_activations", False) and not pipe.compute_cov3D_python and _plain_getters(pc)
             and all(hasattr(pc, a) for a in ("_opacity", "_scaling", "_rotation")))
 
 
@@ -278,5 +290,8 @@ def render_semantic(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_
 
 
 def render_semantic_with_mask(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mask, scaling_modifier=1.0):
-    """[REF gaussian_renderer/__init__.py:462-598]"""
-    return _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier)
+    """[REF gaussian_renderer/__init__.py:462-598].  Unlike render_semantic, the reference returns `semantic_uncertainty` with a
+    leading unit axis here ([1,H,W], REF :588 `(1. - difference)[None, ...]` vs :450) -- kept."""
+    out = _render_semantic_impl(viewpoint_camera, pc, pipe, mask, scaling_modifier)
+    out["semantic_uncertainty"] = out["semantic_uncertainty"][None, ...]
+    return out

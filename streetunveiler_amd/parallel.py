@@ -109,7 +109,10 @@ class ShExchange:
                  reduce_all: bool = False):
         self.group, self.expand, self.all_campos, self.reduce_all = group, expand, all_campos, reduce_all
         self.calls = 0          # exchanges run (tests / diagnostics)
-        self.bytes_sent = 0     # payload bytes this rank contributed to the all-gathers
+        self.bytes_sent = 0     # payload bytes this rank contributed to the collectives
+        self.early_starts = 0   # exchanges whose all-gather was put on the wire between K7 and K8 (sr_backward_colors)
+        self.exchange_ms = 0.0  # host-side wall time spent waiting on the collectives (diagnostic; bench.py reports it)
+        self._early = None
 
     def run(self, gc: torch.Tensor, means3D: torch.Tensor, campos: torch.Tensor, sh_coeffs: int, degree: int,
             also_reduce: Sequence[torch.Tensor] = ()) -> torch.Tensor:
@@ -117,10 +120,15 @@ class ShExchange:
 
         `also_reduce`: further gradient tensors to SUM all-reduce in place; their collective is queued right behind the
         all-gather, so it runs on the communication stream while the expansion kernel runs on the compute stream."""
+        import time
         world = dist.get_world_size(self.group)
         gc = gc.contiguous()
-        flat = torch.empty(world * gc.numel(), dtype=gc.dtype, device=gc.device)   # 1-D in/out: accepted by RCCL and gloo alike
-        h = dist.all_gather_into_tensor(flat, gc.reshape(-1), group=self.group, async_op=True)
+        if self._early is not None and self._early[0] is gc:     # started by `start` between the two halves of the backward
+            _, flat, h = self._early
+        else:
+            flat = torch.empty(world * gc.numel(), dtype=gc.dtype, device=gc.device)   # 1-D in/out: accepted by RCCL and gloo alike
+            h = dist.all_gather_into_tensor(flat, gc.reshape(-1), group=self.group, async_op=True)
+        self._early = None
         gathered = flat.view((world,) + tuple(gc.shape))
         if self.all_campos is not None:      # every rank knows the camera list: nothing to exchange
             cams = self.all_campos.to(device=gc.device, dtype=torch.float32).reshape(world, 3)
@@ -133,7 +141,10 @@ class ShExchange:
         groups, singles = _storage_groups([t for t in also_reduce if t is not None and t.numel() > 0])
         for t in groups + singles:
             pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.bytes_sent += t.numel() * t.element_size()
+        t0 = time.perf_counter()
         h.wait()
+        self.exchange_ms += (time.perf_counter() - t0) * 1e3
         self.calls += 1
         self.bytes_sent += gc.numel() * gc.element_size()
         expand = self.expand
@@ -141,9 +152,22 @@ class ShExchange:
             from diff_surfel_rasterization import _C   # the HIP kernel; no CPU path
             expand = _C.sh_gradient_expand
         out = expand(means3D.detach(), cams, gathered, sh_coeffs, degree)
+        t0 = time.perf_counter()
         for w in pending:
             w.wait()
+        self.exchange_ms += (time.perf_counter() - t0) * 1e3
         return out
+
+    def start(self, gc: torch.Tensor) -> None:
+        """Called by the operator's backward BETWEEN its two halves (sr_backward_blend / sr_backward_colors done, sr_backward_geometry
+        not yet launched): `gc` [P,3] is final, so its all-gather goes on the wire now and overlaps K8.  `run` picks it up."""
+        if not gc.is_contiguous():
+            return
+        world = dist.get_world_size(self.group)
+        flat = torch.empty(world * gc.numel(), dtype=gc.dtype, device=gc.device)
+        h = dist.all_gather_into_tensor(flat, gc.reshape(-1), group=self.group, async_op=True)
+        self._early = (gc, flat, h)
+        self.early_starts += 1
 
 
 _ACTIVE_SH_EXCHANGE: Optional[ShExchange] = None

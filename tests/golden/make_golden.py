@@ -113,9 +113,168 @@ def g3_g4_from_oracle():
         radii_probe=fwd["radii"][::97].copy())
 
 
+# ---------------------------------------------------------------------------------------------------
+# G5 / G6: the reference's OWN gaussian_renderer/__init__.py (render, render_with_mask, render_semantic,
+# render_semantic_with_mask), utils/point_utils.py (depth_to_normal, depths_to_points) and utils/semantic_utils.py
+# (semantic_prob_to_rgb) executed here on the CPU.  The native rasterizer they call is not in the reference tree
+# (un-vendored submodule), so a LINEAR STAND-IN is injected for it for the duration of this script only:
+#     out[c, pixel] = sum_i weight[pixel, i] * attribute[i, c] + T[pixel] * bg[c],   T = 1 - sum_i weight[pixel, i]
+# with a seeded weight matrix (rows with sum 0 = empty pixels, exact ties between classes included).  Everything
+# AROUND the rasterizer call -- boolean-index masking, one-hot class colours, the two 3-channel passes, torch.topk
+# margin, argmax colour lookup, allmap -> regularisation maps, pseudo-normals -- is the reference's real code, and
+# what is recorded is data: inputs + the dicts it returned (+ autograd gradients of its post-processing).
+# The stubs (cv2, plyfile-dependent scene modules, .cuda()) only neutralise imports / device moves that cannot
+# work in this container; they never travel.
+# ---------------------------------------------------------------------------------------------------
+class _LinearRasterizer:
+    """Stand-in for diff_surfel_rasterization inside the generator.  Gaussian identity rides in means3D[:, 0]."""
+    weight = None        # [H*W, N] float64
+    attr7 = None         # [N, 7] per-Gaussian allmap attributes
+    H = W = 0
+    last_allmap = None
+
+    def __init__(self, raster_settings):
+        self.s = raster_settings
+
+    def __call__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        cls = _LinearRasterizer
+        ids = means3D[:, 0].detach().round().long()
+        w = cls.weight[:, ids]                                                   # [HW, n]
+        col = colors_precomp if colors_precomp is not None else shs[:, 0, :]     # SH DC as the colour of the stand-in
+        T = 1.0 - w.sum(1, keepdim=True)
+        img = (w @ col.double() + T * self.s.bg.double().view(1, -1)).float().t().reshape(-1, cls.H, cls.W)
+        allmap = (w @ cls.attr7[ids]).float().t().reshape(7, cls.H, cls.W).clone().requires_grad_(True)
+        cls.last_allmap = allmap
+        radii = torch.ones(ids.shape[0], dtype=torch.int32)
+        radii[ids % 5 == 0] = 0
+        return img, radii, allmap
+
+
+def _linear_scene(N, W, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.rand(H * W, N, generator=g, dtype=torch.float64)
+    w = w * (torch.rand(H * W, N, generator=g) < 0.15)            # sparse contributions
+    w = w / w.sum(1, keepdim=True).clamp_min(1e-9) * torch.rand(H * W, 1, generator=g, dtype=torch.float64)
+    w = w.float().double()                                         # stored as float32 in the fixture, exactly
+    w[: 3 * W] = 0.0                                               # empty pixels: alpha == 0 -> 0/0 -> nan_to_num
+    w[3 * W: 4 * W] = 0.0
+    w[3 * W: 4 * W, 0] = 0.25; w[3 * W: 4 * W, 1] = 0.25           # exact ties between two Gaussians (classes set by the caller)
+    attr = torch.rand(N, 7, generator=g, dtype=torch.float64)
+    attr[:, 0] = attr[:, 0] * 20 + 1      # depth
+    attr[:, 1] = 1.0                      # alpha channel accumulates the weights
+    attr[:, 2:5] = attr[:, 2:5] * 2 - 1   # normal
+    attr[:, 5] = attr[:, 5] * 20 + 1      # median depth
+    return w, attr.float().double()
+
+
+def g5_g6_reference_render():
+    import types
+    from collections import namedtuple
+    saved = {k: sys.modules.get(k) for k in ("cv2", "diff_surfel_rasterization", "scene", "scene.gaussian_model", "scene.mask_gaussian",
+                                             "gaussian_renderer", "utils", "utils.point_utils", "utils.semantic_utils", "utils.sh_utils")}
+    for k in list(sys.modules):
+        if k == "utils" or k.startswith("utils."):
+            del sys.modules[k]
+    Settings = namedtuple("GaussianRasterizationSettings", "image_height image_width tanfovx tanfovy bg scale_modifier viewmatrix projmatrix sh_degree campos prefiltered debug")
+    stub = types.ModuleType("diff_surfel_rasterization")
+    stub.GaussianRasterizationSettings, stub.GaussianRasterizer = Settings, _LinearRasterizer
+    sys.modules["diff_surfel_rasterization"] = stub
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    for name, cls in (("scene.gaussian_model", "GaussianModel"), ("scene.mask_gaussian", "MaskGaussianModel")):
+        m = types.ModuleType(name); setattr(m, cls, type(cls, (), {})); sys.modules[name] = m
+    sys.modules["scene"] = types.ModuleType("scene")
+    orig = (torch.Tensor.cuda, torch.zeros_like, torch.tensor)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    strip = lambda f: (lambda *a, **k: f(*a, **{kk: vv for kk, vv in k.items() if kk != "device"}))
+    torch.zeros_like, torch.tensor = strip(orig[1]), strip(orig[2])
+    sys.path.insert(0, "/root/reference")
+    try:
+        import gaussian_renderer as ref                                    # the reference's real file
+        from streetunveiler_amd.camera import make_camera, yaw_rotation, focal2fov
+
+        class PC:   # the getter surface the reference reads
+            def __init__(self, N, sem, seed):
+                g = torch.Generator().manual_seed(seed)
+                self.get_xyz = torch.cat([torch.arange(N, dtype=torch.float32).view(-1, 1), torch.randn(N, 2, generator=g)], 1)
+                self.get_opacity = torch.rand(N, 1, generator=g); self.get_scaling = torch.rand(N, 2, generator=g)
+                self.get_rotation = torch.randn(N, 4, generator=g); self.get_features = torch.randn(N, 16, 3, generator=g)
+                self.get_semantics = sem; self.get_semantics_32bit = (1 << sem.to(torch.int32))
+                self.active_sh_degree = self.max_sh_degree = 3
+        Pipe = namedtuple("Pipe", "convert_SHs_python compute_cov3D_python depth_ratio debug")
+
+        out = {}
+        cases = [(32, 24, 0.0, (0, 0, 0), 0.0), (40, 20, -17.5, (0.3, -0.2, 1.5), 1.0), (24, 16, 7.5, (0, 0.1, 0), 0.35)]
+        for ci, (W, H, yaw, tvec, ratio) in enumerate(cases):
+            N = 24
+            fx = 0.8 * W
+            cam = make_camera(W, H, focal2fov(fx, W), focal2fov(fx, H), R=yaw_rotation(yaw), t=np.array(tvec, dtype=np.float64))
+            w, attr = _linear_scene(N, W, H, 100 + ci)
+            _LinearRasterizer.weight, _LinearRasterizer.attr7, _LinearRasterizer.H, _LinearRasterizer.W = w, attr, H, W
+            g = torch.Generator().manual_seed(200 + ci)
+            sem = torch.randint(0, 6, (N,), generator=g)
+            sem[0], sem[1] = 2, 5                                           # the tied pair belongs to two different classes
+            pc = PC(N, sem, 300 + ci)
+            pipe = Pipe(False, False, ratio, False)
+            bg = torch.tensor([0.2, 0.5, 0.1])
+            mask = torch.rand(N, generator=g) > 0.35
+            pre = f"c{ci}_"
+            out[pre + "meta"] = np.array([W, H, yaw, *tvec, ratio, cam.FoVx, cam.FoVy], dtype=np.float64)
+            out[pre + "wvt"] = cam.world_view_transform.numpy(); out[pre + "full"] = cam.full_proj_transform.numpy(); out[pre + "center"] = cam.camera_center.numpy()
+            out[pre + "weight"] = w.float().numpy(); out[pre + "attr7"] = attr.float().numpy(); out[pre + "sem"] = sem.numpy(); out[pre + "mask"] = mask.numpy()
+            out[pre + "bg"] = bg.numpy(); out[pre + "features"] = pc.get_features.numpy()
+            # A1 / A2 (+ the semantic-filter variants of render): dict out, and d(loss)/d(allmap) through the reference's post-processing
+            gen = torch.Generator().manual_seed(400 + ci)
+            up = {k: torch.randn(c, H, W, generator=gen) for k, c in (("rend_alpha", 1), ("rend_normal", 3), ("rend_dist", 1), ("surf_depth", 1), ("surf_normal", 3), ("surf_point", 3))}
+            for k, v in up.items():
+                out[pre + "up_" + k] = v.numpy()
+            runs = {"render": lambda: ref.render(cam, pc, pipe, bg),
+                    "render_mask": lambda: ref.render_with_mask(cam, pc, pipe, bg, mask),
+                    "render_bit_rev": lambda: ref.render(cam, pc, pipe, bg, semantic_filter_bit=0b010110, reverse_semantic=True),
+                    "render_bit_fwd": lambda: ref.render(cam, pc, pipe, bg, semantic_filter_bit=0b010110, reverse_semantic=False)}
+            for name, fn in runs.items():
+                r = fn()
+                allmap = _LinearRasterizer.last_allmap
+                sum((r[k] * up[k]).sum() for k in up).backward()
+                full = name in ("render", "render_mask")          # the filter variants only pin the masking (image, radii, subset size)
+                if full:
+                    out[pre + name + "_allmap"] = allmap.detach().numpy()
+                    out[pre + name + "_allmap_grad"] = allmap.grad.numpy()
+                for k in ("render", "radii", "visibility_filter") + (("rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "surf_point") if full else ()):
+                    out[pre + name + "_" + k] = r[k].detach().numpy()
+                out[pre + name + "_n"] = np.array(r["viewspace_points"].shape[0])
+            # A3 / A4
+            sruns = {"semantic": lambda: ref.render_semantic(cam, pc, pipe, bg),
+                     "semantic_mask": lambda: ref.render_semantic_with_mask(cam, pc, pipe, bg, mask),
+                     "semantic_bit_rev": lambda: ref.render_semantic(cam, pc, pipe, bg, semantic_filter_bit=0b100101, reverse_semantic=True),
+                     "semantic_bit_fwd": lambda: ref.render_semantic(cam, pc, pipe, bg, semantic_filter_bit=0b100101, reverse_semantic=False)}
+            for name, fn in sruns.items():
+                r = fn()
+                assert set(r) == {"render_semantics", "semantic_rgb", "semantic_uncertainty"}
+                for k, v in r.items():
+                    out[pre + name + "_" + k] = v.detach().numpy()
+        out["n_cases"] = np.array(len(cases))
+        np.savez_compressed(os.path.join(HERE, "reference_render_golden.npz"), **out)
+    finally:
+        sys.path.remove("/root/reference")
+        torch.Tensor.cuda, torch.zeros_like, torch.tensor = orig
+        for k in list(sys.modules):
+            if k == "utils" or k.startswith("utils.") or k == "gaussian_renderer":
+                del sys.modules[k]
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+            else:
+                sys.modules.pop(k, None)
+
+
 if __name__ == "__main__":
-    g1_g2_from_reference()
-    g3_g4_from_oracle()
+    which = sys.argv[1:] or ["g12", "g34", "g56"]
+    if "g12" in which:
+        g1_g2_from_reference()
+    if "g34" in which:
+        g3_g4_from_oracle()
+    if "g56" in which:
+        g5_g6_reference_render()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

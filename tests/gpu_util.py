@@ -33,7 +33,7 @@ def run_oracle(g, cam, bg, deg, dc=None, da=None, mode="sh", colors=None, Tpre=N
     return fwd, bwd
 
 
-def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=False, tile=None):
+def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=False, tile=None, quadrant_cull=True):
     """Returns dict with outputs, internal state views and (if dc given) input gradients, all numpy."""
     dev = DEV
     s = settings_for(cam, bg, deg, debug)
@@ -49,7 +49,7 @@ def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=Fal
         t["Tpre"] = torch.as_tensor(Tpre).to(dev).requires_grad_(); kw["cov3D_precomp"] = t["Tpre"]
     else:
         kw["scales"] = t["scales"]; kw["rotations"] = t["rotations"]
-    color, radii, allmap = GaussianRasterizer(s, tile=tile)(**kw)
+    color, radii, allmap = GaussianRasterizer(s, tile=tile, quadrant_cull=quadrant_cull)(**kw)
     out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), allmap=allmap.detach().cpu().numpy())
     if dc is not None:
         ((color * dc.to(dev)).sum() + (allmap * da.to(dev)).sum()).backward()
@@ -63,7 +63,7 @@ def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=Fal
     return out
 
 
-def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None, tile=None):
+def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None, tile=None, quadrant_cull=True, decisions=False):
     """Calls _C.rasterize_gaussians directly and returns the state-buffer views as numpy (for bit-exact checks)."""
     dev = DEV
     s = settings_for(cam, bg, deg)
@@ -76,13 +76,18 @@ def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None, tile=None):
     tp = e if Tpre is None else torch.as_tensor(Tpre).to(dev)
     D, color, allmap, radii, geom, binning, img = _C.rasterize_gaussians(
         s.bg, d("means3D"), col, d("opacities"), sc, ro, 1.0, tp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
-        s.image_height, s.image_width, sh, deg, s.campos, False, False, tile=tile)
+        s.image_height, s.image_width, sh, deg, s.campos, False, False, tile=tile, quadrant_cull=quadrant_cull)
+    dec = None
+    if decisions:   # the hard decisions the blend kernels act on, per (list entry, pixel) pair (sr_debug_pair_decisions)
+        valid, use3d = _C.pair_decisions(s.bg, d("means3D"), 1.0, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width,
+                                         deg, s.campos, geom, D, binning, tile=tile)
+        dec = dict(valid=valid.cpu().numpy().view(np.uint64), use3d=use3d.cpu().numpy().view(np.uint64))
     torch.cuda.synchronize()
     W, H = cam.image_width, cam.image_height
     gv = {k: v.cpu().numpy() for k, v in _C.geom_view(geom, P).items()} if P else {}
     bv = {k: v.cpu().numpy() for k, v in _C.binning_view(binning, P, D, W, H, tile or (16, 16)).items()}
     iv = {k: v.cpu().numpy() for k, v in _C.image_view(img, W, H).items()}
-    return dict(D=D, color=color.cpu().numpy(), allmap=allmap.cpu().numpy(), radii=radii.cpu().numpy(), geom=gv, bin=bv, img=iv)
+    return dict(D=D, color=color.cpu().numpy(), allmap=allmap.cpu().numpy(), radii=radii.cpu().numpy(), geom=gv, bin=bv, img=iv, decisions=dec)
 
 
 def assert_close_frac(a, b, atol, rtol, max_bad_frac, hard, name=""):

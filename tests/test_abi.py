@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_sizes(lib):
-    assert lib.sr_abi_version() == 4
+    assert lib.sr_abi_version() == 5
     # pure host arithmetic (no GPU): image state = 3 float planes + 2 u32 planes, 256-B aligned
     assert lib.sr_image_bytes(1920, 1080) >= 1920 * 1080 * 20
     assert lib.sr_backward_workspace_bytes(1000, 5000, 3) >= 5000 * 97
@@ -42,14 +42,14 @@ def test_abi_version_and_sizes(lib):
 
 def test_struct_layouts_match_header():
     # field counts / order mirror the header; sizes follow the C layout rules (8-B pointers)
-    assert ctypes.sizeof(_lib.SrFrame) == 8 * 4 + 4 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.SrFrame) == 8 * 4 + 4 * 8 + 2 * 4 + 4 + 4 + 8    # ... tile shape, flags (+ padding), blend_counters
     assert ctypes.sizeof(_lib.SrGaussians) == 4 * 4 + 8 * 8
     assert ctypes.sizeof(_lib.SrGradients) == 8 * 8
     assert [f[0] for f in _lib.SrFrame._fields_][:3] == ["image_height", "image_width", "tanfovx"]
 
 
 def test_argument_errors_without_gpu(lib):
-    fr = _lib.SrFrame(0, 0, 1.0, 1.0, 1.0, 0, 0, 0, None, None, None, None)
+    fr = _lib.SrFrame(0, 0, 1.0, 1.0, 1.0, 0, 0, 0, None, None, None, None, 0, 0, 0, None)
     g = _lib.SrGaussians(0, 0, 0, 0, None, None, None, None, None, None, None, None)
     d = ctypes.c_uint32(7)
     rc = lib.sr_forward_plan(ctypes.byref(fr), ctypes.byref(g), None, 0, None, ctypes.byref(d), None)

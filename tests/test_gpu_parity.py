@@ -181,21 +181,16 @@ def test_quadrant_culling_is_exact():
     """The per-quadrant culling only drops entries the per-pixel test would skip: images, per-pixel state and
     gradients with culling ON must equal culling OFF (images/state bit for bit; gradients up to the
     order of the 4-wave LDS combine)."""
-    from streetunveiler_amd import _lib
     from tests.gpu_util import run_hip, run_hip_raw
-    lib = _lib.load()
     for (P, W, H, lo, hi, idx) in [(30000, 384, 216, 5e-4, 5e-3, None), (8000, 200, 150, 5e-3, 8e-2, 6), (3000, 160, 96, 2e-2, 3e-1, 1)]:
         cam, g = _scene(P, W, H, P + 1, lo, hi, idx)
         g["opacities"][::7] = 0.003   # below 1/255: can never contribute
         g["opacities"][::11] = 1.0
         dc, da = synthetic_upstream_grads(W, H, seed=P)
         res = {}
-        try:
-            for cull in (1, 0):
-                _lib.check(lib.sr_set_option(_lib.SR_OPT_QUADRANT_CULL, cull), "sr_set_option")
-                res[cull] = (run_hip_raw(g, cam, [0.2, 0.4, 0.6], 3), run_hip(g, cam, [0.2, 0.4, 0.6], 3, dc, da))
-        finally:
-            lib.sr_set_option(_lib.SR_OPT_QUADRANT_CULL, 1)
+        for cull in (1, 0):   # per call: SrFrame.flags & SR_FLAG_NO_QUADRANT_CULL
+            res[cull] = (run_hip_raw(g, cam, [0.2, 0.4, 0.6], 3, quadrant_cull=bool(cull)),
+                         run_hip(g, cam, [0.2, 0.4, 0.6], 3, dc, da, quadrant_cull=bool(cull)))
         (raw1, out1), (raw0, out0) = res[1], res[0]
         np.testing.assert_array_equal(raw1["color"], raw0["color"])
         np.testing.assert_array_equal(raw1["allmap"], raw0["allmap"])

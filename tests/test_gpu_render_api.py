@@ -102,13 +102,10 @@ def test_semantic_filter_mask_and_python_sh_path():
         render(cam.to(DEV), pc, PipelineParams(compute_cov3D_python=True), bg.to(DEV))
 
 
-def test_render_semantic_six_classes():
-    from tests.gpu_util import assert_close_frac
-    P, W, H = 4000, 160, 96
-    cam = synthetic_camera(W, H, index=5)
-    g, sem, pc, t = _model(P, W, H, 9, DEV)
-    out = render_semantic(cam.to(DEV), pc, PipelineParams(), torch.zeros(3, device=DEV))
-    assert out["render_semantics"].shape == (6, H, W) and out["semantic_rgb"].shape == (3, H, W) and out["semantic_uncertainty"].shape == (H, W)
+def _oracle_semantics(g, sem, cam, idx=None):
+    """render_semantics exactly as the reference assembles it: two 3-channel one-hot passes, sky = background
+    [REF gaussian_renderer/__init__.py:346-369, 417-446]."""
+    P = sem.shape[0]
     expect = []
     for i in (0, 3):
         onehot = np.zeros((P, 3), np.float32)
@@ -117,14 +114,90 @@ def test_render_semantic_six_classes():
         bg = np.zeros(3, np.float32)
         if i <= 4 < i + 3:
             bg[4 - i] = 1.0     # sky is background
-        expect.append(_oracle(g, cam, bg, 3, colors=onehot)["color"])
-    expect = np.concatenate(expect, 0)
+        expect.append(_oracle(g, cam, bg, 3, idx=idx, colors=onehot if idx is None else onehot[idx])["color"])
+    return np.concatenate(expect, 0)
+
+
+def _check_derived_semantic_maps(out, expect, H, W, lead_axis):
+    """semantic_uncertainty / semantic_rgb against what the reference computes from the class map with torch.topk(k=2) and
+    argmax [REF gaussian_renderer/__init__.py:448-452, 586-590; utils/semantic_utils.py:128-135]: exactly on the operator's own
+    class map, and within the image tolerance on the oracle's."""
+    from tests.gpu_util import assert_close_frac
+    prob = out["render_semantics"].detach()
+    tv, _ = torch.topk(prob, k=2, dim=0)
+    ref_unc = 1.0 - (tv[0] - tv[1])
+    assert out["semantic_uncertainty"].shape == ((1, H, W) if lead_axis else (H, W))
+    assert torch.equal(out["semantic_uncertainty"].detach().reshape(H, W), ref_unc)
+    colour = torch.tensor([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [255, 0, 255], [0, 255, 255]], device=prob.device)
+    assert torch.equal(out["semantic_rgb"], colour[torch.argmax(prob, dim=0)].permute(2, 0, 1) / 255.0)
+    etv, _ = torch.topk(torch.tensor(expect), k=2, dim=0)
+    assert_close_frac(out["semantic_uncertainty"].detach().reshape(H, W).cpu().numpy(), (1.0 - (etv[0] - etv[1])).numpy(), 2e-4, 0, 4e-4, 4e-2, "semantic_uncertainty")
+    # the class colour agrees with the oracle's wherever the oracle's decision is not within float noise of a tie
+    e = torch.tensor(expect)
+    clear = (etv[0] - etv[1]) > 1e-3
+    same = (torch.argmax(prob, dim=0).cpu() == torch.argmax(e, dim=0))[clear]
+    assert float(same.float().mean()) > 0.9995
+
+
+def test_render_semantic_six_classes():
+    from tests.gpu_util import assert_close_frac
+    P, W, H = 4000, 160, 96
+    cam = synthetic_camera(W, H, index=5)
+    g, sem, pc, t = _model(P, W, H, 9, DEV)
+    out = render_semantic(cam.to(DEV), pc, PipelineParams(), torch.zeros(3, device=DEV))
+    assert out["render_semantics"].shape == (6, H, W) and out["semantic_rgb"].shape == (3, H, W) and out["semantic_uncertainty"].shape == (H, W)
+    expect = _oracle_semantics(g, sem, cam)
     assert_close_frac(out["render_semantics"].detach().cpu().numpy(), expect, 1e-4, 1e-4, 2e-4, 2e-2, "render_semantics")
+    _check_derived_semantic_maps(out, expect, H, W, lead_axis=False)
     # class probabilities + background sum to one wherever the sky class absorbs the leftover transmittance
     np.testing.assert_allclose(out["render_semantics"].detach().sum(0).cpu().numpy(), 1.0, atol=2e-3)
-    m = torch.rand(P, generator=torch.Generator().manual_seed(2)) > 0.5
-    out2 = render_semantic_with_mask(cam.to(DEV), pc, PipelineParams(), torch.zeros(3, device=DEV), m.to(DEV))
-    assert out2["render_semantics"].shape == (6, H, W)
+    # semantic_filter_bit variants select by class bit like render() does
+    bit = (1 << 0) | (1 << 3) | (1 << 5)
+    for reverse in (True, False):
+        keep = ((1 << sem.numpy()) & bit) != 0
+        keep = keep if reverse else ~keep
+        o = render_semantic(cam.to(DEV), pc, PipelineParams(), torch.zeros(3, device=DEV), semantic_filter_bit=bit, reverse_semantic=reverse)
+        e = _oracle_semantics(g, sem, cam, idx=keep)
+        assert_close_frac(o["render_semantics"].detach().cpu().numpy(), e, 1e-4, 1e-4, 2e-4, 2e-2, "render_semantics, filter bit")
+        _check_derived_semantic_maps(o, e, H, W, lead_axis=False)
+
+
+def test_render_semantic_with_mask_against_the_oracle_on_the_subset():
+    """A4 [REF gaussian_renderer/__init__.py:462-598]: boolean-indexed inputs, two 3-channel passes, [1,H,W] uncertainty --
+    oracle on the masked subset, plain and with the mask handed to the operator (fused_mask), forward and backward."""
+    from oracle import surfel_oracle as so
+    from tests.gpu_util import assert_close_frac, assert_grads_close
+    P, W, H = 5000, 176, 104
+    cam = synthetic_camera(W, H, index=1)
+    g, sem, _, _ = _model(P, W, H, 17, DEV)
+    m = torch.rand(P, generator=torch.Generator().manual_seed(2)) > 0.45
+    expect = _oracle_semantics(g, sem, cam, idx=m.numpy())
+    cls_w = torch.tensor([1.0, -0.5, 0.3, 0.8, -1.2, 0.6]).view(6, 1, 1)
+    # oracle gradients: the two passes' gradients add (same geometry, colours are constants)
+    ref = None
+    for i in (0, 3):
+        onehot = np.zeros((P, 3), np.float32)
+        for c in range(3):
+            onehot[sem.numpy() == i + c, c] = 1.0
+        bg = np.zeros(3, np.float32)
+        if i <= 4 < i + 3:
+            bg[4 - i] = 1.0
+        fwd = _oracle(g, cam, bg, 3, idx=m.numpy(), colors=onehot[m.numpy()])
+        bwd = so.rasterize_backward(fwd, np.broadcast_to(cls_w[i:i + 3].numpy(), (3, H, W)).astype(np.float32).copy(), np.zeros((7, H, W), np.float32))
+        ref = bwd if ref is None else {k: ref[k] + bwd[k] for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")}
+    for fused in (False, True):
+        t = {k: v.to(DEV).requires_grad_() for k, v in g.items()}
+        pc = SurfelModel(t["means3D"], t["scales"], t["rotations"], t["opacities"], t["shs"], sem.to(DEV), 3, 3)
+        out = render_semantic_with_mask(cam.to(DEV), pc, PipelineParams(fused_mask=fused), torch.zeros(3, device=DEV), m.to(DEV))
+        assert set(out) == {"render_semantics", "semantic_rgb", "semantic_uncertainty"}
+        assert_close_frac(out["render_semantics"].detach().cpu().numpy(), expect, 1e-4, 1e-4, 2e-4, 2e-2, "masked render_semantics")
+        _check_derived_semantic_maps(out, expect, H, W, lead_axis=True)
+        (out["render_semantics"] * cls_w.to(DEV)).sum().backward()
+        for name, key in (("dL_dmeans3D", "means3D"), ("dL_dopacity", "opacities"), ("dL_dscales", "scales"), ("dL_drotations", "rotations")):
+            got = t[key].grad.cpu().numpy()
+            assert not got[~m.numpy()].any(), name                  # masked-out Gaussians get no gradient
+            assert_grads_close(got[m.numpy()], ref[name], 2e-3, "masked semantic " + name)
+        assert t["shs"].grad is None or not t["shs"].grad.any()      # colours are the one-hot class channels, not the SHs
 
 
 def test_fused_postprocess_matches_torch_restatement():
@@ -153,6 +226,34 @@ def test_fused_postprocess_matches_torch_restatement():
         assert np.abs(ggpu - gref).max() <= 2e-4 * scale, np.abs(ggpu - gref).max() / scale
     with pytest.raises(Exception, match="no CPU path"):
         postprocess_allmap(cam, PipelineParams(), allmap)
+
+
+def test_fused_postprocess_matches_reference_fixture(golden_dir):
+    """csrc/postprocess.hip against tests/golden/reference_render_golden.npz: the dict the reference's own render() /
+    utils.point_utils.depth_to_normal returned for these allmaps, and the gradient its autograd returned."""
+    from streetunveiler_amd.camera import SimpleCamera
+    z = np.load(os.path.join(golden_dir, "reference_render_golden.npz"))
+    maps = ("rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "surf_point")
+    for ci in range(int(z["n_cases"])):
+        pre = f"c{ci}_"
+        W, H, yaw, tx, ty, tz, ratio, fovx, fovy = z[pre + "meta"]
+        W, H = int(W), int(H)
+        cam = SimpleCamera(W, H, float(fovx), float(fovy), torch.tensor(z[pre + "wvt"]).to(DEV), torch.tensor(z[pre + "full"]).to(DEV),
+                           torch.tensor(z[pre + "center"]).to(DEV))
+        for run in ("render", "render_mask"):
+            a = torch.tensor(z[pre + run + "_allmap"]).to(DEV).requires_grad_()
+            out = postprocess_allmap(cam, PipelineParams(depth_ratio=float(ratio)), a)
+            for k in maps:
+                ref = z[pre + run + "_" + k]
+                # where alpha == 0 the reference's surf_normal is 0 * NaN-free values; everything is finite in the fixture
+                np.testing.assert_allclose(out[k].detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()), err_msg=f"{pre}{run} {k}")
+            sum((out[k] * torch.tensor(z[pre + "up_" + k]).to(DEV)).sum() for k in maps).backward()
+            ref = z[pre + run + "_allmap_grad"]
+            got = a.grad.cpu().numpy()
+            fin = np.isfinite(ref)          # the reference's autograd yields NaN (0 * inf) at alpha == 0; the kernel keeps the finite terms
+            assert np.isfinite(got).all() and fin.mean() > 0.8
+            scale = np.abs(ref[fin]).max()
+            assert np.abs(got[fin] - ref[fin]).max() <= 2e-4 * scale, (pre, run, np.abs(got[fin] - ref[fin]).max() / scale)
 
 
 def test_fused_activations_and_ply_checkpoint(tmp_path):

@@ -191,3 +191,48 @@ def test_ply_checkpoint_layout_and_round_trip(tmp_path):
         np.testing.assert_array_equal(back2[k], v)
     with pytest.raises(ValueError):
         load_ply(path, max_sh_degree=2)
+
+
+def test_fused_activations_only_for_models_with_plain_getters(tmp_path):
+    """PipelineParams.fused_activations hands the RAW _opacity/_scaling/_rotation to the operator -- only valid when the model's
+    getters are the plain activations.  A MaskGaussianModel-style model (getters activate `_x + _new_x * mask`
+    [REF scene/mask_gaussian.py:140-176], `_x` frozen) must keep the getter path, or its trainable deltas would be dropped."""
+    from streetunveiler_amd import gaussian_renderer as gr
+
+    class MaskGaussianModel:   # same name and getter structure as the reference class
+        def __init__(self, n):
+            self._xyz = torch.zeros(n, 3)
+            self._opacity, self._new_opacity = torch.zeros(n, 1), torch.full((n, 1), 0.7, requires_grad=True)
+            self._scaling, self._new_scaling = torch.zeros(n, 2), torch.full((n, 2), -1.0, requires_grad=True)
+            self._rotation, self._new_rotation = torch.tensor([[1.0, 0, 0, 0]]).repeat(n, 1), torch.full((n, 4), 0.3, requires_grad=True)
+            self.mask = torch.ones(n)
+        get_xyz = property(lambda s: s._xyz)
+        get_opacity = property(lambda s: torch.sigmoid(s._opacity + s._new_opacity * s.mask[..., None]))
+        get_scaling = property(lambda s: torch.exp(s._scaling + s._new_scaling * s.mask[..., None]))
+        get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation + s._new_rotation * s.mask[..., None]))
+
+    pipe = gr.PipelineParams(fused_activations=True)
+    pc = MaskGaussianModel(5)
+    assert not gr._fused_activations(pc, pipe)
+    means3D, means2D, opacity, scales, rotations, cov = gr._geometry_inputs(pc, pipe, torch.zeros(5, 3), None, 1.0)
+    assert torch.equal(opacity, pc.get_opacity) and torch.equal(scales, pc.get_scaling) and torch.equal(rotations, pc.get_rotation)
+    opacity.sum().backward()
+    assert pc._new_opacity.grad is not None and pc._new_opacity.grad.abs().sum() > 0    # the trainable delta receives the gradient
+
+    class GaussianModel:       # the reference's plain model qualifies by name
+        _opacity = _scaling = _rotation = torch.zeros(1)
+    assert gr._fused_activations(GaussianModel(), pipe)
+    raw = gr.SurfelModel(torch.zeros(2, 3), torch.zeros(2, 2), torch.ones(2, 4), torch.zeros(2, 1), torch.zeros(2, 16, 3), raw=True)
+    act = gr.SurfelModel(torch.zeros(2, 3), torch.ones(2, 2), torch.ones(2, 4), torch.ones(2, 1), torch.zeros(2, 16, 3), raw=False)
+    assert gr._fused_activations(raw, pipe) and not gr._fused_activations(act, pipe)
+    assert not gr._fused_activations(raw, gr.PipelineParams(fused_activations=False))
+    # a checkpoint's SH coefficients are ONE leaf: .grad exists after backward
+    path = os.path.join(tmp_path, "pc.ply")
+    g = torch.Generator().manual_seed(0)
+    src = gr.SurfelModel(torch.randn(7, 3, generator=g), torch.randn(7, 2, generator=g), torch.randn(7, 4, generator=g),
+                         torch.randn(7, 1, generator=g), torch.randn(7, 16, 3, generator=g), torch.arange(7, dtype=torch.int32), raw=True)
+    src.save_ply(path)
+    pc2 = gr.SurfelModel.from_ply(path, device="cpu")
+    assert pc2._features.is_leaf and pc2._features.requires_grad and torch.equal(pc2._features.detach(), src._features)
+    pc2.get_features.square().sum().backward()
+    assert pc2._features.grad is not None

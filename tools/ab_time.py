@@ -1,6 +1,5 @@
 #!/usr/bin/env python
-"""A/B stage timing of the C3 step under library options.  python tools/ab_time.py CODE[,CODE...]
-CODE bits: 1 = quadrant culling on; 0x800 = K6 as one wave per tile; CODE >> 12 = KiB of dynamic LDS per blend wave."""
+"""A/B stage timing of the C3 step with / without the quadrant culling.  python tools/ab_time.py 1,0"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,16 +15,13 @@ s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoV
 m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
 def step():
     for t in list(g.values()) + [m2d]: t.grad = None
-    c, r, a = GaussianRasterizer(s)(means3D=g["means3D"], means2D=m2d, shs=g["shs"], opacities=g["opacities"], scales=g["scales"], rotations=g["rotations"])
+    c, r, a = GaussianRasterizer(s, quadrant_cull=CULL)(means3D=g["means3D"], means2D=m2d, shs=g["shs"], opacities=g["opacities"], scales=g["scales"], rotations=g["rotations"])
     torch.autograd.backward([c, a], [dc, da])
 for cull in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,0").split(",")]:
-    lib.sr_set_option(_lib.SR_OPT_QUADRANT_CULL, cull & 1)
-    lib.sr_set_option(100, (cull >> 4) & 0xFF)
-    lib.sr_set_option(101, cull >> 12)   # KiB of dynamic LDS per blend wave
+    CULL = bool(cull & 1)
     for _ in range(3): step()
     torch.cuda.synchronize(); lib.sr_set_stage_timing(1)
     for _ in range(10): step()
     torch.cuda.synchronize()
     st = _lib.stage_stats(); lib.sr_set_stage_timing(0)
     print(f"cull={cull}", {k: round(ms / n, 4) for k, (ms, n) in st.items() if n})
-lib.sr_set_option(_lib.SR_OPT_QUADRANT_CULL, 1); lib.sr_set_option(100, 0); lib.sr_set_option(101, 0)

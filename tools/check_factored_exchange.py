@@ -33,7 +33,7 @@ def frame(index, exchange, reduce_all=False):
     if exchange:
         with factored_sh_exchange(reduce_all=reduce_all) as ex:
             torch.autograd.backward([color, allmap], [dc, da])
-        assert ex is not None and ex.calls == 1 and ex.bytes_sent == P * 12
+        assert ex is not None and ex.calls == 1 and ex.bytes_sent == P * 12 + (P * 40 if reduce_all else 0) and ex.early_starts == 1
         if not reduce_all:
             allreduce_gradients([t[k].grad for k in names if k != "shs"])
     else:

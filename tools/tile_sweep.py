@@ -16,7 +16,6 @@ s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoV
                                   cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 3, cam.camera_center.to(dev), False, False)
 m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
 rows = []
-lib.sr_set_option(101, int(os.environ.get("SR_BLEND_LDS_KIB", "0")))   # occupancy experiments: extra dynamic LDS per blend wave
 shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ.get("SR_TILES", "8x8,16x8,16x16,32x8,32x16").split(",")]
 for tile in shapes:
     def step():

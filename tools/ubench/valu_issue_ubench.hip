@@ -1,0 +1,67 @@
+// Micro-benchmark: how many wave64 VALU instructions per cycle ONE SIMD sustains as a function of resident waves,
+// in shader cycles (s_memtime), for independent and dependent streams.  Decides whether the blend kernels are at the VALU roof.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_issue_ubench.hip -o /tmp/vi && /tmp/vi
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+constexpr int kUnroll = 8;
+template <int OP, int CH>   // CH independent chains per wave
+__global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, int iters, float a, float b) {
+    float x[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) x[i] = a + threadIdx.x * 1e-3f + i;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+                else if (OP == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "s"(a), "v"(b));
+                else if (OP == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+                else if (OP == 3) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+                else if (OP == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
+                else if (OP == 5) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(x[i]) : "v"(a), "v"(b) : "vcc");
+                else if (OP == 6) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(x[i]));
+                else if (OP == 7) asm volatile("v_mov_b32 %0, %1" : "+v"(x[i]) : "v"(b));
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) s += x[i];
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int OP, int CH> void run(const char* name, float* d, unsigned long long* c, int per_op) {
+    const int iters = 2000;
+    printf("%-22s chains=%d:", name, CH);
+    for (int w : {1, 2, 3, 4, 6, 8}) {
+        const int blocks = 256 * 4 * w;
+        hipLaunchKernelGGL((k<OP, CH>), dim3(blocks), dim3(64), 0, 0, d, c, iters, 1.0001f, 0.5f);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h(blocks);
+        hipMemcpy(h.data(), c, blocks * 8, hipMemcpyDeviceToHost);
+        double mean = 0; for (auto v : h) mean += (double)v; mean /= blocks;
+        // s_memtime counts at a fixed 100 MHz-ish?  report both raw ticks/instr and wall-based rate
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0); hipLaunchKernelGGL((k<OP, CH>), dim3(blocks), dim3(64), 0, 0, d, c, iters, 1.0001f, 0.5f); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double instr_per_simd = (double)w * iters * kUnroll * CH * per_op;
+        printf("  w%d %.2f ns/instr/SIMD (ticks/instr %.2f)", w, ms * 1e6 / instr_per_simd, mean * w / instr_per_simd);
+    }
+    printf("\n");
+}
+int main() {
+    float* d; unsigned long long* c;
+    hipMalloc(&d, 256 * 4 * 8 * 64 * 4); hipMalloc(&c, 256 * 4 * 8 * 8);
+    run<0, 8>("fma vvv", d, c, 1); run<0, 1>("fma vvv", d, c, 1); run<0, 2>("fma vvv", d, c, 1);
+    run<1, 8>("fma svv", d, c, 1);
+    run<2, 8>("mul", d, c, 1);
+    run<3, 8>("exp", d, c, 1); run<4, 8>("rcp", d, c, 1);
+    run<5, 8>("cmp+cndmask(2)", d, c, 2);
+    run<6, 8>("add dpp row_ror", d, c, 1); run<6, 1>("add dpp row_ror", d, c, 1);
+    run<7, 8>("mov", d, c, 1);
+    return 0;
+}
