@@ -1,4 +1,6 @@
 set -x
 cd $GRAFT_REPO_ROOT
-python tools/parity_report.py --gaussians 500000 2>&1 | grep "vs F64\|config" | tail -30
-python -m pytest tests -m gpu -x -q 2>&1 | tail -15
+rm -f gpurun_out/strict_report.jsonl
+SR_PARITY_REPORT=gpurun_out/strict_report.jsonl python -m pytest tests/test_gpu_strict_parity.py -m gpu -q 2>&1 | tail -15
+cat gpurun_out/strict_report.jsonl
+python -m pytest tests -m gpu -x -q 2>&1 | tail -5
