@@ -257,16 +257,18 @@ def geom_view(geom: torch.Tensor, P: int):
     L.check(L.load().sr_geom_view(_ptr(geom), geom.numel(), P, C.byref(v)), "sr_geom_view")
     return dict(splats=_view(geom, v.splats, P * 80, torch.float32).view(P, 20),
                 depth_keys=_view(geom, v.depth_keys, P * 4, torch.int32), tiles_touched=_view(geom, v.tiles_touched, P * 4, torch.int32),
-                clamped=_view(geom, v.clamped, P, torch.uint8), sorted_gid=_view(geom, v.sorted_gid, P * 4, torch.int32),
-                sorted_offsets=_view(geom, v.sorted_offsets, P * 4, torch.int32))
+                clamped=_view(geom, v.clamped, P, torch.uint8), sorted_gid=_view(geom, v.sorted_gid, P * 4, torch.int32))
 
 
 def binning_view(binning: torch.Tensor, P: int, D: int, W: int, H: int, tile=(16, 16)):
     v = L.SrBinningView()
     L.check(L.load().sr_binning_view(_ptr(binning), binning.numel(), P, D, W, H, C.byref(v)), "sr_binning_view")
     tiles = ((W + tile[0] - 1) // tile[0]) * ((H + tile[1] - 1) // tile[1])
-    return dict(tile_keys=_view(binning, v.tile_keys, D * 4, torch.int32), point_list=_view(binning, v.point_list, D * 4, torch.int32),
-                ranges=_view(binning, v.ranges, tiles * 8, torch.int32).view(tiles, 2),
+    ranges = _view(binning, v.ranges, tiles * 8, torch.int32).view(tiles, 2)
+    # tile id of every list entry, rebuilt from the ranges (the partition keeps only the permutation)
+    counts = (ranges[:, 1] - ranges[:, 0]).long()
+    tile_keys = torch.repeat_interleave(torch.arange(tiles, device=binning.device, dtype=torch.int32), counts)
+    return dict(tile_keys=tile_keys, point_list=_view(binning, v.point_list, D * 4, torch.int32), ranges=ranges,
                 tile_order=_view(binning, v.tile_order, tiles * 4, torch.int32))
 
 

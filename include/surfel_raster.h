@@ -129,12 +129,11 @@ typedef struct SrGeomView {
     const uint32_t* tiles_touched; /* [P] */
     const uint8_t* clamped;        /* [P] bit c set when SH colour channel c was clamped at 0 */
     const uint32_t* sorted_gid;    /* [P] Gaussian ids in ascending (depth bits, id) order; culled last */
-    const uint32_t* sorted_offsets;/* [P] inclusive scan of tiles_touched in that order */
 } SrGeomView;
 
 typedef struct SrBinningView {
-    const uint32_t* tile_keys;   /* [D] tile id of every sorted duplicate */
-    const uint32_t* point_list;  /* [D] Gaussian id of every sorted duplicate (tile-major, then depth, then id) */
+    const uint32_t* point_list;  /* [D] Gaussian id of every sorted duplicate (tile-major, then depth, then id); the tile of entry j is
+                                  * the one whose range contains j (the tile ids themselves are not kept after the partition) */
     const uint32_t* ranges;      /* [tiles,2] (begin, end) into point_list; (0,0) for empty tiles */
     const uint32_t* tile_order;  /* [tiles] dispatch order of the blend waves: a permutation, longest list classes first */
 } SrBinningView;

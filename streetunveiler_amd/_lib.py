@@ -38,11 +38,11 @@ class SrGradients(C.Structure):
 
 class SrGeomView(C.Structure):
     _fields_ = [("splats", C.c_void_p), ("depth_keys", C.c_void_p), ("tiles_touched", C.c_void_p), ("clamped", C.c_void_p),
-                ("sorted_gid", C.c_void_p), ("sorted_offsets", C.c_void_p)]
+                ("sorted_gid", C.c_void_p)]
 
 
 class SrBinningView(C.Structure):
-    _fields_ = [("tile_keys", C.c_void_p), ("point_list", C.c_void_p), ("ranges", C.c_void_p), ("tile_order", C.c_void_p)]
+    _fields_ = [("point_list", C.c_void_p), ("ranges", C.c_void_p), ("tile_order", C.c_void_p)]
 
 
 class SrImageView(C.Structure):

@@ -21,16 +21,17 @@ hipError_t launch_sh_gradient_expand(int P, int M, int deg, int V, const float* 
                                      float* dL_dsh, hipStream_t s);
 // binning.hip
 size_t depth_sort_temp_bytes(int P);
+size_t tile_scan_temp_bytes(int P);
 size_t tile_sort_temp_bytes(uint32_t D, int n_tiles);
-hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint32_t* tiles_touched, uint32_t* sorted_keys,
-                          uint32_t* sorted_gid, uint32_t* tt_sorted, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t run_tile_count_scan(int P, const uint32_t* tt_sorted, uint32_t* sorted_offsets, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t run_emit(int P, int tiles_x, const uint2* rect, const uint32_t* sorted_gid, const uint32_t* sorted_offsets,
-                    float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, hipStream_t s);
+hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, uint32_t* sorted_keys,
+                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t run_tile_count_scan(int P, const uint2* rect_sorted, uint32_t* block_offsets, void* block_base, size_t base_bytes, hipStream_t s);
+hipError_t run_emit(int P, int tiles_x, const uint2* rect_sorted, const uint32_t* sorted_gid, const uint32_t* block_offsets,
+                    const uint32_t* block_base, float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* tile_counts,
+                    int n_tiles, hipStream_t s);
 hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
-                         uint32_t* tile_keys, uint32_t* point_list, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t run_tile_ranges(uint32_t D, int n_tiles, const uint32_t* tile_keys, uint2* ranges, hipStream_t s);
-hipError_t run_tile_order(int n_tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
+                         uint32_t* point_list, uint32_t* tile_counts, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t run_tile_ranges_order(int n_tiles, const uint32_t* tile_counts, uint2* ranges, uint32_t* order, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint16_t* hit_mask, int flags,
@@ -45,7 +46,8 @@ hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint32_t* aux_src, uint32_t* aux_out);
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out,
+                            uint32_t* full_hist);
 // knn.hip
 size_t knn_workspace_bytes(int nq, int nr);
 hipError_t knn_mean_dist2(int nq, const float* query, int nr, const float* reference, int K, int take_sqrt, float* out, void* ws,
@@ -126,7 +128,8 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
 
 // ---- buffer layouts ------------------------------------------------------------------------------
 struct GeomLayout {
-    size_t recs, depth_keys, tiles_touched, rect, clamped, sorted_keys, sorted_gid, tt_sorted, sorted_offsets, temp, temp_bytes, total;
+    size_t recs, depth_keys, tiles_touched, rect, clamped, sorted_keys, sorted_gid, rect_sorted, block_offsets, block_base, base_bytes,
+        n_scan_blocks, temp, temp_bytes, total;
 };
 GeomLayout geom_layout(int P) {
     GeomLayout L{};
@@ -140,8 +143,11 @@ GeomLayout geom_layout(int P) {
     L.clamped = take(n);
     L.sorted_keys = take(n * 4);
     L.sorted_gid = take(n * 4);
-    L.tt_sorted = take(n * 4);
-    L.sorted_offsets = take(n * 4);
+    L.rect_sorted = take(n * 8);
+    L.block_offsets = take(n * 4);
+    L.base_bytes = tile_scan_temp_bytes(P);
+    L.block_base = take(L.base_bytes);
+    L.n_scan_blocks = (n + 2047) / 2048;   // the scan's block size (radix_sort.hip kRsTile)
     static thread_local int memo_P = -1;
     static thread_local size_t memo_bytes = 0;
     if (memo_P != P) { memo_bytes = depth_sort_temp_bytes(P); memo_P = P; }
@@ -152,7 +158,7 @@ GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t keys_unsorted, vals_unsorted, tile_keys, point_list, hit_mask, ranges, order, temp, temp_bytes, total;
+    size_t keys_unsorted, vals_unsorted, point_list, hit_mask, ranges, order, tile_counts, temp, temp_bytes, total;
 };
 BinLayout bin_layout(uint32_t D, int W, int H) {
     BinLayout L{};
@@ -162,11 +168,11 @@ BinLayout bin_layout(uint32_t D, int W, int H) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L.keys_unsorted = take(n * 4);
     L.vals_unsorted = take(n * 4);
-    L.tile_keys = take(n * 4);
     L.point_list = take(n * 4);
     L.hit_mask = take(n * 2);
     L.ranges = take((size_t)(tiles > 0 ? tiles : 1) * 8);
     L.order = take((size_t)(tiles > 0 ? tiles : 1) * 4);
+    L.tile_counts = take((size_t)(tiles > 0 ? tiles : 1) * 4);
     static thread_local uint32_t memo_D = 0xFFFFFFFFu;
     static thread_local int memo_tiles = -1;
     static thread_local size_t memo_bytes = 0;
@@ -257,7 +263,7 @@ int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out) {
     if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
     out->splats = at<float>(geom, L.recs); out->depth_keys = at<uint32_t>(geom, L.depth_keys);
     out->tiles_touched = at<uint32_t>(geom, L.tiles_touched); out->clamped = at<uint8_t>(geom, L.clamped);
-    out->sorted_gid = at<uint32_t>(geom, L.sorted_gid); out->sorted_offsets = at<uint32_t>(geom, L.sorted_offsets);
+    out->sorted_gid = at<uint32_t>(geom, L.sorted_gid);
     return SR_OK;
 }
 
@@ -266,7 +272,7 @@ int sr_binning_view(void* binning, size_t binning_bytes, int32_t P, uint32_t D, 
     if (!binning || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     const BinLayout L = bin_layout(D, W, H);
     if (binning_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, L.total);
-    out->tile_keys = at<uint32_t>(binning, L.tile_keys); out->point_list = at<uint32_t>(binning, L.point_list);
+    out->point_list = at<uint32_t>(binning, L.point_list);
     out->ranges = at<uint32_t>(binning, L.ranges); out->tile_order = at<uint32_t>(binning, L.order);
     return SR_OK;
 }
@@ -299,13 +305,13 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     if (int rc = debug_sync(frame, s, "preprocess_forward")) return rc;
     {
         StageTimer t(SR_STAGE_DEPTH_SORT, s);
-        SR_HIP(run_depth_sort(P, at<uint32_t>(geom, L.depth_keys), at<uint32_t>(geom, L.tiles_touched), at<uint32_t>(geom, L.sorted_keys),
-                              at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.tt_sorted), at<void>(geom, L.temp), L.temp_bytes, s));
+        SR_HIP(run_depth_sort(P, at<uint32_t>(geom, L.depth_keys), at<uint2>(geom, L.rect), at<uint32_t>(geom, L.sorted_keys),
+                              at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, s));
     }
     {
         StageTimer t(SR_STAGE_SCAN, s);
-        SR_HIP(run_tile_count_scan(P, at<uint32_t>(geom, L.tt_sorted), at<uint32_t>(geom, L.sorted_offsets), at<void>(geom, L.temp),
-                                   L.temp_bytes, s));
+        SR_HIP(run_tile_count_scan(P, at<uint2>(geom, L.rect_sorted), at<uint32_t>(geom, L.block_offsets), at<void>(geom, L.block_base),
+                                   L.base_bytes, s));
     }
     if (int rc = debug_sync(frame, s, "depth_order")) return rc;
     // the one host read-back of the forward (the reference does the same between scan and duplicateWithKeys)
@@ -314,7 +320,7 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     static thread_local uint32_t* pinned = nullptr;
     if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
     uint32_t* dst = pinned ? pinned : num_rendered_host;
-    SR_HIP(hipMemcpyAsync(dst, at<uint32_t>(geom, L.sorted_offsets) + (P - 1), 4, hipMemcpyDeviceToHost, s));
+    SR_HIP(hipMemcpyAsync(dst, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks, 4, hipMemcpyDeviceToHost, s));   // the scan's grand total
     SR_HIP(hipStreamSynchronize(s));
     if (pinned) *num_rendered_host = *pinned;
     return SR_OK;
@@ -342,22 +348,21 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
         recs = at<float4>(geom, L.recs);
         {
             StageTimer t(SR_STAGE_EMIT, s);
-            SR_HIP(run_emit(P, f.tiles_x, at<uint2>(geom, L.rect), at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.sorted_offsets), recs,
-                            at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted), s));
+            SR_HIP(run_emit(P, f.tiles_x, at<uint2>(geom, L.rect_sorted), at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.block_offsets),
+                            at<uint32_t>(geom, L.block_base), recs, at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
+                            at<uint32_t>(binning, B.tile_counts), n_tiles, s));
         }
         if (int rc = debug_sync(frame, s, "emit_duplicates")) return rc;
-        {
-            StageTimer t(SR_STAGE_TILE_SORT, s);
-            SR_HIP(run_tile_sort(D, n_tiles, at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
-                                 at<uint32_t>(binning, B.tile_keys), at<uint32_t>(binning, B.point_list),
-                                 at<void>(binning, B.temp), B.temp_bytes, s));
-        }
-        if (int rc = debug_sync(frame, s, "tile_sort")) return rc;
     }
     {
+        StageTimer t(SR_STAGE_TILE_SORT, s);
+        SR_HIP(run_tile_sort((P > 0) ? D : 0, n_tiles, at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
+                             at<uint32_t>(binning, B.point_list), at<uint32_t>(binning, B.tile_counts), at<void>(binning, B.temp), B.temp_bytes, s));
+    }
+    if (int rc = debug_sync(frame, s, "tile_sort")) return rc;
+    {
         StageTimer t(SR_STAGE_RANGES, s);
-        SR_HIP(run_tile_ranges((P > 0) ? D : 0, n_tiles, at<uint32_t>(binning, B.tile_keys), at<uint2>(binning, B.ranges), s));
-        SR_HIP(run_tile_order(n_tiles, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), s));
+        SR_HIP(run_tile_ranges_order(n_tiles, at<uint32_t>(binning, B.tile_counts), at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), s));
     }
     if (int rc = debug_sync(frame, s, "tile_ranges")) return rc;
     {
@@ -546,7 +551,7 @@ int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32
     if (n > 0 && (!keys_in || !keys_out || !vals_out || !temp)) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (total_bits < 1 || total_bits > 32) return fail(SR_ERR_INVALID_ARGUMENT, "total_bits %d not in 1..32", total_bits);
     if (temp_bytes < radix_sort_temp_bytes(n)) return fail(SR_ERR_BUFFER_TOO_SMALL, "temp %zu < %zu", temp_bytes, radix_sort_temp_bytes(n));
-    SR_HIP(radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, total_bits, temp, temp_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr));
+    SR_HIP(radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, total_bits, temp, temp_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr, nullptr));
     return SR_OK;
 }
 

@@ -5,7 +5,8 @@
 // (ceil(log2 tiles) bits in 2 passes).  Stability is what makes the final list equal to the reference's
 // 64-bit (tile | depth) sort (binning.hip).
 //
-// One pass = histogram -> two tiny scans -> scatter.  A 256-thread block owns 2048 consecutive items; each
+// One pass = histogram -> one row scan (a block per digit) -> scatter (every scatter block turns the <= 256 row totals into digit
+// bases itself: no third tiny kernel in the dependency chain).  A 256-thread block owns 2048 consecutive items; each
 // wave owns 512 of them and ranks them 64 at a time with the wave64 match-any idiom: `bits` ballots build,
 // for every lane, the mask of lanes holding the same digit; rank = popcount(mask & lanes_below), the run
 // base lives in LDS per (wave, digit).  No atomics on global memory, integer work only, no MFMA.
@@ -18,21 +19,46 @@ constexpr int kRsItems = 8;                       // per thread
 constexpr int kRsTile = kRsThreads * kRsItems;    // 2048 items per block
 constexpr int kRsMaxBins = 256;
 
+// `full_hist` != NULL (last pass of the tile partition): additionally counts the items per FULL key -- the exclusive scan of that
+// histogram is the tile range table, so the sorted keys never have to be written or read back.  At that point the data is already
+// ordered by the key bits below `shift`, a block's 2048 items hold one or two distinct low parts, and the (<= 4 low parts) x
+// (<= 256 digits) counters live in LDS; whatever falls outside (tiny inputs) goes straight to a global atomic.
 __global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, int bits,
-                                                             uint32_t* __restrict__ hist, int nblocks) {
+                                                             uint32_t* __restrict__ hist, int nblocks, uint32_t* __restrict__ full_hist) {
     __shared__ uint32_t s_h[kRsMaxBins];
+    __shared__ uint32_t s_full[4 * kRsMaxBins];
     const int tid = threadIdx.x, bins = 1 << bits;
     const uint32_t mask = (uint32_t)bins - 1u;
     if (tid < bins) s_h[tid] = 0;
-    __syncthreads();
     const uint32_t base = blockIdx.x * (uint32_t)kRsTile;
+    const uint32_t low_mask = (1u << shift) - 1u;
+    uint32_t low_min = 0;
+    if (full_hist) {
+        for (int k = tid; k < 4 * bins; k += kRsThreads) s_full[k] = 0;
+        low_min = keys[base] & low_mask;   // base < n: the grid has ceil(n / tile) blocks
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < kRsItems; ++i) {
         const uint32_t idx = base + (uint32_t)(i * kRsThreads + tid);
-        if (idx < n) atomicAdd(&s_h[(keys[idx] >> shift) & mask], 1u);
+        if (idx < n) {
+            const uint32_t k = keys[idx], d = (k >> shift) & mask;
+            atomicAdd(&s_h[d], 1u);
+            if (full_hist) {
+                const uint32_t rel = (k & low_mask) - low_min;
+                if (rel < 4u) atomicAdd(&s_full[rel * bins + d], 1u);
+                else atomicAdd(&full_hist[k], 1u);
+            }
+        }
     }
     __syncthreads();
     if (tid < bins) hist[(size_t)tid * nblocks + blockIdx.x] = s_h[tid];   // bin-major: row b = per-block counts of digit b
+    if (full_hist) {
+        for (int k = tid; k < 4 * bins; k += kRsThreads) {
+            const uint32_t c = s_full[k];
+            if (c) atomicAdd(&full_hist[((uint32_t)(k & (bins - 1)) << shift) | (low_min + (uint32_t)(k >> bits))], c);
+        }
+    }
 }
 
 // Exclusive scan of every row (one block per digit), row totals out.
@@ -65,26 +91,12 @@ __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __re
     if (tid == 0) row_total[blockIdx.x] = s_carry;
 }
 
-// Exclusive scan of the (<= 256) row totals -> first output position of every digit.
-__global__ __launch_bounds__(kRsMaxBins) void rs_scan_bins_kernel(const uint32_t* __restrict__ row_total, int bins, uint32_t* __restrict__ bin_base) {
-    __shared__ uint32_t s[kRsMaxBins];
-    const int tid = threadIdx.x;
-    s[tid] = tid < bins ? row_total[tid] : 0u;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int b = 0; b < bins; ++b) { const uint32_t c = s[b]; s[b] = run; run += c; }
-    }
-    __syncthreads();
-    if (tid < bins) bin_base[tid] = s[tid];
-}
-
 template <int kBits>   // digit width (compile time: the match-any ballots unroll); 0 = run-time width
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                 uint32_t n, int shift, int bits_rt, const uint32_t* __restrict__ hist,
-                                                                const uint32_t* __restrict__ bin_base, int nblocks,
-                                                                const uint32_t* __restrict__ aux_src, uint32_t* __restrict__ aux_out) {
+                                                                const uint32_t* __restrict__ row_total, int nblocks,
+                                                                const uint2* __restrict__ aux_src, uint2* __restrict__ aux_out) {
     __shared__ uint32_t s_count[kRsThreads / 64][kRsMaxBins];  // items of digit b held by wave w
     __shared__ uint32_t s_run[kRsThreads / 64][kRsMaxBins];    // next block-local slot for (wave, digit)
     __shared__ uint32_t s_lstart[kRsMaxBins];                  // block-local start of digit b
@@ -128,9 +140,23 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         __syncthreads();
         uint32_t off = incl - tot;
         for (int k = 0; k < w; ++k) off += s_wsum[k];
+        // first output position of every digit = exclusive scan of the row totals (<= 256 values, L2-hot: cheaper here, in every
+        // block, than as a kernel of its own between the row scan and this one)
+        const uint32_t rt = tid < bins ? row_total[tid] : 0u;
+        uint32_t rincl = rt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)rincl, d);
+            if (lane >= d) rincl += y;
+        }
+        __syncthreads();   // s_wsum is reused
+        if (lane == 63) s_wsum[w] = rincl;
+        __syncthreads();
+        uint32_t bin_base = rincl - rt;
+        for (int k = 0; k < w; ++k) bin_base += s_wsum[k];
         if (tid < bins) {
             s_lstart[tid] = off;
-            s_gbase[tid] = bin_base[tid] + hist[(size_t)tid * nblocks + blockIdx.x];
+            s_gbase[tid] = bin_base + hist[(size_t)tid * nblocks + blockIdx.x];
             uint32_t run = off;
 #pragma unroll
             for (int k = 0; k < kRsThreads / 64; ++k) { s_run[k][tid] = run; run += s_count[k][tid]; }
@@ -167,18 +193,21 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
             const uint32_t d = (k >> shift) & mask;
             const uint32_t g = s_gbase[d] + (li - s_lstart[d]);
             const uint32_t v = s_val[li];
-            keys_out[g] = k; vals_out[g] = v;
+            if (keys_out) keys_out[g] = k;          // NULL: the caller only wants the permutation (tile partition, last pass)
+            vals_out[g] = v;
             if (aux_out) aux_out[g] = aux_src[v];   // last pass: payload gathered in sorted order (aux_out[i] = aux_src[vals_out[i]])
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Inclusive scan of gathered values: out[i] = sum_{j<=i} src[idx[j]]  (tile counts in depth order, K2).
-// Three small kernels: per-block scan (2048 items) + block totals, scan of the totals, add-back.
+// Tile counts in depth order -> where each Gaussian's duplicates end in emission order (K2).  Two small kernels: an inclusive scan
+// inside every block of 2048 ranks (the count of a rank = area of its packed tile rectangle, which the last pass of the depth sort
+// gathered into depth order) + the block totals; then an exclusive scan of the totals.  The consumer (emit_duplicates_kernel)
+// adds its block's base itself, and totals[nblocks] = D, the number of duplicates, is what the host reads back.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src,
-                                                                 uint32_t n, uint32_t* __restrict__ out, uint32_t* __restrict__ block_total) {
+__global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint2* __restrict__ rect_sorted, uint32_t n, uint32_t* __restrict__ out,
+                                                                 uint32_t* __restrict__ block_total) {
     __shared__ uint32_t s_w[kRsThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t base = blockIdx.x * (uint32_t)kRsTile + (uint32_t)tid * kRsItems;   // 8 consecutive items per thread
@@ -186,8 +215,8 @@ __global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t*
 #pragma unroll
     for (int i = 0; i < kRsItems; ++i) {
         const uint32_t j = base + i;
-        v[i] = j < n ? (idx ? src[idx[j]] : src[j]) : 0u;
-        sum += v[i];
+        const uint32_t wh = j < n ? rect_sorted[j].y : 0u;    // width | height << 16 (0 for culled Gaussians)
+        sum += (wh & 0xFFFFu) * (wh >> 16);
         v[i] = sum;   // inclusive within the thread
     }
     uint32_t incl = sum;
@@ -209,7 +238,7 @@ __global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t*
 }
 
 __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __restrict__ block_total, int nblocks) {
-    // exclusive scan in place, one block, sequential over chunks of 256
+    // exclusive scan in place, one block, sequential over chunks of 256; block_total[nblocks] = grand total
     __shared__ uint32_t s_w[kRsThreads / 64];
     __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -234,17 +263,7 @@ __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __res
         if (tid == kRsThreads - 1) s_carry = carry + wb + incl;
         __syncthreads();
     }
-}
-
-__global__ __launch_bounds__(kRsThreads) void scan_add_kernel(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ block_base) {
-    const uint32_t b = block_base[blockIdx.x];
-    const uint32_t base = blockIdx.x * (uint32_t)kRsTile;
-    if (b == 0) return;
-#pragma unroll
-    for (int i = 0; i < kRsItems; ++i) {
-        const uint32_t j = base + (uint32_t)(i * kRsThreads + threadIdx.x);
-        if (j < n) out[j] += b;
-    }
+    if (tid == 0) block_total[nblocks] = s_carry;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -252,17 +271,20 @@ __global__ __launch_bounds__(kRsThreads) void scan_add_kernel(uint32_t* __restri
 // ---------------------------------------------------------------------------------------------
 static inline int rs_blocks(uint32_t n) { return (int)((n + kRsTile - 1) / kRsTile); }
 
-// scratch: ping-pong (keys, vals) + histogram table + row totals + digit bases
+// scratch: ping-pong (keys, vals) + histogram table + row totals
 size_t radix_sort_temp_bytes(uint32_t n) {
     const size_t nb = (size_t)rs_blocks(n > 0 ? n : 1);
-    return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 2 + align_up(nb * kRsMaxBins * 4, 256) + align_up(kRsMaxBins * 4, 256) * 2;
+    return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 2 + align_up(nb * kRsMaxBins * 4, 256) + align_up(kRsMaxBins * 4, 256);
 }
 
 // Sorts by key bits [0, total_bits) in passes of <= 8 bits (as even as possible); stable; result in keys_out/vals_out.
 // vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.  If aux_out != nullptr the last pass also
-// writes aux_out[i] = aux_src[vals_out[i]] (a payload gathered in sorted order, for free).
+// writes aux_out[i] = aux_src[vals_out[i]] (an 8-B payload gathered in sorted order, for free).  keys_out == nullptr: only the
+// permutation is wanted (the sorted keys are not written).  full_hist != nullptr: the last pass also accumulates the number of
+// items per full key into full_hist[key] (zeroed by the caller).
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint32_t* aux_src, uint32_t* aux_out) {
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out,
+                            uint32_t* full_hist) {
     if (n == 0) return hipSuccess;
     if (temp_bytes < radix_sort_temp_bytes(n)) return hipErrorInvalidValue;
     int passes = (total_bits + 7) / 8;
@@ -273,8 +295,7 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
     uint32_t* tk = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)n * 4, 256);
     uint32_t* tv = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)n * 4, 256);
     uint32_t* hist = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)nb * kRsMaxBins * 4, 256);
-    uint32_t* row_total = reinterpret_cast<uint32_t*>(t); t += align_up(kRsMaxBins * 4, 256);
-    uint32_t* bin_base = reinterpret_cast<uint32_t*>(t);
+    uint32_t* row_total = reinterpret_cast<uint32_t*>(t);
     const uint32_t* ki = keys_in; const uint32_t* vi = vals_in;
     int shift = 0, left = total_bits;
     for (int p = 0; p < passes; ++p) {
@@ -282,14 +303,13 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         int bits = left > 0 ? (left + remaining_passes - 1) / remaining_passes : 1;
         if (bits > 8) bits = 8;
         if (bits < 1) bits = 1;
-        uint32_t* ko = (p & 1) ? keys_out : tk;
-        uint32_t* vo = (p & 1) ? vals_out : tv;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
-        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
-        hipLaunchKernelGGL(rs_scan_bins_kernel, dim3(1), dim3(kRsMaxBins), 0, s, row_total, 1 << bits, bin_base);
         const bool last = p == passes - 1;
+        uint32_t* ko = (p & 1) ? keys_out : tk;   // (last pass: keys_out, possibly NULL)
+        uint32_t* vo = (p & 1) ? vals_out : tv;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb, last ? full_hist : nullptr);
+        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
 #define SR_SCATTER(B) hipLaunchKernelGGL(rs_scatter_kernel<B>, dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
-                                         bin_base, nb, last ? aux_src : nullptr, last ? aux_out : nullptr)
+                                         row_total, nb, last ? aux_src : nullptr, last ? aux_out : nullptr)
         switch (bits) {
             case 8: SR_SCATTER(8); break;
             case 7: SR_SCATTER(7); break;
@@ -303,19 +323,17 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
     return hipGetLastError();
 }
 
-size_t gather_scan_temp_bytes(uint32_t n) { return align_up((size_t)rs_blocks(n > 0 ? n : 1) * 4, 256); }
+size_t tile_count_scan_temp_bytes(uint32_t n) { return align_up(((size_t)rs_blocks(n > 0 ? n : 1) + 1) * 4, 256); }
 
-hipError_t gather_inclusive_scan(const uint32_t* idx, const uint32_t* src, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes,
-                                 hipStream_t s) {
+// out[i] = inclusive scan of the tile counts INSIDE block i / 2048; block_base[b] = exclusive scan of the block totals,
+// block_base[nblocks] = total.  (block_base lives in `temp`.)
+hipError_t tile_count_scan(const uint2* rect_sorted, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    if (temp_bytes < gather_scan_temp_bytes(n)) return hipErrorInvalidValue;
+    if (temp_bytes < tile_count_scan_temp_bytes(n)) return hipErrorInvalidValue;
     const int nb = rs_blocks(n);
     uint32_t* totals = static_cast<uint32_t*>(temp);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(kRsThreads), 0, s, idx, src, n, out, totals);
-    if (nb > 1) {
-        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kRsThreads), 0, s, totals, nb);
-        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(kRsThreads), 0, s, out, n, totals);
-    }
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(kRsThreads), 0, s, rect_sorted, n, out, totals);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kRsThreads), 0, s, totals, nb);
     return hipGetLastError();
 }
 

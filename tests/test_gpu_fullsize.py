@@ -62,7 +62,14 @@ def _properties(P, W, H, check_linearity=True):
     lens = ranges[:, 1] - ranges[:, 0]
     assert int(lens.sum()) == D and (lens >= 0).all()
     nz = lens > 0
-    assert (tile_keys[ranges[nz, 0]] == torch.nonzero(nz).squeeze(1)).all()  # ranges point at their own tile
+    # (the tile ids are rebuilt from the ranges: the partition keeps only the permutation)  every Gaussian appears exactly once in
+    # every tile of its rectangle: as often as K1 counted, and only in tiles its centre +- radius box reaches
+    assert torch.equal(torch.bincount(pl, minlength=P), tiles_touched)
+    rec = gv["splats"]
+    cx, cy, rad = rec[pl, 9], rec[pl, 10], rec[pl, 19]
+    gx = (W + 15) // 16
+    tx, ty = (tile_keys % gx).float(), (tile_keys // gx).float()
+    assert ((cx + rad + 15 >= tx * 16) & (cx - rad < (tx + 1) * 16) & (cy + rad + 15 >= ty * 16) & (cy - rad < (ty + 1) * 16)).all()
     assert torch.isfinite(color).all() and torch.isfinite(allmap).all()
     alpha = allmap[1]
     assert (alpha >= 0).all() and (alpha <= 1 - 1e-4 + 1e-6).all()        # 1 - T with T never below the 1e-4 stop
