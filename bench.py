@@ -4,8 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): 3 M synthetic Gaussians,
+Workload (default = BASELINE.json configs[2], the one the metric is quoted on): 3 M synthetic Gaussians,
 1920x1080, SH degree 3, all 7 aux-map gradients live, inputs resident in HBM before the timed region.
+`--config c2 | c3 | c5` selects a BASELINE configuration as a whole (sizes, live gradients, label); explicit --gaussians /
+--width / --height / --no-aux give a "custom" workload that is labelled as such.
 N > 1: frames shard one-per-GPU (camera k yawed), then ONE gradient all-reduce (58 floats/Gaussian) per step
 over RCCL -- weak scaling, value = P * frames / s summed over ranks.
 Prints ONE JSON line on rank 0.
@@ -29,22 +31,41 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak = 64 FLOP/clk/SIMD (pla
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+# BASELINE.json configs: (Gaussians, width, height, aux gradients live, what BASELINE says)
+CONFIGS = {
+    "c2": (500_000, 1920, 1080, False, "C2: 500k synthetic Gaussians, 1920x1080, SH degree 3, fwd+bwd on 1xMI355X (colour + alpha gradients live)"),
+    "c3": (3_000_000, 1920, 1080, True, "C3: 3M Gaussians, 1920x1080, fwd+bwd with depth/normal aux outputs (all 7 aux-map gradients live)"),
+    "c5": (6_000_000, 3840, 2160, True, "C5 scene on the GPUs given: 6M Gaussians, 3840x2160, SH degree 3 (BASELINE quotes it on 8 GPUs with a tile sweep: tools/tile_sweep.py)"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)   # SURVEY 8d timing protocol: 10 warm-up + 50 timed
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--gaussians", type=int, default=3_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="a BASELINE configuration as a whole (default: c3)")
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--sh-degree", type=int, default=3)
-    ap.add_argument("--no-aux", action="store_true", help="C2 variant: only colour + alpha gradients live")
+    ap.add_argument("--no-aux", action="store_true", help="only colour + alpha gradients live (as in C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", choices=["factored", "allreduce"], default="factored",
                     help="N > 1 gradient exchange: factored = all-gather 12-B colour gradients + local SH expansion + all-reduce of "
                          "the other 40 B/Gaussian; allreduce = plain all-reduce of all 232 B/Gaussian")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-oracle work for the cpu_baseline leg")
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-oracle work for the cpu_baseline leg")
+    a = ap.parse_args()
+    custom = any(v is not None for v in (a.gaussians, a.width, a.height)) or (a.no_aux and a.config is None)
+    P, W, H, aux, label = CONFIGS[a.config or "c3"]
+    a.gaussians = a.gaussians if a.gaussians is not None else P
+    a.width = a.width if a.width is not None else W
+    a.height = a.height if a.height is not None else H
+    a.no_aux = a.no_aux or not aux
+    a.tag = "custom" if custom and (a.gaussians, a.width, a.height, not a.no_aux) != (P, W, H, aux) else (a.config or "c3")
+    a.label = label if a.tag != "custom" else (f"custom: {a.gaussians} synthetic Gaussians, {a.width}x{a.height}, SH degree {a.sh_degree}, fwd+bwd, "
+                                               f"{'colour+alpha' if a.no_aux else 'all 7 aux-map'} gradients live")
+    return a
 
 
 def algorithmic_bytes(P, V, D, npx, deg):
@@ -59,22 +80,57 @@ def algorithmic_bytes(P, V, D, npx, deg):
     }
 
 
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json:
-    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md
-    prescribes).  PMC counters cannot be read from inside the timed run, so this is the last profiled value for the
-    default C3 workload; None for any other workload."""
-    if (args.gaussians, args.width, args.height, args.sh_degree, args.no_aux) != (3_000_000, 1920, 1080, 3, False):
+def profiled(kind, args):
+    """Latest committed rocprofv3 summary of THIS workload (profiles/rNN_<tag>_<kind>.json, e.g. r02_c3_hbm_traffic.json; the
+    round-1 files carry no tag and are C3).  PMC counters cannot be read from inside the timed run, so bench.py quotes the last
+    profiled value of the same command; None for a workload that has no committed profile."""
+    if args.tag == "custom" or args.sh_degree != 3:
         return None, None
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.tag}_{kind}.json")))
+    if not files and args.tag == "c3":
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{kind}.json")))
     if not files:
         return None, None
     try:
-        d = json.load(open(files[-1]))["kernels"]
-        return d["sr::" + kernel]["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+        return json.load(open(files[-1]))["kernels"], os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel`: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, corrected as MI355X_MICROARCH.md
+    prescribes (tools/collect_profiles.py)."""
+    d, src = profiled("hbm_traffic", args)
+    try:
+        return d["sr::" + kernel]["traffic_bytes_per_launch"], src
+    except Exception:
+        return None, None
+
+
+# Measured VALU issue cost per wave64 instruction and SIMD on MI355X (tools/ubench/valu_issue_ubench.hip, >= 2 waves per SIMD,
+# profiles/r02_valu_issue_ubench.txt): plain FP32 ops 1.05-1.3 ns (VOP2 v_mul / v_fmac 1.05, VOP3 v_fma 1.17-1.3, cmp + cndmask
+# 1.35), an SGPR source operand 1.75, DPP 1.8, v_rcp / v_exp 3.4, v_permlane32_swap 3.9.  The datasheet's 2 cycles (0.83 ns at
+# 2.4 GHz) per instruction are not reached by any of them: plain v_fma_f32 tops out at 103 TFLOP/s of the 157 TFLOP/s spec.
+VALU_NS = {"plain": 1.25, "trans": 3.4, "dpp": 1.8, "swap": 3.9}
+
+
+def valu_issue_roof(kernel, ms, args):
+    """Fraction of the measured VALU issue roof: the kernel's instruction counts (committed SQ counter pass) priced with VALU_NS,
+    spread over the chip's 1024 SIMDs, against its measured duration."""
+    d, src = profiled("sq_counters", args)
+    try:
+        k = d["sr::" + kernel]
+        n, trans = k["SQ_INSTS_VALU"], k.get("SQ_INSTS_VALU_TRANS_F32", 0)
+        # cross-lane ops of the blend backward's per-entry reduction: 18 half / row-pair swaps and ~15 DPP ops per list entry with a hit
+        swaps = dpp = 0
+        floor_ms = ((n - trans - swaps - dpp) * VALU_NS["plain"] + trans * VALU_NS["trans"]) / 1024 * 1e-6
+        return {"valu_insts_per_launch": int(n), "transcendental": int(trans), "ns_per_inst_per_simd": round(ms * 1e6 * 1024 / n, 3),
+                "issue_floor_ms": round(floor_ms, 4), "frac_of_issue_roof": round(floor_ms / ms, 4), "source": src,
+                "how": "instructions x measured issue cost (plain 1.25 ns, transcendental 3.4 ns per wave64 instruction and SIMD; "
+                       "swaps / DPP priced as plain = a lower bound of the floor) / 1024 SIMDs, vs the measured launch duration"}
+    except Exception:
+        return None
 
 
 def cpu_baseline(args, g, cam, dc, da):
@@ -87,7 +143,7 @@ def cpu_baseline(args, g, cam, dc, da):
               image_height=args.height, sh_degree=args.sh_degree)
     best = None
     spent = 0.0
-    for n in (25_000, 100_000, 400_000, 1_600_000):
+    for n in (25_000, 100_000, 400_000, 1_600_000, args.gaussians):
         n = min(n, args.gaussians)
         sub = {k: v[:n].numpy() for k, v in g.items()}
         t0 = time.perf_counter()
@@ -96,12 +152,13 @@ def cpu_baseline(args, g, cam, dc, da):
         dt = time.perf_counter() - t0
         spent += dt
         best = (n, dt, fwd["num_rendered"])
-        if dt * 4 + spent > args.cpu_seconds * 1.5 or n == args.gaussians:
+        nxt = {25_000: 100_000, 100_000: 400_000, 400_000: 1_600_000}.get(n, args.gaussians)
+        if n == args.gaussians or dt * (min(nxt, args.gaussians) / n) + spent > args.cpu_seconds * 1.5:
             break
     n, dt, D = best
     return {"value": n / dt / 1e6, "unit": "Msplats/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/surfel_oracle.c fwd+bwd, first {n} Gaussians of the same scene at {args.width}x{args.height} "
-                      f"(D={D}), {dt:.1f} s wall, OpenMP {threads} threads"}
+            "sample": (f"oracle/surfel_oracle.c fwd+bwd, " + ("the whole scene" if n == args.gaussians else f"first {n} Gaussians of the same scene")
+                       + f" at {args.width}x{args.height} (D={D}), {dt:.1f} s wall, OpenMP {threads} threads")}
 
 
 def main():
@@ -133,6 +190,8 @@ def main():
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     leaves = [params["means3D"], params["shs"], params["opacities"], params["scales"], params["rotations"], means2D]
 
+    exchange_log = {"ms": 0.0, "bytes": 0, "calls": 0, "early_starts": 0}
+
     def step():
         for t in leaves:
             t.grad = None
@@ -141,12 +200,17 @@ def main():
         if world > 1 and args.exchange == "factored":
             # SH gradient: all-gather of the 12-B colour gradients + local expansion; the other 40 B/Gaussian: one
             # all-reduce, queued behind it inside backward -- every gradient leaves backward summed over the ranks
-            with factored_sh_exchange(all_campos=all_campos, reduce_all=True):
+            with factored_sh_exchange(all_campos=all_campos, reduce_all=True) as ex:
                 torch.autograd.backward([color, allmap], [dc, da])
+            exchange_log["ms"] += ex.exchange_ms; exchange_log["bytes"] += ex.bytes_sent; exchange_log["calls"] += ex.calls
+            exchange_log["early_starts"] += ex.early_starts
         else:
             torch.autograd.backward([color, allmap], [dc, da])
             if world > 1:
+                t0 = time.perf_counter()
                 allreduce_gradients([t.grad for t in leaves[:5]])   # 232 B/Gaussian, one collective over the flat buffer
+                exchange_log["ms"] += (time.perf_counter() - t0) * 1e3; exchange_log["calls"] += 1
+                exchange_log["bytes"] += sum(t.grad.numel() * 4 for t in leaves[:5])
         return radii
 
     # scene statistics (outside the timed region)
@@ -174,6 +238,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange_check = None
+
     if world > 1:   # bring the communicator up before anything is timed, whatever --warmup says
         w = torch.zeros(1024, device=dev); wg = torch.empty(1024 * world, device=dev)
         dist.all_reduce(w); dist.all_gather_into_tensor(wg, w)
@@ -184,6 +250,14 @@ def main():
             try:
                 step()
                 sync()
+                # self-check of the collective path on its first real outing (RCCL over xGMI has only ever been exercised by the
+                # driver's multi-GPU run): the factored exchange must give the gradients of the plain all-reduce
+                fact = [t.grad.clone() for t in leaves[:5]]
+                args.exchange = "allreduce"; step(); sync(); args.exchange = "factored"
+                worst = max(float((a - t.grad).abs().max() / (t.grad.abs().max() + 1e-30)) for a, t in zip(fact, leaves[:5]))
+                exchange_check = {"factored_vs_allreduce_max_rel_err": worst, "ok": bool(worst < 1e-4)}
+                if not exchange_check["ok"]:
+                    raise RuntimeError(f"factored exchange disagrees with the plain all-reduce ({worst:.2e})")
             except Exception as e:   # noqa: BLE001
                 print(f"[rank {rank}] factored exchange unavailable ({type(e).__name__}: {e}); using all-reduce", file=sys.stderr, flush=True)
                 args.exchange = "allreduce"
@@ -191,6 +265,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    exchange_log.update(ms=0.0, bytes=0, calls=0, early_starts=0)
     # Timed region: HIP events around the two blend kernels only (the roofline kernels; a pair of events costs a few
     # microseconds of stream time, all nine stages would add ~1.4 % to the step).  The other stages are timed right after
     # the timed region, on extra untimed steps.
@@ -204,6 +279,7 @@ def main():
         marks[k + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    timed_exchange = dict(exchange_log)
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4)
     stats = _lib.stage_stats()
@@ -244,20 +320,25 @@ def main():
                 "lane_utilisation": round(blend_counts["contributing_pairs"] / lane_tests, 4) if lane_tests else None,
                 "issued": None if issued is None else round(issued, 2), "issued_frac": None if issued is None else round(issued / FP32_VALU_PEAK_TFLOPS, 4),
                 "useful": None if useful is None else round(useful, 2), "useful_frac": None if useful is None else round(useful / FP32_VALU_PEAK_TFLOPS, 4),
-                "note": "issued = 64 lanes x quadrant tests, useful = pairs that contribute; the kernels are bound by VALU issue and latency, "
-                        "not by memory (profiles/r01_sq_counters.json, DESIGN.md 4",
+                "issue_roof": {"render_forward_kernel": valu_issue_roof("render_forward_kernel", group_ms["blend_fwd"], args),
+                               "render_backward_kernel": valu_issue_roof("render_backward_kernel", group_ms["blend_bwd"], args)},
+                "note": "issued = 64 lanes x quadrant tests, useful = pairs that contribute; the kernels are bound by VALU instruction issue "
+                        "(issue_roof: instruction counts priced with the measured per-instruction issue cost), not by memory (DESIGN.md 4)",
                 "D_eff_blend_bytes": blend_counts["staged_entries_D_eff"] * 296 + npx * 160}
         out = {
-            "metric": "Msplats/s fwd+bwd @1920x1080, 3M Gaussians", "value": round(value, 3), "unit": "Msplats/s",
+            "metric": f"Msplats/s fwd+bwd @{W}x{H}, {P / 1e6:g}M Gaussians", "value": round(value, 3), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "step_ms_percentiles": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3: {P} synthetic Gaussians, {W}x{H}, SH degree {deg}, fwd+bwd, "
-                                   f"{'colour+alpha' if args.no_aux else 'all 7 aux-map'} gradients live",
+            "config": {"workload": args.label, "baseline_config": args.tag,
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D, "visible_per_P": round(V / P, 4), "D_per_P": round(D / P, 3),
                        "frames_per_step": world, "parallelism": f"frame-sharded dp{world}" if world > 1 else "single GPU",
-                       **({"gradient_exchange": ("all-gather of 12-B colour gradients + local SH expansion + all-reduce of 40 B/Gaussian"
-                                                 if args.exchange == "factored" else "all-reduce of 232 B/Gaussian")} if world > 1 else {})},
+                       **({"gradient_exchange": ("all-gather of 12-B colour gradients (started between K7 and K8) + local SH expansion + "
+                                                 "all-reduce of 40 B/Gaussian" if args.exchange == "factored" else "all-reduce of 232 B/Gaussian"),
+                           "exchange_ms_per_step_rank0_host_wait": round(timed_exchange["ms"] / args.steps, 4),
+                           "exchange_bytes_sent_per_step_rank0": int(timed_exchange["bytes"] / args.steps),
+                           "exchange_early_starts_per_step": timed_exchange["early_starts"] / args.steps,
+                           "exchange_selfcheck": exchange_check} if world > 1 else {})},
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": None if ach is None else round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 5),

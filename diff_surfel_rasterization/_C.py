@@ -201,6 +201,64 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
 
 
+def class_distortions(bg, means3D, classes, opacities, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                      image_height, image_width, campos, n_classes, debug=False, activations=0, mask=None):
+    """Per-class distortion pass, forward (sr_forward_plan + sr_class_forward_render): `classes` [P] integer class of every
+    Gaussian (negative or >= n_classes: in no class).  -> (num_rendered, dist[n_classes,H,W], radii, class_cols, geom, binning, class_image)."""
+    lib = L.load()
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise L.SurfelRasterError("means3D must have dimensions (num_points, 3)")
+    means3D = _f32c(means3D, "means3D"); opacities = _f32c(opacities, "opacities"); scales = _f32c(scales, "scales"); rotations = _f32c(rotations, "rotations")
+    dev = means3D.device
+    P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
+    if classes.numel() != P:
+        raise L.SurfelRasterError("classes must have one entry per Gaussian")
+    cols = torch.zeros((P, 3), dtype=torch.float32, device=dev)     # class id in the first colour slot of the splat record
+    cols[:, 0] = classes.to(device=dev, dtype=torch.float32).reshape(P)
+    with torch.cuda.device(dev):
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, 0, campos, False, debug)
+        mask = _mask(mask, P, dev)
+        g = _gaussians(means3D, opacities, scales, rotations, None, cols, None, activations, mask)
+        dist = torch.empty((int(n_classes), H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty((lib.sr_geom_bytes(P),), dtype=torch.uint8, device=dev)
+        cimg = torch.empty((lib.sr_class_image_bytes(W, H, int(n_classes)),), dtype=torch.uint8, device=dev)
+        stream = _stream(dev)
+        D = C.c_uint32(0)
+        L.check(lib.sr_forward_plan(C.byref(fr), C.byref(g), _ptr(geom), geom.numel(), _ptr(radii), C.byref(D), stream), "sr_forward_plan")
+        num_rendered = int(D.value)
+        binning = torch.empty((lib.sr_binning_bytes(P, num_rendered, W, H),), dtype=torch.uint8, device=dev)
+        L.check(lib.sr_class_forward_render(C.byref(fr), C.byref(g), int(n_classes), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
+                                            _ptr(cimg), cimg.numel(), num_rendered, _ptr(dist), stream), "sr_class_forward_render")
+    del keep
+    return num_rendered, dist, radii, cols, geom, binning, cimg
+
+
+def class_distortions_backward(bg, means3D, radii, cols, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                               dL_ddist, campos, n_classes, geom, num_rendered, binning, cimg, debug=False, activations=0):
+    """-> (dL_dmeans2D[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dscales[P,2], dL_drotations[P,4]) of the per-class pass."""
+    lib = L.load()
+    means3D = _f32c(means3D, "means3D"); scales = _f32c(scales, "scales"); rotations = _f32c(rotations, "rotations")
+    dL_ddist = _f32c(dL_ddist, "dL_ddist")
+    dev = means3D.device
+    P = int(means3D.shape[0])
+    H, W = int(dL_ddist.shape[1]), int(dL_ddist.shape[2])
+    with torch.cuda.device(dev):
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, 0, campos, False, debug)
+        g = _gaussians(means3D, means3D, scales, rotations, None, cols, None, activations)
+        flat = torch.empty(P * 10, dtype=torch.float32, device=dev)     # means3D | opacity | scales | rotations: one buffer, one all-reduce
+        dL_dmeans3D, dL_dopacity = flat[:3 * P].view(P, 3), flat[3 * P:4 * P].view(P, 1)
+        dL_dscales, dL_drotations = flat[4 * P:6 * P].view(P, 2), flat[6 * P:].view(P, 4)
+        dL_dmeans2D = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered), 3),), dtype=torch.uint8, device=dev)
+        grads = L.SrGradients(_ptr(dL_dmeans2D), None, _ptr(dL_dopacity), _ptr(dL_dmeans3D), None, None, _ptr(dL_dscales), _ptr(dL_drotations))
+        L.check(lib.sr_class_backward(C.byref(fr), C.byref(g), int(n_classes), _ptr(radii), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
+                                      _ptr(cimg), cimg.numel(), int(num_rendered), _ptr(dL_ddist), _ptr(ws), ws.numel(), C.byref(grads),
+                                      _stream(dev)), "sr_class_backward")
+    del keep
+    return dL_dmeans2D, dL_dopacity, dL_dmeans3D, dL_dscales, dL_drotations
+
+
 def pair_decisions(bg, means3D, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, degree, campos,
                    geomBuffer, num_rendered, binningBuffer, tile=None):
     """Test hook (sr_debug_pair_decisions): -> (valid[D, nq] int64, use3d[D, nq] int64) ballots per (list entry, 8x8 quadrant)."""

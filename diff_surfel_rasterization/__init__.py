@@ -127,6 +127,30 @@ class _RasterizeGaussians(torch.autograd.Function):
                 none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None, None, None)
 
 
+class _ClassDistortions(torch.autograd.Function):
+    """The per-class distortion pass (include/surfel_raster.h, sr_class_forward_render / sr_class_backward)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, scales, rotations, classes, n_classes, raster_settings, activations, mask):
+        s = raster_settings
+        num_rendered, dist, radii, cols, geom, binning, cimg = _C.class_distortions(
+            s.bg, means3D, classes, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
+            s.image_height, s.image_width, s.campos, n_classes, s.debug, activations, mask)
+        ctx.raster_settings, ctx.num_rendered, ctx.n_classes, ctx.activations = s, num_rendered, int(n_classes), int(activations)
+        ctx.save_for_backward(means3D, scales, rotations, radii, cols, geom, binning, cimg)
+        ctx.mark_non_differentiable(radii)
+        return dist, radii
+
+    @staticmethod
+    def backward(ctx, grad_dist, grad_radii):
+        s = ctx.raster_settings
+        means3D, scales, rotations, radii, cols, geom, binning, cimg = ctx.saved_tensors
+        g2d, gop, g3d, gsc, grot = _C.class_distortions_backward(
+            s.bg, means3D, radii, cols, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
+            grad_dist, s.campos, ctx.n_classes, geom, ctx.num_rendered, binning, cimg, s.debug, ctx.activations)
+        return g3d, g2d, gop, gsc, grot, None, None, None, None, None
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False, tile=None, quadrant_cull: bool = True,
                  blend_counters=None):
@@ -151,6 +175,14 @@ class GaussianRasterizer(nn.Module):
         with torch.no_grad():
             s = self.raster_settings
             return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
+
+    def class_distortions(self, means3D, means2D, opacities, scales, rotations, classes, n_classes, mask=None):
+        """Extension: the distortion maps of the class-filtered renders of ONE view in one pass.
+        `classes` [P] integer class per Gaussian (negative / >= n_classes: in no class).  Returns (dist[n_classes,H,W], radii[P]);
+        dist[k] == allmap[6] of this operator called on the Gaussians of class k only, differentiable w.r.t. means3D, means2D
+        (densification proxy), opacities, scales, rotations.  16x16 tile, n_classes <= 6."""
+        return _ClassDistortions.apply(means3D, means2D, opacities, scales, rotations, classes, int(n_classes), self.raster_settings,
+                                       self.activations, mask)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, mask=None, extra_colors=None):

@@ -195,6 +195,24 @@ int sr_backward_geometry(const SrFrame* frame, const SrGaussians* g, const int32
                          void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered, void* workspace,
                          size_t workspace_bytes, const SrGradients* grads, void* stream);
 
+/* Per-class distortion pass.  The reference's training iteration renders the same view once per semantic class
+ * with the other classes boolean-indexed away and keeps only `rend_dist` of each (/root/reference/train.py:94-103 ->
+ * gaussian_renderer/__init__.py:89-105, 165): five full rasterizations for five distortion maps.  This pass runs K1..K5 once and
+ * returns all maps: out_dist[k] == allmap[6] of the operator called on the class-k subset (same list order, same thresholds, same
+ * early termination per class), and the backward returns the gradients of all of them together.
+ *   - class ids: colors_precomp[P,3], column 0 holds the class of a Gaussian as a float (0 .. n_classes-1; negative or >= n_classes =
+ *     in no class, contributes nowhere); shs must be NULL.  sr_forward_plan is called first, exactly as for a render.
+ *   - class_image: sr_class_image_bytes(W, H, n_classes) bytes of caller-owned state between forward and backward.
+ *   - out_dist / dL_ddist: [n_classes, H, W].  grads: as sr_backward (dL_dcolors / dL_dsh are not produced: pass NULL).
+ *   - 16x16 tile only; 1 <= n_classes <= 6. */
+size_t sr_class_image_bytes(int32_t image_width, int32_t image_height, int32_t n_classes);
+int sr_class_forward_render(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, void* geom, size_t geom_bytes, void* binning,
+                            size_t binning_bytes, void* class_image, size_t class_image_bytes, uint32_t num_rendered, float* out_dist,
+                            void* stream);
+int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, const int32_t* radii, void* geom, size_t geom_bytes,
+                      void* binning, size_t binning_bytes, void* class_image, size_t class_image_bytes, uint32_t num_rendered,
+                      const float* dL_ddist, void* workspace, size_t workspace_bytes, const SrGradients* grads, void* stream);
+
 /* Frame-parallel SH gradient (no reference counterpart -- the reference is single-GPU).  The SH adjoint is
  * linear in the clamp-masked colour gradient and its only other per-view input is the camera position, so ranks that
  * rendered n_views frames of the SAME Gaussians all-gather dL_dcolors (12 B/Gaussian) instead of all-reducing dL_dsh

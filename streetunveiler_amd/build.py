@@ -29,11 +29,12 @@ SOURCES = [
     ("binning.hip", []),
     ("radix_sort.hip", []),
     ("render.hip", []),
+    ("render_class.hip", []),
     ("postprocess.hip", []),
     ("knn.hip", ["-ffp-contract=off"]),         # squared distances bit-identical to the brute-force oracle
     ("api.hip", []),
 ]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "surfel_raster.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "blend_common.h"), os.path.join(os.path.dirname(HERE), "include", "surfel_raster.h")]
 
 
 def _stale(target: str, deps) -> bool:

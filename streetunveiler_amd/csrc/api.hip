@@ -41,6 +41,12 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
                                   const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s);
 hipError_t launch_pair_decisions(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                  unsigned long long* valid_bits, unsigned long long* use3d_bits, hipStream_t s);
+hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list,
+                                const float4* recs, float* out_dist, float* cls_state, uint32_t* cls_last, uint32_t* tile_total, uint16_t* hit_mask,
+                                int cull, hipStream_t s);
+hipError_t launch_class_backward(const FrameDev& f, int n_classes, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list,
+                                 const float4* recs, const float* cls_state, const uint32_t* cls_last, const uint32_t* tile_total,
+                                 const float* dL_ddist, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s);
 hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii, const uint8_t* clamped, const float4* recs, const float4* inst_grads,
                                   const uint8_t* written, const uint32_t* tiles_touched, bool mask_clamped, float* dL_dcolors, hipStream_t s);
 // radix_sort.hip
@@ -326,26 +332,19 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     return SR_OK;
 }
 
-int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning,
-                      size_t binning_bytes, void* image, size_t image_bytes, uint32_t D, float* out_color,
-                      float* out_allmap, void* stream) {
-    if (int rc = check_common(frame, g)) return rc;
-    if (!binning || !image || !out_color || !out_allmap) return fail(SR_ERR_INVALID_ARGUMENT, "binning / image / out_color / out_allmap is NULL");
+namespace {
+// K3..K5 (duplicate emission, tile partition, tile ranges + dispatch order): shared by the blend forward and the per-class pass
+int bin_duplicates(const SrFrame* frame, const SrGaussians* g, const FrameDev& f, void* geom, size_t geom_bytes, void* binning, const BinLayout& B,
+                   uint32_t D, hipStream_t s, float4** recs_out) {
     const int P = g->P;
-    const int W = frame->image_width, H = frame->image_height;
-    const BinLayout B = bin_layout(D, W, H);
-    const ImgLayout I = img_layout(W, H);
-    if (binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, B.total);
-    if (image_bytes < I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, I.total);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const FrameDev f = make_frame(frame, g);
     const int n_tiles = f.tiles_x * f.tiles_y;
-    float4* recs = nullptr;
+    *recs_out = nullptr;
     if (P > 0 && D > 0) {
         if (!geom) return fail(SR_ERR_INVALID_ARGUMENT, "geom is NULL");
         const GeomLayout L = geom_layout(P);
         if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
-        recs = at<float4>(geom, L.recs);
+        float4* recs = at<float4>(geom, L.recs);
+        *recs_out = recs;
         {
             StageTimer t(SR_STAGE_EMIT, s);
             SR_HIP(run_emit(P, f.tiles_x, at<uint2>(geom, L.rect_sorted), at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.block_offsets),
@@ -364,7 +363,46 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
         StageTimer t(SR_STAGE_RANGES, s);
         SR_HIP(run_tile_ranges_order(n_tiles, at<uint32_t>(binning, B.tile_counts), at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), s));
     }
-    if (int rc = debug_sync(frame, s, "tile_ranges")) return rc;
+    return debug_sync(frame, s, "tile_ranges");
+}
+
+struct ClassLayout { size_t state, last, tile_total, total; };
+ClassLayout class_layout(int W, int H, int n_classes) {
+    ClassLayout L{};
+    const size_t hw = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1), n = (size_t)(n_classes > 0 ? n_classes : 1);
+    const size_t tiles = (size_t)((W + kTile - 1) / kTile) * (size_t)((H + kTile - 1) / kTile);
+    L.state = 0;
+    L.last = align_up(n * 3 * hw * 4, 256);
+    L.tile_total = L.last + align_up(n * hw * 4, 256);
+    L.total = L.tile_total + align_up((tiles > 0 ? tiles : 1) * n * 4, 256);
+    return L;
+}
+
+int check_class_pass(const SrFrame* frame, const SrGaussians* g, int n_classes) {
+    if (int rc = check_common(frame, g)) return rc;
+    if (n_classes < 1 || n_classes > 6) return fail(SR_ERR_UNSUPPORTED, "n_classes %d not in 1..6", n_classes);
+    const int tw = frame->tile_width > 0 ? frame->tile_width : kTile, th = frame->tile_height > 0 ? frame->tile_height : kTile;
+    if (tw != 16 || th != 16) return fail(SR_ERR_UNSUPPORTED, "the per-class distortion pass is built for the 16x16 tile");
+    if (g->P > 0 && (g->shs || !g->colors_precomp || (g->color_channels != 0 && g->color_channels != 3)))
+        return fail(SR_ERR_INVALID_ARGUMENT, "the per-class distortion pass takes the class ids in colors_precomp[P,3] (column 0), no SHs");
+    return SR_OK;
+}
+}  // namespace
+
+int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning,
+                      size_t binning_bytes, void* image, size_t image_bytes, uint32_t D, float* out_color,
+                      float* out_allmap, void* stream) {
+    if (int rc = check_common(frame, g)) return rc;
+    if (!binning || !image || !out_color || !out_allmap) return fail(SR_ERR_INVALID_ARGUMENT, "binning / image / out_color / out_allmap is NULL");
+    const int W = frame->image_width, H = frame->image_height;
+    const BinLayout B = bin_layout(D, W, H);
+    const ImgLayout I = img_layout(W, H);
+    if (binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, B.total);
+    if (image_bytes < I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, I.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame(frame, g);
+    float4* recs = nullptr;
+    if (int rc = bin_duplicates(frame, g, f, geom, geom_bytes, binning, B, D, s, &recs)) return rc;
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
         const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0);
@@ -373,6 +411,65 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
                                      reinterpret_cast<unsigned long long*>(frame->blend_counters), s));
     }
     return debug_sync(frame, s, "render_forward");
+}
+
+size_t sr_class_image_bytes(int32_t W, int32_t H, int32_t n_classes) { return class_layout(W, H, n_classes).total; }
+
+int sr_class_forward_render(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, void* geom, size_t geom_bytes, void* binning,
+                            size_t binning_bytes, void* class_image, size_t class_image_bytes, uint32_t D, float* out_dist, void* stream) {
+    if (int rc = check_class_pass(frame, g, n_classes)) return rc;
+    if (!binning || !class_image || !out_dist) return fail(SR_ERR_INVALID_ARGUMENT, "binning / class_image / out_dist is NULL");
+    const int W = frame->image_width, H = frame->image_height;
+    const BinLayout B = bin_layout(D, W, H);
+    const ClassLayout C = class_layout(W, H, n_classes);
+    if (binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, B.total);
+    if (class_image_bytes < C.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "class image buffer %zu < %zu", class_image_bytes, C.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame(frame, g);
+    float4* recs = nullptr;
+    if (int rc = bin_duplicates(frame, g, f, geom, geom_bytes, binning, B, D, s, &recs)) return rc;
+    {
+        StageTimer t(SR_STAGE_BLEND_FWD, s);
+        SR_HIP(launch_class_forward(f, n_classes, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), recs, out_dist,
+                                    at<float>(class_image, C.state), at<uint32_t>(class_image, C.last), at<uint32_t>(class_image, C.tile_total),
+                                    at<uint16_t>(binning, B.hit_mask), (frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1, s));
+    }
+    return debug_sync(frame, s, "class_forward");
+}
+
+int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, const int32_t* radii, void* geom, size_t geom_bytes,
+                      void* binning, size_t binning_bytes, void* class_image, size_t class_image_bytes, uint32_t D, const float* dL_ddist,
+                      void* workspace, size_t workspace_bytes, const SrGradients* grads, void* stream) {
+    if (int rc = check_class_pass(frame, g, n_classes)) return rc;
+    if (!grads) return fail(SR_ERR_INVALID_ARGUMENT, "grads is NULL");
+    const int P = g->P;
+    if (P == 0) return SR_OK;
+    if (!radii || !geom || !binning || !class_image || !dL_ddist || !workspace) return fail(SR_ERR_INVALID_ARGUMENT, "NULL buffer argument");
+    const int W = frame->image_width, H = frame->image_height;
+    const GeomLayout L = geom_layout(P);
+    const BinLayout B = bin_layout(D, W, H);
+    const ClassLayout C = class_layout(W, H, n_classes);
+    if (geom_bytes < L.total || binning_bytes < B.total || class_image_bytes < C.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "state buffer too small");
+    if (workspace_bytes < sr_backward_workspace_bytes(P, D, 3)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P, D, 3));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame(frame, g);
+    float4* inst_grads = static_cast<float4*>(workspace);
+    uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(3), 256);
+    {
+        StageTimer t(SR_STAGE_BLEND_BWD, s);
+        if (D > 0) SR_HIP(hipMemsetAsync(written, 0, D, s));
+        if (D > 0)
+            SR_HIP(launch_class_backward(f, n_classes, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
+                                         at<float>(class_image, C.state), at<uint32_t>(class_image, C.last), at<uint32_t>(class_image, C.tile_total), dL_ddist,
+                                         at<uint16_t>(binning, B.hit_mask), inst_grads, written, s));
+    }
+    if (int rc = debug_sync(frame, s, "class_backward")) return rc;
+    {
+        StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
+        SR_HIP(launch_preprocess_backward(P, f, *g, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), inst_grads, written,
+                                          at<uint32_t>(geom, L.tiles_touched), *grads, s));
+    }
+    return debug_sync(frame, s, "preprocess_backward");
 }
 
 namespace {

@@ -1,0 +1,241 @@
+// blend_common.h -- device helpers shared by the blend kernels (render.hip: K6 / K7 / decision dump; render_class.hip: the
+// per-class distortion pass): staging of list entries into the tile-local form, exact quadrant culling, the ray-splat test,
+// the emission index of a duplicate, and the wave-level transpose-reduction of the per-entry gradient sums.
+#pragma once
+#include "common.h"
+
+namespace sr {
+
+constexpr int kWave = 64;
+constexpr int kXcds = 8;   // MI355X: 8 accelerator dies, workgroup i runs on XCD i % 8
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kFN = kFar / (kFar - kNear);
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// counters of the K6 counter variant (SrFrame.blend_counters, caller-owned, 8 x u64): [0] entries staged, [1] entries with a
+// non-zero quadrant mask, [2] quadrant tests executed, [3] quadrant tests with >= 1 valid lane, [4] valid (pixel, entry) pairs,
+// [5] / [6] tests with a valid pixel in rows 0-3 / rows 4-7 of the quadrant
+
+// ---------------------------------------------------------------------------------------------
+// Quadrant culling.  A list entry can only contribute to a pixel if alpha = min(0.99, opacity*G) >= 1/255,
+// i.e. rho = min(rho3d, rho2d) <= thr = 2 ln(255 opacity).  {rho3d <= thr} is the image of the disc
+// u^2+v^2 <= thr under the splat's homography -- an ellipse with dual conic C* = Q diag(thr,thr,-1) Q^T --
+// and {rho2d <= thr} is a disc of radius sqrt(thr/2) around means2D.  The staging lane bounds that union by
+// an octagon (support in directions x, y, x+y, x-y from the tangent-line equation l^T C* l = 0) and tests it
+// against the tile's 8x8 quadrants (QX x QY of them; 2 x 2 for the reference's 16x16 tile).  (A second, nearly exact test in the splat's (u,v) plane removes another
+// 9 % of the tests but costs more at staging than it saves -- measured, not kept.)  Entries dropped here are entries the per-pixel test would skip anyway (`continue` in Appendix A.4),
+// so results are unchanged; the bound has 0.3 px / 1 % slack for float rounding and keeps the entry whenever
+// anything is degenerate or NaN.  Inputs are tile-local (origin at
+// the tile centre), which keeps the conic free of cancellation.
+// ---------------------------------------------------------------------------------------------
+template <int QX, int QY>
+__device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my,
+                                                  float opacity, float yshift) {
+    constexpr uint32_t kAll = (1u << (QX * QY)) - 1u;
+    float thr = 2.f * __logf(255.f * opacity);
+    thr = thr * 1.01f + 0.01f;
+    if (thr <= 0.f) return 0u;
+    const float c22 = thr * (Tw[0] * Tw[0] + Tw[1] * Tw[1]) - Tw[2] * Tw[2];
+    if (!(c22 < 0.f)) return kAll;  // the cutoff disc reaches the camera plane: unbounded footprint
+    const float c00 = thr * (Tu[0] * Tu[0] + Tu[1] * Tu[1]) - Tu[2] * Tu[2];
+    const float c01 = thr * (Tu[0] * Tv[0] + Tu[1] * Tv[1]) - Tu[2] * Tv[2];
+    const float c11 = thr * (Tv[0] * Tv[0] + Tv[1] * Tv[1]) - Tv[2] * Tv[2];
+    const float c02 = thr * (Tu[0] * Tw[0] + Tu[1] * Tw[1]) - Tu[2] * Tw[2];
+    const float c12 = thr * (Tv[0] * Tw[0] + Tv[1] * Tw[1]) - Tv[2] * Tw[2];
+    const float inv = fast_rcp(c22);
+    const float r = __builtin_amdgcn_sqrtf(0.5f * thr);
+    float lo[4], hi[4];
+    const float QA[4] = {c00, c11, c00 + 2.f * c01 + c11, c00 - 2.f * c01 + c11};
+    const float QB[4] = {c02, c12, c02 + c12, c02 - c12};
+    const float ctr[4] = {mx, my, mx + my, mx - my};
+    const float rad[4] = {r, r, r * 1.4142137f, r * 1.4142137f};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float disc = QB[d] * QB[d] - QA[d] * c22;
+        const float half = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) * (-inv) * 1.01f;
+        const float dc = QB[d] * inv;
+        lo[d] = fminf(dc - half, ctr[d] - rad[d]);
+        hi[d] = fmaxf(dc + half, ctr[d] + rad[d]);
+    }
+    // the wave's quadrants sit `yshift` below the local origin: shift the bounds instead of the (compile-time) rectangles
+    lo[1] -= yshift; hi[1] -= yshift; lo[2] -= yshift; hi[2] -= yshift; lo[3] += yshift; hi[3] += yshift;
+    const float m = 0.3f;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < QX * QY; ++q) {   // quadrant (q % QX, q / QX) of the tile, coordinates relative to the tile centre
+        const float x0 = (float)((q % QX) * 8 - QX * 4) - m, x1 = (float)((q % QX) * 8 - QX * 4 + 7) + m;
+        const float y0 = (float)((q / QX) * 8 - QY * 4) - m, y1 = (float)((q / QX) * 8 - QY * 4 + 7) + m;
+        const bool out = lo[0] > x1 || hi[0] < x0 || lo[1] > y1 || hi[1] < y0 || lo[2] > x1 + y1 || hi[2] < x0 + y0 ||
+                         lo[3] > x1 - y0 || hi[3] < x0 - y1;
+        if (out) continue;
+        mask |= 1u << q;
+    }
+    return mask;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Staged entry layout in LDS (struct-of-quads, s_e[quad][slot]):
+//   e0 = A.xyz B.x | e1 = B.yz C.xy | e2 = C.z Tw.xyz | e3 = xy'.x xy'.y opacity c5
+//   e4 = n.xyz c0  | e5 = c1 c2 c3 c4  | (9 channels only) e6 = c6 c7 c8 -
+// with A = Tv' x Tw, B = Tw x Tu', C = Tu' x Tv' and ' = relative to the tile centre (Xc, Yc); c0..c2 = rgb.  SURVEY 8f N1:
+// NC = 6 blends six precomputed channels (the two 3-channel one-hot passes of render_semantic as ONE pass), NC = 9 blends the
+// SH colour AND six precomputed channels (render + render_semantic as one pass).  Channels 3.. come straight from the caller's
+// [P,6] array at staging time: columns 3..5 for NC = 6 (columns 0..2 went through K1 into the record), all six for NC = 9.
+// ---------------------------------------------------------------------------------------------
+template <int NC> constexpr int entry_quads() { return NC == 9 ? 7 : 6; }
+
+__device__ __forceinline__ float4 load_extra(const float* __restrict__ colors6, uint32_t gid, int first) {
+    const float* c = colors6 + 6 * (size_t)gid + first;
+    return make_float4(c[0], c[1], c[2], 0.f);
+}
+
+template <int QX, int QY, int NC>
+__device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], const float4 ex, const float4 ey, float Xc, float Yc, int cull,
+                                                float4 (*s_e)[kWave], int slot, float yshift = 0.f) {
+    const float Tw[3] = {q[1].z, q[1].w, q[2].x};
+    const float Tu[3] = {q[0].x - Xc * Tw[0], q[0].y - Xc * Tw[1], q[0].z - Xc * Tw[2]};
+    const float Tv[3] = {q[0].w - Yc * Tw[0], q[1].x - Yc * Tw[1], q[1].y - Yc * Tw[2]};
+    const float A[3] = {Tv[1] * Tw[2] - Tv[2] * Tw[1], Tv[2] * Tw[0] - Tv[0] * Tw[2], Tv[0] * Tw[1] - Tv[1] * Tw[0]};
+    const float B[3] = {Tw[1] * Tu[2] - Tw[2] * Tu[1], Tw[2] * Tu[0] - Tw[0] * Tu[2], Tw[0] * Tu[1] - Tw[1] * Tu[0]};
+    const float C[3] = {Tu[1] * Tv[2] - Tu[2] * Tv[1], Tu[2] * Tv[0] - Tu[0] * Tv[2], Tu[0] * Tv[1] - Tu[1] * Tv[0]};
+    const float mx = q[2].y - Xc, my = q[2].z - Yc, opacity = q[2].w;
+    s_e[0][slot] = make_float4(A[0], A[1], A[2], B[0]);
+    s_e[1][slot] = make_float4(B[1], B[2], C[0], C[1]);
+    s_e[2][slot] = make_float4(C[2], Tw[0], Tw[1], Tw[2]);
+    s_e[3][slot] = make_float4(mx, my, opacity, ex.z);
+    s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[4].x);
+    s_e[5][slot] = make_float4(q[4].y, q[4].z, ex.x, ex.y);
+    if (NC == 9) s_e[6][slot] = make_float4(ey.x, ey.y, ey.z, 0.f);
+    return cull ? quadrant_mask<QX, QY>(Tu, Tv, Tw, mx, my, opacity, yshift) : (1u << (QX * QY)) - 1u;
+}
+
+struct Hit {
+    float sx, sy, dx, dy, depth, G, alpha, pz_inv;
+    bool use3d;
+};
+
+// Ray-splat intersection + alpha at tile-local pixel (xl, yl); branch-free, returns the validity predicate
+// (the chain of `continue`s of Appendix A.4, with the same comparison senses so NaNs behave alike).
+__device__ __forceinline__ bool intersect(float xl, float yl, const float4 e0, const float4 e1, const float4 e2, const float4 e3,
+                                          Hit& h) {
+    const float ppx = fmaf(xl, e0.x, fmaf(yl, e0.w, e1.z));
+    const float ppy = fmaf(xl, e0.y, fmaf(yl, e1.x, e1.w));
+    const float ppz = fmaf(xl, e0.z, fmaf(yl, e1.y, e2.x));
+    h.pz_inv = fast_rcp(ppz);
+    h.sx = ppx * h.pz_inv; h.sy = ppy * h.pz_inv;
+    const float rho3d = h.sx * h.sx + h.sy * h.sy;
+    h.dx = e3.x - xl; h.dy = e3.y - yl;
+    const float rho2d = kFilterInvSquare * (h.dx * h.dx + h.dy * h.dy);
+    h.use3d = rho3d <= rho2d;
+    const float rho = fminf(rho3d, rho2d);
+    h.depth = h.use3d ? (h.sx * e2.y + h.sy * e2.z) + e2.w : e2.w;
+    const float power = -0.5f * rho;
+    h.G = __builtin_amdgcn_exp2f(power * kLog2e);
+    h.alpha = fminf(kAlphaCap, e3.z * h.G);
+    return (ppz != 0.f) & !(h.depth < kNear) & !(power > 0.f) & !(h.alpha < kAlphaFloor);
+}
+
+// Emission index of the duplicate (tile tx,ty ; Gaussian gid): duplicates are emitted per Gaussian, y-major /
+// x-minor over its tile rectangle (same expressions as K1 / K3 -> same rectangle).
+__device__ __forceinline__ uint32_t emission_index(const float4 (&q)[kRecQuads], uint32_t first, int tx, int ty, const FrameDev& f) {
+    const float cx = q[2].y, cy = q[2].z, radius = q[4].w;
+    int minx = (int)((cx - radius) * f.inv_tile_w), miny = (int)((cy - radius) * f.inv_tile_h);
+    int maxx = (int)((cx + radius + (float)(f.tile_w - 1)) * f.inv_tile_w);
+    minx = min(f.tiles_x, max(0, minx)); maxx = min(f.tiles_x, max(0, maxx));
+    miny = min(f.tiles_y, max(0, miny));
+    return first + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+}
+
+__device__ __forceinline__ void load_record(const float4* __restrict__ recs, uint32_t gid, float4 (&q)[kRecQuads]) {
+    const float4* r = recs + (size_t)gid * kRecQuads;
+#pragma unroll
+    for (int k = 0; k < kRecQuads; ++k) q[k] = r[k];
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// wave-level transpose-reduction of 24 values per lane (gfx950):
+//   fold across the two 32-lane halves with v_permlane32_swap (value k <-> k+12), across row pairs with
+//   v_permlane16_swap (k <-> k+6), then a 4-step DPP row rotation sum.  60 VALU ops for 24 values (a plain
+//   butterfly needs 144 cross-lane ops).  Afterwards every lane of 16-lane row g holds, in v[0..5], the
+//   64-lane totals of values 6g .. 6g+5.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fold32(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void fold16(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int kCtrl>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), kCtrl, 0xf, 0xf, false));
+}
+// value of lane ^ 4, without the LDS crossbar: a row rotation by 12 (= left by 4) into the lanes whose bit 2 is clear (DPP
+// banks 0 and 2) and by 4 into the others (banks 1 and 3); row_ror:n delivers lane (l - n) mod 16
+__device__ __forceinline__ float dpp_xor4(float x) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x12C, 0xf, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, __float_as_int(x), 0x124, 0xf, 0xA, false);
+    return __int_as_float(t);
+}
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp_mov<0x128>(x);  // row_ror:8
+    x += dpp_mov<0x124>(x);  // row_ror:4
+    x += dpp_mov<0x122>(x);  // row_ror:2
+    x += dpp_mov<0x121>(x);  // row_ror:1
+    return x;
+}
+// Returns the 64-lane total of ONE value per lane: lane l ends up with value index
+//   6*(l>>4) + 3*bit3(l) + (bit2(l) ? 2 : bit1(l)), valid unless bit2 and bit1 are both set; bit0 is a replica.
+// Folds all the way down (24 -> 12 -> 6 -> 3 -> 2 -> 1 values per lane), so the expensive cross-lane steps
+// shrink geometrically: 18 swap-adds + 7 in-row exchanges instead of 18 swap-adds + 24 DPP adds
+// (tools/ubench/reduce_ubench.hip: 416 vs 633 SIMD cycles per reduction).
+__device__ __forceinline__ float wave_reduce24(float (&v)[24], int lane) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) fold32(v[k], v[k + 12]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fold16(v[k], v[k + 6]);
+    const bool h8 = (lane & 8) != 0, h4 = (lane & 4) != 0, h2 = (lane & 2) != 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float keep = h8 ? v[k + 3] : v[k], send = h8 ? v[k] : v[k + 3];
+        v[k] = keep + dpp_mov<0x128>(send);  // row_ror:8
+    }
+    {
+        const float keep0 = h4 ? v[2] : v[0], send0 = h4 ? v[0] : v[2];
+        const float keep1 = h4 ? 0.f : v[1], send1 = h4 ? v[1] : 0.f;
+        v[0] = keep0 + dpp_xor4(send0);
+        v[1] = keep1 + dpp_xor4(send1);
+    }
+    {
+        const float keep = h2 ? v[1] : v[0], send = h2 ? v[0] : v[1];
+        v[0] = keep + dpp_mov<0x4E>(send);   // quad_perm:[2,3,0,1] = lane ^ 2
+    }
+    return v[0] + dpp_mov<0xB1>(v[0]);       // quad_perm:[1,0,3,2] = lane ^ 1
+}
+
+// 64-lane totals of three more values (the 9-channel variant): afterwards every lane of 16-lane row r holds the total of value r
+// (row 3: zero).  Two half folds, one row-pair fold, one in-row sum.
+__device__ __forceinline__ float wave_reduce3(float a, float b, float c) {
+    float d = 0.f;
+    fold32(a, b); fold32(c, d);   // a: lanes < 32 hold a's half sums, lanes >= 32 b's;  c: c's | zeros
+    fold16(a, c);                 // rows 0..3: a, c, b, zero
+    return row_sum16(a);
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, m));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+}
+
+template <int QX, int QY>
+__device__ __forceinline__ uint32_t decode_hits(uint16_t h) {   // see the hit_mask store in K6
+    // two-band tiles (16x16, 32x16): low byte = the QX quadrant bits of the upper band, high byte = those of the lower band
+    return QY == 2 ? (((uint32_t)h & ((1u << QX) - 1u)) | ((((uint32_t)h >> 8) & ((1u << QX) - 1u)) << QX)) : (uint32_t)h;
+}
+
+
+}  // namespace sr

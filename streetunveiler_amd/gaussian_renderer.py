@@ -283,6 +283,32 @@ def render_and_semantic(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scal
     return rets
 
 
+def render_class_distortions(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, class_ids=None, scaling_modifier=1.0):
+    """The per-class distortion maps of one view in ONE rasterization (extension).  The reference's training iteration
+    obtains them with one full `render(..., semantic_filter_bit=1 << k, reverse_semantic=True)["rend_dist"]` per class
+    [REF train.py:94-103]; here preprocess, sort and binning run once and the blend keeps one transmittance chain per class.
+    `class_ids`: the classes wanted (default: every concerned class but the sky, as in the reference's loop).
+    Returns {"rend_dist": [len(class_ids), 1, H, W], "viewspace_points", "visibility_filter", "radii"}; rend_dist[j] equals the
+    reference call for class_ids[j]; gradients flow to xyz / opacity / scaling / rotation."""
+    if class_ids is None:
+        class_ids = [i for i, n in enumerate(concerned_classes_list) if n != "sky"]
+    class_ids = [int(c) for c in class_ids]
+    dev = pc.get_xyz.device
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier),
+                                    fused_activations=_fused_activations(pc, pipe))
+    means3D, means2D, opacity, scales, rotations, cov3D_precomp = _geometry_inputs(pc, pipe, screenspace_points, None, scaling_modifier)
+    assert cov3D_precomp is None
+    # class of a Gaussian -> its chain (position in class_ids), -1 = not rendered
+    lut = torch.full((max(max(class_ids) + 1, len(concerned_classes_list)),), -1, dtype=torch.int32, device=dev)
+    lut[torch.tensor(class_ids, device=dev)] = torch.arange(len(class_ids), dtype=torch.int32, device=dev)
+    sem = pc.get_semantics.to(torch.int64).clamp(0, lut.numel() - 1)
+    chain = torch.where((pc.get_semantics >= 0) & (pc.get_semantics < lut.numel()), lut[sem], torch.full_like(lut[sem], -1))
+    dist, radii = rasterizer.class_distortions(means3D=means3D, means2D=means2D, opacities=opacity, scales=scales, rotations=rotations,
+                                               classes=chain, n_classes=len(class_ids))
+    return {"rend_dist": dist.unsqueeze(1), "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
+
+
 def render_semantic(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
                     semantic_filter_bit: Optional[int] = None, reverse_semantic: Optional[bool] = None):
     """[REF gaussian_renderer/__init__.py:327-460] (bg_color is accepted and, as in the reference, unused)."""

@@ -392,3 +392,59 @@ def test_extensions_compose():
     assert_close_frac(o["render_semantics"].detach().cpu().numpy(), s["render_semantics"].detach().cpu().numpy(), 1e-4, 1e-4, 2e-4, 2e-2, "composed semantics")
     assert o["radii"].shape == (P,) and not o["radii"][~m].any()
     assert float((o["radii"][m] != a["radii"]).float().mean()) < 1e-3
+
+
+def test_class_distortions_one_pass_equals_the_per_class_renders():
+    """render_class_distortions == the reference's loop `render(..., semantic_filter_bit=1 << k, reverse_semantic=True)
+    ["rend_dist"]` [REF train.py:94-103] -- against the CPU oracle on each class subset (forward and the summed backward), and against
+    this build's own per-class render() calls."""
+    from oracle import surfel_oracle as so
+    from streetunveiler_amd.gaussian_renderer import render_class_distortions
+    from tests.gpu_util import assert_close_frac, assert_grads_close
+    P, W, H = 9000, 240, 136
+    cam = synthetic_camera(W, H, index=3)
+    g, sem, _, _ = _model(P, W, H, 41, DEV)
+    classes = [0, 1, 2, 3, 5]          # every concerned class but the sky
+    gen = torch.Generator().manual_seed(9)
+    g_dist = torch.rand(len(classes), 1, H, W, generator=gen) + 0.5      # upstream gradients of the five maps
+    bg = torch.zeros(3)
+
+    def fresh():
+        t = {k: v.to(DEV).requires_grad_() for k, v in g.items()}
+        return t, SurfelModel(t["means3D"], t["scales"], t["rotations"], t["opacities"], t["shs"], sem.to(DEV), 3, 3)
+
+    t1, pc1 = fresh()
+    out = render_class_distortions(cam.to(DEV), pc1, PipelineParams(), bg.to(DEV))
+    assert out["rend_dist"].shape == (len(classes), 1, H, W) and out["radii"].shape == (P,)
+    (out["rend_dist"] * g_dist.to(DEV)).sum().backward()
+    # (a) oracle on every class subset
+    ref = {k: np.zeros_like(g[n].numpy()) for k, n in (("dL_dmeans3D", "means3D"), ("dL_dopacity", "opacities"), ("dL_dscales", "scales"), ("dL_drotations", "rotations"))}
+    ref2d = np.zeros((P, 3), np.float32)
+    vis_any = np.zeros(P, bool)
+    for j, k in enumerate(classes):
+        idx = (sem.numpy() == k)
+        fwd = _oracle(g, cam, bg.numpy(), 3, idx=idx)
+        assert_close_frac(out["rend_dist"][j, 0].detach().cpu().numpy(), fwd["allmap"][6], 1e-5, 1e-4, 2e-4, 2e-2, f"class {k} rend_dist")
+        da = np.zeros((7, H, W), np.float32); da[6] = g_dist[j, 0].numpy()
+        bwd = so.rasterize_backward(fwd, np.zeros((3, H, W), np.float32), da)
+        for name in ref:
+            ref[name][idx] += bwd[name]
+        ref2d[idx] += bwd["dL_dmeans2D"]
+        vis_any[idx] |= fwd["radii"] > 0
+        np.testing.assert_array_equal(out["radii"].cpu().numpy()[idx], fwd["radii"])
+    for name, key in (("dL_dmeans3D", "means3D"), ("dL_dopacity", "opacities"), ("dL_dscales", "scales"), ("dL_drotations", "rotations")):
+        assert np.abs(ref[name]).max() > 0
+        assert_grads_close(t1[key].grad.cpu().numpy(), ref[name], 2e-3, "class pass " + name)
+    assert_grads_close(out["viewspace_points"].grad.cpu().numpy(), ref2d, 2e-3, "class pass dL_dmeans2D")
+    assert not t1["means3D"].grad[torch.tensor(sem.numpy() == 4)].any()      # the sky class is in no chain
+    # (b) the reference's call pattern on this build: five class-filtered render() calls
+    t2, pc2 = fresh()
+    loss = 0
+    for j, k in enumerate(classes):
+        o = render(cam.to(DEV), pc2, PipelineParams(), bg.to(DEV), semantic_filter_bit=1 << k, reverse_semantic=True)
+        d = o["rend_dist"]
+        assert float((d - out["rend_dist"][j]).detach().abs().max()) <= 1e-6 * max(1.0, float(d.detach().abs().max())), k
+        loss = loss + (d * g_dist[j].to(DEV)).sum()
+    loss.backward()
+    for key in ("means3D", "opacities", "scales", "rotations"):
+        assert_grads_close(t1[key].grad.cpu().numpy(), t2[key].grad.cpu().numpy(), 2e-5, "one pass vs five renders d" + key, max_bad_frac=0.0, hard=2e-5)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Turns the rocprofv3 CSVs of one gpurun profiling call (gpurun_out/<dir>) into the committed evidence files
-profiles/<tag>_kernel_stats.csv, <tag>_hbm_traffic.json, <tag>_sq_counters.json.
-    python tools/collect_profiles.py gpurun_out/r01 r01
+"""Turns the rocprofv3 CSVs of one profiling call (tools/profile_round.sh -> gpurun_out/<dir>) into the evidence files
+<tag>_kernel_stats.csv, <tag>_hbm_traffic.json, <tag>_sq_counters.json, <tag>_bench.json (tag = round + workload, e.g. r02_c3).
+    python tools/collect_profiles.py gpurun_out/r02_c3 r02_c3 [output dir, default profiles/]
 The profiling call itself (on the GPU box):
     rocprofv3 --kernel-trace --stats --output-format csv -d D -o trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d D -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
@@ -11,7 +11,8 @@ The profiling call itself (on the GPU box):
 import collections, csv, json, os, re, sys
 
 src, tag = sys.argv[1], sys.argv[2]
-dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(dst, exist_ok=True)
 
 
 def short(name, pool=True):
@@ -40,19 +41,27 @@ def per_kernel(fn, counter):
 fe, wr = per_kernel(f"{src}/fetch_counter_collection.csv", "FETCH_SIZE"), per_kernel(f"{src}/write_counter_collection.csv", "WRITE_SIZE")
 out = {k: {"FETCH_SIZE_KiB": round(fe[k]), "WRITE_SIZE_KiB": round(wr.get(k, 0)), "traffic_bytes_per_launch": int((2 * fe[k] + wr.get(k, 0)) * 1024)}
        for k in fe if k.startswith("sr::")}
-json.dump({"how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (--kernel-trace only), python bench.py --steps 3 --warmup 1, "
-                  "C3 workload; traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md (FETCH_SIZE reads 1/2 of a wide coalesced "
+json.dump({"how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (--kernel-trace only), python bench.py --config <cfg> --steps 3 --warmup 1; "
+                  "traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md (FETCH_SIZE reads 1/2 of a wide coalesced "
                   "stream on gfx950 -- confirmed on preprocess_forward_kernel: 2*FETCH = the 232 B x 3 M it reads; WRITE_SIZE is exact on streaming "
                   "stores; for the 16-B record gathers of the blend kernels the 2x is an upper bound)",
            "kernels": out}, open(f"{dst}/{tag}_hbm_traffic.json", "w"), indent=1)
-names = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY"]
+passes = {"sq": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY"],
+          "sq2": ["SQ_INSTS_VALU_TRANS_F32", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_BRANCH",
+                  "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_SCA"]}
 sq = {}
-if os.path.exists(f"{src}/sq_counter_collection.csv"):
-    for n in names:
-        for k, v in per_kernel(f"{src}/sq_counter_collection.csv", n).items():
-            if k.startswith("sr::"):
-                sq.setdefault(k, {})[n] = round(v)
-    json.dump({"how": "rocprofv3 --pmc " + " ".join(names) + " --kernel-trace, bench.py --steps 3 --warmup 1 (C3); averages per launch; "
-                      "SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles", "kernels": sq}, open(f"{dst}/{tag}_sq_counters.json", "w"), indent=1)
+for run, names in passes.items():
+    fn = f"{src}/{run}_counter_collection.csv"
+    if os.path.exists(fn):
+        for n in names:
+            for k, v in per_kernel(fn, n).items():
+                if k.startswith("sr::"):
+                    sq.setdefault(k, {})[n] = round(v)
+if sq:
+    json.dump({"how": "rocprofv3 --pmc <8 SQ counters> --kernel-trace in separate passes (" + " | ".join(" ".join(v) for v in passes.values()) +
+                      "), bench.py --config <cfg> --steps 3 --warmup 1; averages per launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles",
+               "kernels": sq}, open(f"{dst}/{tag}_sq_counters.json", "w"), indent=1)
+if os.path.exists(f"{src}/bench.json") and os.path.getsize(f"{src}/bench.json") > 10:
+    json.dump(json.load(open(f"{src}/bench.json")), open(f"{dst}/{tag}_bench.json", "w"), indent=1)
 for k in ("sr::render_forward_kernel", "sr::render_backward_kernel", "sr::preprocess_backward_kernel", "sr::preprocess_forward_kernel"):
     print(k, out.get(k), sq.get(k))
