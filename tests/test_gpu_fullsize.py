@@ -35,6 +35,10 @@ def test_c2_500k_against_oracle():
     check_allmap(out["allmap"], fwd["allmap"], "C2")
     for k in ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"]:
         assert_grads_close(out[k], bwd[k], 2e-3, "C2 " + k)
+    # ... and the strict bar at the full C2 size: identical decisions, float64 arbiter (tests/test_gpu_strict_parity.py)
+    from tests.gpu_util import assert_strict_parity, forced_f64_reference
+    _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da)
+    assert_strict_parity(out, fwd64, bwd64, tag="C2 ")
 
 
 def _properties(P, W, H, check_linearity=True):
@@ -101,3 +105,30 @@ def test_4k_frame_properties():
     """3840x2160 (the C5 resolution) on one GPU with 1.5 M Gaussians: ragged 135-row tile grid, D/P ~ 11."""
     D = _properties(1_500_000, 3840, 2160, check_linearity=False)
     assert D > 10 * 1_500_000 * 0.8
+
+
+def test_c5_scene_6m_at_4k_properties():
+    """BASELINE config 5's scene in full on one GPU: 6 M Gaussians at 3840x2160 (D ~ 67 M): the single-GPU half of C5 (the 8-GPU
+    half shards frames, one per GPU, of exactly this workload)."""
+    D = _properties(6_000_000, 3840, 2160, check_linearity=False)
+    assert 60_000_000 < D < 75_000_000      # SURVEY 8d calibration: D/P ~ 11.2 at 3840x2160
+
+
+@pytest.mark.parametrize("tile", [(32, 16), (8, 8)])
+def test_tile_shapes_at_full_resolution_against_oracle(tile):
+    """BASELINE config 5's tile-size sweep at full 1920x1080 resolution (C2's 500 k Gaussians, so that the CPU oracle finishes in
+    seconds): the two extreme shapes bin bit-exactly like the oracle run with the same BLOCK_X x BLOCK_Y and pass the strict bar."""
+    from tests.gpu_util import assert_strict_parity, forced_f64_reference, run_hip, run_hip_raw, run_oracle
+    P = 500_000
+    cam = synthetic_camera(W, H)
+    g = synthetic_gaussians(P, W, H, seed=0)
+    bg = np.zeros(3, np.float32)
+    dc, da = synthetic_upstream_grads(W, H, seed=1)
+    fwd, _ = run_oracle(g, cam, bg, 3, tile=tile)
+    raw = run_hip_raw(g, cam, bg, 3, tile=tile)
+    assert raw["D"] == fwd["num_rendered"]
+    np.testing.assert_array_equal(raw["bin"]["point_list"].view(np.uint32), fwd["point_list"])
+    np.testing.assert_array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])
+    out = run_hip(g, cam, bg, 3, dc, da, tile=tile)
+    _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da, tile=tile)
+    assert_strict_parity(out, fwd64, bwd64, tag=f"tile {tile} ")

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_render_api.py -m gpu -x -q -k class_dist 2>&1 | tail -15
-python tools/time_class_distortions.py 2>&1 | tail -4
+python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q --durations=8 2>&1 | tail -20
