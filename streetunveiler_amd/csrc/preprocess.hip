@@ -62,29 +62,33 @@ __device__ __forceinline__ void build_B(const float* __restrict__ proj, int W, i
 __device__ __forceinline__ float dot3(const float* a, float x, float y, float z) { return (a[0] * x + a[1] * y) + a[2] * z; }
 
 // SH rows are 3*M floats per Gaussian (192 B for M = 16).  One thread per Gaussian reading its own row
-// would touch 64 different cache lines per load instruction; instead a 256-thread block moves its 256 rows
+// would touch 64 different cache lines per load instruction; instead a block of kPreBlock threads moves its rows
 // through LDS with fully coalesced 16-B accesses (48 KB in, and for K8 48 KB out), and each thread works on
 // its row in LDS.  Row stride 52 floats (48 + 4 pad) keeps per-thread ds_read_b128 conflict-free.
 constexpr int kShRowFloats = 48;   // fast path: M == 16
 constexpr int kShLdsStride = 52;
+#ifndef SR_PRE_BLOCK
+#define SR_PRE_BLOCK 128
+#endif
+constexpr int kPreBlock = SR_PRE_BLOCK;   // threads (= Gaussians) per block of K1 / K8 / the SH expansion
 
 __device__ __forceinline__ void sh_rows_to_lds(const float* __restrict__ shs, int base, int P, float* s_sh, int tid) {
-    const int nrows = min(256, P - base);
+    const int nrows = min(kPreBlock, P - base);
     const int nvec = nrows * (kShRowFloats / 4);
     const float4* src = reinterpret_cast<const float4*>(shs + (size_t)base * kShRowFloats);
     float4* dst = reinterpret_cast<float4*>(s_sh);
-    for (int f = tid; f < nvec; f += 256) {
+    for (int f = tid; f < nvec; f += kPreBlock) {
         const int row = f / 12, c4 = f - row * 12;
         dst[row * (kShLdsStride / 4) + c4] = src[f];
     }
 }
 
 __device__ __forceinline__ void sh_rows_from_lds(float* __restrict__ out, int base, int P, const float* s_sh, int tid) {
-    const int nrows = min(256, P - base);
+    const int nrows = min(kPreBlock, P - base);
     const int nvec = nrows * (kShRowFloats / 4);
     float4* dst = reinterpret_cast<float4*>(out + (size_t)base * kShRowFloats);
     const float4* src = reinterpret_cast<const float4*>(s_sh);
-    for (int f = tid; f < nvec; f += 256) {
+    for (int f = tid; f < nvec; f += kPreBlock) {
         const int row = f / 12, c4 = f - row * 12;
         dst[f] = src[row * (kShLdsStride / 4) + c4];
     }
@@ -184,14 +188,14 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const RowIn sh, RowO
 // K1
 // ---------------------------------------------------------------------------------------------
 template <bool kLdsSH>
-__global__ __launch_bounds__(256) void preprocess_forward_kernel(
+__global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ transMat_precomp,
     const uint8_t* __restrict__ mask, float4* __restrict__ recs, uint32_t* __restrict__ depth_keys,
     uint32_t* __restrict__ tiles_touched, uint2* __restrict__ rect, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii) {
-    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
-    const int tid = threadIdx.x, base = blockIdx.x * 256;
+    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? kPreBlock * kShLdsStride : 4];
+    const int tid = threadIdx.x, base = blockIdx.x * kPreBlock;
     const int i = base + tid;
     if (kLdsSH) {
         sh_rows_to_lds(shs, base, P, s_sh, tid);
@@ -305,14 +309,14 @@ __global__ __launch_bounds__(256) void preprocess_forward_kernel(
 // contributed) and are skipped without being read.
 // ---------------------------------------------------------------------------------------------
 template <bool kLdsSH, int NC>
-__global__ __launch_bounds__(256) void preprocess_backward_kernel(
+__global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
     int P, FrameDev f, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float4* __restrict__ recs,
     const float4* __restrict__ inst_grads, const uint8_t* __restrict__ written, const uint32_t* __restrict__ tiles_touched,
     SrGradients out) {
-    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
-    const int tid = threadIdx.x, base = blockIdx.x * 256;
+    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? kPreBlock * kShLdsStride : 4];
+    const int tid = threadIdx.x, base = blockIdx.x * kPreBlock;
     const int i = base + tid;
     const int M = f.sh_coeffs;
     if (kLdsSH) {
@@ -557,11 +561,11 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 }
 
 template <bool kLdsSH>
-__global__ __launch_bounds__(256) void sh_gradient_expand_kernel(int P, int M, int deg, int V, const float* __restrict__ means3D,
+__global__ __launch_bounds__(kPreBlock) void sh_gradient_expand_kernel(int P, int M, int deg, int V, const float* __restrict__ means3D,
                                                                   const float* __restrict__ campos, const float* __restrict__ gc,
                                                                   float* __restrict__ dL_dsh) {
-    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? 256 * kShLdsStride : 4];
-    const int tid = threadIdx.x, base = blockIdx.x * 256;
+    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? kPreBlock * kShLdsStride : 4];
+    const int tid = threadIdx.x, base = blockIdx.x * kPreBlock;
     const int i = base + tid;
     if (i < P) {
         float acc[48];
@@ -613,7 +617,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 hipError_t launch_preprocess_forward(int P, const FrameDev& f, const SrGaussians& g, float4* recs, uint32_t* depth_keys,
                                      uint32_t* tiles_touched, uint2* rect, uint8_t* clamped, int32_t* radii, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    const dim3 grid((P + 255) / 256), block(256);
+    const dim3 grid((P + kPreBlock - 1) / kPreBlock), block(kPreBlock);
     if (g.shs && g.sh_coeffs == 16 && aligned16(g.shs))
         hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, 0, s, P, f, g.means3D, g.opacities, g.scales,
                            g.rotations, g.shs, g.colors_precomp, g.transMat_precomp, g.mask, recs, depth_keys, tiles_touched, rect, clamped, radii);
@@ -627,7 +631,7 @@ hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussian
                                       const uint8_t* clamped, const float4* recs, const float4* inst_grads, const uint8_t* written,
                                       const uint32_t* tiles_touched, const SrGradients& out, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    const dim3 grid((P + 255) / 256), block(256);
+    const dim3 grid((P + kPreBlock - 1) / kPreBlock), block(kPreBlock);
     if (f.colors == 9 && g.sh_coeffs == 16 && aligned16(g.shs) && (!out.dL_dsh || aligned16(out.dL_dsh)))
         hipLaunchKernelGGL((preprocess_backward_kernel<true, 9>), grid, block, 0, s, P, f, g.means3D, g.scales, g.rotations, g.shs,
                            g.transMat_precomp, radii, clamped, recs, inst_grads, written, tiles_touched, out);
@@ -649,7 +653,7 @@ hipError_t launch_preprocess_backward(int P, const FrameDev& f, const SrGaussian
 hipError_t launch_sh_gradient_expand(int P, int M, int deg, int V, const float* means3D, const float* campos, const float* gc,
                                      float* dL_dsh, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    const dim3 grid((P + 255) / 256), block(256);
+    const dim3 grid((P + kPreBlock - 1) / kPreBlock), block(kPreBlock);
     if (M == 16 && aligned16(dL_dsh))
         hipLaunchKernelGGL(sh_gradient_expand_kernel<true>, grid, block, 0, s, P, M, deg, V, means3D, campos, gc, dL_dsh);
     else
