@@ -280,7 +280,8 @@ size_t radix_sort_temp_bytes(uint32_t n) {
 // Sorts by key bits [0, total_bits) in passes of <= 8 bits (as even as possible); stable; result in keys_out/vals_out.
 // vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.  If aux_out != nullptr the last pass also
 // writes aux_out[i] = aux_src[vals_out[i]] (an 8-B payload gathered in sorted order, for free).  keys_out == nullptr: only the
-// permutation is wanted (the sorted keys are not written).  full_hist != nullptr: the last pass also accumulates the number of
+// permutation is wanted (the sorted keys are not written; with more than two passes the intermediate odd passes then park their
+// keys in keys_in, which is overwritten -- the tile partition's input is scratch).  full_hist != nullptr: the last pass also accumulates the number of
 // items per full key into full_hist[key] (zeroed by the caller).
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out,
@@ -305,6 +306,7 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         if (bits < 1) bits = 1;
         const bool last = p == passes - 1;
         uint32_t* ko = (p & 1) ? keys_out : tk;   // (last pass: keys_out, possibly NULL)
+        if (!ko && !last) ko = const_cast<uint32_t*>(keys_in);
         uint32_t* vo = (p & 1) ? vals_out : tv;
         hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb, last ? full_hist : nullptr);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);

@@ -132,3 +132,19 @@ def test_tile_shapes_at_full_resolution_against_oracle(tile):
     out = run_hip(g, cam, bg, 3, dc, da, tile=tile)
     _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da, tile=tile)
     assert_strict_parity(out, fwd64, bwd64, tag=f"tile {tile} ")
+
+
+def test_more_than_65536_tiles_against_oracle():
+    """3840x2160 with 8x8 tiles = 129 600 tiles (17 key bits): the tile partition runs four radix passes there instead of two;
+    list, ranges and images against the oracle with the same tile."""
+    from tests.gpu_util import assert_close_frac, run_hip_raw, run_oracle
+    P, W4, H4, tile = 150_000, 3840, 2160, (8, 8)
+    cam = synthetic_camera(W4, H4)
+    g = synthetic_gaussians(P, W4, H4, seed=5)
+    bg = np.zeros(3, np.float32)
+    fwd, _ = run_oracle(g, cam, bg, 3, tile=tile)
+    raw = run_hip_raw(g, cam, bg, 3, tile=tile)
+    assert raw["D"] == fwd["num_rendered"] and fwd["ranges"].shape[0] == 480 * 270
+    np.testing.assert_array_equal(raw["bin"]["point_list"].view(np.uint32), fwd["point_list"])
+    np.testing.assert_array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])
+    assert_close_frac(raw["color"], fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, "4K 8x8 color")
