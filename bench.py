@@ -301,7 +301,7 @@ def main():
         npx = W * H
         ab = algorithmic_bytes(P, V, D, npx, deg)
         stage_ms = {k: (ms / n if n else None) for k, (ms, n) in stats.items()}
-        groups = {"preprocess": ["preprocess"], "binning": ["depth_sort", "scan", "emit", "tile_sort", "ranges"],
+        groups = {"preprocess": ["preprocess"], "binning": ["depth_sort", "scan", "expand_x", "expand_y", "ranges"],
                   "blend_fwd": ["blend_fwd"], "blend_bwd": ["blend_bwd"], "preprocess_bwd": ["preprocess_bwd"]}
         group_ms = {k: sum(stage_ms[s] or 0.0 for s in v) for k, v in groups.items()}
         dominant = max(("blend_fwd", "blend_bwd"), key=lambda k: group_ms[k])  # the north-star kernels

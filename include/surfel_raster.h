@@ -124,7 +124,7 @@ typedef struct SrGradients {
 
 /* Views into the caller-owned state buffers (for tests / debugging; all device pointers). */
 typedef struct SrGeomView {
-    const float* splats;           /* [P,20] packed record: Tu.xyz Tv.x | Tv.yz Tw.xy | Tw.z xy.x xy.y opacity | n.xyz first-duplicate-index(u32 bits) | r g b radius */
+    const float* splats;           /* [P,20] packed record: Tu.xyz Tv.x | Tv.yz Tw.xy | Tw.z xy.x xy.y opacity | n.xyz view-depth | r g b radius */
     const uint32_t* depth_keys;    /* [P] float bits of view-space depth; 0xFFFFFFFF when culled */
     const uint32_t* tiles_touched; /* [P] */
     const uint8_t* clamped;        /* [P] bit c set when SH colour channel c was clamped at 0 */
@@ -272,7 +272,7 @@ int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32
  * stream time: the full set adds ~1.4 % to a 4.5 ms step).  sr_stage_stats() waits for the recorded events and returns the
  * summed duration (ms) and the number of launches of one stage since timing was (re-)enabled. */
 typedef enum SrStage {
-    SR_STAGE_PREPROCESS = 0, SR_STAGE_DEPTH_SORT = 1, SR_STAGE_SCAN = 2, SR_STAGE_EMIT = 3, SR_STAGE_TILE_SORT = 4,
+    SR_STAGE_PREPROCESS = 0, SR_STAGE_DEPTH_SORT = 1, SR_STAGE_SCAN = 2, SR_STAGE_EXPAND_X = 3, SR_STAGE_EXPAND_Y = 4,
     SR_STAGE_RANGES = 5, SR_STAGE_BLEND_FWD = 6, SR_STAGE_BLEND_BWD = 7, SR_STAGE_PREPROCESS_BWD = 8, SR_STAGE_COUNT = 9
 } SrStage;
 void sr_set_stage_timing(int enable);

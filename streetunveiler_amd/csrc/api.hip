@@ -22,15 +22,15 @@ hipError_t launch_sh_gradient_expand(int P, int M, int deg, int V, const float* 
 // binning.hip
 size_t depth_sort_temp_bytes(int P);
 size_t tile_scan_temp_bytes(int P);
-size_t tile_sort_temp_bytes(uint32_t D, int n_tiles);
+size_t expand_x_hist_bytes(int P, int tiles_x);
+size_t expand_y_hist_bytes(uint32_t D, int tiles_y);
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, uint32_t* sorted_keys,
                           uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t run_tile_count_scan(int P, const uint2* rect_sorted, uint32_t* block_offsets, void* block_base, size_t base_bytes, hipStream_t s);
-hipError_t run_emit(int P, int tiles_x, const uint2* rect_sorted, const uint32_t* sorted_gid, const uint32_t* block_offsets,
-                    const uint32_t* block_base, float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* tile_counts,
-                    int n_tiles, hipStream_t s);
-hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
-                         uint32_t* point_list, uint32_t* tile_counts, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t run_tile_count_scan(int P, const uint32_t* tiles_touched, uint32_t* first, void* block_base, size_t base_bytes, hipStream_t s);
+hipError_t run_expand_columns(int P, int tiles_x, int n_tiles, const uint2* rect_sorted, const uint32_t* sorted_gid, uint2* columns,
+                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, hipStream_t s);
+hipError_t run_expand_rows(uint32_t D, int tiles_x, int tiles_y, const uint2* columns, const uint32_t* n_columns, uint32_t* hist, uint32_t* row_total,
+                           uint32_t* point_list, uint32_t* tile_counts, hipStream_t s);
 hipError_t run_tile_ranges_order(int n_tiles, const uint32_t* tile_counts, uint2* ranges, uint32_t* order, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
@@ -52,8 +52,7 @@ hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out,
-                            uint32_t* full_hist);
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out);
 // knn.hip
 size_t knn_workspace_bytes(int nq, int nr);
 hipError_t knn_mean_dist2(int nq, const float* query, int nr, const float* reference, int K, int take_sqrt, float* out, void* ws,
@@ -134,7 +133,7 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
 
 // ---- buffer layouts ------------------------------------------------------------------------------
 struct GeomLayout {
-    size_t recs, depth_keys, tiles_touched, rect, clamped, sorted_keys, sorted_gid, rect_sorted, block_offsets, block_base, base_bytes,
+    size_t recs, depth_keys, tiles_touched, rect, clamped, sorted_keys, sorted_gid, rect_sorted, first, block_base, base_bytes,
         n_scan_blocks, temp, temp_bytes, total;
 };
 GeomLayout geom_layout(int P) {
@@ -150,7 +149,7 @@ GeomLayout geom_layout(int P) {
     L.sorted_keys = take(n * 4);
     L.sorted_gid = take(n * 4);
     L.rect_sorted = take(n * 8);
-    L.block_offsets = take(n * 4);
+    L.first = take(n * 4);
     L.base_bytes = tile_scan_temp_bytes(P);
     L.block_base = take(L.base_bytes);
     L.n_scan_blocks = (n + 2047) / 2048;   // the scan's block size (radix_sort.hip kRsTile)
@@ -164,27 +163,25 @@ GeomLayout geom_layout(int P) {
 }
 
 struct BinLayout {
-    size_t keys_unsorted, vals_unsorted, point_list, hit_mask, ranges, order, tile_counts, temp, temp_bytes, total;
+    size_t columns, point_list, hit_mask, ranges, order, tile_counts, row_total, n_columns, hist, hist_bytes, total;
 };
+constexpr int kMaxTilesPerAxis = 1024;   // binning.hip kXpMaxBins
 BinLayout bin_layout(uint32_t D, int W, int H) {
     BinLayout L{};
     const size_t n = (size_t)(D > 0 ? D : 1);
     const int tiles = ((W + 7) / 8) * ((H + 7) / 8);   // sized for the smallest tile shape (8x8); the reference's 16x16 uses a quarter
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    L.keys_unsorted = take(n * 4);
-    L.vals_unsorted = take(n * 4);
+    L.columns = take(n * 8);   // column items of the expanding partition: at most D of them
     L.point_list = take(n * 4);
     L.hit_mask = take(n * 2);
     L.ranges = take((size_t)(tiles > 0 ? tiles : 1) * 8);
     L.order = take((size_t)(tiles > 0 ? tiles : 1) * 4);
     L.tile_counts = take((size_t)(tiles > 0 ? tiles : 1) * 4);
-    static thread_local uint32_t memo_D = 0xFFFFFFFFu;
-    static thread_local int memo_tiles = -1;
-    static thread_local size_t memo_bytes = 0;
-    if (memo_D != D || memo_tiles != tiles) { memo_bytes = tile_sort_temp_bytes(D, tiles > 0 ? tiles : 1); memo_D = D; memo_tiles = tiles; }
-    L.temp_bytes = memo_bytes;
-    L.temp = take(L.temp_bytes);
+    L.row_total = take((size_t)kMaxTilesPerAxis * 4);
+    L.n_columns = take(4);
+    L.hist_bytes = expand_y_hist_bytes(D, (H + 7) / 8);
+    L.hist = take(L.hist_bytes);
     L.total = off;
     return L;
 }
@@ -310,24 +307,30 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     }
     if (int rc = debug_sync(frame, s, "preprocess_forward")) return rc;
     {
+        StageTimer t(SR_STAGE_SCAN, s);
+        SR_HIP(run_tile_count_scan(P, at<uint32_t>(geom, L.tiles_touched), at<uint32_t>(geom, L.first), at<void>(geom, L.block_base),
+                                   L.base_bytes, s));
+    }
+    if (int rc = debug_sync(frame, s, "emission_scan")) return rc;
+    // the one host read-back of the forward (the reference does the same between scan and duplicateWithKeys)
+    // through a pinned word (one per host thread; with the event below the only things this library keeps): a DMA copy instead
+    // of the staged pageable path.  The depth sort is queued BEHIND the copy and the host waits for the copy only, so the GPU sorts
+    // while the caller wakes up, sizes the binning buffer from D and queues the second phase.
+    static thread_local uint32_t* pinned = nullptr;
+    static thread_local hipEvent_t copied = nullptr;
+    if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
+    if (!copied && hipEventCreateWithFlags(&copied, hipEventDisableTiming) != hipSuccess) copied = nullptr;
+    uint32_t* dst = pinned ? pinned : num_rendered_host;
+    SR_HIP(hipMemcpyAsync(dst, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks, 4, hipMemcpyDeviceToHost, s));   // the scan's grand total
+    if (copied && pinned) SR_HIP(hipEventRecord(copied, s));
+    {
         StageTimer t(SR_STAGE_DEPTH_SORT, s);
         SR_HIP(run_depth_sort(P, at<uint32_t>(geom, L.depth_keys), at<uint2>(geom, L.rect), at<uint32_t>(geom, L.sorted_keys),
                               at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, s));
     }
-    {
-        StageTimer t(SR_STAGE_SCAN, s);
-        SR_HIP(run_tile_count_scan(P, at<uint2>(geom, L.rect_sorted), at<uint32_t>(geom, L.block_offsets), at<void>(geom, L.block_base),
-                                   L.base_bytes, s));
-    }
-    if (int rc = debug_sync(frame, s, "depth_order")) return rc;
-    // the one host read-back of the forward (the reference does the same between scan and duplicateWithKeys)
-    // through a pinned word (one per host thread, the only allocation this library keeps): a DMA copy instead of the
-    // staged pageable path
-    static thread_local uint32_t* pinned = nullptr;
-    if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
-    uint32_t* dst = pinned ? pinned : num_rendered_host;
-    SR_HIP(hipMemcpyAsync(dst, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks, 4, hipMemcpyDeviceToHost, s));   // the scan's grand total
-    SR_HIP(hipStreamSynchronize(s));
+    if (int rc = debug_sync(frame, s, "depth_sort")) return rc;
+    if (copied && pinned) SR_HIP(hipEventSynchronize(copied));
+    else SR_HIP(hipStreamSynchronize(s));
     if (pinned) *num_rendered_host = *pinned;
     return SR_OK;
 }
@@ -345,20 +348,26 @@ int bin_duplicates(const SrFrame* frame, const SrGaussians* g, const FrameDev& f
         if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
         float4* recs = at<float4>(geom, L.recs);
         *recs_out = recs;
+        if (f.tiles_x > kMaxTilesPerAxis || f.tiles_y > kMaxTilesPerAxis)
+            return fail(SR_ERR_INVALID_ARGUMENT, "%d x %d tiles: at most %d per axis (use a larger tile)", f.tiles_x, f.tiles_y, kMaxTilesPerAxis);
+        if (L.temp_bytes < expand_x_hist_bytes(P, f.tiles_x)) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom scratch too small for the column histogram");
         {
-            StageTimer t(SR_STAGE_EMIT, s);
-            SR_HIP(run_emit(P, f.tiles_x, at<uint2>(geom, L.rect_sorted), at<uint32_t>(geom, L.sorted_gid), at<uint32_t>(geom, L.block_offsets),
-                            at<uint32_t>(geom, L.block_base), recs, at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
-                            at<uint32_t>(binning, B.tile_counts), n_tiles, s));
+            StageTimer t(SR_STAGE_EXPAND_X, s);
+            SR_HIP(run_expand_columns(P, f.tiles_x, n_tiles, at<uint2>(geom, L.rect_sorted), at<uint32_t>(geom, L.sorted_gid), at<uint2>(binning, B.columns),
+                                      at<uint32_t>(binning, B.n_columns), at<uint32_t>(geom, L.temp), at<uint32_t>(binning, B.row_total),
+                                      at<uint32_t>(binning, B.tile_counts), s));
         }
-        if (int rc = debug_sync(frame, s, "emit_duplicates")) return rc;
+        if (int rc = debug_sync(frame, s, "expand_columns")) return rc;
+        {
+            StageTimer t(SR_STAGE_EXPAND_Y, s);
+            SR_HIP(run_expand_rows(D, f.tiles_x, f.tiles_y, at<uint2>(binning, B.columns), at<uint32_t>(binning, B.n_columns),
+                                   at<uint32_t>(binning, B.hist), at<uint32_t>(binning, B.row_total), at<uint32_t>(binning, B.point_list),
+                                   at<uint32_t>(binning, B.tile_counts), s));
+        }
+        if (int rc = debug_sync(frame, s, "expand_rows")) return rc;
+    } else {
+        SR_HIP(hipMemsetAsync(at<uint32_t>(binning, B.tile_counts), 0, sizeof(uint32_t) * (size_t)n_tiles, s));   // (no partition ran)
     }
-    {
-        StageTimer t(SR_STAGE_TILE_SORT, s);
-        SR_HIP(run_tile_sort((P > 0) ? D : 0, n_tiles, at<uint32_t>(binning, B.keys_unsorted), at<uint32_t>(binning, B.vals_unsorted),
-                             at<uint32_t>(binning, B.point_list), at<uint32_t>(binning, B.tile_counts), at<void>(binning, B.temp), B.temp_bytes, s));
-    }
-    if (int rc = debug_sync(frame, s, "tile_sort")) return rc;
     {
         StageTimer t(SR_STAGE_RANGES, s);
         SR_HIP(run_tile_ranges_order(n_tiles, at<uint32_t>(binning, B.tile_counts), at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), s));
@@ -452,7 +461,8 @@ int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_clas
     if (geom_bytes < L.total || binning_bytes < B.total || class_image_bytes < C.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "state buffer too small");
     if (workspace_bytes < sr_backward_workspace_bytes(P, D, 3)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P, D, 3));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const FrameDev f = make_frame(frame, g);
+    FrameDev f = make_frame(frame, g);
+    f.first = at<uint32_t>(geom, L.first); f.first_base = at<uint32_t>(geom, L.block_base);
     float4* inst_grads = static_cast<float4*>(workspace);
     uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(3), 256);
     {
@@ -491,6 +501,7 @@ int backward_ctx(const SrFrame* frame, const SrGaussians* g, void* geom, size_t 
     if (workspace_bytes < sr_backward_workspace_bytes(c->P, D, g->color_channels)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(c->P, D, g->color_channels));
     c->s = static_cast<hipStream_t>(stream);
     c->f = make_frame(frame, g);
+    c->f.first = at<uint32_t>(geom, c->L.first); c->f.first_base = at<uint32_t>(geom, c->L.block_base);
     // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous).  K7 writes a record --
     // and sets the slot's byte in `written` -- only where some pixel contributed; K8 looks at the byte before it touches the
     // record, so neither the records nor anything but these D bytes need clearing.
@@ -528,7 +539,8 @@ int sr_backward_colors(const SrFrame* frame, const SrGaussians* g, const int32_t
     if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
     if (workspace_bytes < sr_backward_workspace_bytes(P, D, g->color_channels)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const FrameDev f = make_frame(frame, g);
+    FrameDev f = make_frame(frame, g);
+    f.first = at<uint32_t>(geom, L.first); f.first_base = at<uint32_t>(geom, L.block_base);
     const uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(g->color_channels), 256);
     StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
     SR_HIP(launch_color_gradients(P, f, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), static_cast<const float4*>(workspace), written,
@@ -648,7 +660,7 @@ int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32
     if (n > 0 && (!keys_in || !keys_out || !vals_out || !temp)) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (total_bits < 1 || total_bits > 32) return fail(SR_ERR_INVALID_ARGUMENT, "total_bits %d not in 1..32", total_bits);
     if (temp_bytes < radix_sort_temp_bytes(n)) return fail(SR_ERR_BUFFER_TOO_SMALL, "temp %zu < %zu", temp_bytes, radix_sort_temp_bytes(n));
-    SR_HIP(radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, total_bits, temp, temp_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr, nullptr));
+    SR_HIP(radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, total_bits, temp, temp_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr));
     return SR_OK;
 }
 

@@ -1,19 +1,17 @@
-// binning.hip -- K2..K5: depth ordering of Gaussians, tile-count scan, duplicate emission,
-// stable tile partition, tile ranges.
+// binning.hip -- K2..K5: depth ordering of Gaussians, tile-count scan, expanding tile partition, tile ranges.
 //
 // The reference algorithm emits one (tile<<32 | depth_bits, gaussian)
 // pair per touched tile and LSD-radix-sorts all D 64-bit keys.  The result is the list ordered by
-// (tile, depth bits, gaussian id).  This build produces the *same list, bit for bit*, with ~1/3 of
-// the HBM traffic by splitting the key:
+// (tile, depth bits, gaussian id).  This build produces the *same list, bit for bit*, without ever materialising the
+// (tile, id) pairs:
 //   1. sort the P Gaussians once by their 32-bit depth key (stable => ties keep ascending id);
-//   2. emit duplicates in that order (coalesced, wave-cooperative); the duplicates of one Gaussian are
-//      contiguous in this emission order (first[gid] + (ty - miny) * w + (tx - minx)), which is where
-//      K7 stores the per-duplicate gradient records so that K8 can sum them as one contiguous span;
-//   3. stable-partition the D duplicates by tile id only (ceil(log2(tiles)) bits, 2 radix passes
-//      of 8-byte pairs instead of 6 passes of 12-byte pairs); the last pass keeps only the permutation
-//      (point_list) and counts the duplicates per tile on the way, so the tile ranges are one exclusive
-//      scan of 8 160 counters -- the sorted keys are never written or read back.
-// Stability of both sorts makes (tile, depth, id) the final order.  Integer work only.
+//   2. scan the tile counts (in id order): the duplicates of one Gaussian own the contiguous "emission" indices
+//      first[gid] + (ty - miny) * w + (tx - minx), which is where K7 stores the per-duplicate gradient records so that
+//      K8 can sum them as one contiguous span (and the total D is the one word the host reads back);
+//   3. partition by tile column while expanding rectangles along x, then by tile row while expanding along y
+//      (the "expanding partition" below); pass Y also counts the entries per tile, so the tile ranges are one
+//      exclusive scan of 8 160 counters.
+// Stability of every step makes (tile, depth, id) the final order.  Integer work only.
 #include "common.h"
 
 namespace sr {
@@ -21,64 +19,281 @@ namespace sr {
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out,
-                            uint32_t* full_hist);
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out);
 size_t tile_count_scan_temp_bytes(uint32_t n);
-hipError_t tile_count_scan(const uint2* rect_sorted, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
-constexpr int kScanTile = 2048;   // ranks per block of the tile-count scan (radix_sort.hip kRsTile)
+hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 
-// K3: wave-cooperative duplicate emission.  Each wave owns 64 consecutive depth ranks; the lanes
-// then walk the wave's contiguous output span 64 slots at a time (coalesced 4-B stores), finding the
-// owning Gaussian of each slot by a 6-step binary search over the wave's exclusive offsets in LDS.
-__global__ __launch_bounds__(256) void emit_duplicates_kernel(int P, int tiles_x, const uint2* __restrict__ rect_sorted,
-                                                              const uint32_t* __restrict__ sorted_gid,
-                                                              const uint32_t* __restrict__ block_offsets,   // inclusive scan inside blocks of kScanTile ranks
-                                                              const uint32_t* __restrict__ block_base,      // exclusive scan of the block totals; [nblocks] = D
-                                                              float4* __restrict__ recs,
-                                                              uint32_t* __restrict__ keys_out,
-                                                              uint32_t* __restrict__ vals_out,
-                                                              uint32_t* __restrict__ tile_counts, int n_tiles) {
-    __shared__ uint32_t s_start[4][65];
-    __shared__ uint32_t s_gid[4][64];
-    __shared__ int s_minx[4][64], s_miny[4][64], s_w[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    // side job: clear the per-tile duplicate counters that the last pass of the tile partition accumulates into
-    for (int k = r; k < n_tiles; k += gridDim.x * blockDim.x) tile_counts[k] = 0;
-    // global inclusive offset of a rank = its block-local scan value + the base of its scan block
-    auto offset_of = [&](int rank) { return block_offsets[rank] + block_base[rank / kScanTile]; };
-    uint32_t incl = 0, count = 0, gid = 0;
-    int minx = 0, miny = 0, w = 0;
-    if (r < P) {
-        gid = sorted_gid[r];
-        const uint2 rc = rect_sorted[r];   // K1's tile rectangle, gathered into depth order by the last pass of the depth sort
-        minx = (int)(rc.x & 0xFFFFu); miny = (int)(rc.x >> 16); w = (int)(rc.y & 0xFFFFu);
-        count = (uint32_t)w * (rc.y >> 16);
-        incl = offset_of(r);
-    } else {
-        // ranks past P: inherit the last inclusive offset so the search stays monotone
-        incl = offset_of(P - 1);
-    }
-    const uint32_t excl = incl - count;
-    // emission index of this Gaussian's first duplicate, parked in slot 15 of its record (K7 derives the others and gets
-    // it for free with the record gather)
-    if (r < P && count) reinterpret_cast<float*>(recs)[(size_t)gid * kRecFloats + 15] = __uint_as_float(excl);
-    s_start[wave][lane] = excl;
-    if (lane == 63) s_start[wave][64] = incl;
-    s_gid[wave][lane] = gid; s_minx[wave][lane] = minx; s_miny[wave][lane] = miny; s_w[wave][lane] = w;
-    __syncthreads();
-    const uint32_t span_begin = s_start[wave][0], span_end = s_start[wave][64];
-    for (uint32_t slot = span_begin + lane; slot < span_end; slot += 64) {
-        // largest j with s_start[j] <= slot  (counts of zero are skipped automatically)
-        int lo = 0;
+// ---------------------------------------------------------------------------------------------
+// K3 + K4: the "expanding partition".  The final list is ordered by (tile row, tile column, depth rank), so an LSD partition runs
+// over the tile column first and the tile row second -- and a Gaussian's rectangle only has to be expanded along the axis a pass
+// partitions by:
+//   pass X: the P Gaussians in depth order, each expanded into its w tile columns, stably partitioned by column
+//           -> "column items" (gaussian id, first row, rows, column), sum(w) of them (~ D / 2.3);
+//   pass Y: the column items, each expanded into its h rows, stably partitioned by row -> the D entries of point_list.
+// No duplicate is ever written in unsorted form: the only D-sized traffic is the final 4-B store per entry.  (Emitting all D (tile, id) pairs and running two radix passes over them moved 3.5x the bytes.)
+// One pass = histogram -> row scan -> scatter, like the radix sort's; what differs is that the "keys" of a block are generated, not
+// loaded: a block owns 2048 input items, a block-local prefix sum of their lengths maps every expanded slot back to (item, offset)
+// by binary search in LDS, and the slots are ranked, reordered in LDS and written out in batches of 2048 with the wave64 match-any
+// idiom.  The histogram needs no expansion at all: +1 at the first digit of an item, -1 behind its last, prefix sum (LDS).
+// Pass Y's histogram kernel also produces the number of entries per tile (the input is ordered by column, so a block sees one or two
+// columns: 4 x rows difference counters in LDS), whose exclusive scan is the range table (K5).
+// ---------------------------------------------------------------------------------------------
+constexpr int kXpThreads = 256, kXpWaves = kXpThreads / 64;
+constexpr int kXpInputsX = 1024, kXpInputsY = 2048;   // input items per block (pass X has only P / 1024 ~ 11 blocks per CU as it is)
+template <int AXIS> constexpr int xp_inputs() { return AXIS == 0 ? kXpInputsX : kXpInputsY; }
+constexpr int kXpBatch = 2048;     // expanded slots ranked + reordered in LDS at a time
+constexpr int kXpMaxBins = 1024;   // tiles per image axis
+// column item: x = gaussian id, y = first row | rows << 10 | column << 21
+__device__ inline uint32_t pack_column(int miny, int h, int tx) { return (uint32_t)miny | ((uint32_t)h << 10) | ((uint32_t)tx << 21); }
+
+// exclusive prefix of x over the block's threads (+ the block total); s_w: kXpWaves words of scratch
+__device__ inline uint32_t block_exclusive_scan(uint32_t x, uint32_t* s_w, uint32_t& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = x;
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
-            if (s_start[wave][lo + step] <= slot) lo += step;
-        const uint32_t local = slot - s_start[wave][lo];
-        const int ww = s_w[wave][lo];
-        const int dy = (int)(local / (uint32_t)ww), dx = (int)(local - (uint32_t)dy * (uint32_t)ww);
-        keys_out[slot] = (uint32_t)((s_miny[wave][lo] + dy) * tiles_x + s_minx[wave][lo] + dx);
-        vals_out[slot] = s_gid[wave][lo];
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += y;
+    }
+    __syncthreads();   // s_w may still be in use from the previous scan
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < kXpWaves; ++k) { const uint32_t c = s_w[k]; if (k < w) off += c; tot += c; }
+    total = tot;
+    return off + incl - x;
+}
+
+template <int AXIS> __device__ inline void expansion_of(uint2 item, int& start, int& len) {
+    if (AXIS == 0) { start = (int)(item.x & 0xFFFFu); len = (int)(item.y & 0xFFFFu); }            // rect: minx | miny << 16, w | h << 16
+    else { start = (int)(item.y & 1023u); len = (int)((item.y >> 10) & 2047u); }                  // column item
+}
+
+// hist[d * stride + block] = expanded slots of digit d in this block.  n_dev != NULL: the item count lives on the device (pass Y).
+template <int AXIS>
+__global__ __launch_bounds__(kXpThreads) void expand_hist_kernel(const uint2* __restrict__ in, uint32_t n_host, const uint32_t* __restrict__ n_dev,
+                                                                 int bins, uint32_t* __restrict__ hist, int stride, int tiles_x,
+                                                                 uint32_t* __restrict__ tile_counts, int n_tiles) {
+    __shared__ uint32_t s_diff[kXpMaxBins + 1];
+    __shared__ uint32_t s_full[AXIS ? 4 : 1][AXIS ? kXpMaxBins + 1 : 1];
+    __shared__ uint32_t s_w[kXpWaves];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (AXIS == 0)   // side job: clear the per-tile counters pass Y accumulates into
+        for (int k = blockIdx.x * kXpThreads + tid; k < n_tiles; k += gridDim.x * kXpThreads) tile_counts[k] = 0;
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    constexpr int kInputs = xp_inputs<AXIS>();
+    const uint32_t base = blockIdx.x * (uint32_t)kInputs;
+    if (base >= n) return;
+    for (int k = tid; k <= bins; k += kXpThreads) s_diff[k] = 0;
+    int tx0 = 0;
+    if (AXIS == 1) {
+        for (int k = tid; k < 4 * (kXpMaxBins + 1); k += kXpThreads) (&s_full[0][0])[k] = 0;
+        tx0 = (int)(in[base].y >> 21);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kInputs / kXpThreads; ++i) {
+        const uint32_t idx = base + (uint32_t)(i * kXpThreads + tid);
+        if (idx < n) {
+            const uint2 it = in[idx];
+            int start, len; expansion_of<AXIS>(it, start, len);
+            if (len) {
+                atomicAdd(&s_diff[start], 1u); atomicSub(&s_diff[start + len], 1u);
+                if (AXIS == 1) {
+                    const int tx = (int)(it.y >> 21);
+                    const uint32_t rel = (uint32_t)(tx - tx0);
+                    if (rel < 4u) { atomicAdd(&s_full[rel][start], 1u); atomicSub(&s_full[rel][start + len], 1u); }
+                    else for (int k = 0; k < len; ++k) atomicAdd(&tile_counts[(start + k) * tiles_x + tx], 1u);   // tiny inputs only
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {   // prefix sum over the digits, 4 consecutive digits per thread
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int b = 4 * tid + j; sum += b < bins ? s_diff[b] : 0u; v[j] = sum; }
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan(sum, s_w, total);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int b = 4 * tid + j; if (b < bins) hist[(size_t)b * stride + blockIdx.x] = excl + v[j]; }
+    }
+    if (AXIS == 1 && tx0 + w < tiles_x) {   // wave w: the rows of column tx0 + w
+        uint32_t carry = 0;
+        for (int c = 0; c < bins; c += 64) {
+            const int row = c + lane;
+            uint32_t incl = row < bins ? s_full[w][row] : 0u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += y;
+            }
+            const uint32_t cnt = carry + incl;
+            if (row < bins && cnt) atomicAdd(&tile_counts[row * tiles_x + tx0 + w], cnt);
+            carry += (uint32_t)__shfl((int)incl, 63);
+        }
+    }
+}
+
+// Exclusive scan of every histogram row (one block per digit) + the row totals.
+__global__ __launch_bounds__(kXpThreads) void expand_scan_rows_kernel(uint32_t* __restrict__ hist, int stride, uint32_t n_host,
+                                                                      const uint32_t* __restrict__ n_dev, int inputs_per_block,
+                                                                      uint32_t* __restrict__ row_total) {
+    __shared__ uint32_t s_w[kXpWaves];
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const int nblocks = (int)((n + (uint32_t)inputs_per_block - 1) / (uint32_t)inputs_per_block);
+    uint32_t* row = hist + (size_t)blockIdx.x * stride;
+    uint32_t carry = 0;
+    for (int c = 0; c < nblocks; c += kXpThreads) {
+        const int i = c + (int)threadIdx.x;
+        const uint32_t x = i < nblocks ? row[i] : 0u;
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan(x, s_w, total);
+        if (i < nblocks) row[i] = carry + excl;
+        carry += total;
+    }
+    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
+template <int AXIS, int kBits>
+__global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
+    const uint2* __restrict__ in, uint32_t n_host, const uint32_t* __restrict__ n_dev, int bins, const uint32_t* __restrict__ hist, int stride,
+    const uint32_t* __restrict__ row_total,
+    // pass X: ids in depth order, outputs
+    const uint32_t* __restrict__ sorted_gid, uint2* __restrict__ columns_out, uint32_t* __restrict__ n_columns_out,
+    // pass Y
+    uint32_t* __restrict__ point_list) {
+    constexpr int kBins = 1 << kBits;
+    constexpr int kPer = kBins / kXpThreads > 0 ? kBins / kXpThreads : 1;   // digits per thread in the block-wide digit scans
+    constexpr int kInputs = xp_inputs<AXIS>(), kXpPerThread = kInputs / kXpThreads;
+    __shared__ uint32_t s_prefix[kInputs + 1];            // s_prefix[j] = expanded slots of the block's items before item j
+    __shared__ uint32_t s_count[kXpWaves][kBins];         // slots of digit d held by wave w (this batch); then, in place, the next
+                                                          // batch-local position for (wave, digit)
+    __shared__ uint32_t s_lstart[kBins];                  // batch-local start of digit d
+    __shared__ uint32_t s_goff[kBins];                    // global position of the block's next slot of digit d
+    __shared__ uint32_t s_w[kXpWaves];
+    __shared__ uint32_t s_id[kXpBatch];                   // the batch, stably reordered by digit: gaussian id,
+    __shared__ uint32_t s_rows[AXIS == 0 ? kXpBatch : 1]; //   first row | rows << 10 (pass X),
+    __shared__ uint16_t s_dig[kXpBatch];                  //   digit
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    const uint32_t base = blockIdx.x * (uint32_t)kInputs;
+    if (base >= n) return;
+    const int n_items = (int)min((uint32_t)kInputs, n - base);
+    uint32_t E;   // expanded slots of this block
+    {
+        uint32_t incl[kXpPerThread], sum = 0;
+#pragma unroll
+        for (int i = 0; i < kXpPerThread; ++i) {
+            const int j = tid * kXpPerThread + i;
+            int start = 0, len = 0;
+            if (j < n_items) {
+                const uint2 it = in[base + j];
+                expansion_of<AXIS>(it, start, len);
+            }
+            sum += (uint32_t)len;
+            incl[i] = sum;
+        }
+        const uint32_t excl = block_exclusive_scan(sum, s_w, E);
+#pragma unroll
+        for (int i = 0; i < kXpPerThread; ++i) s_prefix[tid * kXpPerThread + i + 1] = excl + incl[i];
+        if (tid == 0) s_prefix[0] = 0;
+    }
+    {   // first output position of every digit (exclusive scan of the row totals) + this block's offset inside the digit
+        uint32_t v[kPer], sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { const int d = tid * kPer + j; const uint32_t c = (d < bins) ? row_total[d] : 0u; v[j] = sum; sum += c; }
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan(sum, s_w, total);
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { const int d = tid * kPer + j; if (d < kBins) s_goff[d] = d < bins ? excl + v[j] + hist[(size_t)d * stride + blockIdx.x] : 0u; }
+        if (AXIS == 0 && blockIdx.x == 0 && tid == 0) *n_columns_out = total;   // number of column items = pass Y's input size
+    }
+    for (uint32_t q0 = 0; q0 < E; q0 += kXpBatch) {
+        for (int k = tid; k < kXpWaves * kBins; k += kXpThreads) (&s_count[0][0])[k] = 0;
+        __syncthreads();   // (also orders s_prefix / s_goff writes and the previous batch's write-out)
+        uint32_t dig[kXpBatch / kXpThreads], id[kXpBatch / kXpThreads], rows[AXIS == 0 ? kXpBatch / kXpThreads : 1];
+#pragma unroll
+        for (int i = 0; i < kXpBatch / kXpThreads; ++i) {
+            const uint32_t slot = q0 + (uint32_t)(w * (kXpBatch / kXpWaves) + i * 64 + lane);
+            dig[i] = 0; id[i] = 0;
+            if (AXIS == 0) rows[i] = 0;
+            if (slot < E) {
+                int lo = 0;   // largest j with s_prefix[j] <= slot (empty items are skipped automatically)
+#pragma unroll
+                for (int step = kInputs / 2; step > 0; step >>= 1)
+                    if (lo + step < n_items && s_prefix[lo + step] <= slot) lo += step;
+                const uint2 it = in[base + lo];
+                int start, len; expansion_of<AXIS>(it, start, len);
+                dig[i] = (uint32_t)start + (slot - s_prefix[lo]);
+                if (AXIS == 0) { id[i] = sorted_gid[base + lo]; rows[i] = (it.x >> 16) | ((it.y >> 16) << 10); }
+                else id[i] = it.x;
+                atomicAdd(&s_count[w][dig[i]], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t tot[kPer];
+        {   // batch-local exclusive scan over the digits, then the per-wave run starts
+            uint32_t sum = 0;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int d = tid * kPer + j;
+                tot[j] = 0;
+                if (d < kBins) {
+#pragma unroll
+                    for (int k = 0; k < kXpWaves; ++k) tot[j] += s_count[k][d];
+                }
+                sum += tot[j];
+            }
+            uint32_t total;
+            uint32_t run = block_exclusive_scan(sum, s_w, total);
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int d = tid * kPer + j;
+                if (d < kBins) {
+                    s_lstart[d] = run;
+#pragma unroll
+                    for (int k = 0; k < kXpWaves; ++k) { const uint32_t c = s_count[k][d]; s_count[k][d] = run; run += c; }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kXpBatch / kXpThreads; ++i) {
+            const uint32_t slot = q0 + (uint32_t)(w * (kXpBatch / kXpWaves) + i * 64 + lane);
+            const bool live = slot < E;
+            const uint32_t d = dig[i];
+            unsigned long long same = __ballot(live);        // lanes holding the same digit as this lane
+#pragma unroll
+            for (int b = 0; b < kBits; ++b) {
+                const unsigned long long vote = __ballot((d >> b) & 1u);
+                same &= ((d >> b) & 1u) ? vote : ~vote;
+            }
+            const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            uint32_t pos = 0;
+            if (live) pos = s_count[w][d] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (live && rank == 0) s_count[w][d] += (uint32_t)__popcll(same);  // one leader per digit advances the run
+            __builtin_amdgcn_wave_barrier();
+            if (live) { s_id[pos] = id[i]; s_dig[pos] = (uint16_t)d; if (AXIS == 0) s_rows[pos] = rows[i]; }
+        }
+        __syncthreads();
+        // coalesced write-out: consecutive batch slots of one digit are consecutive in global memory
+        const uint32_t count = min((uint32_t)kXpBatch, E - q0);
+#pragma unroll
+        for (int i = 0; i < kXpBatch / kXpThreads; ++i) {
+            const uint32_t li = (uint32_t)(i * kXpThreads + tid);
+            if (li < count) {
+                const uint32_t d = s_dig[li];
+                const uint32_t g = s_goff[d] + (li - s_lstart[d]);
+                if (AXIS == 0) columns_out[g] = make_uint2(s_id[li], s_rows[li] | (d << 21));
+                else point_list[g] = s_id[li];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { const int d = tid * kPer + j; if (d < kBins) s_goff[d] += tot[j]; }
     }
 }
 
@@ -169,12 +384,6 @@ __global__ __launch_bounds__(kOrderThreads) void tile_ranges_order_kernel(int n_
     }
 }
 
-static int bits_for(uint32_t n) {  // number of bits needed to represent values in [0, n)
-    int b = 0;
-    while ((1ull << b) < (unsigned long long)n) ++b;
-    return b < 1 ? 1 : b;
-}
-
 // temp-storage sizes (pure host arithmetic) --------------------------------------------------------
 size_t depth_sort_temp_bytes(int P) {
     const uint32_t n = (uint32_t)(P > 0 ? P : 1);
@@ -182,41 +391,61 @@ size_t depth_sort_temp_bytes(int P) {
 }
 size_t tile_scan_temp_bytes(int P) { return tile_count_scan_temp_bytes((uint32_t)(P > 0 ? P : 1)); }
 
-size_t tile_sort_temp_bytes(uint32_t D, int n_tiles) {
-    (void)n_tiles;
-    return align_up(radix_sort_temp_bytes(D > 0 ? D : 1), 256);
-}
+// histogram tables of the two passes: [digits][blocks] words.  Pass X's lives in the depth sort's scratch (free by then, and
+// always large enough: 8 B per Gaussian against <= 4 B), pass Y's in the binning buffer.
+size_t expand_x_hist_bytes(int P, int tiles_x) { return (size_t)tiles_x * (((size_t)(P > 0 ? P : 1) + kXpInputsX - 1) / kXpInputsX) * 4; }
+size_t expand_y_hist_bytes(uint32_t D, int tiles_y) { return (size_t)tiles_y * (((size_t)(D > 0 ? D : 1) + kXpInputsY - 1) / kXpInputsY) * 4; }
 
 // launchers ---------------------------------------------------------------------------------------
 // K2: stable sort of (depth key, gaussian id) -- ties keep ascending id, culled Gaussians (key 0xFFFFFFFF) end up last.
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, uint32_t* sorted_keys,
                           uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    // the last pass also gathers the tile rectangles into depth order, so the scan and the emission read sequentially
-    return radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, rect, rect_sorted, nullptr);
+    // the last pass also gathers the tile rectangles into depth order, so the scan and the partition read sequentially
+    return radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, rect, rect_sorted);
 }
 
-// K2: scan of the tile counts in depth order (block-local values in block_offsets, block bases + total in block_base).
-hipError_t run_tile_count_scan(int P, const uint2* rect_sorted, uint32_t* block_offsets, void* block_base, size_t base_bytes, hipStream_t s) {
+// K2: emission offsets = scan of tiles_touched in id order (block-local values in first, block bases + total D in block_base).
+hipError_t run_tile_count_scan(int P, const uint32_t* tiles_touched, uint32_t* first, void* block_base, size_t base_bytes, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    return tile_count_scan(rect_sorted, block_offsets, (uint32_t)P, block_base, base_bytes, s);
+    return tile_count_scan(tiles_touched, first, (uint32_t)P, block_base, base_bytes, s);
 }
 
-hipError_t run_emit(int P, int tiles_x, const uint2* rect_sorted, const uint32_t* sorted_gid, const uint32_t* block_offsets,
-                    const uint32_t* block_base, float4* recs, uint32_t* keys_unsorted, uint32_t* vals_unsorted, uint32_t* tile_counts,
-                    int n_tiles, hipStream_t s) {
+template <int AXIS, typename... Args>
+static void launch_expand_scatter(int bins, int blocks, hipStream_t s, Args... a) {
+    if (bins <= 128) hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 7>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
+    else if (bins <= 256) hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 8>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
+    else if (bins <= 512) hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 9>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
+    else hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 10>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
+}
+
+// K3: Gaussians in depth order -> column items ordered by (tile column, depth).  Also zeroes tile_counts.  n_columns (device word) receives the number of column items.
+hipError_t run_expand_columns(int P, int tiles_x, int n_tiles, const uint2* rect_sorted, const uint32_t* sorted_gid, uint2* columns,
+                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_duplicates_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, tiles_x, rect_sorted, sorted_gid,
-                       block_offsets, block_base, recs, keys_unsorted, vals_unsorted, tile_counts, n_tiles);
+    if (tiles_x > kXpMaxBins) return hipErrorInvalidValue;
+    const int nb = (P + kXpInputsX - 1) / kXpInputsX;
+    hipLaunchKernelGGL(expand_hist_kernel<0>, dim3(nb), dim3(kXpThreads), 0, s, rect_sorted, (uint32_t)P, (const uint32_t*)nullptr, tiles_x, hist, nb,
+                       tiles_x, tile_counts, n_tiles);
+    hipLaunchKernelGGL(expand_scan_rows_kernel, dim3(tiles_x), dim3(kXpThreads), 0, s, hist, nb, (uint32_t)P, (const uint32_t*)nullptr, kXpInputsX, row_total);
+    launch_expand_scatter<0>(tiles_x, nb, s, rect_sorted, (uint32_t)P, (const uint32_t*)nullptr, tiles_x, (const uint32_t*)hist, nb,
+                             (const uint32_t*)row_total, sorted_gid, columns, n_columns, (uint32_t*)nullptr);
     return hipGetLastError();
 }
 
-// K4: only the permutation leaves the last pass; tile_counts[tile] (zeroed by the emission kernel) receives the duplicates per tile
-hipError_t run_tile_sort(uint32_t D, int n_tiles, const uint32_t* keys_unsorted, const uint32_t* vals_unsorted,
-                         uint32_t* point_list, uint32_t* tile_counts, void* temp, size_t temp_bytes, hipStream_t s) {
-    if (D == 0) return hipMemsetAsync(tile_counts, 0, sizeof(uint32_t) * (size_t)n_tiles, s);   // (no emission ran)
-    return radix_sort_pairs(keys_unsorted, vals_unsorted, nullptr, point_list, D, bits_for((uint32_t)n_tiles), temp, temp_bytes, s, nullptr,
-                            nullptr, tile_counts);
+// K4: column items -> point_list ordered by (tile row, tile column, depth) + the entries per tile.  The number of column items is
+// only known on the device; the grid is sized for the upper bound D and surplus blocks leave at once.
+hipError_t run_expand_rows(uint32_t D, int tiles_x, int tiles_y, const uint2* columns, const uint32_t* n_columns, uint32_t* hist, uint32_t* row_total,
+                           uint32_t* point_list, uint32_t* tile_counts, hipStream_t s) {
+    if (D == 0) return hipSuccess;
+    if (tiles_y > kXpMaxBins) return hipErrorInvalidValue;
+    const int nb = (int)((D + kXpInputsY - 1) / kXpInputsY);
+    hipLaunchKernelGGL(expand_hist_kernel<1>, dim3(nb), dim3(kXpThreads), 0, s, columns, D, n_columns, tiles_y, hist, nb, tiles_x, tile_counts,
+                       tiles_x * tiles_y);
+    hipLaunchKernelGGL(expand_scan_rows_kernel, dim3(tiles_y), dim3(kXpThreads), 0, s, hist, nb, D, n_columns, kXpInputsY, row_total);
+    launch_expand_scatter<1>(tiles_y, nb, s, columns, D, n_columns, tiles_y, (const uint32_t*)hist, nb, (const uint32_t*)row_total,
+                             (const uint32_t*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, point_list);
+    return hipGetLastError();
 }
 
 hipError_t run_tile_ranges_order(int n_tiles, const uint32_t* tile_counts, uint2* ranges, uint32_t* order, hipStream_t s) {

@@ -21,8 +21,7 @@ constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
 
 // Packed per-Gaussian record, 5 x float4 = 80 B, 16-B aligned (one gather = five dwordx4 loads):
 //   q0 = Tu.x Tu.y Tu.z Tv.x | q1 = Tv.y Tv.z Tw.x Tw.y | q2 = Tw.z xy.x xy.y opacity
-//   q3 = n.x n.y n.z first   | q4 = r g b radius      (first = emission index of the Gaussian's first duplicate, u32 bits,
-//                                                        written by K3; K1 leaves the view-space depth there)
+//   q3 = n.x n.y n.z depth   | q4 = r g b radius      (depth = view-space depth; not read by the blend kernels)
 constexpr int kRecQuads = 5;
 constexpr int kRecFloats = SR_SPLAT_FLOATS;
 
@@ -50,7 +49,12 @@ struct FrameDev {
     const float* view;
     const float* proj;
     const float* campos;
+    // emission index of every Gaussian's first duplicate = first[gid] + first_base[gid / kScanTile] (geom buffer, K2); backward only
+    const uint32_t* first;
+    const uint32_t* first_base;
 };
+constexpr int kScanTile = 2048;   // Gaussians per block of the emission-offset scan
+__device__ __forceinline__ uint32_t first_index(const FrameDev& f, uint32_t gid) { return f.first[gid] + f.first_base[gid / kScanTile]; }
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

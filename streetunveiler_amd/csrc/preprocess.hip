@@ -304,8 +304,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // K8: per-Gaussian backward (Appendix A.6).  First sums the Gaussian's per-(tile, Gaussian) gradient records: K7 stores
-// them in emission order, where they form the contiguous span [first, first + tiles_touched) (first rides in slot 15 of
-// the splat record); ascending order -> deterministic.  Slots whose `written` flag is clear got no record from K7 (no pixel
+// them in emission order, where they form the contiguous span [first, first + tiles_touched) (first[] = FrameDev.first, a compact
+// array by Gaussian id written by K3); ascending order -> deterministic.  Slots whose `written` flag is clear got no record from K7 (no pixel
 // contributed) and are skipped without being read.
 // ---------------------------------------------------------------------------------------------
 template <bool kLdsSH, int NC>
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
                 float4 g[kGQ];
 #pragma unroll
                 for (int k = 0; k < kGQ; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const uint32_t first = __float_as_uint(rec[3].w), cnt = tiles_touched[i];
+                const uint32_t first = first_index(f, (uint32_t)i), cnt = tiles_touched[i];
                 // Four records per trip.  K7 writes a record only where some pixel contributed -- about 40 % of a Gaussian's span --
                 // and sets the slot's byte in `written`; the flags of the next trip are in flight behind this trip's records.
                 constexpr int kTrip = 4;
@@ -513,12 +513,12 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
 __global__ __launch_bounds__(256) void color_gradient_kernel(int P, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
                                                              const float4* __restrict__ recs, const float4* __restrict__ inst_grads,
                                                              const uint8_t* __restrict__ written, const uint32_t* __restrict__ tiles_touched,
-                                                             int mask_clamped, float* __restrict__ dL_dcolors) {
+                                                             FrameDev f, int mask_clamped, float* __restrict__ dL_dcolors) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (radii[i] > 0) {
-        const uint32_t first = __float_as_uint(recs[(size_t)i * kRecQuads + 3].w), end = first + tiles_touched[i];
+        const uint32_t first = first_index(f, (uint32_t)i), end = first + tiles_touched[i];
         for (uint32_t e = first; e < end; ++e) {
             if (!written[e]) continue;
             const float4* gr = inst_grads + (size_t)e * kGradQuads;
@@ -663,10 +663,9 @@ hipError_t launch_sh_gradient_expand(int P, int M, int deg, int V, const float* 
 
 hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii, const uint8_t* clamped, const float4* recs, const float4* inst_grads,
                                   const uint8_t* written, const uint32_t* tiles_touched, bool mask_clamped, float* dL_dcolors, hipStream_t s) {
-    (void)f;
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(color_gradient_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, clamped, recs, inst_grads, written, tiles_touched,
-                       mask_clamped ? 1 : 0, dL_dcolors);
+                       f, mask_clamped ? 1 : 0, dL_dcolors);
     return hipGetLastError();
 }
 

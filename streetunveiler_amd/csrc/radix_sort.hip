@@ -17,48 +17,24 @@ namespace sr {
 constexpr int kRsThreads = 256;
 constexpr int kRsItems = 8;                       // per thread
 constexpr int kRsTile = kRsThreads * kRsItems;    // 2048 items per block
+static_assert(kRsTile == kScanTile, "first_index() divides by the scan's block size");
 constexpr int kRsMaxBins = 256;
 
-// `full_hist` != NULL (last pass of the tile partition): additionally counts the items per FULL key -- the exclusive scan of that
-// histogram is the tile range table, so the sorted keys never have to be written or read back.  At that point the data is already
-// ordered by the key bits below `shift`, a block's 2048 items hold one or two distinct low parts, and the (<= 4 low parts) x
-// (<= 256 digits) counters live in LDS; whatever falls outside (tiny inputs) goes straight to a global atomic.
 __global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, int bits,
-                                                             uint32_t* __restrict__ hist, int nblocks, uint32_t* __restrict__ full_hist) {
+                                                             uint32_t* __restrict__ hist, int nblocks) {
     __shared__ uint32_t s_h[kRsMaxBins];
-    __shared__ uint32_t s_full[4 * kRsMaxBins];
     const int tid = threadIdx.x, bins = 1 << bits;
     const uint32_t mask = (uint32_t)bins - 1u;
     if (tid < bins) s_h[tid] = 0;
     const uint32_t base = blockIdx.x * (uint32_t)kRsTile;
-    const uint32_t low_mask = (1u << shift) - 1u;
-    uint32_t low_min = 0;
-    if (full_hist) {
-        for (int k = tid; k < 4 * bins; k += kRsThreads) s_full[k] = 0;
-        low_min = keys[base] & low_mask;   // base < n: the grid has ceil(n / tile) blocks
-    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kRsItems; ++i) {
         const uint32_t idx = base + (uint32_t)(i * kRsThreads + tid);
-        if (idx < n) {
-            const uint32_t k = keys[idx], d = (k >> shift) & mask;
-            atomicAdd(&s_h[d], 1u);
-            if (full_hist) {
-                const uint32_t rel = (k & low_mask) - low_min;
-                if (rel < 4u) atomicAdd(&s_full[rel * bins + d], 1u);
-                else atomicAdd(&full_hist[k], 1u);
-            }
-        }
+        if (idx < n) atomicAdd(&s_h[(keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
     if (tid < bins) hist[(size_t)tid * nblocks + blockIdx.x] = s_h[tid];   // bin-major: row b = per-block counts of digit b
-    if (full_hist) {
-        for (int k = tid; k < 4 * bins; k += kRsThreads) {
-            const uint32_t c = s_full[k];
-            if (c) atomicAdd(&full_hist[((uint32_t)(k & (bins - 1)) << shift) | (low_min + (uint32_t)(k >> bits))], c);
-        }
-    }
 }
 
 // Exclusive scan of every row (one block per digit), row totals out.
@@ -193,7 +169,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
             const uint32_t d = (k >> shift) & mask;
             const uint32_t g = s_gbase[d] + (li - s_lstart[d]);
             const uint32_t v = s_val[li];
-            if (keys_out) keys_out[g] = k;          // NULL: the caller only wants the permutation (tile partition, last pass)
+            keys_out[g] = k;
             vals_out[g] = v;
             if (aux_out) aux_out[g] = aux_src[v];   // last pass: payload gathered in sorted order (aux_out[i] = aux_src[vals_out[i]])
         }
@@ -201,12 +177,12 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tile counts in depth order -> where each Gaussian's duplicates end in emission order (K2).  Two small kernels: an inclusive scan
-// inside every block of 2048 ranks (the count of a rank = area of its packed tile rectangle, which the last pass of the depth sort
-// gathered into depth order) + the block totals; then an exclusive scan of the totals.  The consumer (emit_duplicates_kernel)
-// adds its block's base itself, and totals[nblocks] = D, the number of duplicates, is what the host reads back.
+// Emission offsets (K2): the duplicates of Gaussian i own the gradient-record slots first[i] .. first[i] + tiles_touched[i] - 1,
+// first = exclusive scan of tiles_touched in ID order (any order would do; this one needs no gather and no scattered store).  Two small
+// kernels: an exclusive scan inside every block of 2048 Gaussians + the block totals; then an exclusive scan of the totals.  Consumers
+// add the block base themselves (common.h first_index()); totals[nblocks] = D, the number of duplicates, is what the host reads back.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint2* __restrict__ rect_sorted, uint32_t n, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ out,
                                                                  uint32_t* __restrict__ block_total) {
     __shared__ uint32_t s_w[kRsThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -215,9 +191,8 @@ __global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint2* __
 #pragma unroll
     for (int i = 0; i < kRsItems; ++i) {
         const uint32_t j = base + i;
-        const uint32_t wh = j < n ? rect_sorted[j].y : 0u;    // width | height << 16 (0 for culled Gaussians)
-        sum += (wh & 0xFFFFu) * (wh >> 16);
-        v[i] = sum;   // inclusive within the thread
+        v[i] = sum;   // exclusive within the thread
+        sum += j < n ? counts[j] : 0u;
     }
     uint32_t incl = sum;
 #pragma unroll
@@ -279,13 +254,9 @@ size_t radix_sort_temp_bytes(uint32_t n) {
 
 // Sorts by key bits [0, total_bits) in passes of <= 8 bits (as even as possible); stable; result in keys_out/vals_out.
 // vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.  If aux_out != nullptr the last pass also
-// writes aux_out[i] = aux_src[vals_out[i]] (an 8-B payload gathered in sorted order, for free).  keys_out == nullptr: only the
-// permutation is wanted (the sorted keys are not written; with more than two passes the intermediate odd passes then park their
-// keys in keys_in, which is overwritten -- the tile partition's input is scratch).  full_hist != nullptr: the last pass also accumulates the number of
-// items per full key into full_hist[key] (zeroed by the caller).
+// writes aux_out[i] = aux_src[vals_out[i]] (an 8-B payload gathered in sorted order, for free).
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out,
-                            uint32_t* full_hist) {
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out) {
     if (n == 0) return hipSuccess;
     if (temp_bytes < radix_sort_temp_bytes(n)) return hipErrorInvalidValue;
     int passes = (total_bits + 7) / 8;
@@ -305,10 +276,9 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         if (bits > 8) bits = 8;
         if (bits < 1) bits = 1;
         const bool last = p == passes - 1;
-        uint32_t* ko = (p & 1) ? keys_out : tk;   // (last pass: keys_out, possibly NULL)
-        if (!ko && !last) ko = const_cast<uint32_t*>(keys_in);
+        uint32_t* ko = (p & 1) ? keys_out : tk;
         uint32_t* vo = (p & 1) ? vals_out : tv;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb, last ? full_hist : nullptr);
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
 #define SR_SCATTER(B) hipLaunchKernelGGL(rs_scatter_kernel<B>, dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
                                          row_total, nb, last ? aux_src : nullptr, last ? aux_out : nullptr)
@@ -327,14 +297,14 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
 
 size_t tile_count_scan_temp_bytes(uint32_t n) { return align_up(((size_t)rs_blocks(n > 0 ? n : 1) + 1) * 4, 256); }
 
-// out[i] = inclusive scan of the tile counts INSIDE block i / 2048; block_base[b] = exclusive scan of the block totals,
+// out[i] = exclusive scan of counts INSIDE block i / 2048; block_base[b] = exclusive scan of the block totals,
 // block_base[nblocks] = total.  (block_base lives in `temp`.)
-hipError_t tile_count_scan(const uint2* rect_sorted, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s) {
+hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (temp_bytes < tile_count_scan_temp_bytes(n)) return hipErrorInvalidValue;
     const int nb = rs_blocks(n);
     uint32_t* totals = static_cast<uint32_t*>(temp);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(kRsThreads), 0, s, rect_sorted, n, out, totals);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(kRsThreads), 0, s, counts, n, out, totals);
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kRsThreads), 0, s, totals, nb);
     return hipGetLastError();
 }

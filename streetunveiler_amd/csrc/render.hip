@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
 // K7
 // ---------------------------------------------------------------------------------------------
 // Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
-// (first[gid] + its index inside the Gaussian's tile rectangle; first[gid] rides in slot 15 of the splat record), where the
+// (first[gid] + its index inside the Gaussian's tile rectangle; first[] = FrameDev.first, fetched next to the record), where the
 // records of one Gaussian are contiguous; K8 sums them.  Only entries with a contributing pixel get a record, and a 1 in
 // `written[]` at the same index (zeroed per call).  Gradient record slots: see common.h.
 // Register budget: three waves per SIMD (<= 168 VGPRs) wherever the per-pixel state allows it -- the loop is latency-bound
@@ -273,7 +273,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
     if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
         const uint32_t pos = range.x + (rounds - 1) * kWave + lane;
         const uint32_t gid = point_list[pos];
-        load_record(recs, gid, nr);
+        load_record(recs, gid, nr); nr[3].w = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
         if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
         nhit = decode_hits<QX, QY>(hit_mask[pos]);
@@ -299,7 +299,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
         if (rd > 0) {  // next round is always full
             const uint32_t pos = range.x + rbase - kWave + lane;
             const uint32_t gid = point_list[pos];
-            load_record(recs, gid, nr);
+            load_record(recs, gid, nr); nr[3].w = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
             if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
             nhit = decode_hits<QX, QY>(hit_mask[pos]);

@@ -184,7 +184,7 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 nr[kRecQuads];
     uint32_t nhit = 0;
-    auto fetch = [&](uint32_t pos) { load_record(recs, point_list[pos], nr); nhit = decode_hits<QX, QY>(hit_mask[pos]); };
+    auto fetch = [&](uint32_t pos) { const uint32_t gid = point_list[pos]; load_record(recs, gid, nr); nr[3].w = __uint_as_float(first_index(f, gid)); nhit = decode_hits<QX, QY>(hit_mask[pos]); };
     if ((uint32_t)((rounds - 1) * kWave + lane) < total) fetch(range.x + (rounds - 1) * kWave + lane);
     for (int rd = rounds - 1; rd >= 0; --rd) {
         const uint32_t rbase = (uint32_t)rd * kWave;

@@ -35,7 +35,7 @@ for tile in shapes:
     st = {k: round(ms / n, 4) for k, (ms, n) in _lib.stage_stats().items() if n}; lib.sr_set_stage_timing(0)
     ms = t0.elapsed_time(t1) / 10
     row = dict(tile=f"{tile[0]}x{tile[1]}", duplicates_D=int(D), ms_per_step=round(ms, 3), msplats_per_s=round(P / ms / 1e3, 1),
-               binning_ms=round(sum(st[k] for k in ("depth_sort", "scan", "emit", "tile_sort", "ranges")), 3), **st)
+               binning_ms=round(sum(st[k] for k in ("depth_sort", "scan", "expand_x", "expand_y", "ranges")), 3), **st)
     rows.append(row); print(json.dumps(row), flush=True)
 out = dict(scene=f"{P} Gaussians, {W}x{H}, SH 3, fwd+bwd, 1 GPU", rows=rows)
 os.makedirs("gpurun_out", exist_ok=True)
