@@ -49,12 +49,7 @@ __device__ inline uint32_t pack_column(int miny, int h, int tx) { return (uint32
 // exclusive prefix of x over the block's threads (+ the block total); s_w: kXpWaves words of scratch
 __device__ inline uint32_t block_exclusive_scan(uint32_t x, uint32_t* s_w, uint32_t& total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t incl = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += y;
-    }
+    uint32_t incl = wave_inclusive_scan(x);
     __syncthreads();   // s_w may still be in use from the previous scan
     if (lane == 63) s_w[w] = incl;
     __syncthreads();
@@ -123,12 +118,7 @@ __global__ __launch_bounds__(kXpThreads) void expand_hist_kernel(const uint2* __
         uint32_t carry = 0;
         for (int c = 0; c < bins; c += 64) {
             const int row = c + lane;
-            uint32_t incl = row < bins ? s_full[w][row] : 0u;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
-                if (lane >= d) incl += y;
-            }
+            uint32_t incl = wave_inclusive_scan(row < bins ? s_full[w][row] : 0u);
             const uint32_t cnt = carry + incl;
             if (row < bins && cnt) atomicAdd(&tile_counts[row * tiles_x + tx0 + w], cnt);
             carry += (uint32_t)__shfl((int)incl, 63);
@@ -324,10 +314,8 @@ __global__ __launch_bounds__(kOrderThreads) void tile_ranges_order_kernel(int n_
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kOrderClasses; ++k) {
-        uint32_t v = my_cls[k];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
-        if (lane == 0 && v) atomicAdd(&s_cls_base[k], v);
+        const uint32_t v = wave_inclusive_scan(my_cls[k]);   // lane 63: the wave's total
+        if (lane == 63 && v) atomicAdd(&s_cls_base[k], v);
     }
     __syncthreads();
     if (tid == 0) { uint32_t run = 0; for (int k = 0; k < kOrderClasses; ++k) { const uint32_t c = s_cls_base[k]; s_cls_base[k] = run; run += c; } }
@@ -339,9 +327,7 @@ __global__ __launch_bounds__(kOrderThreads) void tile_ranges_order_kernel(int n_
         uint32_t c[kPer], sum = 0;
 #pragma unroll
         for (int i = 0; i < kPer; ++i) { c[i] = t0 + i < n_tiles ? counts[t0 + i] : 0u; sum += c[i]; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += y; }
+        uint32_t incl = wave_inclusive_scan(sum);
         if (lane == 63) s_wsum[w] = incl;
         // tiles per class in this thread / wave
         uint32_t mine[kOrderClasses];
@@ -354,9 +340,7 @@ __global__ __launch_bounds__(kOrderThreads) void tile_ranges_order_kernel(int n_
         uint32_t before[kOrderClasses];   // tiles of class k in lower lanes of this wave
 #pragma unroll
         for (int k = 0; k < kOrderClasses; ++k) {
-            uint32_t v = mine[k];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)v, d); if (lane >= d) v += y; }
+            uint32_t v = wave_inclusive_scan(mine[k]);
             before[k] = v - mine[k];
             if (lane == 63) s_cls[k][w] = v;
         }

@@ -58,4 +58,17 @@ __device__ __forceinline__ uint32_t first_index(const FrameDev& f, uint32_t gid)
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Inclusive prefix sum over the 64 lanes of a wave: DPP row shifts inside the rows of 16 lanes, then the two row broadcasts
+// (six VALU instructions; __shfl_up goes through the LDS crossbar six times).  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)v;
+}
+
 }  // namespace sr

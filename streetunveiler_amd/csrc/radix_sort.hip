@@ -48,12 +48,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __re
     for (int c = 0; c < nblocks; c += kRsThreads) {
         const int i = c + tid;
         const uint32_t x = i < nblocks ? row[i] : 0u;
-        uint32_t incl = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += y;
-        }
+        uint32_t incl = wave_inclusive_scan(x);
         if (lane == 63) s_w[w] = incl;
         __syncthreads();
         uint32_t wbase = 0;
@@ -106,12 +101,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
 #pragma unroll
             for (int k = 0; k < kRsThreads / 64; ++k) tot += s_count[k][tid];
         }
-        uint32_t incl = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += y;
-        }
+        uint32_t incl = wave_inclusive_scan(tot);
         if (lane == 63) s_wsum[w] = incl;
         __syncthreads();
         uint32_t off = incl - tot;
@@ -119,12 +109,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         // first output position of every digit = exclusive scan of the row totals (<= 256 values, L2-hot: cheaper here, in every
         // block, than as a kernel of its own between the row scan and this one)
         const uint32_t rt = tid < bins ? row_total[tid] : 0u;
-        uint32_t rincl = rt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = (uint32_t)__shfl_up((int)rincl, d);
-            if (lane >= d) rincl += y;
-        }
+        uint32_t rincl = wave_inclusive_scan(rt);
         __syncthreads();   // s_wsum is reused
         if (lane == 63) s_wsum[w] = rincl;
         __syncthreads();
@@ -187,27 +172,31 @@ __global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t*
     __shared__ uint32_t s_w[kRsThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t base = blockIdx.x * (uint32_t)kRsTile + (uint32_t)tid * kRsItems;   // 8 consecutive items per thread
+    uint32_t c[kRsItems];
+    if (base + kRsItems <= n) {   // two 16-B loads
+        const uint4 c0 = reinterpret_cast<const uint4*>(counts + base)[0], c1 = reinterpret_cast<const uint4*>(counts + base)[1];
+        c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kRsItems; ++i) c[i] = base + i < n ? counts[base + i] : 0u;
+    }
     uint32_t v[kRsItems], sum = 0;
 #pragma unroll
     for (int i = 0; i < kRsItems; ++i) {
-        const uint32_t j = base + i;
         v[i] = sum;   // exclusive within the thread
-        sum += j < n ? counts[j] : 0u;
+        sum += c[i];
     }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += y;
-    }
+    uint32_t incl = wave_inclusive_scan(sum);
     if (lane == 63) s_w[w] = incl;
     __syncthreads();
     uint32_t off = incl - sum;
     for (int k = 0; k < w; ++k) off += s_w[k];
+    if (base + kRsItems <= n) {
+        reinterpret_cast<uint4*>(out + base)[0] = make_uint4(off + v[0], off + v[1], off + v[2], off + v[3]);
+        reinterpret_cast<uint4*>(out + base)[1] = make_uint4(off + v[4], off + v[5], off + v[6], off + v[7]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < kRsItems; ++i) {
-        const uint32_t j = base + i;
-        if (j < n) out[j] = off + v[i];
+        for (int i = 0; i < kRsItems; ++i) if (base + i < n) out[base + i] = off + v[i];
     }
     if (tid == kRsThreads - 1) block_total[blockIdx.x] = off + sum;
 }
@@ -222,12 +211,7 @@ __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __res
     for (int c = 0; c < nblocks; c += kRsThreads) {
         const int i = c + tid;
         const uint32_t x = i < nblocks ? block_total[i] : 0u;
-        uint32_t incl = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += y;
-        }
+        uint32_t incl = wave_inclusive_scan(x);
         if (lane == 63) s_w[w] = incl;
         __syncthreads();
         uint32_t wb = 0;
