@@ -254,10 +254,10 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
             const uint32_t slot = q0 + (uint32_t)(w * (kXpBatch / kXpWaves) + i * 64 + lane);
             const bool live = slot < E;
             const uint32_t d = dig[i];
-            unsigned long long same = __ballot(live);        // lanes holding the same digit as this lane
+            unsigned long long same = ballot64(live);        // lanes holding the same digit as this lane
 #pragma unroll
             for (int b = 0; b < kBits; ++b) {
-                const unsigned long long vote = __ballot((d >> b) & 1u);
+                const unsigned long long vote = ballot64(((d >> b) & 1u) != 0u);
                 same &= ((d >> b) & 1u) ? vote : ~vote;
             }
             const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));

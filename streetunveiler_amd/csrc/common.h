@@ -58,6 +58,9 @@ __device__ __forceinline__ uint32_t first_index(const FrameDev& f, uint32_t gid)
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Mask of the lanes where p holds.  (HIP's __ballot takes an int: a bool costs a v_cndmask + v_cmp on the way to the same s_and.)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // Inclusive prefix sum over the 64 lanes of a wave: DPP row shifts inside the rows of 16 lanes, then the two row broadcasts
 // (six VALU instructions; __shfl_up goes through the LDS crossbar six times).  All 64 lanes must be active.
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {

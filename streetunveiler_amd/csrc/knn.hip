@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(const float4* _
             const float gz = fmaxf(0.f, fmaxf(bl.z - whi[2], wlo[2] - bh.z));
             need = !(((gx * gx + gy * gy) + gz * gz) > bound);
         }
-        unsigned long long todo = __ballot(need);
+        unsigned long long todo = ballot64(need);
         while (todo) {
             const int b = g + __builtin_ctzll(todo);
             todo &= todo - 1;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(const float4* _
                         pz = fmaxf(0.f, fmaxf(bl.z - q.z, q.z - bh.z));
             const float pd = (px * px + py * py) + pz * pz;
             const bool mine = valid && !(pd > reject) && !(pd > best[K - 1]);
-            if (!__any(mine)) continue;
+            if (ballot64(mine) == 0) continue;
             const int first = b * kKnnBox, last = min(nr, first + kKnnBox);
             for (int j = first; j < last; ++j) {
                 const float4 c = r_sorted[j];   // wave-uniform address

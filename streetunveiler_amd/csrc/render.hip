@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
         C3[q] = C4[q] = C5[q] = C6[q] = C7[q] = C8[q] = 0.f;
         Dsum[q] = M1[q] = M2[q] = dist[q] = med[q] = 0.f;
         lastc[q] = 0; medc[q] = 0xFFFFFFFFu;
-        if (__ballot(!done[q]) != 0) alive |= 1u << q;
+        if (ballot64(!done[q]) != 0) alive |= 1u << q;
     }
 
     float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f), ny = nx;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
             if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
         }
-        unsigned long long bits = __ballot((m & alive) != 0);
+        unsigned long long bits = ballot64((m & alive) != 0);
         if (kStats && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
         unsigned long long hit[NQ];
 #pragma unroll
@@ -120,11 +120,11 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                 Hit h;
                 const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & !done[q];
                 if (kStats) {
-                    const unsigned long long vb = __ballot(valid);
+                    const unsigned long long vb = ballot64(valid);
                     if (lane == 0) { atomicAdd(&g_stats[2], 1ull); if (vb) atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)__popcll(vb));
                                      if (vb & 0xFFFFFFFFull) atomicAdd(&g_stats[5], 1ull); if (vb >> 32) atomicAdd(&g_stats[6], 1ull); }
                 }
-                if (__ballot(valid) == 0) continue;
+                if (ballot64(valid) == 0) continue;
                 hit[q] |= 1ull << j;
                 const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                 if (valid) {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                         lastc[q] = contributor;
                     }
                 }
-                if (__ballot(!done[q]) == 0) alive &= ~(1u << q);
+                if (ballot64(!done[q]) == 0) alive &= ~(1u << q);
             }
         }
         // exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel here
@@ -304,7 +304,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
             nhit = decode_hits<QX, QY>(hit_mask[pos]);
         }
-        unsigned long long bits = __ballot(m != 0);
+        unsigned long long bits = ballot64(m != 0);
         unsigned long long wrote = 0ull;   // scalar: entries of this round that got a contribution (only those get a record)
         while (bits) {
             const int j = 63 - __clzll((long long)bits);
@@ -326,7 +326,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                 Hit h;
                 const float xq = xl0 + (float)((q % QX) * 8), yq = yl0 + (float)((q / QX) * 8);
                 const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc[q]);
-                if (__ballot(valid) == 0) continue;
+                if (ballot64(valid) == 0) continue;
                 any = true;
                 const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                 if (valid) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kWave) void pair_decisions_kernel(FrameDev f, const
             for (int q = 0; q < NQ; ++q) {
                 Hit h;
                 const bool valid = intersect(xl0 + (float)((q % QX) * 8), yl0 + (float)((q / QX) * 8), e0, e1, e2, e3, h);
-                const unsigned long long vb = __ballot(valid), ub = __ballot(h.use3d);
+                const unsigned long long vb = ballot64(valid), ub = ballot64(h.use3d);
                 if (lane == 0) { valid_bits[(size_t)(range.x + base + j) * NQ + q] = vb; use3d_bits[(size_t)(range.x + base + j) * NQ + q] = ub; }
             }
         }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
             T[c][q] = 1.f; M1[c][q] = M2[c][q] = dist[c][q] = 0.f; lastc[c][q] = 0;
             if (outside) done |= 1u << (c * NQ + q);
         }
-        if (__ballot(!outside) != 0) {
+        if (ballot64(!outside) != 0) {
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) alive |= 1u << (c * NQ + q);
         }
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
             m = has_class ? (m & (alive >> (ci * NQ)) & 3u) : 0u;
         }
         if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
-        unsigned long long bits = __ballot(m != 0);
+        unsigned long long bits = ballot64(m != 0);
         unsigned long long hit[NQ] = {0ull, 0ull};
         while (bits) {
             const int j = __ffsll((long long)bits) - 1;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
                     if (cj != c) continue;        // wave-uniform: the entry's class picks the chain
                     const uint32_t bit = 1u << (c * NQ + q);
                     const bool valid = ok & !(done & bit);
-                    if (__ballot(valid) == 0) continue;
+                    if (ballot64(valid) == 0) continue;
                     hit[q] |= 1ull << j;
                     if (valid) {
                         const float test_T = T[c][q] * (1.f - h.alpha);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
                             lastc[c][q] = contributor;
                         }
                     }
-                    if (__ballot(!(done & bit)) == 0) alive &= ~bit;
+                    if (ballot64(!(done & bit)) == 0) alive &= ~bit;
                 }
             }
         }
@@ -206,7 +206,7 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
             for (int k = 0; k < kGQ; ++k) z[k] = zero4;
         }
         if (rd > 0) fetch(range.x + rbase - kWave + lane);
-        unsigned long long bits = __ballot(m != 0);
+        unsigned long long bits = ballot64(m != 0);
         unsigned long long wrote = 0ull;
         while (bits) {
             const int j = 63 - __clzll((long long)bits);
@@ -227,7 +227,7 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
                 Hit h;
                 const float xq = xl0 + (float)((q % QX) * 8), yq = yl0 + (float)((q / QX) * 8);
                 const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc[q]);
-                if (__ballot(valid) == 0) continue;
+                if (ballot64(valid) == 0) continue;
                 any = true;
                 if (valid) {
                     const float Twx = e2.y, Twy = e2.z;
