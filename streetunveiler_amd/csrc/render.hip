@@ -305,7 +305,10 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             nhit = decode_hits<QX, QY>(hit_mask[pos]);
         }
         unsigned long long bits = ballot64(m != 0);
-        unsigned long long wrote = 0ull;   // scalar: entries of this round that got a contribution (only those get a record)
+        // entries of this round that get a record: those with an (entry, quadrant) pair that reached a pixel in the forward.  (Such a
+        // pair has a valid lane here too -- same decisions, bit for bit -- unless every pixel it reached stopped at the transmittance
+        // floor instead of blending: that rare entry gets a record of zeros rather than a wave-wide `any lane valid` test per pair.)
+        const unsigned long long wrote = bits;
         while (bits) {
             const int j = 63 - __clzll((long long)bits);
             bits &= ~(1ull << j);
@@ -319,17 +322,14 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                 asm volatile("" : "+v"(v[k]));   // opaque zero: every quadrant block accumulates in place (no phi copies of constants)
             }
             float w6 = 0.f, w7 = 0.f, w8 = 0.f;   // colour channels 6..8 (9-channel variant)
-            bool any = false;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
                 const float xq = xl0 + (float)((q % QX) * 8), yq = yl0 + (float)((q / QX) * 8);
                 const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc[q]);
-                if (ballot64(valid) == 0) continue;
-                any = true;
-                const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                 if (valid) {
+                    const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                     const float Twx = e2.y, Twy = e2.z;
                     const float one_m_inv = fast_rcp(1.f - h.alpha);
                     T[q] *= one_m_inv;                 // transmittance in front of this entry
@@ -370,8 +370,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     }
                 }
             }
-            if (any) {
-                wrote |= 1ull << j;
+            {
                 const float tot = wave_reduce24(v, lane);
                 if ((lane & 1) == 0 && (lane & 6) != 6)
                     s_out[j][6 * (lane >> 4) + ((lane & 8) ? 3 : 0) + ((lane & 4) ? 2 : ((lane >> 1) & 1))] = tot;

@@ -207,7 +207,7 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
         }
         if (rd > 0) fetch(range.x + rbase - kWave + lane);
         unsigned long long bits = ballot64(m != 0);
-        unsigned long long wrote = 0ull;
+        const unsigned long long wrote = bits;   // every entry with a forward hit gets a record (see K7)
         while (bits) {
             const int j = 63 - __clzll((long long)bits);
             bits &= ~(1ull << j);
@@ -220,15 +220,12 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
                 v[k] = 0.f;
                 if (k < 15) asm volatile("" : "+v"(v[k]));   // opaque zero for the live accumulators (see K7); 15..23 stay constant zero
             }
-            bool any = false;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (!(mj & (1u << q))) continue;
                 Hit h;
                 const float xq = xl0 + (float)((q % QX) * 8), yq = yl0 + (float)((q / QX) * 8);
                 const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc[q]);
-                if (ballot64(valid) == 0) continue;
-                any = true;
                 if (valid) {
                     const float Twx = e2.y, Twy = e2.z;
                     const float one_m_inv = fast_rcp(1.f - h.alpha);
@@ -259,8 +256,7 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
                     }
                 }
             }
-            if (any) {
-                wrote |= 1ull << j;
+            {
                 const float tot = wave_reduce24(v, lane);
                 if ((lane & 1) == 0 && (lane & 6) != 6)
                     s_out[j][6 * (lane >> 4) + ((lane & 8) ? 3 : 0) + ((lane & 4) ? 2 : ((lane >> 1) & 1))] = tot;
