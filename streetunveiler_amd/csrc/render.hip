@@ -68,7 +68,8 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     const uint32_t n_total = range.y - range.x;
 
     float xl[NQ], yl[NQ];
-    bool done[NQ];
+    // T[q] > 0: the pixel is live.  T[q] < 0: done (saturated, or outside the image) -- |T[q]| is its final transmittance.  (A separate
+    // flag per pixel costs a byte compare, two moves and a four-instruction all-done test per quadrant test.)
     float T[NQ], C0[NQ], C1[NQ], C2[NQ], N0[NQ], N1[NQ], N2[NQ], Dsum[NQ], M1[NQ], M2[NQ], dist[NQ], med[NQ];
     float C3[NQ], C4[NQ], C5[NQ], C6[NQ], C7[NQ], C8[NQ];   // only live in the 6- / 9-channel variants
     uint32_t lastc[NQ], medc[NQ];
@@ -77,12 +78,11 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     for (int q = 0; q < NQ; ++q) {
         const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
         xl[q] = (float)((q % QX) * 8 + lx - QX * 4); yl[q] = (float)((q / QX) * 8 + ly - QY * 4) + yshift;
-        done[q] = !(px < f.W && py < f.H);
-        T[q] = 1.f; C0[q] = C1[q] = C2[q] = N0[q] = N1[q] = N2[q] = 0.f;
+        T[q] = (px < f.W && py < f.H) ? 1.f : -1.f; C0[q] = C1[q] = C2[q] = N0[q] = N1[q] = N2[q] = 0.f;
         C3[q] = C4[q] = C5[q] = C6[q] = C7[q] = C8[q] = 0.f;
         Dsum[q] = M1[q] = M2[q] = dist[q] = med[q] = 0.f;
         lastc[q] = 0; medc[q] = 0xFFFFFFFFu;
-        if (ballot64(!done[q]) != 0) alive |= 1u << q;
+        if (ballot64(T[q] > 0.f) != 0) alive |= 1u << q;
     }
 
     float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f), ny = nx;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
             for (int q = 0; q < NQ; ++q) {
                 if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
-                const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & !done[q];
+                const bool valid = intersect(xl[q], yl[q], e0, e1, e2, e3, h) & (T[q] > 0.f);
                 if (kStats) {
                     const unsigned long long vb = ballot64(valid);
                     if (lane == 0) { atomicAdd(&g_stats[2], 1ull); if (vb) atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)__popcll(vb));
@@ -129,9 +129,8 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                 const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                 if (valid) {
                     const float test_T = T[q] * (1.f - h.alpha);
-                    if (test_T < kTStop) {
-                        done[q] = true;  // this entry is NOT blended
-                    } else {
+                    const bool go = !(test_T < kTStop);   // else: done, and this entry is NOT blended
+                    if (go) {
                         const float w = h.alpha * T[q];
                         const float A = 1.f - T[q];
                         const float mm = kFN * (1.f - kNear * fast_rcp(h.depth));
@@ -144,11 +143,11 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
                         C0[q] += e4.w * w; C1[q] += e5.x * w; C2[q] += e5.y * w;
                         if (NC >= 6) { C3[q] += e5.z * w; C4[q] += e5.w * w; C5[q] += e3.w * w; }
                         if (NC == 9) { const float4 e6 = s_e[6][j]; C6[q] += e6.x * w; C7[q] += e6.y * w; C8[q] += e6.z * w; }
-                        T[q] = test_T;
                         lastc[q] = contributor;
                     }
+                    T[q] = go ? test_T : -T[q];
                 }
-                if (ballot64(!done[q]) == 0) alive &= ~(1u << q);
+                if (ballot64(T[q] > 0.f) == 0) alive &= ~(1u << q);
             }
         }
         // exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel here
@@ -169,23 +168,24 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
         const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
         if (px < f.W && py < f.H) {
             const size_t pix = (size_t)py * f.W + px;
-            final_T[pix] = T[q]; final_T[HW + pix] = M1[q]; final_T[2 * HW + pix] = M2[q];
+            const float Tq = fabsf(T[q]);
+            final_T[pix] = Tq; final_T[HW + pix] = M1[q]; final_T[2 * HW + pix] = M2[q];
             n_contrib[pix] = lastc[q]; n_contrib[HW + pix] = medc[q];
-            out_color[pix] = C0[q] + T[q] * bg0;
-            out_color[HW + pix] = C1[q] + T[q] * bg1;
-            out_color[2 * HW + pix] = C2[q] + T[q] * bg2;
+            out_color[pix] = C0[q] + Tq * bg0;
+            out_color[HW + pix] = C1[q] + Tq * bg1;
+            out_color[2 * HW + pix] = C2[q] + Tq * bg2;
             if (NC >= 6) {
-                out_color[3 * HW + pix] = C3[q] + T[q] * f.bg[3];
-                out_color[4 * HW + pix] = C4[q] + T[q] * f.bg[4];
-                out_color[5 * HW + pix] = C5[q] + T[q] * f.bg[5];
+                out_color[3 * HW + pix] = C3[q] + Tq * f.bg[3];
+                out_color[4 * HW + pix] = C4[q] + Tq * f.bg[4];
+                out_color[5 * HW + pix] = C5[q] + Tq * f.bg[5];
             }
             if (NC == 9) {
-                out_color[6 * HW + pix] = C6[q] + T[q] * f.bg[6];
-                out_color[7 * HW + pix] = C7[q] + T[q] * f.bg[7];
-                out_color[8 * HW + pix] = C8[q] + T[q] * f.bg[8];
+                out_color[6 * HW + pix] = C6[q] + Tq * f.bg[6];
+                out_color[7 * HW + pix] = C7[q] + Tq * f.bg[7];
+                out_color[8 * HW + pix] = C8[q] + Tq * f.bg[8];
             }
             out_allmap[pix] = Dsum[q];
-            out_allmap[HW + pix] = 1.f - T[q];
+            out_allmap[HW + pix] = 1.f - Tq;
             out_allmap[2 * HW + pix] = N0[q]; out_allmap[3 * HW + pix] = N1[q]; out_allmap[4 * HW + pix] = N2[q];
             out_allmap[5 * HW + pix] = med[q];
             out_allmap[6 * HW + pix] = dist[q];
