@@ -129,11 +129,12 @@ __device__ __forceinline__ bool intersect(float xl, float yl, const float4 e0, c
     const float rho2d = kFilterInvSquare * (h.dx * h.dx + h.dy * h.dy);
     h.use3d = rho3d <= rho2d;
     const float rho = fminf(rho3d, rho2d);
-    h.depth = h.use3d ? (h.sx * e2.y + h.sy * e2.z) + e2.w : e2.w;
-    const float power = -0.5f * rho;
-    h.G = __builtin_amdgcn_exp2f(power * kLog2e);
+    h.depth = h.use3d ? fmaf(h.sx, e2.y, fmaf(h.sy, e2.z, e2.w)) : e2.w;
+    h.G = __builtin_amdgcn_exp2f(rho * (-0.5f * kLog2e));   // exp(-rho / 2)
     h.alpha = fminf(kAlphaCap, e3.z * h.G);
-    return (ppz != 0.f) & !(h.depth < kNear) & !(power > 0.f) & !(h.alpha < kAlphaFloor);
+    // (the reference also skips on `power > 0`: never true -- rho3d and rho2d are sums of squares, fminf drops a NaN operand, and a NaN
+    // power fails that test as well -- so the comparison is not evaluated here)
+    return (ppz != 0.f) & !(h.depth < kNear) & !(h.alpha < kAlphaFloor);
 }
 
 // Emission index of the duplicate (tile tx,ty ; Gaussian gid): duplicates are emitted per Gaussian, y-major /
