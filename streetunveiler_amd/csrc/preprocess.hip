@@ -30,19 +30,23 @@ __device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
 
 // Parameter activations of the reference's GaussianModel, fused into K1 / K8 on request
 // [REF scene/gaussian_model.py:63-75: scaling exp, opacity sigmoid, rotation torch.nn.functional.normalize].
-__device__ __forceinline__ float2 load_scales(const float* __restrict__ scales, int i, int act) {
-    float2 s = reinterpret_cast<const float2*>(scales)[i];
+__device__ __forceinline__ float2 activate_scales(float2 s, int act) {
     if (act & SR_ACT_EXP_SCALES) { s.x = expf(s.x); s.y = expf(s.y); }
     return s;
 }
-__device__ __forceinline__ float4 load_rotation(const float* __restrict__ rotations, int i, int act, float& norm) {
-    float4 q = reinterpret_cast<const float4*>(rotations)[i];
+__device__ __forceinline__ float2 load_scales(const float* __restrict__ scales, int i, int act) {
+    return activate_scales(reinterpret_cast<const float2*>(scales)[i], act);
+}
+__device__ __forceinline__ float4 activate_rotation(float4 q, int act, float& norm) {
     norm = 1.f;
     if (act & SR_ACT_NORMALIZE_ROTATIONS) {
         norm = fmaxf(sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w), 1e-12f);
         q.x /= norm; q.y /= norm; q.z /= norm; q.w /= norm;
     }
     return q;
+}
+__device__ __forceinline__ float4 load_rotation(const float* __restrict__ rotations, int i, int act, float& norm) {
+    return activate_rotation(reinterpret_cast<const float4*>(rotations)[i], act, norm);
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -197,6 +201,18 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? kPreBlock * kShLdsStride : 4];
     const int tid = threadIdx.x, base = blockIdx.x * kPreBlock;
     const int i = base + tid;
+    // every per-Gaussian input is requested up front, in front of the SH staging and its barrier: one memory round trip instead of four
+    // dependent ones (SH rows | centre | rotation + scales | opacity) -- this kernel waits on memory at three waves per SIMD
+    float px = 0.f, py = 0.f, pz = 0.f, raw_opacity = 0.f;
+    float4 raw_rot = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 raw_scales = make_float2(0.f, 0.f);
+    bool kept = true;
+    if (i < P) {
+        px = means3D[3 * i]; py = means3D[3 * i + 1]; pz = means3D[3 * i + 2];
+        raw_opacity = opacities[i];
+        if (!transMat_precomp) { raw_rot = reinterpret_cast<const float4*>(rotations)[i]; raw_scales = reinterpret_cast<const float2*>(scales)[i]; }
+        if (mask) kept = mask[i] != 0;   // masked out == not there (same as boolean-indexing the inputs)
+    }
     if (kLdsSH) {
         sh_rows_to_lds(shs, base, P, s_sh, tid);
         __syncthreads();
@@ -209,12 +225,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     uint8_t out_clamped = 0;
     float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
 
-    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
     const float* v = f.view;
     const float vx = ((v[0] * px + v[4] * py) + v[8] * pz) + v[12];
     const float vy = ((v[1] * px + v[5] * py) + v[9] * pz) + v[13];
     const float vz = ((v[2] * px + v[6] * py) + v[10] * pz) + v[14];
-    bool alive = vz > kNear && (!mask || mask[i]);   // masked out == not there (same as boolean-indexing the inputs)
+    bool alive = vz > kNear && kept;
     if (alive) {
         float Tm[9], nrm[3];
         if (transMat_precomp) {
@@ -225,8 +240,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
             float B[12], R[9];
             build_B(f.proj, f.W, f.H, B);
             float qn;
-            quat_to_R(load_rotation(rotations, i, f.activations, qn), R);
-            const float2 s = load_scales(scales, i, f.activations);
+            quat_to_R(activate_rotation(raw_rot, f.activations, qn), R);
+            const float2 s = activate_scales(raw_scales, f.activations);
             const float su = f.scale_modifier * s.x, sv = f.scale_modifier * s.y;
             const float L0[3] = {R[0] * su, R[3] * su, R[6] * su};
             const float L1[3] = {R[1] * sv, R[4] * sv, R[7] * sv};
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
                 out_key = __float_as_uint(vz);
                 q0 = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
                 q1 = make_float4(Tv[1], Tv[2], Tw[0], Tw[1]);
-                q2 = make_float4(Tw[2], cx, cy, (f.activations & SR_ACT_SIGMOID_OPACITY) ? sigmoidf(opacities[i]) : opacities[i]);
+                q2 = make_float4(Tw[2], cx, cy, (f.activations & SR_ACT_SIGMOID_OPACITY) ? sigmoidf(raw_opacity) : raw_opacity);
                 q3 = make_float4(nrm[0], nrm[1], nrm[2], vz);
                 q4 = make_float4(rgb[0], rgb[1], rgb[2], radius);
             }
