@@ -293,41 +293,56 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
 // heavy-tailed tile loads, and on uniform scenes (one or two classes) the order stays the locality-friendly index order.
 // One block: thread t owns a contiguous chunk of tiles.
 constexpr int kOrderThreads = 1024, kOrderClasses = 16;
+// inclusive prefix sum inside every row of 16 lanes (DPP row shifts)
+__device__ __forceinline__ uint32_t row_inclusive_scan16(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    return (uint32_t)v;
+}
 __global__ __launch_bounds__(kOrderThreads) void tile_ranges_order_kernel(int n_tiles, const uint32_t* __restrict__ counts, uint2* __restrict__ ranges,
                                                                           uint32_t* __restrict__ order) {
-    __shared__ uint32_t s_cls[kOrderClasses][kOrderThreads / 64];   // tiles per (class, wave) -> order offsets
-    __shared__ uint32_t s_wsum[kOrderThreads / 64];
+    constexpr int kPer = 8, kWaves = kOrderThreads / 64, kChunk = kOrderThreads * kPer;
+    static_assert(kWaves == 16 && kOrderClasses == 16, "the cross-wave prefix below runs on 16 x 16 values, one 16-lane row per class");
+    __shared__ uint32_t s_cls[kOrderClasses][kWaves];   // tiles per (class, wave) of the current chunk
+    __shared__ uint32_t s_off[kOrderClasses][kWaves];   // ... of the lower waves
+    __shared__ uint32_t s_tot[kOrderClasses];           // tiles per class of the current chunk
+    __shared__ uint32_t s_wsum[kWaves], s_woff[kWaves];
     __shared__ uint32_t s_carry, s_cls_base[kOrderClasses];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    constexpr int kPer = 8, kWaves = kOrderThreads / 64;
     // class 0: 2^20 entries and more, ..., class 14: 64..127, class 15: fewer than 64 (or none)
     auto cls_of = [](uint32_t len) { return len ? min(kOrderClasses - 1, max(0, (int)__clz(len) - 11)) : kOrderClasses - 1; };
-    // pass 1: class totals over all tiles (coalesced, one tile per thread and trip)
-    uint32_t my_cls[kOrderClasses];
-#pragma unroll
-    for (int k = 0; k < kOrderClasses; ++k) my_cls[k] = 0;
-    for (int t = tid; t < n_tiles; t += kOrderThreads) { const int c = cls_of(counts[t]);
-#pragma unroll
-        for (int k = 0; k < kOrderClasses; ++k) my_cls[k] += (c == k); }
+    const bool single_chunk = n_tiles <= kChunk;   // (every tile shape at 1920 x 1080 but 8 x 8): the class totals fall out of the chunk itself
     if (tid < kOrderClasses) s_cls_base[tid] = 0;
     if (tid == 0) s_carry = 0;
-    __syncthreads();
+    if (!single_chunk) {
+        // class totals over all tiles first (coalesced, one tile per thread and trip): where every class starts in `order`
+        uint32_t my_cls[kOrderClasses];
 #pragma unroll
-    for (int k = 0; k < kOrderClasses; ++k) {
-        const uint32_t v = wave_inclusive_scan(my_cls[k]);   // lane 63: the wave's total
-        if (lane == 63 && v) atomicAdd(&s_cls_base[k], v);
+        for (int k = 0; k < kOrderClasses; ++k) my_cls[k] = 0;
+        for (int t = tid; t < n_tiles; t += kOrderThreads) { const int c = cls_of(counts[t]);
+#pragma unroll
+            for (int k = 0; k < kOrderClasses; ++k) my_cls[k] += (c == k); }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kOrderClasses; ++k) {
+            const uint32_t v = wave_inclusive_scan(my_cls[k]);   // lane 63: the wave's total
+            if (lane == 63 && v) atomicAdd(&s_cls_base[k], v);
+        }
+        __syncthreads();
+        if (tid == 0) { uint32_t run = 0; for (int k = 0; k < kOrderClasses; ++k) { const uint32_t c = s_cls_base[k]; s_cls_base[k] = run; run += c; } }
     }
     __syncthreads();
-    if (tid == 0) { uint32_t run = 0; for (int k = 0; k < kOrderClasses; ++k) { const uint32_t c = s_cls_base[k]; s_cls_base[k] = run; run += c; } }
-    __syncthreads();
-    // pass 2: chunks of kOrderThreads * kPer consecutive tiles, thread t owns kPer consecutive ones: ranges by a block scan with carry,
+    // chunks of kOrderThreads * kPer consecutive tiles, thread t owns kPer consecutive ones: ranges by a block scan with carry,
     // order positions by a per-class scan in tile order (stable inside a class)
-    for (int base = 0; base < n_tiles; base += kOrderThreads * kPer) {
+    for (int base = 0; base < n_tiles; base += kChunk) {
         const int t0 = base + tid * kPer;
         uint32_t c[kPer], sum = 0;
 #pragma unroll
         for (int i = 0; i < kPer; ++i) { c[i] = t0 + i < n_tiles ? counts[t0 + i] : 0u; sum += c[i]; }
-        uint32_t incl = wave_inclusive_scan(sum);
+        const uint32_t incl = wave_inclusive_scan(sum);
         if (lane == 63) s_wsum[w] = incl;
         // tiles per class in this thread / wave
         uint32_t mine[kOrderClasses];
@@ -340,15 +355,29 @@ __global__ __launch_bounds__(kOrderThreads) void tile_ranges_order_kernel(int n_
         uint32_t before[kOrderClasses];   // tiles of class k in lower lanes of this wave
 #pragma unroll
         for (int k = 0; k < kOrderClasses; ++k) {
-            uint32_t v = wave_inclusive_scan(mine[k]);
+            const uint32_t v = wave_inclusive_scan(mine[k]);
             before[k] = v - mine[k];
             if (lane == 63) s_cls[k][w] = v;
         }
         __syncthreads();
-        uint32_t run = s_carry + incl - sum;
-        for (int j = 0; j < w; ++j) run += s_wsum[j];
+        // prefix over the waves: 16 classes x 16 waves on 256 threads (a 16-lane row per class), the wave totals on 16 more
+        if (tid < kOrderClasses * kWaves) {
+            const uint32_t v = s_cls[tid >> 4][tid & 15], in = row_inclusive_scan16(v);
+            s_off[tid >> 4][tid & 15] = in - v;
+            if ((tid & 15) == 15) s_tot[tid >> 4] = in;
+        } else if (tid < kOrderClasses * kWaves + 64) {
+            const int j = tid - kOrderClasses * kWaves;
+            const uint32_t v = j < kWaves ? s_wsum[j] : 0u, in = row_inclusive_scan16(v);
+            if (j < kWaves) s_woff[j] = in - v;
+        }
+        __syncthreads();
+        if (single_chunk) {
+            if (tid == 0) { uint32_t run = 0; for (int k = 0; k < kOrderClasses; ++k) { s_cls_base[k] = run; run += s_tot[k]; } }
+            __syncthreads();
+        }
+        uint32_t run = s_carry + s_woff[w] + incl - sum;
 #pragma unroll
-        for (int k = 0; k < kOrderClasses; ++k) { uint32_t o = s_cls_base[k] + before[k]; for (int j = 0; j < w; ++j) o += s_cls[k][j]; before[k] = o; }
+        for (int k = 0; k < kOrderClasses; ++k) before[k] += s_cls_base[k] + s_off[k][w];
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
             if (t0 + i < n_tiles) {
@@ -363,7 +392,7 @@ __global__ __launch_bounds__(kOrderThreads) void tile_ranges_order_kernel(int n_
         }
         __syncthreads();
         if (tid == kOrderThreads - 1) s_carry = run;
-        if (tid < kOrderClasses) { uint32_t add = 0; for (int j = 0; j < kWaves; ++j) add += s_cls[tid][j]; s_cls_base[tid] += add; }
+        if (tid < kOrderClasses) s_cls_base[tid] += s_tot[tid];
         __syncthreads();
     }
 }
