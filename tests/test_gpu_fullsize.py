@@ -148,3 +148,9 @@ def test_more_than_65536_tiles_against_oracle():
     np.testing.assert_array_equal(raw["bin"]["point_list"].view(np.uint32), fwd["point_list"])
     np.testing.assert_array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])
     assert_close_frac(raw["color"], fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, "4K 8x8 color")
+    # the dispatch order over 16 chunks of 8192 tiles: a permutation, length classes descending, index order inside a class
+    order = raw["bin"]["tile_order"].view(np.uint32).astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(480 * 270))
+    ln = (fwd["ranges"][:, 1].astype(np.int64) - fwd["ranges"][:, 0])[order]
+    cls = np.where(ln > 0, np.minimum(15, np.maximum(0, 20 - np.floor(np.log2(np.maximum(ln, 1))).astype(np.int64))), 15)
+    assert (np.diff(cls) >= 0).all() and all((np.diff(order[cls == c]) > 0).all() for c in np.unique(cls))
