@@ -133,7 +133,7 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
 
 // ---- buffer layouts ------------------------------------------------------------------------------
 struct GeomLayout {
-    size_t recs, depth_keys, tiles_touched, rect, clamped, sorted_keys, sorted_gid, rect_sorted, first, block_base, base_bytes,
+    size_t recs, depth_keys, tiles_touched, rect, clamped, sorted_keys, sorted_gid, rect_sorted, first, sh_jac, block_base, base_bytes,
         n_scan_blocks, temp, temp_bytes, total;
 };
 GeomLayout geom_layout(int P) {
@@ -150,6 +150,7 @@ GeomLayout geom_layout(int P) {
     L.sorted_gid = take(n * 4);
     L.rect_sorted = take(n * 8);
     L.first = take(n * 4);
+    L.sh_jac = take(n * 36);
     L.base_bytes = tile_scan_temp_bytes(P);
     L.block_base = take(L.base_bytes);
     L.n_scan_blocks = (n + 2047) / 2048;   // the scan's block size (radix_sort.hip kRsTile)
@@ -299,7 +300,8 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     const GeomLayout L = geom_layout(P);
     if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const FrameDev f = make_frame(frame, g);
+    FrameDev f = make_frame(frame, g);
+    f.sh_jac = at<float>(geom, L.sh_jac);
     {
         StageTimer t(SR_STAGE_PREPROCESS, s);
         SR_HIP(launch_preprocess_forward(P, f, *g, at<float4>(geom, L.recs), at<uint32_t>(geom, L.depth_keys),
@@ -462,7 +464,7 @@ int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_clas
     if (workspace_bytes < sr_backward_workspace_bytes(P, D, 3)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P, D, 3));
     hipStream_t s = static_cast<hipStream_t>(stream);
     FrameDev f = make_frame(frame, g);
-    f.first = at<uint32_t>(geom, L.first); f.first_base = at<uint32_t>(geom, L.block_base);
+    f.first = at<uint32_t>(geom, L.first); f.first_base = at<uint32_t>(geom, L.block_base); f.sh_jac = at<float>(geom, L.sh_jac);
     float4* inst_grads = static_cast<float4*>(workspace);
     uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(3), 256);
     {
@@ -501,7 +503,7 @@ int backward_ctx(const SrFrame* frame, const SrGaussians* g, void* geom, size_t 
     if (workspace_bytes < sr_backward_workspace_bytes(c->P, D, g->color_channels)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(c->P, D, g->color_channels));
     c->s = static_cast<hipStream_t>(stream);
     c->f = make_frame(frame, g);
-    c->f.first = at<uint32_t>(geom, c->L.first); c->f.first_base = at<uint32_t>(geom, c->L.block_base);
+    c->f.first = at<uint32_t>(geom, c->L.first); c->f.first_base = at<uint32_t>(geom, c->L.block_base); c->f.sh_jac = at<float>(geom, c->L.sh_jac);
     // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous).  K7 writes a record --
     // and sets the slot's byte in `written` -- only where some pixel contributed; K8 looks at the byte before it touches the
     // record, so neither the records nor anything but these D bytes need clearing.
@@ -540,7 +542,7 @@ int sr_backward_colors(const SrFrame* frame, const SrGaussians* g, const int32_t
     if (workspace_bytes < sr_backward_workspace_bytes(P, D, g->color_channels)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     FrameDev f = make_frame(frame, g);
-    f.first = at<uint32_t>(geom, L.first); f.first_base = at<uint32_t>(geom, L.block_base);
+    f.first = at<uint32_t>(geom, L.first); f.first_base = at<uint32_t>(geom, L.block_base); f.sh_jac = at<float>(geom, L.sh_jac);
     const uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(g->color_channels), 256);
     StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
     SR_HIP(launch_color_gradients(P, f, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), static_cast<const float4*>(workspace), written,

@@ -52,6 +52,7 @@ struct FrameDev {
     // emission index of every Gaussian's first duplicate = first[gid] + first_base[gid / kScanTile] (geom buffer, K2); backward only
     const uint32_t* first;
     const uint32_t* first_base;
+    float* sh_jac;   // [P][9] d rgb / d centre through the SH view direction (geom buffer; K1 writes it, K8 reads it instead of the SH rows)
 };
 constexpr int kScanTile = 2048;   // Gaussians per block of the emission-offset scan
 __device__ __forceinline__ uint32_t first_index(const FrameDev& f, uint32_t gid) { return f.first[gid] + f.first_base[gid / kScanTile]; }

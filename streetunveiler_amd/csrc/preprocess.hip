@@ -127,65 +127,68 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const Row sh, float dx, float
     }
 }
 
-// SH backward.  Reads sh[k] and then overwrites the same slot of `dsh` with dL/dsh[k] (dsh may alias sh: the
-// LDS row is transformed in place); returns dL/d(dir) contributions in ddir.  Coefficients above the active
-// degree get 0.
-template <class RowIn, class RowOut>
-__device__ __forceinline__ void sh_backward(int deg, int M, const RowIn sh, RowOut dsh, bool want_dsh, float x, float y, float z,
-                                            const float gcol[3], float ddir[3]) {
-    ddir[0] = ddir[1] = ddir[2] = 0.f;
+// d rgb[c] / d centre through the SH view direction, J[3 c + k] = ((d_c - dir (dir . d_c)) / len)[k] with d_c = d rgb[c] / d dir
+// [REF the direction half of computeColorFromSH's backward, Appendix A.6].  K1 evaluates it next to the colour, from the SH row it
+// holds anyway, so that K8 needs 36 B per Gaussian instead of reading the 192-B row again.
+template <class Row>
+__device__ __forceinline__ void sh_dir_jacobian(int deg, const Row sh, float x, float y, float z, float len, float J[9]) {
+#pragma clang fp contract(fast)   // not part of the bit-exact contract with the oracle (gradients are compared with a tolerance)
+    const float inv_len = 1.f / len;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float g = gcol[c];
         float dx = 0.f, dy = 0.f, dz = 0.f;
         if (deg > 0) {
             dx = -kSH_C1 * sh[9 + c]; dy = -kSH_C1 * sh[3 + c]; dz = kSH_C1 * sh[6 + c];
             if (deg > 1) {
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                dx += kSH_C2[0] * y * sh[12 + c] + kSH_C2[2] * 2.f * -x * sh[18 + c] + kSH_C2[3] * z * sh[21 + c] + kSH_C2[4] * 2.f * x * sh[24 + c];
-                dy += kSH_C2[0] * x * sh[12 + c] + kSH_C2[1] * z * sh[15 + c] + kSH_C2[2] * 2.f * -y * sh[18 + c] + kSH_C2[4] * 2.f * -y * sh[24 + c];
-                dz += kSH_C2[1] * y * sh[15 + c] + kSH_C2[2] * 2.f * 2.f * z * sh[18 + c] + kSH_C2[3] * x * sh[21 + c];
+                dx += (kSH_C2[0] * y) * sh[12 + c] + (-2.f * kSH_C2[2] * x) * sh[18 + c] + (kSH_C2[3] * z) * sh[21 + c] + (2.f * kSH_C2[4] * x) * sh[24 + c];
+                dy += (kSH_C2[0] * x) * sh[12 + c] + (kSH_C2[1] * z) * sh[15 + c] + (-2.f * kSH_C2[2] * y) * sh[18 + c] + (-2.f * kSH_C2[4] * y) * sh[24 + c];
+                dz += (kSH_C2[1] * y) * sh[15 + c] + (4.f * kSH_C2[2] * z) * sh[18 + c] + (kSH_C2[3] * x) * sh[21 + c];
                 if (deg > 2) {
-                    dx += kSH_C3[0] * sh[27 + c] * 3.f * 2.f * xy + kSH_C3[1] * sh[30 + c] * yz + kSH_C3[2] * sh[33 + c] * -2.f * xy +
-                          kSH_C3[3] * sh[36 + c] * -3.f * 2.f * xz + kSH_C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
-                          kSH_C3[5] * sh[42 + c] * 2.f * xz + kSH_C3[6] * sh[45 + c] * 3.f * (xx - yy);
-                    dy += kSH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + kSH_C3[1] * sh[30 + c] * xz + kSH_C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) +
-                          kSH_C3[3] * sh[36 + c] * -3.f * 2.f * yz + kSH_C3[4] * sh[39 + c] * -2.f * xy + kSH_C3[5] * sh[42 + c] * -2.f * yz +
-                          kSH_C3[6] * sh[45 + c] * -3.f * 2.f * xy;
-                    dz += kSH_C3[1] * sh[30 + c] * xy + kSH_C3[2] * sh[33 + c] * 4.f * 2.f * yz + kSH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) +
-                          kSH_C3[4] * sh[39 + c] * 4.f * 2.f * xz + kSH_C3[5] * sh[42 + c] * (xx - yy);
+                    dx += (6.f * kSH_C3[0] * xy) * sh[27 + c] + (kSH_C3[1] * yz) * sh[30 + c] + (-2.f * kSH_C3[2] * xy) * sh[33 + c] +
+                          (-6.f * kSH_C3[3] * xz) * sh[36 + c] + (kSH_C3[4] * (-3.f * xx + 4.f * zz - yy)) * sh[39 + c] +
+                          (2.f * kSH_C3[5] * xz) * sh[42 + c] + (3.f * kSH_C3[6] * (xx - yy)) * sh[45 + c];
+                    dy += (3.f * kSH_C3[0] * (xx - yy)) * sh[27 + c] + (kSH_C3[1] * xz) * sh[30 + c] + (kSH_C3[2] * (-3.f * yy + 4.f * zz - xx)) * sh[33 + c] +
+                          (-6.f * kSH_C3[3] * yz) * sh[36 + c] + (-2.f * kSH_C3[4] * xy) * sh[39 + c] + (-2.f * kSH_C3[5] * yz) * sh[42 + c] +
+                          (-6.f * kSH_C3[6] * xy) * sh[45 + c];
+                    dz += (kSH_C3[1] * xy) * sh[30 + c] + (8.f * kSH_C3[2] * yz) * sh[33 + c] + (3.f * kSH_C3[3] * (2.f * zz - xx - yy)) * sh[36 + c] +
+                          (8.f * kSH_C3[4] * xz) * sh[39 + c] + (kSH_C3[5] * (xx - yy)) * sh[42 + c];
                 }
             }
         }
-        ddir[0] += dx * g; ddir[1] += dy * g; ddir[2] += dz * g;
+        const float nd = (x * dx + y * dy) + z * dz;
+        J[3 * c + 0] = (dx - x * nd) * inv_len; J[3 * c + 1] = (dy - y * nd) * inv_len; J[3 * c + 2] = (dz - z * nd) * inv_len;
     }
-    if (want_dsh) {
+}
+
+// SH adjoint: dsh[k] = basis_k(dir) * dL/drgb.  Coefficients above the active degree get 0.
+template <class RowOut>
+__device__ __forceinline__ void sh_basis_adjoint(int deg, int M, RowOut dsh, float x, float y, float z, const float gcol[3]) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float g = gcol[c];
-            dsh[c] = kSH_C0 * g;
-            if (deg > 0) {
-                dsh[3 + c] = -kSH_C1 * y * g; dsh[6 + c] = kSH_C1 * z * g; dsh[9 + c] = -kSH_C1 * x * g;
-                if (deg > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    dsh[12 + c] = kSH_C2[0] * xy * g; dsh[15 + c] = kSH_C2[1] * yz * g;
-                    dsh[18 + c] = kSH_C2[2] * (2.f * zz - xx - yy) * g;
-                    dsh[21 + c] = kSH_C2[3] * xz * g; dsh[24 + c] = kSH_C2[4] * (xx - yy) * g;
-                    if (deg > 2) {
-                        dsh[27 + c] = kSH_C3[0] * y * (3.f * xx - yy) * g;
-                        dsh[30 + c] = kSH_C3[1] * xy * z * g;
-                        dsh[33 + c] = kSH_C3[2] * y * (4.f * zz - xx - yy) * g;
-                        dsh[36 + c] = kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
-                        dsh[39 + c] = kSH_C3[4] * x * (4.f * zz - xx - yy) * g;
-                        dsh[42 + c] = kSH_C3[5] * z * (xx - yy) * g;
-                        dsh[45 + c] = kSH_C3[6] * x * (xx - 3.f * yy) * g;
-                    }
+    for (int c = 0; c < 3; ++c) {
+        const float g = gcol[c];
+        dsh[c] = kSH_C0 * g;
+        if (deg > 0) {
+            dsh[3 + c] = -kSH_C1 * y * g; dsh[6 + c] = kSH_C1 * z * g; dsh[9 + c] = -kSH_C1 * x * g;
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                dsh[12 + c] = kSH_C2[0] * xy * g; dsh[15 + c] = kSH_C2[1] * yz * g;
+                dsh[18 + c] = kSH_C2[2] * (2.f * zz - xx - yy) * g;
+                dsh[21 + c] = kSH_C2[3] * xz * g; dsh[24 + c] = kSH_C2[4] * (xx - yy) * g;
+                if (deg > 2) {
+                    dsh[27 + c] = kSH_C3[0] * y * (3.f * xx - yy) * g;
+                    dsh[30 + c] = kSH_C3[1] * xy * z * g;
+                    dsh[33 + c] = kSH_C3[2] * y * (4.f * zz - xx - yy) * g;
+                    dsh[36 + c] = kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                    dsh[39 + c] = kSH_C3[4] * x * (4.f * zz - xx - yy) * g;
+                    dsh[42 + c] = kSH_C3[5] * z * (xx - yy) * g;
+                    dsh[45 + c] = kSH_C3[6] * x * (xx - 3.f * yy) * g;
                 }
             }
         }
-        const int used = (deg + 1) * (deg + 1);
-        for (int k = used * 3; k < M * 3; ++k) dsh[k] = 0.f;
     }
+    const int used = (deg + 1) * (deg + 1);
+    for (int k = used * 3; k < M * 3; ++k) dsh[k] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -293,8 +296,16 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
                     float dx = px - f.campos[0], dy = py - f.campos[1], dz = pz - f.campos[2];
                     const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
                     dx /= len; dy /= len; dz /= len;
-                    if (kLdsSH) sh_to_rgb(f.sh_degree, s_sh + tid * kShLdsStride, dx, dy, dz, rgb, out_clamped);
-                    else sh_to_rgb(f.sh_degree, shs + (size_t)i * f.sh_coeffs * 3, dx, dy, dz, rgb, out_clamped);
+                    float J[9];
+                    if (kLdsSH) {
+                        sh_to_rgb(f.sh_degree, s_sh + tid * kShLdsStride, dx, dy, dz, rgb, out_clamped);
+                        sh_dir_jacobian(f.sh_degree, s_sh + tid * kShLdsStride, dx, dy, dz, len, J);
+                    } else {
+                        sh_to_rgb(f.sh_degree, shs + (size_t)i * f.sh_coeffs * 3, dx, dy, dz, rgb, out_clamped);
+                        sh_dir_jacobian(f.sh_degree, shs + (size_t)i * f.sh_coeffs * 3, dx, dy, dz, len, J);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) f.sh_jac[9 * (size_t)i + k] = J[k];
                 }
                 out_radius = (int32_t)radius;
                 out_tiles = (uint32_t)area;
@@ -334,10 +345,6 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
     const int tid = threadIdx.x, base = blockIdx.x * kPreBlock;
     const int i = base + tid;
     const int M = f.sh_coeffs;
-    if (kLdsSH) {
-        sh_rows_to_lds(shs, base, P, s_sh, tid);
-        __syncthreads();
-    }
     if (i < P) {
         float g_means3D[3] = {0, 0, 0}, g_scales[2] = {0, 0}, g_rot[4] = {0, 0, 0, 0}, g_m2d[2] = {0, 0};
         float dT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dTr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_col[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_opa = 0.f;
@@ -477,13 +484,12 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
                 // with SHs as the colour source dL_dcolors (optional) carries the clamp-masked dL/drgb: the one per-view
                 // input of the SH adjoint, which is all a frame-parallel rank has to ship (sh_gradient_expand_kernel)
                 g_col[0] = gc[0]; g_col[1] = gc[1]; g_col[2] = gc[2];
-                float ddir[3];
-                if (kLdsSH) sh_backward(f.sh_degree, M, row, row, out.dL_dsh != nullptr, x, y, z, gc, ddir);
-                else sh_backward(f.sh_degree, M, shs + (size_t)i * M * 3, dsh_g, dsh_g != nullptr, x, y, z, gc, ddir);
-                const float nd = (x * ddir[0] + y * ddir[1]) + z * ddir[2];
-                g_means3D[0] += (ddir[0] - x * nd) / len;
-                g_means3D[1] += (ddir[1] - y * nd) / len;
-                g_means3D[2] += (ddir[2] - z * nd) / len;
+                if (kLdsSH) { if (out.dL_dsh) sh_basis_adjoint(f.sh_degree, M, row, x, y, z, gc); }
+                else if (dsh_g) sh_basis_adjoint(f.sh_degree, M, dsh_g, x, y, z, gc);
+                // the colour's dependence on the centre through the view direction: K1 left d rgb / d centre (9 floats) behind
+                const float* J = f.sh_jac + 9 * (size_t)i;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g_means3D[k] += (gc[0] * J[k] + gc[1] * J[3 + k]) + gc[2] * J[6 + k];
             }
         } else if (shs) {
             if (kLdsSH) {
