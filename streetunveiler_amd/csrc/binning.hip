@@ -157,6 +157,7 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
     constexpr int kBins = 1 << kBits;
     constexpr int kPer = kBins / kXpThreads > 0 ? kBins / kXpThreads : 1;   // digits per thread in the block-wide digit scans
     constexpr int kInputs = xp_inputs<AXIS>(), kXpPerThread = kInputs / kXpThreads;
+    __shared__ __attribute__((aligned(16))) uint8_t s_start[kXpBatch];                 // 1 where a slot of the current batch is the first slot of an item
     __shared__ uint32_t s_prefix[kInputs + 1];            // s_prefix[j] = expanded slots of the block's items before item j
     __shared__ uint32_t s_count[kXpWaves][kBins];         // slots of digit d held by wave w (this batch); then, in place, the next
                                                           // batch-local position for (wave, digit)
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
     if (base >= n) return;
     const int n_items = (int)min((uint32_t)kInputs, n - base);
     uint32_t E;   // expanded slots of this block
+    uint32_t it_first[kXpPerThread];   // first slot of this thread's items (0xFFFFFFFF: an empty item)
     {
         uint32_t incl[kXpPerThread], sum = 0;
 #pragma unroll
@@ -182,12 +184,17 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
                 const uint2 it = in[base + j];
                 expansion_of<AXIS>(it, start, len);
             }
+            it_first[i] = len ? sum : 0xFFFFFFFFu;
             sum += (uint32_t)len;
             incl[i] = sum;
         }
+        for (int k = tid; k < kXpBatch / 4; k += kXpThreads) reinterpret_cast<uint32_t*>(s_start)[k] = 0;
         const uint32_t excl = block_exclusive_scan(sum, s_w, E);
 #pragma unroll
-        for (int i = 0; i < kXpPerThread; ++i) s_prefix[tid * kXpPerThread + i + 1] = excl + incl[i];
+        for (int i = 0; i < kXpPerThread; ++i) {
+            s_prefix[tid * kXpPerThread + i + 1] = excl + incl[i];
+            if (it_first[i] != 0xFFFFFFFFu) it_first[i] += excl;
+        }
         if (tid == 0) s_prefix[0] = 0;
     }
     {   // first output position of every digit (exclusive scan of the row totals) + this block's offset inside the digit
@@ -202,18 +209,35 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
     }
     for (uint32_t q0 = 0; q0 < E; q0 += kXpBatch) {
         for (int k = tid; k < kXpWaves * kBins; k += kXpThreads) (&s_count[0][0])[k] = 0;
+        // every non-empty item marks its first slot (the marks of the previous batch were cleared behind its last reader)
+#pragma unroll
+        for (int i = 0; i < kXpPerThread; ++i)
+            if (it_first[i] - q0 < (uint32_t)kXpBatch) s_start[it_first[i] - q0] = 1;   // (an empty item's 0xFFFFFFFF never lands in a batch)
         __syncthreads();   // (also orders s_prefix / s_goff writes and the previous batch's write-out)
+        // slot -> item.  Empty items only ever follow the non-empty ones (culled Gaussians sort last; a column item has >= 1 row), so
+        // the item of a slot is the number of marks up to it, minus one: one binary search per wave and batch for the wave's first
+        // slot, then a ballot of the marks and a popcount per row of 64 slots.
+        const uint32_t s0 = q0 + (uint32_t)(w * (kXpBatch / kXpWaves));
+        uint32_t marks_before = 0;   // marks in front of the current row (block-wide count)
+        if (s0 < E) {
+            int lo = 0;   // largest j with s_prefix[j] <= s0
+#pragma unroll
+            for (int step = kInputs / 2; step > 0; step >>= 1)
+                if (lo + step < n_items && s_prefix[lo + step] <= s0) lo += step;
+            marks_before = (uint32_t)lo + (s_prefix[lo] == s0 ? 0u : 1u);
+        }
         uint32_t dig[kXpBatch / kXpThreads], id[kXpBatch / kXpThreads], rows[AXIS == 0 ? kXpBatch / kXpThreads : 1];
 #pragma unroll
         for (int i = 0; i < kXpBatch / kXpThreads; ++i) {
-            const uint32_t slot = q0 + (uint32_t)(w * (kXpBatch / kXpWaves) + i * 64 + lane);
+            const uint32_t slot = s0 + (uint32_t)(i * 64 + lane);
             dig[i] = 0; id[i] = 0;
             if (AXIS == 0) rows[i] = 0;
+            const bool mark = slot < E && s_start[slot - q0] != 0;
+            const unsigned long long marks = ballot64(mark);
+            const uint32_t lo = marks_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(marks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)marks, 0u)) +
+                                (mark ? 1u : 0u) - 1u;
+            marks_before += (uint32_t)__popcll(marks);
             if (slot < E) {
-                int lo = 0;   // largest j with s_prefix[j] <= slot (empty items are skipped automatically)
-#pragma unroll
-                for (int step = kInputs / 2; step > 0; step >>= 1)
-                    if (lo + step < n_items && s_prefix[lo + step] <= slot) lo += step;
                 const uint2 it = in[base + lo];
                 int start, len; expansion_of<AXIS>(it, start, len);
                 dig[i] = (uint32_t)start + (slot - s_prefix[lo]);
@@ -223,6 +247,7 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
             }
         }
         __syncthreads();
+        for (int k = tid; k < kXpBatch / 4; k += kXpThreads) reinterpret_cast<uint32_t*>(s_start)[k] = 0;   // for the next batch
         uint32_t tot[kPer];
         {   // batch-local exclusive scan over the digits, then the per-wave run starts
             uint32_t sum = 0;
