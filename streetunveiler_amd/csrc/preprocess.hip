@@ -127,6 +127,109 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const Row sh, float dx, float
     }
 }
 
+// ---- K1's SH rows in two halves ---------------------------------------------------------------------------------------------
+// K1 is bound by how many waves fit beside its LDS (26 KB per block of 128 rows: three waves per SIMD; with half of that it runs
+// 40 % slower).  So the rows go through LDS one half at a time -- coefficients 0..7, then 8..15, 96 B each -- and the colour (and
+// the direction Jacobian) are accumulated across the two halves.  The colour keeps the exact operation order of sh_to_rgb(): the
+// cut falls between two terms of its left-to-right sum.
+constexpr int kShHalfFloats = 24, kShHalfStride = 28;   // 7 quads per row: an odd quad stride keeps per-thread ds_read_b128 conflict-free
+__device__ __forceinline__ void sh_half_load(const float* __restrict__ shs, int base, int P, int half, int tid, float4 (&r)[6]) {
+    const int nrows = min(kPreBlock, P - base);
+    const float4* src = reinterpret_cast<const float4*>(shs + (size_t)base * kShRowFloats);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int f = tid + k * kPreBlock, row = f / 6, c4 = f - row * 6;
+        r[k] = row < nrows ? src[row * 12 + half * 6 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void sh_half_store(float* s_sh, int tid, const float4 (&r)[6]) {
+    float4* dst = reinterpret_cast<float4*>(s_sh);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int f = tid + k * kPreBlock, row = f / 6, c4 = f - row * 6;
+        dst[row * (kShHalfStride / 4) + c4] = r[k];
+    }
+}
+// first half of sh_to_rgb(): coefficients 0..7 (lo[3 k + c])
+__device__ __forceinline__ void sh_to_rgb_lo(int deg, const float* lo, float x, float y, float z, float res[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float r = kSH_C0 * lo[c];
+        if (deg > 0) {
+            r = r - kSH_C1 * y * lo[3 + c] + kSH_C1 * z * lo[6 + c] - kSH_C1 * x * lo[9 + c];
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + kSH_C2[0] * xy * lo[12 + c] + kSH_C2[1] * yz * lo[15 + c] + kSH_C2[2] * (2.f * zz - xx - yy) * lo[18 + c] +
+                    kSH_C2[3] * xz * lo[21 + c];
+            }
+        }
+        res[c] = r;
+    }
+}
+// second half: coefficients 8..15 (hi[3 (k - 8) + c]), then the offset and the clamp
+__device__ __forceinline__ void sh_to_rgb_hi(int deg, const float* hi, float x, float y, float z, const float res[3], float rgb[3], uint8_t& clamped) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float r = res[c];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y;
+            r = r + kSH_C2[4] * (xx - yy) * hi[c];
+            if (deg > 2) {
+                r = r + kSH_C3[0] * y * (3.f * xx - yy) * hi[3 + c] + kSH_C3[1] * xy * z * hi[6 + c] +
+                    kSH_C3[2] * y * (4.f * zz - xx - yy) * hi[9 + c] +
+                    kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * hi[12 + c] +
+                    kSH_C3[4] * x * (4.f * zz - xx - yy) * hi[15 + c] +
+                    kSH_C3[5] * z * (xx - yy) * hi[18 + c] + kSH_C3[6] * x * (xx - 3.f * yy) * hi[21 + c];
+            }
+        }
+        r += 0.5f;
+        if (r < 0.f) clamped |= (uint8_t)(1u << c);
+        rgb[c] = fmaxf(r, 0.f);
+    }
+}
+// the two halves of sh_dir_jacobian(): d[3 c + axis] accumulates d rgb[c] / d dir; the second half projects and scales
+__device__ __forceinline__ void sh_dir_jacobian_lo(int deg, const float* lo, float x, float y, float z, float d[9]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (deg > 0) {
+            dx = -kSH_C1 * lo[9 + c]; dy = -kSH_C1 * lo[3 + c]; dz = kSH_C1 * lo[6 + c];
+            if (deg > 1) {
+                dx += (kSH_C2[0] * y) * lo[12 + c] + (-2.f * kSH_C2[2] * x) * lo[18 + c] + (kSH_C2[3] * z) * lo[21 + c];
+                dy += (kSH_C2[0] * x) * lo[12 + c] + (kSH_C2[1] * z) * lo[15 + c] + (-2.f * kSH_C2[2] * y) * lo[18 + c];
+                dz += (kSH_C2[1] * y) * lo[15 + c] + (4.f * kSH_C2[2] * z) * lo[18 + c] + (kSH_C2[3] * x) * lo[21 + c];
+            }
+        }
+        d[3 * c] = dx; d[3 * c + 1] = dy; d[3 * c + 2] = dz;
+    }
+}
+__device__ __forceinline__ void sh_dir_jacobian_hi(int deg, const float* hi, float x, float y, float z, float len, const float d[9], float J[9]) {
+#pragma clang fp contract(fast)
+    const float inv_len = 1.f / len;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float dx = d[3 * c], dy = d[3 * c + 1], dz = d[3 * c + 2];
+        if (deg > 1) {
+            dx += (2.f * kSH_C2[4] * x) * hi[c];
+            dy += (-2.f * kSH_C2[4] * y) * hi[c];
+            if (deg > 2) {
+                dx += (6.f * kSH_C3[0] * xy) * hi[3 + c] + (kSH_C3[1] * yz) * hi[6 + c] + (-2.f * kSH_C3[2] * xy) * hi[9 + c] +
+                      (-6.f * kSH_C3[3] * xz) * hi[12 + c] + (kSH_C3[4] * (-3.f * xx + 4.f * zz - yy)) * hi[15 + c] +
+                      (2.f * kSH_C3[5] * xz) * hi[18 + c] + (3.f * kSH_C3[6] * (xx - yy)) * hi[21 + c];
+                dy += (3.f * kSH_C3[0] * (xx - yy)) * hi[3 + c] + (kSH_C3[1] * xz) * hi[6 + c] + (kSH_C3[2] * (-3.f * yy + 4.f * zz - xx)) * hi[9 + c] +
+                      (-6.f * kSH_C3[3] * yz) * hi[12 + c] + (-2.f * kSH_C3[4] * xy) * hi[15 + c] + (-2.f * kSH_C3[5] * yz) * hi[18 + c] +
+                      (-6.f * kSH_C3[6] * xy) * hi[21 + c];
+                dz += (kSH_C3[1] * xy) * hi[6 + c] + (8.f * kSH_C3[2] * yz) * hi[9 + c] + (3.f * kSH_C3[3] * (2.f * zz - xx - yy)) * hi[12 + c] +
+                      (8.f * kSH_C3[4] * xz) * hi[15 + c] + (kSH_C3[5] * (xx - yy)) * hi[18 + c];
+            }
+        }
+        const float nd = (x * dx + y * dy) + z * dz;
+        J[3 * c + 0] = (dx - x * nd) * inv_len; J[3 * c + 1] = (dy - y * nd) * inv_len; J[3 * c + 2] = (dz - z * nd) * inv_len;
+    }
+}
+
 // d rgb[c] / d centre through the SH view direction, J[3 c + k] = ((d_c - dir (dir . d_c)) / len)[k] with d_c = d rgb[c] / d dir
 // [REF the direction half of computeColorFromSH's backward, Appendix A.6].  K1 evaluates it next to the colour, from the SH row it
 // holds anyway, so that K8 needs 36 B per Gaussian instead of reading the 192-B row again.
@@ -201,7 +304,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     const float* __restrict__ colors_precomp, const float* __restrict__ transMat_precomp,
     const uint8_t* __restrict__ mask, float4* __restrict__ recs, uint32_t* __restrict__ depth_keys,
     uint32_t* __restrict__ tiles_touched, uint2* __restrict__ rect, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii) {
-    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? kPreBlock * kShLdsStride : 4];
+    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? kPreBlock * kShHalfStride : 4];
     const int tid = threadIdx.x, base = blockIdx.x * kPreBlock;
     const int i = base + tid;
     // every per-Gaussian input is requested up front, in front of the SH staging and its barrier: one memory round trip instead of four
@@ -216,11 +319,16 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
         if (!transMat_precomp) { raw_rot = reinterpret_cast<const float4*>(rotations)[i]; raw_scales = reinterpret_cast<const float2*>(scales)[i]; }
         if (mask) kept = mask[i] != 0;   // masked out == not there (same as boolean-indexing the inputs)
     }
+    float4 half_b[6];   // the second halves of the block's SH rows: in flight during the geometry
     if (kLdsSH) {
-        sh_rows_to_lds(shs, base, P, s_sh, tid);
+        float4 half_a[6];
+        sh_half_load(shs, base, P, 0, tid, half_a);
+        sh_half_load(shs, base, P, 1, tid, half_b);
+        sh_half_store(s_sh, tid, half_a);
         __syncthreads();
     }
-    if (i >= P) return;
+    const bool in_range = i < P;
+    if (!kLdsSH && !in_range) return;   // (with LDS staging every thread stays for the barriers below)
     // defaults for a culled Gaussian
     int32_t out_radius = 0;
     uint32_t out_tiles = 0, out_key = kCulledKey;
@@ -232,7 +340,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     const float vx = ((v[0] * px + v[4] * py) + v[8] * pz) + v[12];
     const float vy = ((v[1] * px + v[5] * py) + v[9] * pz) + v[13];
     const float vz = ((v[2] * px + v[6] * py) + v[10] * pz) + v[14];
-    bool alive = vz > kNear && kept;
+    bool alive = in_range && vz > kNear && kept;
+    bool need_sh = false;   // the colour comes from the SHs: evaluated behind the geometry, across the two LDS halves
+    float sdx = 0.f, sdy = 0.f, sdz = 0.f, slen = 1.f, sradius = 0.f;
     if (alive) {
         float Tm[9], nrm[3];
         if (transMat_precomp) {
@@ -288,7 +398,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
             miny = min(f.tiles_y, max(0, miny)); maxy = min(f.tiles_y, max(0, maxy));
             const int area = (maxx - minx) * (maxy - miny);
             if (area > 0) {
-                float rgb[3];
+                float rgb[3] = {0.f, 0.f, 0.f};
                 if (colors_precomp && f.colors != 9) {   // 9 channels: rgb from the SHs, the six extra channels go straight to the blend kernels
                     const float* c = colors_precomp + (size_t)f.colors * i;   // channels 3..5 (if any) are read by the blend kernels
                     rgb[0] = c[0]; rgb[1] = c[1]; rgb[2] = c[2];
@@ -296,16 +406,15 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
                     float dx = px - f.campos[0], dy = py - f.campos[1], dz = pz - f.campos[2];
                     const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
                     dx /= len; dy /= len; dz /= len;
-                    float J[9];
                     if (kLdsSH) {
-                        sh_to_rgb(f.sh_degree, s_sh + tid * kShLdsStride, dx, dy, dz, rgb, out_clamped);
-                        sh_dir_jacobian(f.sh_degree, s_sh + tid * kShLdsStride, dx, dy, dz, len, J);
+                        need_sh = true; sdx = dx; sdy = dy; sdz = dz; slen = len; sradius = radius;   // (q4 is completed below)
                     } else {
+                        float J[9];
                         sh_to_rgb(f.sh_degree, shs + (size_t)i * f.sh_coeffs * 3, dx, dy, dz, rgb, out_clamped);
                         sh_dir_jacobian(f.sh_degree, shs + (size_t)i * f.sh_coeffs * 3, dx, dy, dz, len, J);
-                    }
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) f.sh_jac[9 * (size_t)i + k] = J[k];
+                        for (int k = 0; k < 9; ++k) f.sh_jac[9 * (size_t)i + k] = J[k];
+                    }
                 }
                 out_radius = (int32_t)radius;
                 out_tiles = (uint32_t)area;
@@ -318,6 +427,26 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
                 q4 = make_float4(rgb[0], rgb[1], rgb[2], radius);
             }
         }
+    }
+    if (kLdsSH) {
+        const float* row = s_sh + tid * kShHalfStride;
+        float res[3] = {0.f, 0.f, 0.f}, dd[9];
+        if (need_sh) {
+            sh_to_rgb_lo(f.sh_degree, row, sdx, sdy, sdz, res);
+            sh_dir_jacobian_lo(f.sh_degree, row, sdx, sdy, sdz, dd);
+        }
+        __syncthreads();   // every thread is done with the first halves
+        sh_half_store(s_sh, tid, half_b);
+        __syncthreads();
+        if (need_sh) {
+            float rgb[3], J[9];
+            sh_to_rgb_hi(f.sh_degree, row, sdx, sdy, sdz, res, rgb, out_clamped);
+            sh_dir_jacobian_hi(f.sh_degree, row, sdx, sdy, sdz, slen, dd, J);
+            q4 = make_float4(rgb[0], rgb[1], rgb[2], sradius);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) f.sh_jac[9 * (size_t)i + k] = J[k];
+        }
+        if (!in_range) return;
     }
     radii[i] = out_radius;
     tiles_touched[i] = out_tiles;
