@@ -40,7 +40,7 @@ namespace sr {
 // each, all walking the parent's list: fewer pixels per lane -> fewer registers -> more waves per SIMD, which is what these
 // latency-bound loops want, at the price of staging every entry SPLIT times.
 template <bool kStats, int NC, int QX, int QY, int SPLIT>
-__global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats && NC == 3 && QX == 2 && QY == 1 && SPLIT == 2 ? 6 : 1, !kStats && NC == 3 && QX == 2 && QY == 1 && SPLIT == 2 ? 6 : 8))) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const float4* __restrict__ recs,
                                                                 const float* __restrict__ extra,
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8 * SPLIT) + part * (QY * 8);
     // local origin = centre of the binning tile (shared with K7: identical staged values, identical decisions)
     const float Xc = (float)(tx0 + QX * 4), Yc = (float)((tile / f.tiles_x) * (QY * 8 * SPLIT) + QY * SPLIT * 4);
-    const float yshift = (float)(part * (QY * 8) - QY * (SPLIT - 1) * 4);   // this band's quadrants relative to that centre
+    const int yshift_px = part * (QY * 8) - QY * (SPLIT - 1) * 4;   // this band's quadrants relative to that centre
+    const float yshift = (float)yshift_px;
     const int lx = lane & 7, ly = lane >> 3;
     const uint2 range = ranges[tile];
     const uint32_t n_total = range.y - range.x;
@@ -95,7 +96,9 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         uint32_t m = 0;
-        if ((uint32_t)lane < n) m = stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, cull & 1, s_e, lane, yshift);
+        int ys = yshift_px;
+        asm volatile("" : "+s"(ys));   // converted again in every round: one v_cvt per 64 entries instead of a register held across the walk
+        if ((uint32_t)lane < n) m = stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, cull & 1, s_e, lane, (float)ys);
         if (base + kWave + lane < n_total) {
             const uint32_t gid = point_list[range.x + base + kWave + lane];
             load_record(recs, gid, nr);
@@ -163,9 +166,12 @@ __global__ __launch_bounds__(kWave) void render_forward_kernel(FrameDev f, const
     }
     const size_t HW = (size_t)f.H * f.W;
     const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
+    int lane_again = threadIdx.x;
+    asm volatile("" : "+v"(lane_again));   // the pixel coordinates are recomputed here instead of living in registers across the list walk
+    const int lx2 = lane_again & 7, ly2 = lane_again >> 3;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
+        const int px = tx0 + (q % QX) * 8 + lx2, py = ty0 + (q / QX) * 8 + ly2;
         if (px < f.W && py < f.H) {
             const size_t pix = (size_t)py * f.W + px;
             const float Tq = fabsf(T[q]);
