@@ -157,14 +157,15 @@ int sr_binning_view(void* binning, size_t binning_bytes, int32_t P, uint32_t num
                     int32_t image_height, SrBinningView* out);
 int sr_image_view(void* image, size_t image_bytes, int32_t image_width, int32_t image_height, SrImageView* out);
 
-/* Forward, phase 1 (K1 preprocess + depth ordering + tile-count scan).
+/* Forward, phase 1 (K1 preprocess + tile-count scan + depth ordering).
  * Writes radii[P] (int32) and the geometry state; returns D = number of (tile, Gaussian) duplicates in
- * *num_rendered_host after ONE stream synchronisation (the same host read-back the reference does
- * between its scan and duplicateWithKeys). */
+ * *num_rendered_host after ONE host wait (the same read-back the reference does between its scan and duplicateWithKeys;
+ * the depth sort is queued behind the copy of D, so the GPU keeps working while the caller sizes the binning buffer). */
 int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, int32_t* radii,
                     uint32_t* num_rendered_host, void* stream);
 
-/* Forward, phase 2 (K3 duplicate emission, K4 tile sort, K5 ranges, K6 blend).
+/* Forward, phase 2 (K3 / K4 expanding tile partition: column pass over the Gaussians, row pass over the column items; K5 ranges + dispatch
+ * order; K6 blend).
  * out_color [NC,H,W], out_allmap [7,H,W] (0 sum w*depth, 1 alpha, 2-4 sum w*normal (view space),
  * 5 median depth, 6 distortion). */
 int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning,
