@@ -56,6 +56,22 @@ __global__ __launch_bounds__(64) void kpk(float* out, int iters, float a, float 
     for (int i = 0; i < 8; ++i) s += x[i].x + x[i].y;
     out[blockIdx.x * 64 + threadIdx.x] = s;
 }
+__global__ __launch_bounds__(64) void kmov64(float* out, int iters, float a, float b) {
+    float2v x[8], bb = {b, b};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = float2v{a + threadIdx.x * 1e-3f + i, b + i};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_mov_b64 %0, %1" : "+v"(x[i]) : "v"(bb));
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i].x + x[i].y;
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+}
 template <int OP, int CH> void run(const char* name, float* d, unsigned long long* c, int per_op) {
     const int iters = 2000;
     printf("%-22s chains=%d:", name, CH);
@@ -97,6 +113,18 @@ int main() {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipLaunchKernelGGL(kpk, dim3(blocks), dim3(64), 0, 0, d, 10, 1.0001f, 0.5f);
             hipEventRecord(e0); hipLaunchKernelGGL(kpk, dim3(blocks), dim3(64), 0, 0, d, iters, 1.0001f, 0.5f); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("  w%d %.2f ns/instr/SIMD", w, ms * 1e6 / ((double)w * iters * kUnroll * 8));
+        }
+        printf("\n");
+    }
+    {   // 64-bit move: two registers per instruction
+        printf("mov_b64 (2 regs/instr) chains=8:");
+        for (int w : {1, 2, 3, 4, 8}) {
+            const int blocks = 256 * 4 * w, iters = 2000;
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipLaunchKernelGGL(kmov64, dim3(blocks), dim3(64), 0, 0, d, 10, 1.0001f, 0.5f);
+            hipEventRecord(e0); hipLaunchKernelGGL(kmov64, dim3(blocks), dim3(64), 0, 0, d, iters, 1.0001f, 0.5f); hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("  w%d %.2f ns/instr/SIMD", w, ms * 1e6 / ((double)w * iters * kUnroll * 8));
         }
