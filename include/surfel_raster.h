@@ -266,6 +266,12 @@ size_t sr_debug_radix_sort_temp_bytes(uint32_t n);
 int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                         int total_bits, void* temp, size_t temp_bytes, void* stream);
 
+/* Test hook for the hardware property the sort kernels rank by: within one wave instruction, ds_add_rtn_u32 returns the old values
+ * to the lanes that hit the same LDS address in ascending lane order.  ranks[i] = what lane i % 64 of its wave got back when every
+ * lane added 1 to counter digits[i] % bins of its wave (n a multiple of 256, processed 256 per block step, 8 steps per block, the
+ * counters running on across the steps; bins <= 1024).  All device pointers. */
+int sr_debug_lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t n, int bins, void* stream);
+
 /* Profiling aid -- the one piece of process-wide state in this library (mutex-protected: autograd runs the backward on its own
  * thread).  sr_set_stage_timing(1) makes every later call bracket each stage with a pair of HIP events recorded
  * on the caller's stream (no host sync while recording; up to 512 launches per stage); sr_set_stage_timing(2 * mask),

@@ -53,6 +53,7 @@ hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out);
+hipError_t lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t n, int bins, hipStream_t s);
 // knn.hip
 size_t knn_workspace_bytes(int nq, int nr);
 hipError_t knn_mean_dist2(int nq, const float* query, int nr, const float* reference, int K, int take_sqrt, float* out, void* ws,
@@ -652,6 +653,13 @@ int sr_postprocess_backward(int32_t W, int32_t H, float fovx, float fovy, float 
     if (!allmap || !scratch6 || !g_allmap) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     SR_HIP(launch_postprocess_backward(cam, allmap, g_rend_normal, g_surf_depth, g_surf_normal, g_surf_point, scratch6, g_allmap,
                                        static_cast<hipStream_t>(stream)));
+    return SR_OK;
+}
+
+int sr_debug_lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t n, int bins, void* stream) {
+    if (n > 0 && (!digits || !ranks)) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (bins < 1 || bins > 1024 || (n % 256u) != 0u) return fail(SR_ERR_INVALID_ARGUMENT, "bins %d not in 1..1024 or n %u not a multiple of 256", bins, n);
+    SR_HIP(lds_atomic_ranks(digits, ranks, n, bins, static_cast<hipStream_t>(stream)));
     return SR_OK;
 }
 

@@ -279,18 +279,9 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
             const uint32_t slot = q0 + (uint32_t)(w * (kXpBatch / kXpWaves) + i * 64 + lane);
             const bool live = slot < E;
             const uint32_t d = dig[i];
-            unsigned long long same = ballot64(live);        // lanes holding the same digit as this lane
-#pragma unroll
-            for (int b = 0; b < kBits; ++b) {
-                const unsigned long long vote = ballot64(((d >> b) & 1u) != 0u);
-                same &= ((d >> b) & 1u) ? vote : ~vote;
-            }
-            const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            // stable rank by ONE LDS atomic: its return values come back in ascending lane order (radix_sort.hip)
             uint32_t pos = 0;
-            if (live) pos = s_count[w][d] + rank;
-            __builtin_amdgcn_wave_barrier();
-            if (live && rank == 0) s_count[w][d] += (uint32_t)__popcll(same);  // one leader per digit advances the run
-            __builtin_amdgcn_wave_barrier();
+            if (live) pos = atomicAdd(&s_count[w][d], 1u);
             if (live) { s_id[pos] = id[i]; s_dig[pos] = (uint16_t)d; if (AXIS == 0) s_rows[pos] = rows[i]; }
         }
         __syncthreads();

@@ -7,9 +7,8 @@
 //
 // One pass = histogram -> one row scan (a block per digit) -> scatter (every scatter block turns the <= 256 row totals into digit
 // bases itself: no third tiny kernel in the dependency chain).  A 256-thread block owns 2048 consecutive items; each
-// wave owns 512 of them and ranks them 64 at a time with the wave64 match-any idiom: `bits` ballots build,
-// for every lane, the mask of lanes holding the same digit; rank = popcount(mask & lanes_below), the run
-// base lives in LDS per (wave, digit).  No atomics on global memory, integer work only, no MFMA.
+// wave owns 512 of them and ranks them 64 at a time with one LDS atomic per item on the (wave, digit) run counter (see the rank
+// phase below).  No atomics on global memory, integer work only, no MFMA.
 #include "common.h"
 
 namespace sr {
@@ -129,18 +128,13 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         const uint32_t idx = wbase + (uint32_t)(i * 64 + lane);
         const bool live = idx < n;
         const uint32_t d = (key[i] >> shift) & mask;
-        unsigned long long same = ballot64(live);        // lanes holding the same digit as this lane
-#pragma unroll
-        for (int b = 0; b < bits; ++b) {
-            const unsigned long long vote = ballot64(((d >> b) & 1u) != 0u);
-            same &= ((d >> b) & 1u) ? vote : ~vote;
-        }
-        const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        // rank among the wave's items of the same digit, in item order: ONE LDS atomic.  ds_add_rtn_u32 hands its return values to the
+        // lanes of an instruction that hit the same address in ascending lane order on gfx950 (not documented; checked on the device
+        // by tests/test_gpu_parity.py::test_lds_atomic_returns_in_lane_order and, indirectly, by every bit-exact binning test), and the
+        // rows of a wave are issued in order -- so the old value IS the stable position.  (The match-any ballots this replaces cost
+        // ~6 VALU instructions per key bit and row.)
         uint32_t pos = 0;
-        if (live) pos = s_run[w][d] + rank;
-        __builtin_amdgcn_wave_barrier();
-        if (live && rank == 0) s_run[w][d] += (uint32_t)__popcll(same);  // one leader per digit advances the run
-        __builtin_amdgcn_wave_barrier();
+        if (live) pos = atomicAdd(&s_run[w][d], 1u);
         if (live) { s_key[pos] = key[i]; s_val[pos] = val[i]; }
     }
     __syncthreads();
@@ -223,6 +217,23 @@ __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __res
         __syncthreads();
     }
     if (tid == 0) block_total[nblocks] = s_carry;
+}
+
+// Test hook (sr_debug_lds_atomic_ranks): the lane order of LDS atomic returns, the property the rank phase above relies on.
+__global__ __launch_bounds__(kRsThreads) void lds_atomic_ranks_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t n, int bins) {
+    __shared__ uint32_t s_cnt[kRsThreads / 64][1024];
+    const int tid = threadIdx.x, w = tid >> 6;
+    for (int i = tid; i < (kRsThreads / 64) * 1024; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    for (int it = 0; it < kRsItems; ++it) {
+        const uint32_t idx = (blockIdx.x * (uint32_t)kRsItems + it) * kRsThreads + tid;
+        if (idx < n) ranks[idx] = atomicAdd(&s_cnt[w][digits[idx] % (uint32_t)bins], 1u);
+    }
+}
+hipError_t lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t n, int bins, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(lds_atomic_ranks_kernel, dim3((n + kRsTile - 1) / kRsTile), dim3(kRsThreads), 0, s, digits, ranks, n, bins);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -201,6 +201,35 @@ def test_quadrant_culling_is_exact():
             assert np.abs(out1[k] - out0[k]).max() <= 2e-5 * scale, k
 
 
+def test_lds_atomic_returns_in_lane_order():
+    """The rank phase of the sort / partition kernels is ONE LDS atomic per item: it relies on ds_add_rtn_u32 handing its return values
+    to the lanes of a wave instruction that hit the same address in ascending lane order (not documented for gfx950).  Checked here
+    on the device for digit alphabets from 1 (every lane the same address) to 1000, 2 M lane-items each."""
+    from streetunveiler_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    n = 256 * 8 * 1024
+    for bins in (1, 2, 3, 7, 16, 68, 120, 256, 1000):
+        g = torch.Generator().manual_seed(bins)
+        digits = torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64).to(torch.int32).to(dev)
+        ranks = torch.empty(n, dtype=torch.int32, device=dev)
+        assert lib.sr_debug_lds_atomic_ranks(digits.data_ptr(), ranks.data_ptr(), n, bins, torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        d = (digits.cpu().numpy().view(np.uint32) % np.uint32(bins)).reshape(-1, 8, 4, 64)      # block, step, wave, lane
+        r = ranks.cpu().numpy().reshape(-1, 8, 4, 64)
+        # expected: the number of earlier (step, lane) items of the same wave with the same digit
+        d2 = d.transpose(0, 2, 1, 3).reshape(-1, 512)    # per wave: items in issue order (step-major, lane-minor)
+        r2 = r.transpose(0, 2, 1, 3).reshape(-1, 512)
+        order = np.argsort(d2, axis=1, kind="stable")
+        ds = np.take_along_axis(d2, order, axis=1)
+        first = np.concatenate([np.ones((ds.shape[0], 1), bool), ds[:, 1:] != ds[:, :-1]], axis=1)
+        pos = np.arange(512)[None, :]
+        start = np.maximum.accumulate(np.where(first, pos, 0), axis=1)
+        expect = np.empty_like(r2)
+        np.put_along_axis(expect, order, (pos - start).astype(r2.dtype), axis=1)
+        np.testing.assert_array_equal(r2, expect, err_msg=f"bins={bins}")
+
+
 def test_radix_sort_stability_and_edges():
     """The hand-written LSD radix sort behind K2/K4: stable, correct at ragged sizes and for every bit count."""
     import ctypes as C
