@@ -32,9 +32,10 @@ hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, vo
 //   pass Y: the column items, each expanded into its h rows, stably partitioned by row -> the D entries of point_list.
 // No duplicate is ever written in unsorted form: the only D-sized traffic is the final 4-B store per entry.  (Emitting all D (tile, id) pairs and running two radix passes over them moved 3.5x the bytes.)
 // One pass = histogram -> row scan -> scatter, like the radix sort's; what differs is that the "keys" of a block are generated, not
-// loaded: a block owns 2048 input items, a block-local prefix sum of their lengths maps every expanded slot back to (item, offset)
-// by binary search in LDS, and the slots are ranked, reordered in LDS and written out in batches of 2048 with the wave64 match-any
-// idiom.  The histogram needs no expansion at all: +1 at the first digit of an item, -1 behind its last, prefix sum (LDS).
+// loaded: a block owns 1024 / 2048 input items; a block-local prefix sum of their lengths gives every item its first slot, the items
+// mark those slots in LDS, and a ballot of the marks + a popcount map a row of 64 slots back to (item, offset); the slots are then
+// ranked (one LDS atomic each, radix_sort.hip), reordered in LDS and written out in batches of 2048.  The histogram needs no
+// expansion at all: +1 at the first digit of an item, -1 behind its last, prefix sum (LDS).
 // Pass Y's histogram kernel also produces the number of entries per tile (the input is ordered by column, so a block sees one or two
 // columns: 4 x rows difference counters in LDS), whose exclusive scan is the range table (K5).
 // ---------------------------------------------------------------------------------------------

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __re
     if (tid == 0) row_total[blockIdx.x] = s_carry;
 }
 
-template <int kBits>   // digit width (compile time: the match-any ballots unroll); 0 = run-time width
+template <int kBits>   // digit width (compile time); 0 = run-time width <= 8
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                 uint32_t n, int shift, int bits_rt, const uint32_t* __restrict__ hist,
