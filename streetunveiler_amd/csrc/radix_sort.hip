@@ -67,8 +67,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
                                                                 uint32_t n, int shift, int bits_rt, const uint32_t* __restrict__ hist,
                                                                 const uint32_t* __restrict__ row_total, int nblocks,
                                                                 const uint2* __restrict__ aux_src, uint2* __restrict__ aux_out) {
-    __shared__ uint32_t s_count[kRsThreads / 64][kRsMaxBins];  // items of digit b held by wave w
-    __shared__ uint32_t s_run[kRsThreads / 64][kRsMaxBins];    // next block-local slot for (wave, digit)
+    __shared__ uint32_t s_run[kRsThreads / 64][kRsMaxBins];    // items of digit b held by wave w; then, in place, the next block-local slot for (wave, digit)
     __shared__ uint32_t s_lstart[kRsMaxBins];                  // block-local start of digit b
     __shared__ uint32_t s_gbase[kRsMaxBins];                   // global position of the block's first item of digit b
     __shared__ uint32_t s_wsum[kRsThreads / 64];
@@ -76,7 +75,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     const int bits = kBits ? kBits : bits_rt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, bins = 1 << bits;
     const uint32_t mask = (uint32_t)bins - 1u;
-    for (int b = tid; b < (kRsThreads / 64) * kRsMaxBins; b += kRsThreads) (&s_count[0][0])[b] = 0;
+    for (int b = tid; b < (kRsThreads / 64) * kRsMaxBins; b += kRsThreads) (&s_run[0][0])[b] = 0;
     __syncthreads();
     // wave w owns items [wbase, wbase + 512), 64 at a time in order -> stable
     const uint32_t tile_base = blockIdx.x * (uint32_t)kRsTile;
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         if (idx < n) {
             key[i] = keys_in[idx];
             val[i] = vals_in ? vals_in[idx] : idx;   // first pass of an index sort: the value is the position itself
-            atomicAdd(&s_count[w][(key[i] >> shift) & mask], 1u);
+            atomicAdd(&s_run[w][(key[i] >> shift) & mask], 1u);
         }
     }
     __syncthreads();
@@ -98,7 +97,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         uint32_t tot = 0;
         if (tid < bins) {
 #pragma unroll
-            for (int k = 0; k < kRsThreads / 64; ++k) tot += s_count[k][tid];
+            for (int k = 0; k < kRsThreads / 64; ++k) tot += s_run[k][tid];
         }
         uint32_t incl = wave_inclusive_scan(tot);
         if (lane == 63) s_wsum[w] = incl;
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
             s_gbase[tid] = bin_base + hist[(size_t)tid * nblocks + blockIdx.x];
             uint32_t run = off;
 #pragma unroll
-            for (int k = 0; k < kRsThreads / 64; ++k) { s_run[k][tid] = run; run += s_count[k][tid]; }
+            for (int k = 0; k < kRsThreads / 64; ++k) { const uint32_t c = s_run[k][tid]; s_run[k][tid] = run; run += c; }
         }
     }
     __syncthreads();
