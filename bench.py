@@ -166,6 +166,9 @@ def main():
     from streetunveiler_amd.parallel import allreduce_gradients, factored_sh_exchange, init_distributed
     rank, world, local_rank = init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # SURFEL_EXCHANGE_SINGLE_RANK=1 (with torchrun --nproc-per-node 1): take the frame-parallel branches on a one-rank RCCL group -- the
+    # same calls an N-GPU run makes, exercised on a single GPU (functional check; the JSON line then reports n_gpus 1 with an exchange)
+    multi = world > 1 or os.environ.get("SURFEL_EXCHANGE_SINGLE_RANK") == "1"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())  # (the modulo only matters for the gloo smoke test)
     torch.cuda.set_device(dev)
@@ -186,7 +189,7 @@ def main():
                                              cam.camera_center.to(dev), False, False)
     rasterizer = GaussianRasterizer(settings)
     # the camera list is replicated: every rank knows every rank's camera position
-    all_campos = torch.stack([synthetic_camera(W, H, index=r, n_cams=world).camera_center for r in range(world)]).to(dev) if world > 1 else None
+    all_campos = torch.stack([synthetic_camera(W, H, index=r, n_cams=world).camera_center for r in range(world)]).to(dev) if multi else None
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     leaves = [params["means3D"], params["shs"], params["opacities"], params["scales"], params["rotations"], means2D]
 
@@ -197,7 +200,7 @@ def main():
             t.grad = None
         color, radii, allmap = rasterizer(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
                                           opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
-        if world > 1 and args.exchange == "factored":
+        if multi and args.exchange == "factored":
             # SH gradient: all-gather of the 12-B colour gradients + local expansion; the other 40 B/Gaussian: one
             # all-reduce, queued behind it inside backward -- every gradient leaves backward summed over the ranks
             with factored_sh_exchange(all_campos=all_campos, reduce_all=True) as ex:
@@ -206,7 +209,7 @@ def main():
             exchange_log["early_starts"] += ex.early_starts
         else:
             torch.autograd.backward([color, allmap], [dc, da])
-            if world > 1:
+            if multi:
                 t0 = time.perf_counter()
                 allreduce_gradients([t.grad for t in leaves[:5]])   # 232 B/Gaussian, one collective over the flat buffer
                 exchange_log["ms"] += (time.perf_counter() - t0) * 1e3; exchange_log["calls"] += 1
@@ -234,13 +237,13 @@ def main():
                     "quadrant_tests_with_a_hit": int(st[3]), "contributing_pairs": int(st[4])}
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     exchange_check = None
 
-    if world > 1:   # bring the communicator up before anything is timed, whatever --warmup says
+    if multi:   # bring the communicator up before anything is timed, whatever --warmup says
         w = torch.zeros(1024, device=dev); wg = torch.empty(1024 * world, device=dev)
         dist.all_reduce(w); dist.all_gather_into_tensor(wg, w)
         sync()
@@ -290,7 +293,7 @@ def main():
     stats_all = _lib.stage_stats()
     lib.sr_set_stage_timing(0)
     stats = {k: (stats[k] if stats[k][1] else stats_all[k]) for k in stats_all}
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -332,13 +335,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.label, "baseline_config": args.tag,
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D, "visible_per_P": round(V / P, 4), "D_per_P": round(D / P, 3),
-                       "frames_per_step": world, "parallelism": f"frame-sharded dp{world}" if world > 1 else "single GPU",
+                       "frames_per_step": world, "parallelism": f"frame-sharded dp{world}" if multi else "single GPU",
                        **({"gradient_exchange": ("all-gather of 12-B colour gradients (started between K7 and K8) + local SH expansion + "
                                                  "all-reduce of 40 B/Gaussian" if args.exchange == "factored" else "all-reduce of 232 B/Gaussian"),
                            "exchange_ms_per_step_rank0_host_wait": round(timed_exchange["ms"] / args.steps, 4),
                            "exchange_bytes_sent_per_step_rank0": int(timed_exchange["bytes"] / args.steps),
                            "exchange_early_starts_per_step": timed_exchange["early_starts"] / args.steps,
-                           "exchange_selfcheck": exchange_check} if world > 1 else {})},
+                           "exchange_selfcheck": exchange_check} if multi else {})},
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": None if ach is None else round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 5),
@@ -356,7 +359,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g_cpu, cam, dc_cpu, da_cpu)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -27,12 +27,21 @@ import torch.distributed as dist
 _BUCKET_INPLACE_BYTES = 32 << 20  # tensors at least this large are all-reduced in place
 
 
+def _exchange_wanted(group=None) -> bool:
+    """True when the frame-parallel collectives have to run: a group of more than one rank -- or, with
+    SURFEL_EXCHANGE_SINGLE_RANK=1, any initialised group (a one-rank RCCL group on a single GPU runs the very same calls:
+    tests/test_gpu_parity.py::test_factored_sh_exchange_over_rccl_with_one_rank)."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("SURFEL_EXCHANGE_SINGLE_RANK") == "1"
+
+
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from the torchrun environment. Returns (rank, world_size, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("SURFEL_EXCHANGE_SINGLE_RANK") == "1") and not dist.is_initialized():
         if backend is None:
             # SURFEL_DIST_BACKEND=gloo lets the N>1 path be exercised on a box with fewer GPUs than ranks
             backend = os.environ.get("SURFEL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -77,7 +86,7 @@ def allreduce_gradients(grads: Sequence[torch.Tensor], group=None, average: bool
 
     Gradients that the rasterizer's backward carved out of one flat buffer (diff_surfel_rasterization._C) are reduced
     with ONE collective over that buffer; anything else: large tensors in place, small ones through one bucket."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _exchange_wanted(group):
         return
     world = dist.get_world_size(group)
     grads = [g for g in grads if g is not None and g.numel() > 0]
@@ -189,7 +198,7 @@ def factored_sh_exchange(group=None, expand: Optional[Callable] = None, all_camp
     No-op when torch.distributed is not initialised or the group has one rank."""
     global _ACTIVE_SH_EXCHANGE
     prev = _ACTIVE_SH_EXCHANGE
-    ex = ShExchange(group, expand, all_campos, reduce_all) if dist.is_initialized() and dist.get_world_size(group) > 1 else None
+    ex = ShExchange(group, expand, all_campos, reduce_all) if _exchange_wanted(group) else None
     _ACTIVE_SH_EXCHANGE = ex
     try:
         yield ex
@@ -213,7 +222,7 @@ def reduce_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor
     local_accum[vis] = torch.norm(viewspace_grad[vis], dim=-1, keepdim=True)
     local_denom[vis] = 1
     local_max = torch.where(vis, radii.to(max_radii2D.dtype), torch.zeros_like(max_radii2D))
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _exchange_wanted(group):
         dist.all_reduce(local_accum, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(local_denom, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(local_max, op=dist.ReduceOp.MAX, group=group)

@@ -385,6 +385,20 @@ def test_factored_sh_exchange_two_ranks_one_gpu():
     assert "factored exchange OK" in r.stdout
 
 
+def test_factored_sh_exchange_over_rccl_with_one_rank():
+    """The frame-parallel exchange over the real backend (`nccl` = RCCL) on this one GPU: a one-rank group runs the same calls as an
+    N-rank one -- all-gather of the colour gradients on the communication stream, started between K7 and K8, local SH expansion, the flat
+    40-B all-reduce -- and must reproduce the local gradients (tools/check_factored_exchange.py, SURFEL_EXCHANGE_SINGLE_RANK=1)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SURFEL_EXCHANGE_SINGLE_RANK="1", SURFEL_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_factored_exchange.py")], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "factored exchange OK (world 1, backend nccl)" in r.stdout
+
+
 @pytest.mark.parametrize("tile", [(8, 8), (16, 8), (32, 8), (32, 16)])
 def test_tile_shape_sweep(tile):
     """BASELINE config 5's tile-size sweep: every shape bins bit-exactly like the oracle run with the same BLOCK_X x BLOCK_Y,
