@@ -114,6 +114,13 @@ def test_c5_scene_6m_at_4k_properties():
     assert 60_000_000 < D < 75_000_000      # SURVEY 8d calibration: D/P ~ 11.2 at 3840x2160
 
 
+def test_20m_gaussians_properties():
+    """Seven times the C3 scene (20 M Gaussians, D ~ 89 M, 37 GB of state): byte offsets beyond 2^32 in every buffer, 19 532 blocks in
+    the column pass, 43 642 in the row pass -- same list / image / determinism properties."""
+    D = _properties(20_000_000, W, H, check_linearity=False)
+    assert 80_000_000 < D < 100_000_000
+
+
 @pytest.mark.parametrize("tile", [(32, 16), (8, 8)])
 def test_tile_shapes_at_full_resolution_against_oracle(tile):
     """BASELINE config 5's tile-size sweep at full 1920x1080 resolution (C2's 500 k Gaussians, so that the CPU oracle finishes in
