@@ -669,11 +669,28 @@ __global__ __launch_bounds__(256) void color_gradient_kernel(int P, const int32_
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (radii[i] > 0) {
         const uint32_t first = first_index(f, (uint32_t)i), end = first + tiles_touched[i];
-        for (uint32_t e = first; e < end; ++e) {
-            if (!written[e]) continue;
-            const float4* gr = inst_grads + (size_t)e * kGradQuads;
-            const float4 g4 = gr[4]; const float g5x = gr[5].x;
-            c0 += g4.z; c1 += g4.w; c2 += g5x;
+        // four slots per trip, the next trip's flags in flight behind this trip's records (as in K8; same ascending order of the adds)
+        constexpr int kTrip = 4;
+        auto load_flags = [&](uint32_t e, uint8_t (&fl)[kTrip]) {
+#pragma unroll
+            for (int t = 0; t < kTrip; ++t) fl[t] = e + t < end ? written[e + t] : (uint8_t)0;
+        };
+        uint8_t fl[kTrip], fn[kTrip] = {0, 0, 0, 0};
+        load_flags(first, fl);
+        for (uint32_t e = first; e < end; e += kTrip) {
+            if (e + kTrip < end) load_flags(e + kTrip, fn);
+            float4 a4[kTrip]; float a5[kTrip];
+#pragma unroll
+            for (int t = 0; t < kTrip; ++t) {
+                const float4* gr = inst_grads + (size_t)(e + t) * kGradQuads;
+                a4[t] = fl[t] ? gr[4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                a5[t] = fl[t] ? gr[5].x : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < kTrip; ++t) {
+                if (fl[t]) { c0 += a4[t].z; c1 += a4[t].w; c2 += a5[t]; }
+                fl[t] = fn[t];
+            }
         }
         if (mask_clamped) { const uint8_t cl = clamped[i]; if (cl & 1) c0 = 0.f; if (cl & 2) c1 = 0.f; if (cl & 4) c2 = 0.f; }
     }
