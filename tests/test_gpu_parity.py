@@ -389,9 +389,11 @@ def test_factored_sh_exchange_over_rccl_with_one_rank():
     """The frame-parallel exchange over the real backend (`nccl` = RCCL) on this one GPU: a one-rank group runs the same calls as an
     N-rank one -- all-gather of the colour gradients on the communication stream, started between K7 and K8, local SH expansion, the flat
     40-B all-reduce -- and must reproduce the local gradients (tools/check_factored_exchange.py, SURFEL_EXCHANGE_SINGLE_RANK=1)."""
-    import subprocess, sys
+    import socket, subprocess, sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SURFEL_EXCHANGE_SINGLE_RANK="1", SURFEL_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
+    env = dict(os.environ, SURFEL_EXCHANGE_SINGLE_RANK="1", SURFEL_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_factored_exchange.py")], cwd=root, env=env, capture_output=True,
                        text=True, timeout=600)
