@@ -60,7 +60,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             fused["tile"] = ctx.tile
         if mask is not None:   # only the forward looks at it: masked-out Gaussians get radius 0 and, with that, zero gradients
             fused["mask"] = mask
-        if probe:              # tests / profiling: {"quadrant_cull": bool, "blend_counters": int64[8] device tensor}
+        if probe:              # tests / profiling: {"quadrant_cull": bool, "blend_counters": int64[8] device tensor, "ballot_ranking": bool}
             fused.update(probe)
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
@@ -78,6 +78,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered, color, allmap, radii, geomBuffer, binningBuffer, imgBuffer = out
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
+        # frame-parallel ranks may exchange the SH gradient in factored form (streetunveiler_amd.parallel): the exchange of the enclosing
+        # `factored_sh_exchange` block rides on this node -- the backward runs on autograd's thread and consults no global state.
+        # (Only when the SHs are the sole colour source: the 9-channel pass keeps its SH gradient local, as _C does.)
+        from streetunveiler_amd.parallel import active_sh_exchange
+        ctx.sh_exchange = active_sh_exchange() if sh.numel() and not colors_precomp.numel() else None
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -95,10 +100,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, grad_allmap, sh, s.sh_degree, s.campos, geomBuffer,
                 ctx.num_rendered, binningBuffer, imgBuffer, s.debug)
-        # frame-parallel ranks may exchange the SH gradient in factored form (streetunveiler_amd.parallel)
-        from streetunveiler_amd.parallel import active_sh_exchange
-        # (only when the SHs are the sole colour source: the 9-channel pass keeps its SH gradient local, as _C does)
-        exchange = active_sh_exchange() if sh.numel() and not colors_precomp.numel() else None
+        exchange = ctx.sh_exchange
         kwargs = {"defer_sh": True} if exchange is not None else {}
         if exchange is not None and hasattr(exchange, "start"):
             # the 12-B colour gradients are final right after the blend backward: their all-gather goes on the wire while K8 runs
@@ -153,14 +155,15 @@ class _ClassDistortions(torch.autograd.Function):
 
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False, tile=None, quadrant_cull: bool = True,
-                 blend_counters=None):
+                 blend_counters=None, ballot_ranking: bool = False):
         """`fused_activations=True` (extension): `opacities`, `scales`, `rotations` are the RAW parameters
         (`_opacity`, `_scaling`, `_rotation` of the reference's GaussianModel); sigmoid / exp / normalize run inside the
         preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values.
         `tile=(w, h)`: binning tile shape, default the reference's compile-time 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
         16x16, 32x8, 32x16); images and gradients do not depend on it beyond float summation order.
         `quadrant_cull=False` / `blend_counters` (int64[8] device tensor): this call's SrFrame.flags / SrFrame.blend_counters --
-        test and profiling switches with identical results (include/surfel_raster.h)."""
+        test and profiling switches with identical results (include/surfel_raster.h); `ballot_ranking=True`: SR_FLAG_BALLOT_RANKING,
+        the binning's fallback ranking (identical lists)."""
         super().__init__()
         self.raster_settings = raster_settings
         self.activations = 7 if fused_activations else 0
@@ -170,6 +173,8 @@ class GaussianRasterizer(nn.Module):
             self.probe["quadrant_cull"] = False
         if blend_counters is not None:
             self.probe["blend_counters"] = blend_counters
+        if ballot_ranking:
+            self.probe["ballot_ranking"] = True
 
     def markVisible(self, positions):
         with torch.no_grad():

@@ -39,10 +39,13 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 5
+#define SR_ABI_VERSION 6
 #define SR_TILE 16            /* default 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y); see SrFrame.tile_width */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
 #define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
+#define SR_MAX_TILES_PER_AXIS 1024 /* tiles per image axis the binning handles (10-bit row / column fields of the expanding partition):
+                                    * frames up to 16384 px per axis with the 16x16 tile, 8192 px with 8x8, 32768 px wide with 32x16;
+                                    * larger frames are refused with SR_ERR_INVALID_ARGUMENT (pick a larger tile) */
 
 /* SrGaussians.activations == the GaussianModel activations
  * (/root/reference/scene/gaussian_model.py:63-75, getters :101-123) */
@@ -80,11 +83,17 @@ typedef struct SrFrame {
     uint64_t* blend_counters; /* NULL, or device [8] u64 owned by the caller: selects the COUNTING variant of the forward blend (same
                                * results, slow), which adds to [0] list entries staged, [1] entries kept by the quadrant culling,
                                * [2] (entry, quadrant) tests run, [3] tests with >= 1 contributing pixel, [4] contributing (pixel, entry)
-                               * pairs, [5] / [6] tests with a contributing pixel in rows 0-3 / rows 4-7 of the quadrant */
+                               * pairs, [5] / [6] tests with a contributing pixel in rows 0-3 / rows 4-7 of the quadrant.  16x16 tile with
+                               * 3 or 6 colour channels; any other request returns SR_ERR_UNSUPPORTED (never silent zeros) */
 } SrFrame;
 #define SR_FLAG_NO_QUADRANT_CULL 1u  /* forward blend: run every list entry against every 8x8 quadrant instead of dropping entries that
                                       * provably cannot reach alpha >= 1/255 there.  Results are bit-identical either way (a test
                                       * requires it); the switch exists for that test and for A/B timing */
+#define SR_FLAG_BALLOT_RANKING 2u    /* binning: rank the items of a wave with match-any ballots instead of LDS-atomic return values.  The
+                                      * atomic path relies on gfx950 returning ds_add_rtn_u32 results in lane order (undocumented), so
+                                      * the library checks that property on every device before its first sort (sr_rank_mode) and falls
+                                      * back to the ballots by itself; this flag forces the fallback for one call (tests, A/B timing).
+                                      * The lists are bit-identical either way */
 
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
  * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp
@@ -264,7 +273,13 @@ int sr_debug_pair_decisions(const SrFrame* frame, const SrGaussians* g, void* ge
  * [0, total_bits); vals_in == NULL means value = index.  temp: sr_debug_radix_sort_temp_bytes(n) bytes. */
 size_t sr_debug_radix_sort_temp_bytes(uint32_t n);
 int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                        int total_bits, void* temp, size_t temp_bytes, void* stream);
+                        int total_bits, void* temp, size_t temp_bytes, uint32_t flags /* SR_FLAG_BALLOT_RANKING or 0 */, void* stream);
+
+/* How the sort / partition kernels of the current device rank items (the run-time guard of the LDS-atomic lane-order assumption):
+ * runs the self-check on first use (one tiny kernel + one stream wait per device and process), then returns the cached answer:
+ * 1 = LDS-atomic return values (the property holds), 2 = match-any ballots (it does not: the fallback is in use), or
+ * SR_ERR_UNSUPPORTED if neither ranking reproduces the reference ranks on this device. */
+int sr_rank_mode(void* stream);
 
 /* Test hook for the hardware property the sort kernels rank by: within one wave instruction, ds_add_rtn_u32 returns the old values
  * to the lanes that hit the same LDS address in ascending lane order.  ranks[i] = what lane i % 64 of its wave got back when every

@@ -29,7 +29,7 @@ TILE = 16
 
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (idempotent)."""
-    srcs = [os.path.join(_HERE, "surfel_oracle.c"), os.path.join(_HERE, "surfel_blend.inc"), os.path.join(_HERE, "knn_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("surfel_oracle.c", "surfel_blend.inc", "surfel_k8.inc", "knn_oracle.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libsurfel_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -62,15 +62,47 @@ def _p(a, ty=C.c_float):
     return a.ctypes.data_as(C.POINTER(ty))
 
 
+_GEOMETRY_KEYS = ("radii", "means2D", "depths", "transMat", "normal_opacity", "rgb", "clamped", "tiles_touched", "rect",
+                  "num_rendered", "keys", "point_list", "ranges")
+
+
+def _preprocess_and_bin(L, P, deg, M, means3D, scales, rotations, opacities, shs, colors_precomp, transMat_precomp, view, proj, cam,
+                        W, H, scale_modifier, tile):
+    """K1 (so_preprocess_forward) and K2-K5 (so_bin: duplicate keys, stable 64-bit sort, tile ranges)."""
+    o = dict(
+        radii=np.zeros(P, np.int32), means2D=np.zeros((P, 2), np.float32), depths=np.zeros(P, np.float32),
+        transMat=np.zeros((P, 9), np.float32), normal_opacity=np.zeros((P, 4), np.float32),
+        rgb=np.zeros((P, 3), np.float32), clamped=np.zeros((P, 3), np.uint8),
+        tiles_touched=np.zeros(P, np.uint32), rect=np.zeros((P, 4), np.int32))
+    L.so_preprocess_forward(P, deg, M, _p(means3D), _p(scales), _p(rotations), _p(opacities), _p(shs),
+                            _p(colors_precomp), _p(transMat_precomp), _p(view), _p(proj), _p(cam), W, H,
+                            C.c_float(scale_modifier), _p(o["radii"], C.c_int32), _p(o["means2D"]), _p(o["depths"]),
+                            _p(o["transMat"]), _p(o["normal_opacity"]), _p(o["rgb"]), _p(o["clamped"], C.c_uint8),
+                            _p(o["tiles_touched"], C.c_uint32), _p(o["rect"], C.c_int32))
+    D = int(L.so_count_duplicates(P, _p(o["tiles_touched"], C.c_uint32)))
+    gx, gy = (W + int(tile[0]) - 1) // int(tile[0]), (H + int(tile[1]) - 1) // int(tile[1])
+    o["num_rendered"] = D
+    o["ranges"] = np.zeros((gx * gy, 2), np.uint32)
+    keys_buf = np.zeros(max(D, 1), np.uint64); vals_buf = np.zeros(max(D, 1), np.uint32)
+    rc = L.so_bin(P, W, H, _p(o["radii"], C.c_int32), _p(o["depths"]), _p(o["rect"], C.c_int32),
+                  _p(o["tiles_touched"], C.c_uint32), C.c_uint64(D), _p(keys_buf, C.c_uint64),
+                  _p(vals_buf, C.c_uint32), _p(o["ranges"], C.c_uint32))
+    assert rc == 0, f"so_bin failed: {rc}"
+    o["keys"] = keys_buf[:D]; o["point_list"] = vals_buf[:D]
+    return o, vals_buf
+
+
 def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None, colors_precomp=None,
                       transMat_precomp=None, *, viewmatrix, projmatrix, campos, bg, image_width: int,
                       image_height: int, sh_degree: int = 0, scale_modifier: float = 1.0,
-                      stages: bool = True, tile=(16, 16), forced=None, f64: bool = False) -> Dict[str, np.ndarray]:
+                      stages: bool = True, tile=(16, 16), forced=None, f64: bool = False, reuse=None) -> Dict[str, np.ndarray]:
     """K1..K6. Returns every stage's outputs (dict of numpy arrays).  `tile` = (BLOCK_X, BLOCK_Y), 16x16 in the reference.
     `forced` = dict(valid=u64[D,nq], use3d=u64[D,nq], n_contrib=u32[2,H,W]): blend with the hard decisions of another
     implementation (sr_debug_pair_decisions + its n_contrib) -- see so_render_forward; the backward then uses them too.
     `f64=True`: the blend (K6, and K7 in rasterize_backward) is evaluated in double precision on the same float32 per-Gaussian
-    inputs (surfel_blend.inc compiled with REAL = double): the arbiter of the parity report, not the oracle."""
+    inputs (surfel_blend.inc compiled with REAL = double): the arbiter of the parity report, not the oracle.
+    `reuse` = the dict of an earlier call on the SAME inputs: K1 and the binning (the 64-bit key sort) are taken from it and only the
+    blend runs again (forced / float64 variants of one scene at full size)."""
     L = lib()
     L.so_set_tile(int(tile[0]), int(tile[1]))
     means3D = _f32(means3D); P = means3D.shape[0]
@@ -83,28 +115,14 @@ def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None,
     cam = _f32(campos).reshape(3); bgc = _f32(bg).reshape(3)
     W, H = int(image_width), int(image_height)
     M = shs.shape[1] if shs is not None else 0
-    o = dict(
-        radii=np.zeros(P, np.int32), means2D=np.zeros((P, 2), np.float32), depths=np.zeros(P, np.float32),
-        transMat=np.zeros((P, 9), np.float32), normal_opacity=np.zeros((P, 4), np.float32),
-        rgb=np.zeros((P, 3), np.float32), clamped=np.zeros((P, 3), np.uint8),
-        tiles_touched=np.zeros(P, np.uint32), rect=np.zeros((P, 4), np.int32))
-    L.so_preprocess_forward(P, int(sh_degree), M, _p(means3D), _p(scales), _p(rotations), _p(opacities), _p(shs),
-                            _p(colors_precomp), _p(transMat_precomp), _p(view), _p(proj), _p(cam), W, H,
-                            C.c_float(scale_modifier), _p(o["radii"], C.c_int32), _p(o["means2D"]), _p(o["depths"]),
-                            _p(o["transMat"]), _p(o["normal_opacity"]), _p(o["rgb"]), _p(o["clamped"], C.c_uint8),
-                            _p(o["tiles_touched"], C.c_uint32), _p(o["rect"], C.c_int32))
-    D = int(L.so_count_duplicates(P, _p(o["tiles_touched"], C.c_uint32)))
-    gx, gy = (W + int(tile[0]) - 1) // int(tile[0]), (H + int(tile[1]) - 1) // int(tile[1])
-    o["num_rendered"] = D
-    o["keys"] = np.zeros(max(D, 1), np.uint64)[:D]
-    o["point_list"] = np.zeros(max(D, 1), np.uint32)[:D]
-    o["ranges"] = np.zeros((gx * gy, 2), np.uint32)
-    keys_buf = np.zeros(max(D, 1), np.uint64); vals_buf = np.zeros(max(D, 1), np.uint32)
-    rc = L.so_bin(P, W, H, _p(o["radii"], C.c_int32), _p(o["depths"]), _p(o["rect"], C.c_int32),
-                  _p(o["tiles_touched"], C.c_uint32), C.c_uint64(D), _p(keys_buf, C.c_uint64),
-                  _p(vals_buf, C.c_uint32), _p(o["ranges"], C.c_uint32))
-    assert rc == 0, f"so_bin failed: {rc}"
-    o["keys"] = keys_buf[:D]; o["point_list"] = vals_buf[:D]
+    if reuse is not None:   # K1 + binning of an earlier call on the same inputs
+        assert reuse["_inputs"]["tile"] == (int(tile[0]), int(tile[1])) and reuse["radii"].shape[0] == P
+        o = {k: reuse[k] for k in _GEOMETRY_KEYS}
+        vals_buf = reuse["_inputs"]["vals_buf"]
+    else:
+        o, vals_buf = _preprocess_and_bin(L, P, int(sh_degree), M, means3D, scales, rotations, opacities, shs, colors_precomp,
+                                          transMat_precomp, view, proj, cam, W, H, float(scale_modifier), tile)
+    D = int(o["num_rendered"])
     rt, ct = (np.float64, C.c_double) if f64 else (np.float32, C.c_float)
     o["color"] = np.zeros((3, H, W), rt); o["allmap"] = np.zeros((7, H, W), rt)
     o["final_T"] = np.zeros((3, H, W), rt); o["n_contrib"] = np.zeros((2, H, W), np.uint32)
@@ -142,10 +160,24 @@ def rasterize_backward(fwd: Dict[str, np.ndarray], dL_dcolor, dL_dallmap) -> Dic
         _p(fwd["normal_opacity"]), _p(fwd["rgb"]), _p(i["bg"]), _p(fwd["final_T"], ct), _p(fwd["n_contrib"], C.c_uint32),
         _p(dL_dcolor), _p(dL_dallmap), _p(g["dL_dcolors"], ct), _p(g["dL_dnormal3D"], ct), _p(g["dL_dtransMat"], ct),
         _p(g["dL_dmean2D_raw"], ct), _p(g["dL_dopacity"], ct), _p(i["forced"][0], C.c_uint64), _p(i["forced"][1], C.c_uint64))
-    if f64:   # K8 is the float32 per-Gaussian chain in every variant: hand it the double sums rounded once
+    if f64:
+        # the float64 arbiter of the WHOLE backward: K8 in double precision on the double sums (surfel_k8.inc, REAL = double) ->
+        # "<name>64"; then, as before, the float32 K8 on the double sums rounded once -> "<name>"
         g["dL_dopacity64"] = g["dL_dopacity"].copy()
+        g64 = dict(dL_dmeans3D64=np.zeros((P, 3)), dL_dscales64=np.zeros((P, 2)), dL_drotations64=np.zeros((P, 4)), dL_dmeans2D64=np.zeros((P, 3)))
+        dsh64 = np.zeros((P, max(M, 1), 3))
+        dT64 = g["dL_dtransMat"].copy()
+        L.so_preprocess_backward_f64(P, i["deg"], M, _p(i["means3D"]), _p(i["scales"]), _p(i["rotations"]), _p(i["shs"]),
+                                     _p(i["transMat_precomp"]), _p(i["view"]), _p(i["proj"]), _p(i["cam"]), W, H,
+                                     C.c_double(i["scale_modifier"]), _p(fwd["radii"], C.c_int32), _p(fwd["clamped"], C.c_uint8),
+                                     _p(fwd["transMat"]), _p(dT64, C.c_double), _p(g["dL_dnormal3D"], C.c_double), _p(g["dL_dmean2D_raw"], C.c_double),
+                                     _p(g["dL_dcolors"], C.c_double), _p(g64["dL_dmeans3D64"], C.c_double), _p(g64["dL_dscales64"], C.c_double),
+                                     _p(g64["dL_drotations64"], C.c_double), _p(dsh64, C.c_double), _p(g64["dL_dmeans2D64"], C.c_double))
+        g64["dL_dsh64"] = dsh64 if M else dsh64[:, :0]
+        g64["dL_dtransMat64"] = dT64
         for k in ("dL_dcolors", "dL_dnormal3D", "dL_dtransMat", "dL_dmean2D_raw", "dL_dopacity"):
             g[k] = np.ascontiguousarray(g[k], dtype=np.float32)
+        g.update(g64)
     g["dL_dtransMat_render"] = g["dL_dtransMat"].copy()
     g["dL_dmeans3D"] = np.zeros((P, 3), np.float32); g["dL_dscales"] = np.zeros((P, 2), np.float32)
     g["dL_drotations"] = np.zeros((P, 4), np.float32); g["dL_dmeans2D"] = np.zeros((P, 3), np.float32)
@@ -167,15 +199,17 @@ def rasterize_backward(fwd: Dict[str, np.ndarray], dL_dcolor, dL_dallmap) -> Dic
 DEFAULT_EPS = dict(alpha=2e-5, T=1e-4, path=1e-3, near=1e-5, median=2e-5)
 
 
-def render_margins(fwd: Dict[str, np.ndarray], eps: Optional[Dict[str, float]] = None) -> Dict[str, np.ndarray]:
-    """Decision margins of the forward blend (so_render_margins): `pixel`[H,W], `median`[H,W], `gaussian`[P]; > 1 = robust."""
+def render_margins(fwd: Dict[str, np.ndarray], eps: Optional[Dict[str, float]] = None, f64: bool = False) -> Dict[str, np.ndarray]:
+    """Decision margins of the forward blend (so_render_margins): `pixel`[H,W], `median`[H,W], `gaussian`[P]; > 1 = robust.
+    `f64=True`: the deciding quantities are evaluated in double precision on the float32 per-Gaussian state (so_render_margins_f64),
+    i.e. the margins are distances of the TRUE decisions from their thresholds, free of this oracle's own float32 noise."""
     L = lib()
     i = fwd["_inputs"]; P = i["means3D"].shape[0]; W, H = i["W"], i["H"]
     L.so_set_tile(*i["tile"])
     e = dict(DEFAULT_EPS); e.update(eps or {})
     ev = np.array([e["alpha"], e["T"], e["path"], e["near"], e["median"]], np.float32)
     pm = np.zeros((H, W), np.float32); mm = np.zeros((H, W), np.float32); gm = np.zeros(P, np.float32)
-    L.so_render_margins(P, W, H, _p(fwd["ranges"], C.c_uint32), _p(i["vals_buf"], C.c_uint32), _p(fwd["means2D"]),
+    (L.so_render_margins_f64 if f64 else L.so_render_margins)(P, W, H, _p(fwd["ranges"], C.c_uint32), _p(i["vals_buf"], C.c_uint32), _p(fwd["means2D"]),
                         _p(fwd["transMat"]), _p(fwd["normal_opacity"]), _p(ev), _p(pm), _p(mm), _p(gm))
     return dict(pixel=pm, median=mm, gaussian=gm, eps=e)
 

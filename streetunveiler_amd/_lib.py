@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(HERE, "lib", "libsurfel_raster.so")
 
 SR_ACT_EXP_SCALES, SR_ACT_SIGMOID_OPACITY, SR_ACT_NORMALIZE_ROTATIONS = 1, 2, 4
 SR_FLAG_NO_QUADRANT_CULL = 1
+SR_FLAG_BALLOT_RANKING = 2
+SR_ABI_VERSION = 6
 SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "expand_x", "expand_y", "ranges", "blend_fwd", "blend_bwd",
                   "preprocess_bwd"]
 
@@ -52,7 +54,7 @@ class SrImageView(C.Structure):
 # every symbol include/surfel_raster.h declares (checked by tests/test_abi.py)
 EXPORTS = ["sr_abi_version", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
            "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan", "sr_sh_gradient_expand", "sr_knn_workspace_bytes", "sr_knn_mean_dist2",
-           "sr_forward_render", "sr_backward", "sr_backward_blend", "sr_backward_colors", "sr_backward_geometry", "sr_debug_pair_decisions", "sr_class_image_bytes", "sr_class_forward_render", "sr_class_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_debug_radix_sort", "sr_debug_radix_sort_temp_bytes", "sr_debug_lds_atomic_ranks", "sr_postprocess_forward",
+           "sr_forward_render", "sr_backward", "sr_backward_blend", "sr_backward_colors", "sr_backward_geometry", "sr_debug_pair_decisions", "sr_class_image_bytes", "sr_class_forward_render", "sr_class_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_debug_radix_sort", "sr_debug_radix_sort_temp_bytes", "sr_debug_lds_atomic_ranks", "sr_rank_mode", "sr_postprocess_forward",
            "sr_postprocess_backward"]
 
 _lib = None
@@ -116,11 +118,12 @@ def load():
     lib.sr_postprocess_backward.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 9
     lib.sr_debug_radix_sort_temp_bytes.argtypes = [C.c_uint32]
     lib.sr_debug_radix_sort_temp_bytes.restype = C.c_size_t
-    lib.sr_debug_radix_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.sr_debug_radix_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+    lib.sr_rank_mode.argtypes = [C.c_void_p]
     lib.sr_debug_lds_atomic_ranks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
     lib.sr_stage_stats.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    if lib.sr_abi_version() != 5:
-        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects 5")
+    if lib.sr_abi_version() != SR_ABI_VERSION:
+        raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects {SR_ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -25,12 +25,12 @@ size_t tile_scan_temp_bytes(int P);
 size_t expand_x_hist_bytes(int P, int tiles_x);
 size_t expand_y_hist_bytes(uint32_t D, int tiles_y);
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, uint32_t* sorted_keys,
-                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, hipStream_t s);
+                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, int rank_mode, hipStream_t s);
 hipError_t run_tile_count_scan(int P, const uint32_t* tiles_touched, uint32_t* first, void* block_base, size_t base_bytes, hipStream_t s);
 hipError_t run_expand_columns(int P, int tiles_x, int n_tiles, const uint2* rect_sorted, const uint32_t* sorted_gid, uint2* columns,
-                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, hipStream_t s);
+                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, int rank_mode, hipStream_t s);
 hipError_t run_expand_rows(uint32_t D, int tiles_x, int tiles_y, const uint2* columns, const uint32_t* n_columns, uint32_t* hist, uint32_t* row_total,
-                           uint32_t* point_list, uint32_t* tile_counts, hipStream_t s);
+                           uint32_t* point_list, uint32_t* tile_counts, int rank_mode, hipStream_t s);
 hipError_t run_tile_ranges_order(int n_tiles, const uint32_t* tile_counts, uint2* ranges, uint32_t* order, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
@@ -52,12 +52,13 @@ hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out);
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode);
+hipError_t launch_rank_selfcheck(uint32_t* result, hipStream_t s);
 hipError_t lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t n, int bins, hipStream_t s);
 // knn.hip
 size_t knn_workspace_bytes(int nq, int nr);
 hipError_t knn_mean_dist2(int nq, const float* query, int nr, const float* reference, int K, int take_sqrt, float* out, void* ws,
-                          size_t ws_bytes, hipStream_t s);
+                          size_t ws_bytes, int rank_mode, hipStream_t s);
 // postprocess.hip
 struct PostCam { int W, H; float fx, fy, depth_ratio; const float* view; };
 hipError_t launch_postprocess_forward(const PostCam& cam, const float* allmap, float* rend_normal, float* surf_depth,
@@ -132,7 +133,46 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
     return SR_OK;
 }
 
+// One 64-B pinned host block per calling thread (with one event per (thread, device) the only things this library keeps): word 0 =
+// the DMA target of the num_rendered read-back, word 8 = the result word of the rank self-check.
+uint32_t* pinned_words() {
+    static thread_local uint32_t* pinned = nullptr;
+    if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
+    return pinned;
+}
+
+// How the sort / partition kernels rank items inside a wave (common.h take_run_slot).  The fast path relies on the lane order of LDS
+// atomic returns, which gfx950 delivers but no document promises -- so the first call on every device runs rank_selfcheck_kernel
+// (~20 us) and the answer is cached per device for the life of the process: kRankAtomic, else the match-any ballots (kRankBallot),
+// else nothing this library can sort with (SR_ERR_UNSUPPORTED).  SR_FLAG_BALLOT_RANKING forces the ballots for one call.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_rank_mode[kMaxDevices];
+int rank_mode(hipStream_t s, bool force_ballot, int* mode) {
+    int dev = 0;
+    SR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(SR_ERR_UNSUPPORTED, "device index %d beyond %d", dev, kMaxDevices);
+    int m = g_rank_mode[dev].load(std::memory_order_acquire);
+    if (m == kRankUnknown) {
+        uint32_t* host = pinned_words();
+        uint32_t* result = nullptr;
+        bool temp = false;
+        if (host && hipHostGetDevicePointer(reinterpret_cast<void**>(&result), host + 8, 0) == hipSuccess && result) host[8] = 0;
+        else { SR_HIP(hipMalloc(reinterpret_cast<void**>(&result), 4)); SR_HIP(hipMemsetAsync(result, 0, 4, s)); temp = true; }
+        SR_HIP(launch_rank_selfcheck(result, s));
+        uint32_t r = 0;
+        if (temp) { SR_HIP(hipMemcpyAsync(&r, result, 4, hipMemcpyDeviceToHost, s)); SR_HIP(hipStreamSynchronize(s)); (void)hipFree(result); }
+        else { SR_HIP(hipStreamSynchronize(s)); r = *reinterpret_cast<volatile uint32_t*>(host + 8); }
+        if (!(r & 0x100u)) return fail(SR_ERR_HIP, "the rank self-check kernel did not report back");
+        m = (r & 1u) ? kRankAtomic : ((r & 2u) ? kRankBallot : kRankNone);
+        g_rank_mode[dev].store(m, std::memory_order_release);
+    }
+    if (m == kRankNone) return fail(SR_ERR_UNSUPPORTED, "neither LDS-atomic nor ballot ranking passes the self-check on device %d", dev);
+    *mode = force_ballot ? (int)kRankBallot : m;
+    return SR_OK;
+}
+
 // ---- buffer layouts ------------------------------------------------------------------------------
+constexpr int kMaxTilesPerAxis = SR_MAX_TILES_PER_AXIS;   // binning.hip kXpMaxBins: 10-bit row / column fields, 1024-entry LDS histograms
 struct GeomLayout {
     size_t recs, depth_keys, tiles_touched, rect, clamped, sorted_keys, sorted_gid, rect_sorted, first, sh_jac, block_base, base_bytes,
         n_scan_blocks, temp, temp_bytes, total;
@@ -157,7 +197,12 @@ GeomLayout geom_layout(int P) {
     L.n_scan_blocks = (n + 2047) / 2048;   // the scan's block size (radix_sort.hip kRsTile)
     static thread_local int memo_P = -1;
     static thread_local size_t memo_bytes = 0;
-    if (memo_P != P) { memo_bytes = depth_sort_temp_bytes(P); memo_P = P; }
+    if (memo_P != P) {   // the depth sort's ping-pong + histogram; later pass X's [tile columns][blocks] histogram (any frame width)
+        memo_bytes = depth_sort_temp_bytes(P);
+        const size_t hx = align_up(expand_x_hist_bytes(P, kMaxTilesPerAxis), 256);
+        if (hx > memo_bytes) memo_bytes = hx;
+        memo_P = P;
+    }
     L.temp_bytes = memo_bytes;
     L.temp = take(L.temp_bytes);
     L.total = off;
@@ -167,7 +212,6 @@ GeomLayout geom_layout(int P) {
 struct BinLayout {
     size_t columns, point_list, hit_mask, ranges, order, tile_counts, row_total, n_columns, hist, hist_bytes, total;
 };
-constexpr int kMaxTilesPerAxis = 1024;   // binning.hip kXpMaxBins
 BinLayout bin_layout(uint32_t D, int W, int H) {
     BinLayout L{};
     const size_t n = (size_t)(D > 0 ? D : 1);
@@ -316,20 +360,27 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     }
     if (int rc = debug_sync(frame, s, "emission_scan")) return rc;
     // the one host read-back of the forward (the reference does the same between scan and duplicateWithKeys)
-    // through a pinned word (one per host thread; with the event below the only things this library keeps): a DMA copy instead
-    // of the staged pageable path.  The depth sort is queued BEHIND the copy and the host waits for the copy only, so the GPU sorts
+    // through a pinned word (one block per host thread; with one event per (thread, device) the only things this library keeps): a DMA
+    // copy instead of the staged pageable path.  The depth sort is queued BEHIND the copy and the host waits for the copy only, so the GPU sorts
     // while the caller wakes up, sizes the binning buffer from D and queues the second phase.
-    static thread_local uint32_t* pinned = nullptr;
-    static thread_local hipEvent_t copied = nullptr;
-    if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
-    if (!copied && hipEventCreateWithFlags(&copied, hipEventDisableTiming) != hipSuccess) copied = nullptr;
+    int sort_mode = kRankUnknown;
+    if (int rc = rank_mode(s, (frame->flags & SR_FLAG_BALLOT_RANKING) != 0, &sort_mode)) return rc;   // (first call on a device: ~20 us self-check)
+    uint32_t* pinned = pinned_words();
+    static thread_local hipEvent_t copied_ev[kMaxDevices] = {};   // one marker per (calling thread, device): an event belongs to its device
+    int dev = 0;
+    SR_HIP(hipGetDevice(&dev));
+    hipEvent_t copied = nullptr;
+    if (dev >= 0 && dev < kMaxDevices) {
+        if (!copied_ev[dev] && hipEventCreateWithFlags(&copied_ev[dev], hipEventDisableTiming) != hipSuccess) copied_ev[dev] = nullptr;
+        copied = copied_ev[dev];
+    }
     uint32_t* dst = pinned ? pinned : num_rendered_host;
     SR_HIP(hipMemcpyAsync(dst, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks, 4, hipMemcpyDeviceToHost, s));   // the scan's grand total
-    if (copied && pinned) SR_HIP(hipEventRecord(copied, s));
+    if (copied && pinned && hipEventRecord(copied, s) != hipSuccess) copied = nullptr;   // (then: wait for the stream instead)
     {
         StageTimer t(SR_STAGE_DEPTH_SORT, s);
         SR_HIP(run_depth_sort(P, at<uint32_t>(geom, L.depth_keys), at<uint2>(geom, L.rect), at<uint32_t>(geom, L.sorted_keys),
-                              at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, s));
+                              at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, sort_mode, s));
     }
     if (int rc = debug_sync(frame, s, "depth_sort")) return rc;
     if (copied && pinned) SR_HIP(hipEventSynchronize(copied));
@@ -354,18 +405,20 @@ int bin_duplicates(const SrFrame* frame, const SrGaussians* g, const FrameDev& f
         if (f.tiles_x > kMaxTilesPerAxis || f.tiles_y > kMaxTilesPerAxis)
             return fail(SR_ERR_INVALID_ARGUMENT, "%d x %d tiles: at most %d per axis (use a larger tile)", f.tiles_x, f.tiles_y, kMaxTilesPerAxis);
         if (L.temp_bytes < expand_x_hist_bytes(P, f.tiles_x)) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom scratch too small for the column histogram");
+        int sort_mode = kRankUnknown;
+        if (int rc = rank_mode(s, (frame->flags & SR_FLAG_BALLOT_RANKING) != 0, &sort_mode)) return rc;
         {
             StageTimer t(SR_STAGE_EXPAND_X, s);
             SR_HIP(run_expand_columns(P, f.tiles_x, n_tiles, at<uint2>(geom, L.rect_sorted), at<uint32_t>(geom, L.sorted_gid), at<uint2>(binning, B.columns),
                                       at<uint32_t>(binning, B.n_columns), at<uint32_t>(geom, L.temp), at<uint32_t>(binning, B.row_total),
-                                      at<uint32_t>(binning, B.tile_counts), s));
+                                      at<uint32_t>(binning, B.tile_counts), sort_mode, s));
         }
         if (int rc = debug_sync(frame, s, "expand_columns")) return rc;
         {
             StageTimer t(SR_STAGE_EXPAND_Y, s);
             SR_HIP(run_expand_rows(D, f.tiles_x, f.tiles_y, at<uint2>(binning, B.columns), at<uint32_t>(binning, B.n_columns),
                                    at<uint32_t>(binning, B.hist), at<uint32_t>(binning, B.row_total), at<uint32_t>(binning, B.point_list),
-                                   at<uint32_t>(binning, B.tile_counts), s));
+                                   at<uint32_t>(binning, B.tile_counts), sort_mode, s));
         }
         if (int rc = debug_sync(frame, s, "expand_rows")) return rc;
     } else {
@@ -413,6 +466,8 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     if (image_bytes < I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, I.total);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const FrameDev f = make_frame(frame, g);
+    if (frame->blend_counters && !(f.tile_w == 16 && f.tile_h == 16 && (f.colors == 3 || f.colors == 6)))
+        return fail(SR_ERR_UNSUPPORTED, "blend_counters: the counting variant of the forward blend exists for the 16x16 tile with 3 or 6 colour channels only");
     float4* recs = nullptr;
     if (int rc = bin_duplicates(frame, g, f, geom, geom_bytes, binning, B, D, s, &recs)) return rc;
     {
@@ -613,7 +668,9 @@ int sr_knn_mean_dist2(int32_t n_query, const float* query, int32_t n_reference, 
     if (n_reference == 0) return fail(SR_ERR_INVALID_ARGUMENT, "empty reference cloud");
     if (!reference || !out || !workspace) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (workspace_bytes < knn_workspace_bytes(nq, n_reference)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, knn_workspace_bytes(nq, n_reference));
-    SR_HIP(knn_mean_dist2(nq, query, n_reference, reference, K, take_sqrt, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream)));
+    int sort_mode = kRankUnknown;
+    if (int rc = rank_mode(static_cast<hipStream_t>(stream), false, &sort_mode)) return rc;
+    SR_HIP(knn_mean_dist2(nq, query, n_reference, reference, K, take_sqrt, out, workspace, workspace_bytes, sort_mode, static_cast<hipStream_t>(stream)));
     return SR_OK;
 }
 
@@ -663,14 +720,22 @@ int sr_debug_lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t 
     return SR_OK;
 }
 
+int sr_rank_mode(void* stream) {
+    int mode = kRankUnknown;
+    if (int rc = rank_mode(static_cast<hipStream_t>(stream), false, &mode)) return rc;
+    return mode;
+}
+
 size_t sr_debug_radix_sort_temp_bytes(uint32_t n) { return radix_sort_temp_bytes(n); }
 
 int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                        int total_bits, void* temp, size_t temp_bytes, void* stream) {
+                        int total_bits, void* temp, size_t temp_bytes, uint32_t flags, void* stream) {
     if (n > 0 && (!keys_in || !keys_out || !vals_out || !temp)) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (total_bits < 1 || total_bits > 32) return fail(SR_ERR_INVALID_ARGUMENT, "total_bits %d not in 1..32", total_bits);
     if (temp_bytes < radix_sort_temp_bytes(n)) return fail(SR_ERR_BUFFER_TOO_SMALL, "temp %zu < %zu", temp_bytes, radix_sort_temp_bytes(n));
-    SR_HIP(radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, total_bits, temp, temp_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr));
+    int sort_mode = kRankUnknown;
+    if (int rc = rank_mode(static_cast<hipStream_t>(stream), (flags & SR_FLAG_BALLOT_RANKING) != 0, &sort_mode)) return rc;
+    SR_HIP(radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, total_bits, temp, temp_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr, sort_mode));
     return SR_OK;
 }
 

@@ -19,7 +19,7 @@ namespace sr {
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out);
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode);
 size_t tile_count_scan_temp_bytes(uint32_t n);
 hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kXpThreads) void expand_scan_rows_kernel(uint32_t* 
     if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
 }
 
-template <int AXIS, int kBits>
+template <int AXIS, int kBits, bool kAtomicRank>
 __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
     const uint2* __restrict__ in, uint32_t n_host, const uint32_t* __restrict__ n_dev, int bins, const uint32_t* __restrict__ hist, int stride,
     const uint32_t* __restrict__ row_total,
@@ -280,9 +280,8 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
             const uint32_t slot = q0 + (uint32_t)(w * (kXpBatch / kXpWaves) + i * 64 + lane);
             const bool live = slot < E;
             const uint32_t d = dig[i];
-            // stable rank by ONE LDS atomic: its return values come back in ascending lane order (radix_sort.hip)
-            uint32_t pos = 0;
-            if (live) pos = atomicAdd(&s_count[w][d], 1u);
+            // stable rank inside the (wave, digit) run: one LDS atomic, or the match-any ballots (common.h take_run_slot)
+            const uint32_t pos = take_run_slot<kAtomicRank>(s_count[w], d, live, kBits);
             if (live) { s_id[pos] = id[i]; s_dig[pos] = (uint16_t)d; if (AXIS == 0) s_rows[pos] = rows[i]; }
         }
         __syncthreads();
@@ -429,10 +428,10 @@ size_t expand_y_hist_bytes(uint32_t D, int tiles_y) { return (size_t)tiles_y * (
 // launchers ---------------------------------------------------------------------------------------
 // K2: stable sort of (depth key, gaussian id) -- ties keep ascending id, culled Gaussians (key 0xFFFFFFFF) end up last.
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, uint32_t* sorted_keys,
-                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, hipStream_t s) {
+                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, int rank_mode, hipStream_t s) {
     if (P == 0) return hipSuccess;
     // the last pass also gathers the tile rectangles into depth order, so the scan and the partition read sequentially
-    return radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, rect, rect_sorted);
+    return radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, rect, rect_sorted, rank_mode);
 }
 
 // K2: emission offsets = scan of tiles_touched in id order (block-local values in first, block bases + total D in block_base).
@@ -441,24 +440,29 @@ hipError_t run_tile_count_scan(int P, const uint32_t* tiles_touched, uint32_t* f
     return tile_count_scan(tiles_touched, first, (uint32_t)P, block_base, base_bytes, s);
 }
 
+template <int AXIS, bool kAtomicRank, typename... Args>
+static void launch_expand_scatter_r(int bins, int blocks, hipStream_t s, Args... a) {
+    if (bins <= 128) hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 7, kAtomicRank>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
+    else if (bins <= 256) hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 8, kAtomicRank>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
+    else if (bins <= 512) hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 9, kAtomicRank>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
+    else hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 10, kAtomicRank>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
+}
 template <int AXIS, typename... Args>
-static void launch_expand_scatter(int bins, int blocks, hipStream_t s, Args... a) {
-    if (bins <= 128) hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 7>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
-    else if (bins <= 256) hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 8>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
-    else if (bins <= 512) hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 9>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
-    else hipLaunchKernelGGL((expand_scatter_kernel<AXIS, 10>), dim3(blocks), dim3(kXpThreads), 0, s, a...);
+static void launch_expand_scatter(int rank_mode, int bins, int blocks, hipStream_t s, Args... a) {
+    if (rank_mode == kRankAtomic) launch_expand_scatter_r<AXIS, true>(bins, blocks, s, a...);
+    else launch_expand_scatter_r<AXIS, false>(bins, blocks, s, a...);
 }
 
 // K3: Gaussians in depth order -> column items ordered by (tile column, depth).  Also zeroes tile_counts.  n_columns (device word) receives the number of column items.
 hipError_t run_expand_columns(int P, int tiles_x, int n_tiles, const uint2* rect_sorted, const uint32_t* sorted_gid, uint2* columns,
-                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, hipStream_t s) {
+                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, int rank_mode, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    if (tiles_x > kXpMaxBins) return hipErrorInvalidValue;
+    if (tiles_x > kXpMaxBins || (rank_mode != kRankAtomic && rank_mode != kRankBallot)) return hipErrorInvalidValue;
     const int nb = (P + kXpInputsX - 1) / kXpInputsX;
     hipLaunchKernelGGL(expand_hist_kernel<0>, dim3(nb), dim3(kXpThreads), 0, s, rect_sorted, (uint32_t)P, (const uint32_t*)nullptr, tiles_x, hist, nb,
                        tiles_x, tile_counts, n_tiles);
     hipLaunchKernelGGL(expand_scan_rows_kernel, dim3(tiles_x), dim3(kXpThreads), 0, s, hist, nb, (uint32_t)P, (const uint32_t*)nullptr, kXpInputsX, row_total);
-    launch_expand_scatter<0>(tiles_x, nb, s, rect_sorted, (uint32_t)P, (const uint32_t*)nullptr, tiles_x, (const uint32_t*)hist, nb,
+    launch_expand_scatter<0>(rank_mode, tiles_x, nb, s, rect_sorted, (uint32_t)P, (const uint32_t*)nullptr, tiles_x, (const uint32_t*)hist, nb,
                              (const uint32_t*)row_total, sorted_gid, columns, n_columns, (uint32_t*)nullptr);
     return hipGetLastError();
 }
@@ -466,14 +470,14 @@ hipError_t run_expand_columns(int P, int tiles_x, int n_tiles, const uint2* rect
 // K4: column items -> point_list ordered by (tile row, tile column, depth) + the entries per tile.  The number of column items is
 // only known on the device; the grid is sized for the upper bound D and surplus blocks leave at once.
 hipError_t run_expand_rows(uint32_t D, int tiles_x, int tiles_y, const uint2* columns, const uint32_t* n_columns, uint32_t* hist, uint32_t* row_total,
-                           uint32_t* point_list, uint32_t* tile_counts, hipStream_t s) {
+                           uint32_t* point_list, uint32_t* tile_counts, int rank_mode, hipStream_t s) {
     if (D == 0) return hipSuccess;
-    if (tiles_y > kXpMaxBins) return hipErrorInvalidValue;
+    if (tiles_y > kXpMaxBins || (rank_mode != kRankAtomic && rank_mode != kRankBallot)) return hipErrorInvalidValue;
     const int nb = (int)((D + kXpInputsY - 1) / kXpInputsY);
     hipLaunchKernelGGL(expand_hist_kernel<1>, dim3(nb), dim3(kXpThreads), 0, s, columns, D, n_columns, tiles_y, hist, nb, tiles_x, tile_counts,
                        tiles_x * tiles_y);
     hipLaunchKernelGGL(expand_scan_rows_kernel, dim3(tiles_y), dim3(kXpThreads), 0, s, hist, nb, D, n_columns, kXpInputsY, row_total);
-    launch_expand_scatter<1>(tiles_y, nb, s, columns, D, n_columns, tiles_y, (const uint32_t*)hist, nb, (const uint32_t*)row_total,
+    launch_expand_scatter<1>(rank_mode, tiles_y, nb, s, columns, D, n_columns, tiles_y, (const uint32_t*)hist, nb, (const uint32_t*)row_total,
                              (const uint32_t*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, point_list);
     return hipGetLastError();
 }

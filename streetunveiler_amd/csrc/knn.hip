@@ -19,7 +19,7 @@
 namespace sr {
 
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out);
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode);
 size_t radix_sort_temp_bytes(uint32_t n);
 
 constexpr int kWave = 64;
@@ -252,7 +252,7 @@ template <class T> static T* wat(void* base, size_t off) { return reinterpret_ca
 
 // query == nullptr / nq == 0: every reference point against the others
 hipError_t knn_mean_dist2(int nq, const float* query, int nr, const float* reference, int K, int take_sqrt, float* out, void* ws,
-                          size_t ws_bytes, hipStream_t s) {
+                          size_t ws_bytes, int rank_mode, hipStream_t s) {
     const bool self = query == nullptr;
     if (self) nq = 0;
     const KnnLayout L = knn_layout(nq, nr);
@@ -265,7 +265,7 @@ hipError_t knn_mean_dist2(int nq, const float* query, int nr, const float* refer
     auto order_cloud = [&](const float* pts, int n, size_t codes, size_t codes_sorted, size_t order, size_t sorted) -> hipError_t {
         hipLaunchKernelGGL(knn_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, bounds, wat<uint32_t>(ws, codes));
         hipError_t e = radix_sort_pairs(wat<uint32_t>(ws, codes), nullptr, wat<uint32_t>(ws, codes_sorted), wat<uint32_t>(ws, order),
-                                        (uint32_t)n, 30, wat<void>(ws, L.sort_temp), temp_bytes, s, nullptr, nullptr);
+                                        (uint32_t)n, 30, wat<void>(ws, L.sort_temp), temp_bytes, s, nullptr, nullptr, rank_mode);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(knn_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, wat<uint32_t>(ws, order), n, wat<float4>(ws, sorted));
         return hipGetLastError();

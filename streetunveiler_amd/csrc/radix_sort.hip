@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __re
     if (tid == 0) row_total[blockIdx.x] = s_carry;
 }
 
-template <int kBits>   // digit width (compile time); 0 = run-time width <= 8
+template <int kBits, bool kAtomicRank>   // digit width (compile time; 0 = run-time width <= 8), ranking (common.h take_run_slot)
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                 uint32_t n, int shift, int bits_rt, const uint32_t* __restrict__ hist,
@@ -127,13 +127,8 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         const uint32_t idx = wbase + (uint32_t)(i * 64 + lane);
         const bool live = idx < n;
         const uint32_t d = (key[i] >> shift) & mask;
-        // rank among the wave's items of the same digit, in item order: ONE LDS atomic.  ds_add_rtn_u32 hands its return values to the
-        // lanes of an instruction that hit the same address in ascending lane order on gfx950 (not documented; checked on the device
-        // by tests/test_gpu_parity.py::test_lds_atomic_returns_in_lane_order and, indirectly, by every bit-exact binning test), and the
-        // rows of a wave are issued in order -- so the old value IS the stable position.  (The match-any ballots this replaces cost
-        // ~6 VALU instructions per key bit and row.)
-        uint32_t pos = 0;
-        if (live) pos = atomicAdd(&s_run[w][d], 1u);
+        // rank among the wave's items of the same digit, in item order, and the advance of the (wave, digit) run (common.h)
+        const uint32_t pos = take_run_slot<kAtomicRank>(s_run[w], d, live, bits);
         if (live) { s_key[pos] = key[i]; s_val[pos] = val[i]; }
     }
     __syncthreads();
@@ -218,6 +213,48 @@ __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __res
     if (tid == 0) block_total[nblocks] = s_carry;
 }
 
+// Run-time guard of the rank phase (api.hip rank_mode, once per device): 256 rounds of 64 items per wave with alphabets from 1 to 1000
+// digits, ranked three ways on running counters -- by LDS atomic returns, by the match-any ballots, and by plain LDS loads / stores
+// (every lane counts the lower lanes holding its digit; the reference).  *result: bit 0 = the atomic returns are the stable ranks,
+// bit 1 = the ballot ranks are.
+__global__ __launch_bounds__(kRsThreads) void rank_selfcheck_kernel(uint32_t* __restrict__ result) {
+    __shared__ uint32_t s_a[kRsThreads / 64][1024], s_b[kRsThreads / 64][1024], s_c[kRsThreads / 64][1024];
+    __shared__ uint32_t s_dig[kRsThreads / 64][64];
+    __shared__ uint32_t s_ok;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < (kRsThreads / 64) * 1024; i += kRsThreads) { (&s_a[0][0])[i] = 0; (&s_b[0][0])[i] = 0; (&s_c[0][0])[i] = 0; }
+    if (tid == 0) s_ok = 3u;
+    __syncthreads();
+    uint32_t ok = 3u;
+    for (int round = 0; round < 256; ++round) {
+        const uint32_t alphabets[8] = {1u, 2u, 3u, 16u, 64u, 256u, 700u, 1000u};
+        const uint32_t bins = alphabets[round & 7];
+        uint32_t h = (uint32_t)(round * 64 + lane) * 2654435761u + (uint32_t)w * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const uint32_t d = (round & 8) ? (h % bins) : ((h >> 3) % ((bins + 3u) / 4u));   // (also heavily repeated digits)
+        const bool live = (round & 16) ? lane < 37 : true;                                // (and partially filled rows)
+        const uint32_t pa = take_run_slot<true>(s_a[w], d, live, 10);
+        const uint32_t pb = take_run_slot<false>(s_b[w], d, live, 10);
+        s_dig[w][lane] = live ? d : 0xFFFFFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t lower = 0, higher = 0;
+        for (int k = 0; k < 64; ++k) { const uint32_t dk = s_dig[w][k]; lower += (k < lane && dk == d); higher += (k > lane && dk == d); }
+        const uint32_t pc = s_c[w][d] + lower;
+        __builtin_amdgcn_wave_barrier();
+        if (live && higher == 0) s_c[w][d] = pc + 1u;   // the last lane of every digit group advances the reference counter
+        __builtin_amdgcn_wave_barrier();
+        if (live && pa != pc) ok &= ~1u;
+        if (live && pb != pc) ok &= ~2u;
+    }
+    atomicAnd(&s_ok, ok);
+    __syncthreads();
+    if (tid == 0) *result = s_ok | 0x100u;   // bit 8: the kernel ran
+}
+hipError_t launch_rank_selfcheck(uint32_t* result, hipStream_t s) {
+    hipLaunchKernelGGL(rank_selfcheck_kernel, dim3(1), dim3(kRsThreads), 0, s, result);
+    return hipGetLastError();
+}
+
 // Test hook (sr_debug_lds_atomic_ranks): the lane order of LDS atomic returns, the property the rank phase above relies on.
 __global__ __launch_bounds__(kRsThreads) void lds_atomic_ranks_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t n, int bins) {
     __shared__ uint32_t s_cnt[kRsThreads / 64][1024];
@@ -250,9 +287,9 @@ size_t radix_sort_temp_bytes(uint32_t n) {
 // vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.  If aux_out != nullptr the last pass also
 // writes aux_out[i] = aux_src[vals_out[i]] (an 8-B payload gathered in sorted order, for free).
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out) {
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode) {
     if (n == 0) return hipSuccess;
-    if (temp_bytes < radix_sort_temp_bytes(n)) return hipErrorInvalidValue;
+    if (temp_bytes < radix_sort_temp_bytes(n) || (rank_mode != kRankAtomic && rank_mode != kRankBallot)) return hipErrorInvalidValue;
     int passes = (total_bits + 7) / 8;
     if (passes < 1) passes = 1;
     if (passes & 1) ++passes;   // even pass count: the ping-pong ends in keys_out/vals_out (an extra pass on zero bits is a stable copy)
@@ -274,8 +311,9 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         uint32_t* vo = (p & 1) ? vals_out : tv;
         hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
-#define SR_SCATTER(B) hipLaunchKernelGGL(rs_scatter_kernel<B>, dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
-                                         row_total, nb, last ? aux_src : nullptr, last ? aux_out : nullptr)
+#define SR_SCATTER_R(B, A) hipLaunchKernelGGL((rs_scatter_kernel<B, A>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
+                                              row_total, nb, last ? aux_src : nullptr, last ? aux_out : nullptr)
+#define SR_SCATTER(B) do { if (rank_mode == kRankAtomic) SR_SCATTER_R(B, true); else SR_SCATTER_R(B, false); } while (0)
         switch (bits) {
             case 8: SR_SCATTER(8); break;
             case 7: SR_SCATTER(7); break;
@@ -283,6 +321,7 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
             default: SR_SCATTER(0); break;
         }
 #undef SR_SCATTER
+#undef SR_SCATTER_R
         ki = ko; vi = vo;
         shift += bits; left -= bits;
     }

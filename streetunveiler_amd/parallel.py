@@ -18,6 +18,7 @@ bucket, large ones (the SH gradient is 83 % of the bytes) are reduced in place w
 from __future__ import annotations
 
 import contextlib
+import contextvars
 import os
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
@@ -112,50 +113,83 @@ def allreduce_gradients(grads: Sequence[torch.Tensor], group=None, average: bool
 
 
 class ShExchange:
-    """State of an active factored SH-gradient exchange (see `factored_sh_exchange`)."""
+    """State of one factored SH-gradient exchange (see `factored_sh_exchange`): created by the context manager, picked up by the
+    operator's FORWARD (which runs on the caller's thread, inside the context) and carried to its backward on the autograd node --
+    autograd runs the backward on a thread of its own, which must not have to consult any process-wide or thread-local state."""
 
     def __init__(self, group=None, expand: Optional[Callable] = None, all_campos: Optional[torch.Tensor] = None,
-                 reduce_all: bool = False):
+                 reduce_all: bool = False, frames_per_rank: int = 1):
         self.group, self.expand, self.all_campos, self.reduce_all = group, expand, all_campos, reduce_all
-        self.calls = 0          # exchanges run (tests / diagnostics)
+        self.frames_per_rank = int(frames_per_rank)
+        assert self.frames_per_rank >= 1
+        assert not (reduce_all and self.frames_per_rank > 1), \
+            "with several frames per rank the other gradients accumulate locally first: all-reduce them after the last backward (finish())"
+        self.calls = 0          # exchanges completed (tests / diagnostics)
         self.bytes_sent = 0     # payload bytes this rank contributed to the collectives
-        self.early_starts = 0   # exchanges whose all-gather was put on the wire between K7 and K8 (sr_backward_colors)
+        self.early_starts = 0   # all-gathers put on the wire between K7 and K8 (sr_backward_colors)
         self.exchange_ms = 0.0  # host-side wall time spent waiting on the collectives (diagnostic; bench.py reports it)
         self._early = None
+        self._held = []         # (gathered [world,P,3] buffer, handle, this frame's camera position) of the frames accumulated so far
+
+    def _gather(self, gc: torch.Tensor):
+        world = dist.get_world_size(self.group)
+        flat = torch.empty(world * gc.numel(), dtype=gc.dtype, device=gc.device)   # 1-D in/out: accepted by RCCL and gloo alike
+        h = dist.all_gather_into_tensor(flat, gc.reshape(-1), group=self.group, async_op=True)
+        self.bytes_sent += gc.numel() * gc.element_size()
+        return flat, h
+
+    def start(self, gc: torch.Tensor) -> None:
+        """Called by the operator's backward BETWEEN its two halves (sr_backward_blend / sr_backward_colors done, sr_backward_geometry
+        not yet launched): `gc` [P,3] is final, so its all-gather goes on the wire now and overlaps K8.  `run` picks it up."""
+        if not gc.is_contiguous():
+            return
+        flat, h = self._gather(gc)
+        self._early = (gc, flat, h)
+        self.early_starts += 1
+
+    def _cameras(self, frames, device) -> torch.Tensor:
+        """Camera position of every view in the order of the gathered gradients: view (frame j, rank r) -> row j * world + r."""
+        world, K = dist.get_world_size(self.group), len(frames)
+        if self.all_campos is not None:      # every rank knows the camera list: [world, 3] or [world, frames_per_rank, 3]
+            cams = self.all_campos.to(device=device, dtype=torch.float32).reshape(world, K, 3)
+            return cams.transpose(0, 1).reshape(K * world, 3).contiguous()
+        mine = torch.stack([f[2] for f in frames]).to(device=device, dtype=torch.float32).reshape(K * 3).contiguous()
+        cams = torch.empty(world * K * 3, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(cams, mine, group=self.group)
+        return cams.view(world, K, 3).transpose(0, 1).reshape(K * world, 3).contiguous()
 
     def run(self, gc: torch.Tensor, means3D: torch.Tensor, campos: torch.Tensor, sh_coeffs: int, degree: int,
-            also_reduce: Sequence[torch.Tensor] = ()) -> torch.Tensor:
-        """gc: this rank's clamp-masked dL/drgb [P,3] -> dL_dsh [P,M,3] summed over all ranks' frames.
+            also_reduce: Sequence[torch.Tensor] = ()) -> Optional[torch.Tensor]:
+        """gc: this rank's clamp-masked dL/drgb [P,3] of one frame.  Returns dL_dsh [P,M,3] summed over all ranks' frames -- or, while
+        fewer than `frames_per_rank` frames have been handed in, None (autograd: no contribution yet): that frame's all-gather is
+        already on the wire and runs under the next frame's kernels; the LAST frame's call expands all world * frames_per_rank views.
 
-        `also_reduce`: further gradient tensors to SUM all-reduce in place; their collective is queued right behind the
-        all-gather, so it runs on the communication stream while the expansion kernel runs on the compute stream."""
+        `also_reduce`: further gradient tensors to SUM all-reduce in place (frames_per_rank == 1 only); their collective is queued
+        right behind the all-gather, so it runs on the communication stream while the expansion kernel runs on the compute stream."""
         import time
         world = dist.get_world_size(self.group)
         gc = gc.contiguous()
         if self._early is not None and self._early[0] is gc:     # started by `start` between the two halves of the backward
             _, flat, h = self._early
         else:
-            flat = torch.empty(world * gc.numel(), dtype=gc.dtype, device=gc.device)   # 1-D in/out: accepted by RCCL and gloo alike
-            h = dist.all_gather_into_tensor(flat, gc.reshape(-1), group=self.group, async_op=True)
+            flat, h = self._gather(gc)
         self._early = None
-        gathered = flat.view((world,) + tuple(gc.shape))
-        if self.all_campos is not None:      # every rank knows the camera list: nothing to exchange
-            cams = self.all_campos.to(device=gc.device, dtype=torch.float32).reshape(world, 3)
-        else:
-            mine = campos.detach().to(device=gc.device, dtype=torch.float32).reshape(3).contiguous()
-            cams = torch.empty(world * 3, dtype=torch.float32, device=gc.device)
-            dist.all_gather_into_tensor(cams, mine, group=self.group)
-            cams = cams.view(world, 3)
+        self._held.append((flat, h, campos.detach().reshape(3)))
+        if len(self._held) < self.frames_per_rank:
+            return None
+        frames, self._held = self._held, []
+        cams = self._cameras(frames, gc.device)
         pending = []
         groups, singles = _storage_groups([t for t in also_reduce if t is not None and t.numel() > 0])
         for t in groups + singles:
             pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.bytes_sent += t.numel() * t.element_size()
         t0 = time.perf_counter()
-        h.wait()
+        for _, hh, _ in frames:
+            hh.wait()
         self.exchange_ms += (time.perf_counter() - t0) * 1e3
         self.calls += 1
-        self.bytes_sent += gc.numel() * gc.element_size()
+        gathered = (frames[0][0] if len(frames) == 1 else torch.cat([f[0] for f in frames])).view((len(frames) * world,) + tuple(gc.shape))
         expand = self.expand
         if expand is None:
             from diff_surfel_rasterization import _C   # the HIP kernel; no CPU path
@@ -167,25 +201,27 @@ class ShExchange:
         self.exchange_ms += (time.perf_counter() - t0) * 1e3
         return out
 
-    def start(self, gc: torch.Tensor) -> None:
-        """Called by the operator's backward BETWEEN its two halves (sr_backward_blend / sr_backward_colors done, sr_backward_geometry
-        not yet launched): `gc` [P,3] is final, so its all-gather goes on the wire now and overlaps K8.  `run` picks it up."""
-        if not gc.is_contiguous():
-            return
-        world = dist.get_world_size(self.group)
-        flat = torch.empty(world * gc.numel(), dtype=gc.dtype, device=gc.device)
-        h = dist.all_gather_into_tensor(flat, gc.reshape(-1), group=self.group, async_op=True)
-        self._early = (gc, flat, h)
-        self.early_starts += 1
+    def finish(self, grads: Sequence[torch.Tensor]) -> None:
+        """frames_per_rank > 1: after the last frame's backward, SUM all-reduce the locally accumulated gradients of everything but the
+        SH coefficients (one collective over the flat buffer the operator's backward carved them from)."""
+        assert not self._held, f"{len(self._held)} of {self.frames_per_rank} frames handed in: the SH gradient of this step was never expanded"
+        import time
+        t0 = time.perf_counter()
+        allreduce_gradients(grads, group=self.group)
+        self.exchange_ms += (time.perf_counter() - t0) * 1e3
+        self.bytes_sent += sum(g.numel() * g.element_size() for g in grads if g is not None)
 
 
-_ACTIVE_SH_EXCHANGE: Optional[ShExchange] = None
+# The exchange a forward call should attach to its autograd node.  A ContextVar: scoped to the `with` block of the calling thread /
+# task, never consulted from the backward (the node carries the object itself).
+_ACTIVE_SH_EXCHANGE: contextvars.ContextVar = contextvars.ContextVar("surfel_sh_exchange", default=None)
 
 
 @contextlib.contextmanager
 def factored_sh_exchange(group=None, expand: Optional[Callable] = None, all_campos: Optional[torch.Tensor] = None,
-                         reduce_all: bool = False):
-    """Within this context the rasterizer's backward returns dL_dsh ALREADY SUMMED over the frame-parallel ranks.
+                         reduce_all: bool = False, frames_per_rank: int = 1):
+    """Rasterizer calls made (FORWARD) within this context return, from their backward, dL_dsh ALREADY SUMMED over the
+    frame-parallel ranks; the backward itself may run anywhere, later, on autograd's own thread.
 
     Each rank's backward all-gathers its clamp-masked colour gradient (12 B/Gaussian; plus the 12-B camera position
     unless `all_campos` [world,3] is given) and expands the SH adjoint of all `world` frames locally, instead of
@@ -195,19 +231,22 @@ def factored_sh_exchange(group=None, expand: Optional[Callable] = None, all_camp
     gradients, to `allreduce_gradients`.  With `reduce_all=True` the backward also all-reduces those four (one collective
     over the flat buffer they are carved from, overlapped with the expansion kernel) and EVERY parameter gradient of the
     operator leaves backward already summed -- then nothing of it may be all-reduced again.
+    `frames_per_rank=K` (gradient accumulation, the lever against the serial compute -> exchange dependency): K rasterizer calls per
+    rank and step attach to this exchange; the colour gradients of frame j travel while frame j + 1 is computed, the backward of the
+    K-th frame returns dL_dsh of all K * world views (the earlier ones return None for it), and `ShExchange.finish(grads)` all-reduces
+    the rest once.  `all_campos` is then [world, K, 3].
     No-op when torch.distributed is not initialised or the group has one rank."""
-    global _ACTIVE_SH_EXCHANGE
-    prev = _ACTIVE_SH_EXCHANGE
-    ex = ShExchange(group, expand, all_campos, reduce_all) if _exchange_wanted(group) else None
-    _ACTIVE_SH_EXCHANGE = ex
+    ex = ShExchange(group, expand, all_campos, reduce_all, frames_per_rank) if _exchange_wanted(group) else None
+    token = _ACTIVE_SH_EXCHANGE.set(ex)
     try:
         yield ex
     finally:
-        _ACTIVE_SH_EXCHANGE = prev
+        _ACTIVE_SH_EXCHANGE.reset(token)
 
 
 def active_sh_exchange() -> Optional[ShExchange]:
-    return _ACTIVE_SH_EXCHANGE
+    """The exchange of the enclosing `factored_sh_exchange` block on THIS thread (the operator's forward stores it on its autograd node)."""
+    return _ACTIVE_SH_EXCHANGE.get()
 
 
 def reduce_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, xyz_gradient_accum: torch.Tensor,

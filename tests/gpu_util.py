@@ -113,7 +113,8 @@ def assert_grads_close(got, ref, rel, name="", max_bad_frac=1e-3, hard=5e-2):
     err = np.abs(got - ref) / scale
     bad = (err > rel).mean() if err.size else 0.0
     assert bad <= max_bad_frac, f"{name}: {bad:.2e} of elements off by more than {rel} of scale {scale:.3e} (max rel err {err.max():.2e})"
-    assert err.max() <= hard, f"{name}: max rel err {err.max():.2e} exceeds hard bound {hard}"
+    if hard is not None:
+        assert err.max() <= hard, f"{name}: max rel err {err.max():.2e} exceeds hard bound {hard}"
 
 
 def check_allmap(got, ref, tag, max_bad_frac=5e-4, hard=2e-2):
@@ -127,15 +128,17 @@ def check_allmap(got, ref, tag, max_bad_frac=5e-4, hard=2e-2):
 
 
 # ---- strict parity: same hard decisions on both sides, float64 arbiter -----------------------------------------------
-def forced_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None):
-    """The blend evaluated in double precision (oracle/surfel_blend.inc, REAL = double) on the float32 per-Gaussian state of the
-    oracle's K1, with the hard decisions the HIP kernels took (sr_debug_pair_decisions + n_contrib).  What differs from the HIP
-    result is rounding only.  -> (raw HIP state incl. decisions, forward dict, backward dict or None)."""
-    raw = run_hip_raw(g, cam, bg, deg, colors=colors, tile=tile, decisions=True)
+def forced_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None, base=None, raw=None):
+    """The blend AND K8 evaluated in double precision (oracle/surfel_blend.inc, surfel_k8.inc, REAL = double) on the float32 per-Gaussian
+    state of the oracle's K1, with the hard decisions the HIP kernels took (sr_debug_pair_decisions + n_contrib).  What differs from
+    the HIP result is rounding only.  `base` = an oracle forward of the same scene (its K1 + binning are reused), `raw` = a
+    run_hip_raw(..., decisions=True) of it.  -> (raw HIP state incl. decisions, forward dict, backward dict or None)."""
+    if raw is None:
+        raw = run_hip_raw(g, cam, bg, deg, colors=colors, tile=tile, decisions=True)
     forced = dict(valid=raw["decisions"]["valid"], use3d=raw["decisions"]["use3d"], n_contrib=raw["img"]["n_contrib"].view(np.uint32))
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
               bg=np.asarray(bg, np.float32), image_width=cam.image_width, image_height=cam.image_height, sh_degree=deg, tile=tile or (16, 16),
-              forced=forced, f64=True)
+              forced=forced, f64=True, reuse=base)
     n = lambda k: g[k].numpy()
     if colors is not None:
         fwd = so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), colors_precomp=colors, **kw)
@@ -153,18 +156,67 @@ def row_errors(got, ref, vis):
     return (np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-3 * np.abs(ref).max()))[vis]
 
 
-# gradient bars of the strict comparison, per row and relative to the ROW's own magnitude (not the tensor's): 99.9 % of the
-# visible rows / every row.  The blend-level tensors sit at the float32 rounding of the sums (measured at BASELINE config 2,
-# profiles/r02_parity.json: p99.9 2.5e-5 / 2.5e-5 / 7e-6 / 4e-5, max 3.3e-3); scales and rotations go through K8's float32
-# per-Gaussian chain (moments -> dL/dT -> quaternion), whose conditioning -- not the blend -- sets their level (the float32
-# oracle shows the same 9e-4 / 4e-3 against the same arbiter).
-STRICT_ROW_BARS = {"dL_dmeans3D": (2e-4, 1e-2), "dL_dopacity": (2e-4, 1e-2), "dL_dsh": (2e-4, 1e-2), "dL_dmeans2D": (3e-4, 1e-2),
-                   "dL_dcolors": (2e-4, 1e-2), "dL_dscales": (2e-3, 5e-2), "dL_drotations": (2e-3, 5e-2)}
+def k8_term_magnitudes(g, cam, dT):
+    """Magnitude of the terms K8 sums into dL_dscales / dL_drotations: Appendix A.6 with every product replaced by its absolute value,
+    on the float64 transMat gradient dT [P,9] (rows Tu | Tv | Tw).  dL_dscales = R^T (B^T dT) has up to 800x cancellation between
+    those terms on the benchmark scenes (profiles/r03_parity_c3.json), so a float32 rounding of the INPUT sums -- either
+    implementation's -- shows up in these two tensors amplified by that factor; K8's own float32 arithmetic does not (float32 K8 on
+    exact sums: p99.9 2e-6).  Rows of these two tensors are therefore measured against this magnitude.  -> (scales[P], rotations[P])."""
+    W, H = cam.image_width, cam.image_height
+    proj = cam.full_proj_transform.numpy().astype(np.float64).reshape(16)
+    B = np.zeros((3, 4))
+    for k in range(4):
+        a0, a1, a3 = proj[4 * k], proj[4 * k + 1], proj[4 * k + 3]
+        B[0, k] = 0.5 * W * a0 + 0.5 * (W - 1) * a3; B[1, k] = 0.5 * H * a1 + 0.5 * (H - 1) * a3; B[2, k] = a3
+    Ba = np.abs(B[:, :3])                                         # [r, k]
+    dTa = np.abs(np.asarray(dT, np.float64)).reshape(-1, 3, 3)   # [P, r, c]
+    dL0 = np.einsum("rk,pr->pk", Ba, dTa[:, :, 0]); dL1 = np.einsum("rk,pr->pk", Ba, dTa[:, :, 1])
+    q = g["rotations"].numpy().astype(np.float64); r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                  2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    Ra = np.abs(R)
+    s = g["scales"].numpy().astype(np.float64)
+    dscale = np.maximum((dL0 * Ra[:, :, 0]).sum(1), (dL1 * Ra[:, :, 1]).sum(1))
+    drot = 2.0 * np.abs(q).max(1) * (dL0 * s[:, :1] + dL1 * s[:, 1:2]).sum(1)   # (the normal column of dL/dR is not a cancellation source)
+    return dscale, drot
 
 
-def assert_strict_parity(hip, fwd64, bwd64=None, tag="", report=None):
+def gradient_row_errors(hip, bwd64, vis, scene=None):
+    """{tensor: per-row error over the visible Gaussians} of the HIP gradients against a float64 backward (blend AND K8 in double where
+    the reference carries "<name>64").  Rows are relative to their own magnitude (row_errors); dL_dscales / dL_drotations -- with
+    `scene` = (g, cam) -- to the magnitude of the terms they sum (k8_term_magnitudes)."""
+    out = {}
+    mags = None
+    if scene is not None and "dL_dtransMat64" in bwd64 and "scales" in scene[0]:
+        ms, mr = k8_term_magnitudes(scene[0], scene[1], bwd64["dL_dtransMat64"])
+        mags = {"dL_dscales": ms, "dL_drotations": mr}
+    for key in STRICT_ROW_BARS:
+        ref = bwd64.get(key + "64", bwd64.get(key))
+        if key not in hip or hip[key] is None or ref is None:
+            continue
+        if mags is not None and key in mags:
+            P = ref.shape[0]
+            r = np.asarray(ref, np.float64).reshape(P, -1); a = np.asarray(hip[key], np.float64).reshape(P, -1)
+            out[key] = (np.abs(a - r).max(1) / (np.maximum(mags[key], np.abs(r).max(1)) + 1e-3 * np.abs(r).max()))[vis]
+        else:
+            out[key] = row_errors(hip[key], ref, vis)
+    return out
+
+
+# Gradient bars, per Gaussian row: 99.9 % of the rows / every row.  Reference = the all-float64 backward.  Every tensor sits at the
+# float32 rounding of the blend's sums (measured at C2 / C3, profiles/r03_parity_*.json: p99.9 <= 4e-5, max 3.3e-3), dL_dscales and
+# dL_drotations included once their rows are measured against the terms they sum (p99.9 1.8e-4 / 1.7e-4, max 2.5e-3 / 3.2e-3; the
+# float32 oracle, forced to the same decisions, shows 1.6e-4 / 2.0e-3 against the same arbiter).  Without `scene` (precomputed
+# transMat: no scale / rotation chain) only the plain row metric applies.  dL_dmeans2D (the densification proxy) is ONE element of
+# dL/dT times Tw.z * W / 2 -- a single float32 sum of cancelling terms rather than a row maximum -- and sits at p99.9 4e-5 on the
+# benchmark scenes, 4e-4 under a train.py-style loss that weights the distortion map by 100 (tests/test_gpu_render_api.py).
+STRICT_ROW_BARS = {"dL_dmeans3D": (2e-4, 1e-2), "dL_dopacity": (2e-4, 1e-2), "dL_dsh": (2e-4, 1e-2), "dL_dmeans2D": (6e-4, 1e-2),
+                   "dL_dcolors": (2e-4, 1e-2), "dL_dscales": (4e-4, 1e-2), "dL_drotations": (4e-4, 1e-2)}
+
+
+def assert_strict_parity(hip, fwd64, bwd64=None, tag="", report=None, scene=None):
     """Images: |hip - f64| <= 1e-4 * (1 + |f64|) for EVERY element of colour and all seven aux maps -- north_star's tolerance, no
-    exempt fraction.  Gradients: STRICT_ROW_BARS."""
+    exempt fraction.  Gradients: STRICT_ROW_BARS (scene = (g, cam) switches dL_dscales / dL_drotations to the term-magnitude metric)."""
     for name, a, b in [("color", hip["color"], fwd64["color"]), ("allmap", hip["allmap"], fwd64["allmap"])]:
         err = np.abs(np.asarray(a, np.float64) - b) / (1.0 + np.abs(b))
         if report is not None:
@@ -173,11 +225,88 @@ def assert_strict_parity(hip, fwd64, bwd64=None, tag="", report=None):
     if bwd64 is None:
         return
     vis = fwd64["radii"] > 0
-    for key, (p999_bar, max_bar) in STRICT_ROW_BARS.items():
-        if key not in hip or hip[key] is None or key not in bwd64:
-            continue
-        e = row_errors(hip[key], bwd64[key], vis)
+    for key, e in gradient_row_errors(hip, bwd64, vis, scene).items():
+        p999_bar, max_bar = STRICT_ROW_BARS[key]
+        if scene is None and key in ("dL_dscales", "dL_drotations"):
+            p999_bar, max_bar = 2e-3, 6e-2   # plain row metric: the cancellation of the chain is in the number (see k8_term_magnitudes)
         if report is not None:
             report[f"{tag}{key}"] = dict(max=float(e.max()), p999=float(np.quantile(e, 0.999)), p99=float(np.quantile(e, 0.99)))
         assert np.quantile(e, 0.999) <= p999_bar and e.max() <= max_bar, \
             f"{tag} {key}: row errors p99.9 {np.quantile(e, 0.999):.2e} (bar {p999_bar:.0e}), max {e.max():.2e} (bar {max_bar:.0e})"
+
+
+# ---- free-running parity: the checker takes its OWN decisions (float64), robust / non-robust classification ----------------
+# Non-robust budget: fraction of pixels / visible Gaussians with some decision within the noise allowance of its threshold
+# (oracle.surfel_oracle.DEFAULT_EPS).  Measured (profiles/r03_parity_*.json): C2 0.11 % of the pixels and 15.5 % of the visible
+# Gaussians, C3 0.40 % and 15.5 % (one near-threshold pair anywhere in a Gaussian's footprint makes the whole row non-robust); the
+# small test scenes with splats hundreds of pixels wide reach about 1 % / 30 %.  The full-size tests pass their own, tighter budgets.
+NONROBUST_PIXEL_BUDGET = 1.5e-2
+NONROBUST_GAUSSIAN_BUDGET = 0.40
+
+
+def free_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None, base=None):
+    """The float64 blend + float64 K8 running FREE on the oracle's float32 per-Gaussian state: every hard decision (contribute,
+    path, stop, median) is the checker's own, taken on exactly evaluated quantities -- nothing comes from the HIP kernels.  With the
+    float64 decision margins (so_render_margins_f64) it says where two correct implementations MUST agree to rounding (robust
+    pixels / Gaussians) and where a decision sits within float32 noise of its threshold.  -> (fwd64, bwd64 or None, margins)."""
+    kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
+              bg=np.asarray(bg, np.float32), image_width=cam.image_width, image_height=cam.image_height, sh_degree=deg, tile=tile or (16, 16),
+              f64=True, reuse=base)
+    n = lambda k: g[k].numpy()
+    if colors is not None:
+        fwd = so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), colors_precomp=colors, **kw)
+    else:
+        fwd = so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), shs=n("shs"), **kw)
+    bwd = so.rasterize_backward(fwd, dc.numpy(), da.numpy()) if dc is not None else None
+    return fwd, bwd, so.render_margins(fwd, f64=True)
+
+
+def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report=None, scene=None, pixel_budget=NONROBUST_PIXEL_BUDGET,
+                       gaussian_budget=NONROBUST_GAUSSIAN_BUDGET):
+    """HIP against the free-running float64 reference.
+      * every ROBUST pixel: same last contributor, colour and the six summed aux maps within 1e-4 * (1 + |value|) -- no exempt
+        fraction; where the median selection is robust too: same median contributor and median depth within the same bar;
+      * every ROBUST visible Gaussian (no near-threshold decision anywhere in its footprint): the strict per-row bars against the
+        all-float64 backward (blend AND K8 in double: "<name>64");
+      * the non-robust remainder is counted against its measured fraction and only has to stay finite and within the loose bars
+        of a flipped contributor (2e-2 per pixel, 5e-2 of the tensor scale per row)."""
+    rob_px = margins["pixel"] > 1.0
+    rob_med = rob_px & (margins["median"] > 1.0)
+    assert (~rob_px).mean() <= pixel_budget, f"{tag}: {(~rob_px).mean():.2e} of the pixels are non-robust"
+    if hip_n_contrib is not None:   # (the render()-level tests do not see the image state)
+        nc = np.asarray(hip_n_contrib).view(np.uint32).reshape(2, *rob_px.shape)
+        assert np.array_equal(nc[0][rob_px], fwd64["n_contrib"][0][rob_px]), f"{tag}: a robust pixel stops at a different entry"
+        assert np.array_equal(nc[1][rob_med], fwd64["n_contrib"][1][rob_med]), f"{tag}: a robust pixel picks a different median"
+    rep = {} if report is None else report
+    for name, a, b, mask in [("color", hip["color"], fwd64["color"], rob_px)] + \
+                            [(f"allmap[{c}]", hip["allmap"][c], fwd64["allmap"][c], rob_med if c == 5 else rob_px) for c in range(7)]:
+        err = np.abs(np.asarray(a, np.float64) - b) / (1.0 + np.abs(b))
+        m = np.broadcast_to(mask, err.shape)
+        rep[f"{tag}{name}"] = dict(robust_max=float(err[m].max()) if m.any() else 0.0, non_robust_max=float(err[~m].max()) if (~m).any() else 0.0,
+                                   non_robust_over_1e4=int((err[~m] > 1e-4).sum()))
+        assert np.isfinite(a).all(), f"{tag} {name}: non-finite output"
+        assert err[m].max() <= 1e-4, f"{tag} {name}: robust pixel off by {err[m].max():.3e} of (1 + |value|) against the free-running float64 reference"
+        if name != "allmap[5]":   # (the median depth of a non-robust pixel is another splat's depth: a selection, not a sum)
+            assert err[~m].max(initial=0.0) <= 2e-2, f"{tag} {name}: non-robust pixel off by {err[~m].max():.3e}"
+    if bwd64 is None:
+        return
+    vis = fwd64["radii"] > 0
+    rob_g = vis & (margins["gaussian"] > 1.0)
+    frac = 1.0 - rob_g.sum() / max(1, vis.sum())
+    assert frac <= gaussian_budget, f"{tag}: {frac:.2f} of the visible Gaussians are non-robust"
+    errs = gradient_row_errors(hip, bwd64, np.ones_like(vis), scene)
+    for key, e in errs.items():
+        p999_bar, max_bar = STRICT_ROW_BARS[key]
+        if scene is None and key in ("dL_dscales", "dL_drotations"):
+            p999_bar, max_bar = 2e-3, 6e-2
+        ref = bwd64.get(key + "64", bwd64.get(key)); P = ref.shape[0]
+        r = np.asarray(ref, np.float64).reshape(P, -1); a = np.asarray(hip[key], np.float64).reshape(P, -1)
+        loose = np.abs(a - r).max(1) / (np.abs(r).max() + 1e-30)
+        er = e[rob_g]
+        rep[f"{tag}{key}"] = dict(robust_rows=int(rob_g.sum()), robust_max=float(er.max()), robust_p999=float(np.quantile(er, 0.999)),
+                                  non_robust_max_of_tensor_scale=float(loose[vis & ~rob_g].max(initial=0.0)))
+        assert np.isfinite(a).all(), f"{tag} {key}: non-finite gradient"
+        assert np.quantile(er, 0.999) <= p999_bar and er.max() <= max_bar, \
+            f"{tag} {key}: robust rows p99.9 {np.quantile(er, 0.999):.2e} (bar {p999_bar:.0e}), max {er.max():.2e} (bar {max_bar:.0e})"
+        assert loose[vis & ~rob_g].max(initial=0.0) <= 5e-2, f"{tag} {key}: a non-robust row is off by {loose[vis & ~rob_g].max():.2e} of the tensor scale"
+        assert not np.abs(a[~vis]).any(), f"{tag} {key}: gradient on an invisible Gaussian"

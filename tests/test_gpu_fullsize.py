@@ -1,8 +1,9 @@
 """GPU (-m gpu): BASELINE.json's full-size configurations.
 
 C2 (500k Gaussians, 1920x1080, SH 3, fwd+bwd) is still small enough for the CPU oracle on the GPU box's host
-(seconds with OpenMP), so it gets the full oracle comparison.  C3 (3 M Gaussians, all aux gradients) and a
-3840x2160 frame are checked through size-independent properties: sortedness / consistency of the tile lists,
+(seconds with OpenMP), and so is C3 (3 M Gaussians, all aux gradients: ~12 s per oracle pass): both get the full oracle comparison
+-- bit-exact lists, the strict float64 bar, the free-running float64 reference with robust / non-robust classification.  C3 again, a
+3840x2160 frame, the C5 scene and a 20 M-Gaussian run are checked through size-independent properties: sortedness / consistency of the tile lists,
 conservation of the duplicate count, determinism (bit-identical reruns -- there are no atomics), linearity of the
 backward in the upstream gradients, and value ranges."""
 import numpy as np
@@ -15,30 +16,53 @@ pytestmark = pytest.mark.gpu
 W, H = 1920, 1080
 
 
-def test_c2_500k_against_oracle():
-    from tests.gpu_util import assert_close_frac, assert_grads_close, run_hip, run_hip_raw, run_oracle
-    P = 500_000
+def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget):
+    """One BASELINE configuration in full against the CPU oracle [REF gaussian_renderer/__init__.py:129-165: the operator call and the
+    meaning of its outputs]:
+      1. integers bit-exact: D, radii, the sorted duplicate list, the tile ranges (the float32 oracle's 64-bit stable sort);
+      2. the classic free-running comparison with the float32 oracle (fraction bars);
+      3. the strict bar: identical decisions (the kernels' own), blend + K8 in float64 -- 1e-4 at every pixel, gradient rows;
+      4. the free-running float64 reference taking its own decisions: identical decisions and the same bars on every ROBUST pixel /
+         Gaussian, the non-robust remainder counted against its measured fraction (tests/gpu_util.py assert_free_parity)."""
+    from tests.gpu_util import (assert_close_frac, assert_free_parity, assert_grads_close, assert_strict_parity, check_allmap,
+                                forced_f64_reference, free_f64_reference, run_hip, run_hip_raw, run_oracle)
     cam = synthetic_camera(W, H)
     g = synthetic_gaussians(P, W, H, seed=0)
     bg = np.zeros(3, np.float32)
-    dc, da = synthetic_upstream_grads(W, H, seed=1, aux=False)      # C2: colour + alpha gradients only
+    dc, da = synthetic_upstream_grads(W, H, seed=1, aux=aux)
     fwd, bwd = run_oracle(g, cam, bg, 3, dc, da)
-    raw = run_hip_raw(g, cam, bg, 3)
+    raw = run_hip_raw(g, cam, bg, 3, decisions=True)
     assert raw["D"] == fwd["num_rendered"]
     np.testing.assert_array_equal(raw["radii"], fwd["radii"])
+    np.testing.assert_array_equal(raw["geom"]["tiles_touched"].view(np.uint32), fwd["tiles_touched"])
     np.testing.assert_array_equal(raw["bin"]["point_list"].view(np.uint32), fwd["point_list"])
     np.testing.assert_array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])
     assert (raw["img"]["n_contrib"].view(np.uint32) != fwd["n_contrib"]).mean() < 1e-3
     out = run_hip(g, cam, bg, 3, dc, da)
-    assert_close_frac(out["color"], fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, "C2 color")
-    from tests.gpu_util import check_allmap
-    check_allmap(out["allmap"], fwd["allmap"], "C2")
+    np.testing.assert_array_equal(out["color"], raw["color"])              # the decision dump describes this very forward
+    assert_close_frac(out["color"], fwd["color"], 1e-4, 1e-4, 2e-4, 2e-2, tag + " color")
+    check_allmap(out["allmap"], fwd["allmap"], tag)
     for k in ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"]:
-        assert_grads_close(out[k], bwd[k], 2e-3, "C2 " + k)
-    # ... and the strict bar at the full C2 size: identical decisions, float64 arbiter (tests/test_gpu_strict_parity.py)
-    from tests.gpu_util import assert_strict_parity, forced_f64_reference
-    _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da)
-    assert_strict_parity(out, fwd64, bwd64, tag="C2 ")
+        # (no per-element cap here: with 3 M rows the float32 oracle's own worst rows -- global-coordinate cancellation of grazing
+        # splats, 0.3 of a row against the float64 arbiter in profiles/r03_parity_c3.json -- exceed any; steps 3 and 4 are the tight ones)
+        assert_grads_close(out[k], bwd[k], 2e-3, f"{tag} {k}", hard=None)
+    _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da, base=fwd, raw=raw)
+    assert_strict_parity(out, fwd64, bwd64, tag=tag + " ", scene=(g, cam))
+    del fwd64, bwd64
+    xfwd, xbwd, margins = free_f64_reference(g, cam, bg, 3, dc, da, base=fwd)
+    assert_free_parity(out, raw["img"]["n_contrib"], xfwd, xbwd, margins, tag=tag + " ", scene=(g, cam), pixel_budget=pixel_budget,
+                       gaussian_budget=gaussian_budget)
+
+
+def test_c2_500k_against_oracle():
+    """BASELINE config 2: 500 k Gaussians, 1920x1080, SH 3, colour + alpha gradients."""
+    _against_oracle(500_000, False, "C2", pixel_budget=2.5e-3, gaussian_budget=0.20)
+
+
+def test_c3_3m_against_oracle():
+    """BASELINE config 3 -- the configuration the metric is quoted on: 3 M Gaussians, 1920x1080, all seven aux-map gradients live.
+    The oracle needs ~12 s per free-running pass on the GPU box's host (128 threads) and ~3 s per forced pass."""
+    _against_oracle(3_000_000, True, "C3", pixel_budget=6e-3, gaussian_budget=0.20)
 
 
 def _properties(P, W, H, check_linearity=True):
@@ -137,8 +161,8 @@ def test_tile_shapes_at_full_resolution_against_oracle(tile):
     np.testing.assert_array_equal(raw["bin"]["point_list"].view(np.uint32), fwd["point_list"])
     np.testing.assert_array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])
     out = run_hip(g, cam, bg, 3, dc, da, tile=tile)
-    _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da, tile=tile)
-    assert_strict_parity(out, fwd64, bwd64, tag=f"tile {tile} ")
+    _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da, tile=tile, base=fwd)
+    assert_strict_parity(out, fwd64, bwd64, tag=f"tile {tile} ", scene=(g, cam))
 
 
 def test_more_than_65536_tiles_against_oracle():

@@ -116,6 +116,11 @@ def test_forward_backward_vs_oracle(P, W, H, deg, lo, hi, cam_index):
     inv = fwd["radii"] == 0
     for k in ["dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D", "dL_dopacity"]:
         assert not np.asarray(out[k])[inv].any(), k
+    # ... and against the free-running float64 reference (its own decisions): 1e-4 and identical stop / median positions at EVERY
+    # robust pixel, strict rows on every robust Gaussian, the non-robust remainder counted (tests/gpu_util.py)
+    from tests.gpu_util import assert_free_parity, free_f64_reference
+    xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, base=fwd)
+    assert_free_parity(out, nc, xfwd, xbwd, margins, tag=f"P{P} ", scene=(g, cam))
 
 
 def test_colors_precomp_and_transmat_precomp():
@@ -244,14 +249,56 @@ def test_radix_sort_stability_and_edges():
             v = None if vals is None else torch.from_numpy(vals.view(np.int32)).to(dev)
             ko, vo = torch.empty_like(k), torch.empty_like(k)
             tmp = torch.empty(lib.sr_debug_radix_sort_temp_bytes(n), dtype=torch.uint8, device=dev)
-            rc = lib.sr_debug_radix_sort(k.data_ptr(), None if v is None else v.data_ptr(), ko.data_ptr(), vo.data_ptr(), n, bits,
-                                         tmp.data_ptr(), tmp.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            _lib.check(rc, "sr_debug_radix_sort")
+            for flags in (0, _lib.SR_FLAG_BALLOT_RANKING):   # the LDS-atomic ranking and its match-any fallback
+                rc = lib.sr_debug_radix_sort(k.data_ptr(), None if v is None else v.data_ptr(), ko.data_ptr(), vo.data_ptr(), n, bits,
+                                             tmp.data_ptr(), tmp.numel(), flags, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                _lib.check(rc, "sr_debug_radix_sort")
+                torch.cuda.synchronize()
+                order = np.argsort(keys, kind="stable")
+                np.testing.assert_array_equal(ko.cpu().numpy().view(np.uint32), keys[order])
+                expect_v = order.astype(np.uint32) if vals is None else vals[order]
+                np.testing.assert_array_equal(vo.cpu().numpy().view(np.uint32), expect_v)
+
+
+def test_rank_self_check_and_forced_ballot_fallback():
+    """The run-time guard of the LDS-atomic lane-order assumption: the library's own self-check (run on first use per device) selects a
+    ranking, and with the match-any fallback FORCED (SrFrame.flags & SR_FLAG_BALLOT_RANKING) the depth order, the duplicate list, the
+    tile ranges and the images are bit-identical to the oracle's / the default path's -- for the 16x16 tile and for a shape whose
+    partition digits are wider (8x8 at 640 px: 80 columns)."""
+    from streetunveiler_amd import _lib
+    from tests.gpu_util import DEV, run_hip_raw, run_oracle, settings_for
+    from diff_surfel_rasterization import _C
+    lib = _lib.load()
+    mode = lib.sr_rank_mode(C_void(torch.cuda.current_stream().cuda_stream))
+    assert mode in (1, 2), f"sr_rank_mode: {mode} ({lib.sr_last_error()})"
+    assert mode == 1, "gfx950 returns LDS atomic results in lane order: the fast ranking should have been selected"
+    for (P, W, H, tile) in [(40000, 640, 360, None), (15000, 640, 200, (8, 8))]:
+        cam, g = _scene(P, W, H, 77, 1e-3, 2e-2)
+        bg = np.array([0.1, 0.0, 0.4], np.float32)
+        fwd, _ = run_oracle(g, cam, bg, 2, tile=tile or (16, 16))
+        s = settings_for(cam, bg, 2)
+        e = torch.empty(0, device=DEV)
+        d = lambda k: g[k].to(DEV)
+        outs = []
+        for ballot in (True, False):
+            D, color, allmap, radii, geom, binning, img = _C.rasterize_gaussians(
+                s.bg, d("means3D"), e, d("opacities"), d("scales"), d("rotations"), 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
+                s.image_height, s.image_width, d("shs"), 2, s.campos, False, False, tile=tile, ballot_ranking=ballot)
             torch.cuda.synchronize()
-            order = np.argsort(keys, kind="stable")
-            np.testing.assert_array_equal(ko.cpu().numpy().view(np.uint32), keys[order])
-            expect_v = order.astype(np.uint32) if vals is None else vals[order]
-            np.testing.assert_array_equal(vo.cpu().numpy().view(np.uint32), expect_v)
+            bv = _C.binning_view(binning, P, D, W, H, tile or (16, 16))
+            gv = _C.geom_view(geom, P)
+            outs.append((D, gv["sorted_gid"].cpu().numpy().copy(), bv["point_list"].cpu().numpy().copy(), bv["ranges"].cpu().numpy().copy(), color.cpu().numpy()))
+        for D, sorted_gid, pl, ranges, color in outs:
+            assert D == fwd["num_rendered"]
+            np.testing.assert_array_equal(pl.view(np.uint32), fwd["point_list"])
+            np.testing.assert_array_equal(ranges.view(np.uint32), fwd["ranges"])
+        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+        np.testing.assert_array_equal(outs[0][4], outs[1][4])
+
+
+def C_void(x):
+    import ctypes
+    return ctypes.c_void_p(x)
 
 
 def test_sh_layout_fallbacks_and_scale_modifier():

@@ -40,7 +40,7 @@ def test_strict_parity_with_identical_decisions(scene):
     np.testing.assert_array_equal(raw["color"], hip["color"])          # the decision dump describes this very forward
     report = {}
     try:
-        assert_strict_parity(hip, fwd64, bwd64, report=report)
+        assert_strict_parity(hip, fwd64, bwd64, report=report, scene=(g, cam))
     finally:
         out = os.environ.get("SR_PARITY_REPORT")
         if out:
@@ -60,4 +60,4 @@ def test_strict_parity_precomputed_colours_and_empty_tiles():
     dc, da = synthetic_upstream_grads(W, H, seed=5)
     hip = run_hip(g, cam, [0, 0, 0], 0, dc, da, colors=colors)
     raw, fwd64, bwd64 = forced_f64_reference(g, cam, [0, 0, 0], 0, dc, da, colors=colors)
-    assert_strict_parity(hip, fwd64, bwd64)
+    assert_strict_parity(hip, fwd64, bwd64, scene=(g, cam))

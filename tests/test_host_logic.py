@@ -151,6 +151,71 @@ def test_factored_sh_exchange_gloo_world2(tmp_path):
         torch.testing.assert_close(r["summed"], expect, rtol=1e-5, atol=1e-6)
 
 
+def _accum_worker(rank, world, port, tmp, K):
+    """Gradient accumulation: K frames per rank attach to ONE exchange; world 4 also checks the view <-> camera pairing for N > 2."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from streetunveiler_amd.parallel import active_sh_exchange, factored_sh_exchange, init_distributed
+    init_distributed(backend="gloo")
+    P = 300
+    means3D = torch.randn(P, 3, generator=torch.Generator().manual_seed(7)) * 3      # same Gaussians on every rank
+    cam_of = lambda r, j: torch.randn(3, generator=torch.Generator().manual_seed(1000 + 10 * r + j)) * 10
+    g = torch.Generator().manual_seed(300 + rank)
+    gcs = [torch.randn(P, 3, generator=g) for _ in range(K)]
+    results = {}
+    for known in (False, True):    # camera positions all-gathered by the exchange / known to every rank as [world, K, 3]
+        all_campos = torch.stack([torch.stack([cam_of(r, j) for j in range(K)]) for r in range(world)]) if known else None
+        rest = torch.full((P * 10,), float(rank + 1))          # the other gradients, accumulated locally over the K frames
+        with factored_sh_exchange(expand=_sh_adjoint_torch, all_campos=all_campos, frames_per_rank=K) as ex:
+            assert active_sh_exchange() is ex
+            outs = [ex.run(gcs[j], means3D, cam_of(rank, j), 16, 3) for j in range(K)]
+        assert all(o is None for o in outs[:-1]) and outs[-1] is not None and ex.calls == 1
+        ex.finish([rest[:P * 3].view(P, 3), rest[P * 3:].view(P, 7)])
+        assert ex.bytes_sent == K * P * 12 + P * 40
+        results[known] = (outs[-1], rest)
+    torch.save(dict(gcs=gcs, cams=[cam_of(rank, j) for j in range(K)], means3D=means3D, free=results[False][0], known=results[True][0],
+                    rest=results[True][1]), os.path.join(tmp, f"a{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K", [(2, 3), (4, 1), (4, 2)])
+def test_factored_exchange_accumulation_and_world4_ordering(tmp_path, world, K):
+    """frames_per_rank = K: the first K - 1 backward calls return no SH gradient, the K-th returns the sum over all world * K views, each
+    gradient paired with ITS camera (a wrong all-gather order for N > 2 would pair rank r's gradient with another rank's camera);
+    finish() all-reduces the locally accumulated rest once."""
+    port = 33500 + (os.getpid() % 2000) + 7 * world + K
+    mp.spawn(_accum_worker, args=(world, port, str(tmp_path), K), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, f"a{r}.pt")) for r in range(world)]
+    expect = sum(_sh_adjoint_torch(r["means3D"], r["cams"][j][None], r["gcs"][j][None], 16, 3) for r in rs for j in range(K))
+    shuffled = sum(_sh_adjoint_torch(r["means3D"], rs[(i + 1) % world]["cams"][j][None], r["gcs"][j][None], 16, 3) for i, r in enumerate(rs) for j in range(K))
+    assert (expect - shuffled).abs().max() > 1e-2          # the pairing matters: the check below would catch a permuted gather
+    for r in rs:
+        torch.testing.assert_close(r["free"], expect, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(r["known"], expect, rtol=1e-5, atol=1e-5)
+        assert torch.equal(r["rest"], torch.full_like(r["rest"], float(sum(range(1, world + 1)))))
+
+
+def test_exchange_rides_on_the_autograd_node_not_on_global_state():
+    """factored_sh_exchange scopes a ContextVar on the calling thread; the operator's forward copies the exchange onto its autograd
+    node, so a backward running later, outside the block and on another thread, still finds it -- and a thread that never entered
+    the block sees none."""
+    import threading
+    import streetunveiler_amd.parallel as par
+    seen = {}
+    ex = par.ShExchange()
+    token = par._ACTIVE_SH_EXCHANGE.set(ex)
+    try:
+        assert par.active_sh_exchange() is ex
+        t = threading.Thread(target=lambda: seen.setdefault("other", par.active_sh_exchange()))
+        t.start(); t.join()
+    finally:
+        par._ACTIVE_SH_EXCHANGE.reset(token)
+    assert seen["other"] is None and par.active_sh_exchange() is None
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diff_surfel_rasterization", "__init__.py")).read()
+    fwd, bwd = src.split("def backward(ctx, grad_out_color", 1)
+    assert "ctx.sh_exchange = active_sh_exchange()" in fwd and "active_sh_exchange" not in bwd.split("class _ClassDistortions")[0]
+
+
 def test_ply_checkpoint_layout_and_round_trip(tmp_path):
     """Reference PLY layout [REF scene/gaussian_model.py:226-259, 338-382]: property names/order, channel-major SH
     features, int32 semantics; binary and ASCII, any property order."""

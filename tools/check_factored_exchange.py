@@ -29,14 +29,16 @@ def frame(index, exchange, reduce_all=False):
     # shs reaches the operator through a cat, like GaussianModel.get_features [REF scene/gaussian_model.py:117-121]
     dc_part, rest = t["shs"][:, :1].detach().requires_grad_(), t["shs"][:, 1:].detach().requires_grad_()
     shs = torch.cat([dc_part, rest], dim=1)
-    color, radii, allmap = GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2d, shs=shs, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+    call = lambda: GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2d, shs=shs, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
     if exchange:
-        with factored_sh_exchange(reduce_all=reduce_all) as ex:
-            torch.autograd.backward([color, allmap], [dc, da])
+        with factored_sh_exchange(reduce_all=reduce_all) as ex:   # the FORWARD attaches the exchange to its autograd node ...
+            color, radii, allmap = call()
+        torch.autograd.backward([color, allmap], [dc, da])        # ... the backward may run outside the block, on autograd's thread
         assert ex is not None and ex.calls == 1 and ex.bytes_sent == P * 12 + (P * 40 if reduce_all else 0) and ex.early_starts == 1
         if not reduce_all:
             allreduce_gradients([t[k].grad for k in names if k != "shs"])
     else:
+        color, radii, allmap = call()
         torch.autograd.backward([color, allmap], [dc, da])
     out = {k: t[k].grad for k in names if k != "shs"}
     out["shs"] = torch.cat([dc_part.grad, rest.grad], dim=1)
