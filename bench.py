@@ -8,8 +8,8 @@ Workload (default = BASELINE.json configs[2], the one the metric is quoted on): 
 1920x1080, SH degree 3, all 7 aux-map gradients live, inputs resident in HBM before the timed region.
 `--config c2 | c3 | c5` selects a BASELINE configuration as a whole (sizes, live gradients, label); explicit --gaussians /
 --width / --height / --no-aux give a "custom" workload that is labelled as such.
-N > 1: frames shard one-per-GPU (camera k yawed), then ONE gradient all-reduce (58 floats/Gaussian) per step
-over RCCL -- weak scaling, value = P * frames / s summed over ranks.
+N > 1: frames shard one-per-GPU (camera k yawed; --frames-per-rank K: K per GPU, gradients accumulated), then ONE gradient
+exchange per step over RCCL -- weak scaling, value = P * frames / s summed over ranks.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--exchange", choices=["factored", "allreduce"], default="factored",
                     help="N > 1 gradient exchange: factored = all-gather 12-B colour gradients + local SH expansion + all-reduce of "
                          "the other 40 B/Gaussian; allreduce = plain all-reduce of all 232 B/Gaussian")
+    ap.add_argument("--frames-per-rank", type=int, default=1,
+                    help="gradient accumulation: K frames (cameras) per rank and step, ONE gradient exchange per step -- the colour gradients of "
+                         "frame j travel while frame j + 1 is computed (factored exchange); value counts all K * N frames")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-oracle work for the cpu_baseline leg")
     a = ap.parse_args()
     custom = any(v is not None for v in (a.gaussians, a.width, a.height)) or (a.no_aux and a.config is None)
@@ -93,7 +96,12 @@ def profiled(kind, args):
     if not files:
         return None, None
     try:
-        return json.load(open(files[-1]))["kernels"], os.path.relpath(files[-1], ROOT)
+        d = json.load(open(files[-1]))
+        rel = os.path.relpath(files[-1], ROOT)
+        # which build the counters were taken from: PMC passes cannot run inside the timed run, so this is a QUOTE of a committed
+        # profile of the same command -- round and HEAD of that profile are part of the citation
+        return d["kernels"], {"file": rel, "round": d.get("round", os.path.basename(rel).split("_")[0]), "head": d.get("head"),
+                              "quoted": "committed rocprofv3 counter pass of the same bench.py command, not measured in this run"}
     except Exception:
         return None, None
 
@@ -113,22 +121,27 @@ def pmc_traffic(kernel, args):
 # 1.35), an SGPR source operand 1.75, DPP 1.8, v_rcp / v_exp 3.4, v_permlane32_swap 3.9.  The datasheet's 2 cycles (0.83 ns at
 # 2.4 GHz) per instruction are not reached by any of them: plain v_fma_f32 tops out at 103 TFLOP/s of the 157 TFLOP/s spec.
 VALU_NS = {"plain": 1.25, "trans": 3.4, "dpp": 1.8, "swap": 3.9}
+# cross-lane instructions of the blend backward's per-entry wave reduction (csrc/blend_common.h wave_reduce24), per list entry that
+# gets a gradient record: v_permlane32_swap / v_permlane16_swap, and DPP moves / DPP-fused adds
+K7_REDUCTION = {"swap": 5, "dpp": 40}
 
 
-def valu_issue_roof(kernel, ms, args):
-    """Fraction of the measured VALU issue roof: the kernel's instruction counts (committed SQ counter pass) priced with VALU_NS,
-    spread over the chip's 1024 SIMDs, against its measured duration."""
+def valu_issue_roof(kernel, ms, args, entries_with_record=0):
+    """Fraction of the measured VALU issue roof: the kernel's instruction counts (committed SQ counter pass) priced with VALU_NS --
+    transcendentals from the counter pass, the backward's lane swaps and DPP operations from the number of list entries that get a
+    gradient record (counted live by the counter variant of K6) -- spread over the chip's 1024 SIMDs, against its measured duration."""
     d, src = profiled("sq_counters", args)
     try:
         k = d["sr::" + kernel]
         n, trans = k["SQ_INSTS_VALU"], k.get("SQ_INSTS_VALU_TRANS_F32", 0)
-        # cross-lane ops of the blend backward's per-entry reduction: 18 half / row-pair swaps and ~15 DPP ops per list entry with a hit
-        swaps = dpp = 0
-        floor_ms = ((n - trans - swaps - dpp) * VALU_NS["plain"] + trans * VALU_NS["trans"]) / 1024 * 1e-6
-        return {"valu_insts_per_launch": int(n), "transcendental": int(trans), "ns_per_inst_per_simd": round(ms * 1e6 * 1024 / n, 3),
+        swaps = K7_REDUCTION["swap"] * entries_with_record if kernel == "render_backward_kernel" else 0
+        dpp = K7_REDUCTION["dpp"] * entries_with_record if kernel == "render_backward_kernel" else 0
+        floor_ms = ((n - trans - swaps - dpp) * VALU_NS["plain"] + trans * VALU_NS["trans"] + swaps * VALU_NS["swap"] + dpp * VALU_NS["dpp"]) / 1024 * 1e-6
+        return {"valu_insts_per_launch": int(n), "transcendental": int(trans), "lane_swaps": int(swaps), "dpp": int(dpp),
+                "ns_per_inst_per_simd": round(ms * 1e6 * 1024 / n, 3),
                 "issue_floor_ms": round(floor_ms, 4), "frac_of_issue_roof": round(floor_ms / ms, 4), "source": src,
-                "how": "instructions x measured issue cost (plain 1.25 ns, transcendental 3.4 ns per wave64 instruction and SIMD; "
-                       "swaps / DPP priced as plain = a lower bound of the floor) / 1024 SIMDs, vs the measured launch duration"}
+                "how": "instructions x measured issue cost per wave64 instruction and SIMD (plain 1.25 ns, transcendental 3.4 ns, "
+                       "v_permlane swap 3.9 ns, DPP 1.8 ns: profiles/r02_valu_issue_ubench.txt) / 1024 SIMDs, vs the measured launch duration"}
     except Exception:
         return None
 
@@ -180,35 +193,54 @@ def main():
 
     P, W, H, deg = args.gaussians, args.width, args.height, args.sh_degree
     g_cpu = synthetic_gaussians(P, W, H, seed=0)
-    cam = synthetic_camera(W, H) if world == 1 else synthetic_camera(W, H, index=rank, n_cams=world)
+    K = max(1, args.frames_per_rank)
+    n_cams = world * K
+    # frame j of rank r = camera r * K + j of the yawed camera batch (one camera, the unrotated one, for the plain single-GPU run)
+    cams = [synthetic_camera(W, H) if n_cams == 1 else synthetic_camera(W, H, index=rank * K + j, n_cams=n_cams) for j in range(K)]
+    cam = cams[0]
     dc_cpu, da_cpu = synthetic_upstream_grads(W, H, seed=1, aux=not args.no_aux)
     params = {k: v.to(dev).requires_grad_() for k, v in g_cpu.items()}
     dc, da = dc_cpu.to(dev), da_cpu.to(dev)
-    settings = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3, device=dev),
-                                             1.0, cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), deg,
-                                             cam.camera_center.to(dev), False, False)
-    rasterizer = GaussianRasterizer(settings)
-    # the camera list is replicated: every rank knows every rank's camera position
-    all_campos = torch.stack([synthetic_camera(W, H, index=r, n_cams=world).camera_center for r in range(world)]).to(dev) if multi else None
+    make_settings = lambda c: GaussianRasterizationSettings(H, W, math.tan(c.FoVx / 2), math.tan(c.FoVy / 2), torch.zeros(3, device=dev),
+                                                            1.0, c.world_view_transform.to(dev), c.full_proj_transform.to(dev), deg,
+                                                            c.camera_center.to(dev), False, False)
+    settings = make_settings(cam)
+    rasterizers = [GaussianRasterizer(settings if j == 0 else make_settings(cams[j])) for j in range(K)]
+    # the camera list is replicated: every rank knows every rank's camera positions ([world, 3], or [world, K, 3] with accumulation)
+    all_campos = None
+    if multi:
+        all_campos = torch.stack([torch.stack([synthetic_camera(W, H, index=r * K + j, n_cams=n_cams).camera_center for j in range(K)])
+                                  for r in range(world)]).to(dev)
+        if K == 1:
+            all_campos = all_campos[:, 0]
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     leaves = [params["means3D"], params["shs"], params["opacities"], params["scales"], params["rotations"], means2D]
 
     exchange_log = {"ms": 0.0, "bytes": 0, "calls": 0, "early_starts": 0}
 
-    def step():
+    def frame(j):   # one frame: operator forward + backward; parameter gradients accumulate in the leaves
+        color, radii, allmap = rasterizers[j](means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                              opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
+        torch.autograd.backward([color, allmap], [dc, da])
+        return radii
+
+    def step():     # K frames per rank, then (N > 1) ONE gradient exchange
         for t in leaves:
             t.grad = None
-        color, radii, allmap = rasterizer(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
-                                          opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
         if multi and args.exchange == "factored":
-            # SH gradient: all-gather of the 12-B colour gradients + local expansion; the other 40 B/Gaussian: one
-            # all-reduce, queued behind it inside backward -- every gradient leaves backward summed over the ranks
-            with factored_sh_exchange(all_campos=all_campos, reduce_all=True) as ex:
-                torch.autograd.backward([color, allmap], [dc, da])
+            # SH gradient: all-gather of the 12-B colour gradients (per frame, started between K7 and K8, travelling under the next
+            # frame's kernels) + local expansion of all K * N views; the other 40 B/Gaussian: one all-reduce -- inside the last
+            # backward for K = 1 (every gradient leaves backward summed over the ranks), after the K-th frame otherwise
+            with factored_sh_exchange(all_campos=all_campos, reduce_all=K == 1, frames_per_rank=K) as ex:
+                for j in range(K):
+                    radii = frame(j)
+                if K > 1:
+                    ex.finish([t.grad for t in (leaves[0], leaves[2], leaves[3], leaves[4])])
             exchange_log["ms"] += ex.exchange_ms; exchange_log["bytes"] += ex.bytes_sent; exchange_log["calls"] += ex.calls
             exchange_log["early_starts"] += ex.early_starts
         else:
-            torch.autograd.backward([color, allmap], [dc, da])
+            for j in range(K):
+                radii = frame(j)
             if multi:
                 t0 = time.perf_counter()
                 allreduce_gradients([t.grad for t in leaves[:5]])   # 232 B/Gaussian, one collective over the flat buffer
@@ -234,7 +266,7 @@ def main():
     torch.cuda.synchronize()
     st = counters.tolist()
     blend_counts = {"staged_entries_D_eff": int(st[0]), "entries_after_quadrant_cull": int(st[1]), "quadrant_tests": int(st[2]),
-                    "quadrant_tests_with_a_hit": int(st[3]), "contributing_pairs": int(st[4])}
+                    "quadrant_tests_with_a_hit": int(st[3]), "contributing_pairs": int(st[4]), "entries_with_a_hit": int(st[7])}
 
     def sync():
         if multi:
@@ -243,10 +275,15 @@ def main():
 
     exchange_check = None
 
+    worlds_seen = None
     if multi:   # bring the communicator up before anything is timed, whatever --warmup says
         w = torch.zeros(1024, device=dev); wg = torch.empty(1024 * world, device=dev)
         dist.all_reduce(w); dist.all_gather_into_tensor(wg, w)
         sync()
+        # what every rank believes the job looks like: its communicator's size (all-gathered over that communicator)
+        mine = torch.tensor([float(dist.get_world_size())], device=dev); seen = torch.empty(world, device=dev)
+        dist.all_gather_into_tensor(seen, mine)
+        worlds_seen = [int(x) for x in seen.tolist()]
         if args.exchange == "factored":
             # one untimed trial step of the factored exchange; should it raise (it would on every rank alike: same code, same
             # arguments), fall back to the plain all-reduce instead of losing the run -- the JSON line says which one ran
@@ -300,7 +337,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = P * world * args.steps / elapsed / 1e6
+        value = P * world * K * args.steps / elapsed / 1e6
         npx = W * H
         ab = algorithmic_bytes(P, V, D, npx, deg)
         stage_ms = {k: (ms / n if n else None) for k, (ms, n) in stats.items()}
@@ -324,33 +361,46 @@ def main():
                 "issued": None if issued is None else round(issued, 2), "issued_frac": None if issued is None else round(issued / FP32_VALU_PEAK_TFLOPS, 4),
                 "useful": None if useful is None else round(useful, 2), "useful_frac": None if useful is None else round(useful / FP32_VALU_PEAK_TFLOPS, 4),
                 "issue_roof": {"render_forward_kernel": valu_issue_roof("render_forward_kernel", group_ms["blend_fwd"], args),
-                               "render_backward_kernel": valu_issue_roof("render_backward_kernel", group_ms["blend_bwd"], args)},
+                               "render_backward_kernel": valu_issue_roof("render_backward_kernel", group_ms["blend_bwd"], args, blend_counts["entries_with_a_hit"])},
                 "note": "issued = 64 lanes x quadrant tests, useful = pairs that contribute; the kernels are bound by VALU instruction issue "
                         "(issue_roof: instruction counts priced with the measured per-instruction issue cost), not by memory (DESIGN.md 4)",
                 "D_eff_blend_bytes": blend_counts["staged_entries_D_eff"] * 296 + npx * 160}
+        # The same fractions with the list entries the blend kernels actually stage (D_eff: what lies behind a tile's saturation
+        # point is never loaded) in place of all D duplicates: the D-based figures count bytes no kernel touches -- a factor of two
+        # on the 4K scene.
+        d_eff = blend_counts["staged_entries_D_eff"]
+        ab_eff = {"blend_fwd": d_eff * 76 + npx * 60, "blend_bwd": d_eff * 76 + d_eff * 72 * 2 + npx * (60 + 40)}
+        frac_eff = ab_eff[dominant] / (group_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS if group_ms[dominant] else None
+        blend_frac_eff = (ab_eff["blend_fwd"] + ab_eff["blend_bwd"]) / (blend_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if blend_ms else None
         out = {
             "metric": f"Msplats/s fwd+bwd @{W}x{H}, {P / 1e6:g}M Gaussians", "value": round(value, 3), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "timed_region_ms": round(elapsed * 1e3, 3),
             "step_ms_percentiles": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.label, "baseline_config": args.tag,
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D, "visible_per_P": round(V / P, 4), "D_per_P": round(D / P, 3),
-                       "frames_per_step": world, "parallelism": f"frame-sharded dp{world}" if multi else "single GPU",
+                       "frames_per_step": world * K, "frames_per_rank": K,
+                       "parallelism": (f"frame-sharded dp{world}" if multi else "single GPU") + (f", {K} frames accumulated per exchange" if K > 1 else ""),
                        **({"gradient_exchange": ("all-gather of 12-B colour gradients (started between K7 and K8) + local SH expansion + "
                                                  "all-reduce of 40 B/Gaussian" if args.exchange == "factored" else "all-reduce of 232 B/Gaussian"),
                            "exchange_ms_per_step_rank0_host_wait": round(timed_exchange["ms"] / args.steps, 4),
                            "exchange_bytes_sent_per_step_rank0": int(timed_exchange["bytes"] / args.steps),
                            "exchange_early_starts_per_step": timed_exchange["early_starts"] / args.steps,
-                           "exchange_selfcheck": exchange_check} if multi else {})},
+                           "exchange_selfcheck": exchange_check, "backend": dist.get_backend(),
+                           "world_size_seen_by_each_rank": worlds_seen} if multi else {})},
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": None if ach is None else round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 5),
-                         "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_ms": round(group_ms[dominant], 4),
+                         "frac_D_eff": None if frac_eff is None else round(frac_eff, 5),
+                         "algorithmic_bytes_per_launch": ab[dominant], "algorithmic_bytes_per_launch_D_eff": ab_eff[dominant],
+                         "avg_launch_ms": round(group_ms[dominant], 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "note": "HBM fraction as BASELINE.json defines it; the blend kernels are FP32-VALU-bound (DESIGN.md 4)",
                          "north_star_blend_fwd_bwd": {"algorithmic_bytes": ab["blend_fwd"] + ab["blend_bwd"], "ms": round(blend_ms, 4),
                                                       "achieved": None if blend_gbs is None else round(blend_gbs, 2),
-                                                      "frac": None if blend_gbs is None else round(blend_gbs / HBM_PEAK_GBS, 5)},
+                                                      "frac": None if blend_gbs is None else round(blend_gbs / HBM_PEAK_GBS, 5),
+                                                      "frac_D_eff": None if blend_frac_eff is None else round(blend_frac_eff, 5)},
                          "valu": valu,
                          "whole_op": {"algorithmic_bytes": sum(ab.values()), "kernel_ms": round(kernels_ms, 4),
                                       "frac": round(sum(ab.values()) / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kernels_ms else None}},

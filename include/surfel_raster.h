@@ -83,7 +83,8 @@ typedef struct SrFrame {
     uint64_t* blend_counters; /* NULL, or device [8] u64 owned by the caller: selects the COUNTING variant of the forward blend (same
                                * results, slow), which adds to [0] list entries staged, [1] entries kept by the quadrant culling,
                                * [2] (entry, quadrant) tests run, [3] tests with >= 1 contributing pixel, [4] contributing (pixel, entry)
-                               * pairs, [5] / [6] tests with a contributing pixel in rows 0-3 / rows 4-7 of the quadrant.  16x16 tile with
+                               * pairs, [5] / [6] tests with a contributing pixel in rows 0-3 / rows 4-7 of the quadrant, [7] entries with a
+                               * contributing pixel anywhere in the tile (= the gradient records the backward writes).  16x16 tile with
                                * 3 or 6 colour channels; any other request returns SR_ERR_UNSUPPORTED (never silent zeros) */
 } SrFrame;
 #define SR_FLAG_NO_QUADRANT_CULL 1u  /* forward blend: run every list entry against every 8x8 quadrant instead of dropping entries that

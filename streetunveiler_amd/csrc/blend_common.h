@@ -15,7 +15,7 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 
 // counters of the K6 counter variant (SrFrame.blend_counters, caller-owned, 8 x u64): [0] entries staged, [1] entries with a
 // non-zero quadrant mask, [2] quadrant tests executed, [3] quadrant tests with >= 1 valid lane, [4] valid (pixel, entry) pairs,
-// [5] / [6] tests with a valid pixel in rows 0-3 / rows 4-7 of the quadrant
+// [5] / [6] tests with a valid pixel in rows 0-3 / rows 4-7 of the quadrant, [7] entries with a valid pixel anywhere in the tile
 
 // ---------------------------------------------------------------------------------------------
 // Quadrant culling.  A list entry can only contribute to a pixel if alpha = min(0.99, opacity*G) >= 1/255,
@@ -188,33 +188,81 @@ __device__ __forceinline__ float row_sum16(float x) {
     x += dpp_mov<0x121>(x);  // row_ror:1
     return x;
 }
-// Returns the 64-lane total of ONE value per lane: lane l ends up with value index
-//   6*(l>>4) + 3*bit3(l) + (bit2(l) ? 2 : bit1(l)), valid unless bit2 and bit1 are both set; bit0 is a replica.
-// Folds all the way down (24 -> 12 -> 6 -> 3 -> 2 -> 1 values per lane), so the expensive cross-lane steps
-// shrink geometrically: 18 swap-adds + 7 in-row exchanges instead of 18 swap-adds + 24 DPP adds
-// (tools/ubench/reduce_ubench.hip: 416 vs 633 SIMD cycles per reduction).
+// Returns the 64-lane totals of the 24 values, one per lane: lane l ends up with the total of value index
+//   reduce24_index(l) = (bit1(l) ? 2 : bit4(l)) + 3 bit5(l) + 6 bit2(l) + 12 bit3(l),
+// valid in the lanes with bit0 clear and not (bit1 and bit4) -- 24 lanes.
+// DPP first: the two in-row levels (lane ^ 8, lane ^ 4) are transposing folds done with bank-masked DPP adds -- the rotated operand
+// rides in the add itself (1.8 ns per wave instruction against 3.9 + 1.05 for a lane swap plus its add), two instructions per pair
+// of registers and no selects: the first writes the banks that keep `a`, the second the banks that keep `b`.  24 -> 12 -> 6 registers
+// cost 36 DPP adds; only then do the cross-row levels run on 6 registers (5 swaps instead of 18), and the quad levels on 2.
+// Measured against the swap-first order it replaces (18 swaps + 9 DPP moves + 27 adds + 14 selects): tools/ubench/reduce_ubench.hip.
+// One asm block: the DPP reads of a register follow its last write by >= 7 instructions inside the block (the hardware wants 2
+// wait states between a VALU write and a DPP read, and the compiler's hazard recogniser does not look into inline asm); the
+// s_nop in front covers whatever wrote the inputs.
+__device__ __forceinline__ void dpp_fold_rows(float (&v)[24]) {
+
+    asm volatile(
+        "s_nop 1\n"
+        // level lane^8, lanes 0-7 of every row: v[k] += v[k] of lane^8 (all lanes written; lanes 8-15 are overwritten next)
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %9, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %10, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %11, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        // ... lanes 8-15 (banks 2, 3) take value k + 12 instead
+        "v_add_f32_dpp %0, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %1, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %2, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %3, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %4, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %5, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %6, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %7, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %8, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %9, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %10, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %11, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        // level lane^4: lanes with bit 2 clear (banks 0, 2) keep register k (partner = lane + 4: row_ror:12), lanes with bit 2 set
+        // (banks 1, 3) take register k + 6 (partner = lane - 4: row_ror:4)
+        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %2, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %4, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %5, %5, %5 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %0, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %1, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %2, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %3, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %4, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %5, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "s_nop 1\n"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]),
+          "+v"(v[11])
+        : "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]), "v"(v[21]), "v"(v[22]),
+          "v"(v[23]));
+
+}
+__device__ __forceinline__ int reduce24_index(int l) { return ((l & 2) ? 2 : ((l >> 4) & 1)) + 3 * ((l >> 5) & 1) + 6 * ((l >> 2) & 1) + 12 * ((l >> 3) & 1); }
+__device__ __forceinline__ bool reduce24_holds_total(int l) { return (l & 1) == 0 && !((l & 2) && (l & 16)); }
 __device__ __forceinline__ float wave_reduce24(float (&v)[24], int lane) {
+    dpp_fold_rows(v);                          // v[0..5]: value k + 6 bit2 + 12 bit3, summed over the lanes {l, l^4, l^8, l^12}
 #pragma unroll
-    for (int k = 0; k < 12; ++k) fold32(v[k], v[k + 12]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) fold16(v[k], v[k + 6]);
-    const bool h8 = (lane & 8) != 0, h4 = (lane & 4) != 0, h2 = (lane & 2) != 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float keep = h8 ? v[k + 3] : v[k], send = h8 ? v[k] : v[k + 3];
-        v[k] = keep + dpp_mov<0x128>(send);  // row_ror:8
-    }
-    {
-        const float keep0 = h4 ? v[2] : v[0], send0 = h4 ? v[0] : v[2];
-        const float keep1 = h4 ? 0.f : v[1], send1 = h4 ? v[1] : 0.f;
-        v[0] = keep0 + dpp_xor4(send0);
-        v[1] = keep1 + dpp_xor4(send1);
-    }
-    {
-        const float keep = h2 ? v[1] : v[0], send = h2 ? v[0] : v[1];
-        v[0] = keep + dpp_mov<0x4E>(send);   // quad_perm:[2,3,0,1] = lane ^ 2
-    }
-    return v[0] + dpp_mov<0xB1>(v[0]);       // quad_perm:[1,0,3,2] = lane ^ 1
+    for (int k = 0; k < 3; ++k) fold32(v[k], v[k + 3]);    // + 3 bit5, summed over both halves
+    float z = 0.f;
+    fold16(v[0], v[1]);                        // bit4 clear: value 0 (+ ...), bit4 set: value 1; summed over all four rows
+    fold16(v[2], z);                           // bit4 clear: value 2; bit4 set: nothing
+    float a = v[0], b = v[2];
+    a += dpp_mov<0x4E>(a); b += dpp_mov<0x4E>(b);    // quad_perm:[2,3,0,1] = lane ^ 2
+    a += dpp_mov<0xB1>(a); b += dpp_mov<0xB1>(b);    // quad_perm:[1,0,3,2] = lane ^ 1: every lane of a quad holds the totals
+    return (lane & 2) ? b : a;
 }
 
 // 64-lane totals of three more values (the 9-channel variant): afterwards every lane of 16-lane row r holds the total of value r

@@ -153,6 +153,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats &
                 if (ballot64(T[q] > 0.f) == 0) alive &= ~(1u << q);
             }
         }
+        if (kStats && lane == 0) {   // [7]: entries with a contributing pixel somewhere in the tile = gradient records K7 will write
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) any |= hit[q];
+            atomicAdd(&g_stats[7], (unsigned long long)__popcll(any));
+        }
         // exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel here
         if ((uint32_t)lane < n) {
             uint32_t hm = 0;
@@ -378,8 +384,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             }
             {
                 const float tot = wave_reduce24(v, lane);
-                if ((lane & 1) == 0 && (lane & 6) != 6)
-                    s_out[j][6 * (lane >> 4) + ((lane & 8) ? 3 : 0) + ((lane & 4) ? 2 : ((lane >> 1) & 1))] = tot;
+                if (reduce24_holds_total(lane)) s_out[j][reduce24_index(lane)] = tot;
                 if (NC == 9) {
                     const float t3 = wave_reduce3(w6, w7, w8);   // row 0: channel 6, row 1: channel 8, row 2: channel 7
                     if ((lane & 15) == 0 && lane < 48) s_out[j][24 + (lane == 0 ? 0 : (lane == 16 ? 2 : 1))] = t3;

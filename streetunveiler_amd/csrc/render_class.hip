@@ -258,8 +258,7 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
             }
             {
                 const float tot = wave_reduce24(v, lane);
-                if ((lane & 1) == 0 && (lane & 6) != 6)
-                    s_out[j][6 * (lane >> 4) + ((lane & 8) ? 3 : 0) + ((lane & 4) ? 2 : ((lane >> 1) & 1))] = tot;
+                if (reduce24_holds_total(lane)) s_out[j][reduce24_index(lane)] = tot;
             }
         }
         if ((wrote >> lane) & 1ull) {

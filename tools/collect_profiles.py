@@ -10,7 +10,16 @@ The profiling call itself (on the GPU box):
 """
 import collections, csv, json, os, re, sys
 
+import subprocess
 src, tag = sys.argv[1], sys.argv[2]
+ROOT_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+try:    # which build the counters describe (run this script in the build container, where .git is; on the GPU box there is none)
+    HEAD = subprocess.run(["git", "-C", ROOT_, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+    if subprocess.run(["git", "-C", ROOT_, "status", "--porcelain", "--", "streetunveiler_amd/csrc", "bench.py"], capture_output=True, text=True).stdout.strip():
+        HEAD += "+uncommitted kernel changes"
+except Exception:
+    HEAD = os.environ.get("SR_HEAD")
+META = {"round": tag.split("_")[0], "head": HEAD}
 dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -41,7 +50,7 @@ def per_kernel(fn, counter):
 fe, wr = per_kernel(f"{src}/fetch_counter_collection.csv", "FETCH_SIZE"), per_kernel(f"{src}/write_counter_collection.csv", "WRITE_SIZE")
 out = {k: {"FETCH_SIZE_KiB": round(fe[k]), "WRITE_SIZE_KiB": round(wr.get(k, 0)), "traffic_bytes_per_launch": int((2 * fe[k] + wr.get(k, 0)) * 1024)}
        for k in fe if k.startswith("sr::")}
-json.dump({"how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (--kernel-trace only), python bench.py --config <cfg> --steps 3 --warmup 1; "
+json.dump({**META, "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (--kernel-trace only), python bench.py --config <cfg> --steps 3 --warmup 1; "
                   "traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md (FETCH_SIZE reads 1/2 of a wide coalesced "
                   "stream on gfx950 -- confirmed on preprocess_forward_kernel: 2*FETCH = the 232 B x 3 M it reads; WRITE_SIZE is exact on streaming "
                   "stores; for the 16-B record gathers of the blend kernels the 2x is an upper bound)",
@@ -58,7 +67,7 @@ for run, names in passes.items():
                 if k.startswith("sr::"):
                     sq.setdefault(k, {})[n] = round(v)
 if sq:
-    json.dump({"how": "rocprofv3 --pmc <8 SQ counters> --kernel-trace in separate passes (" + " | ".join(" ".join(v) for v in passes.values()) +
+    json.dump({**META, "how": "rocprofv3 --pmc <8 SQ counters> --kernel-trace in separate passes (" + " | ".join(" ".join(v) for v in passes.values()) +
                       "), bench.py --config <cfg> --steps 3 --warmup 1; averages per launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles",
                "kernels": sq}, open(f"{dst}/{tag}_sq_counters.json", "w"), indent=1)
 if os.path.exists(f"{src}/bench.json") and os.path.getsize(f"{src}/bench.json") > 10:
