@@ -199,9 +199,13 @@ __device__ __forceinline__ float row_sum16(float x) {
 // One asm block: the DPP reads of a register follow its last write by >= 7 instructions inside the block (the hardware wants 2
 // wait states between a VALU write and a DPP read, and the compiler's hazard recogniser does not look into inline asm); the
 // s_nop in front covers whatever wrote the inputs.
+// NV = 24, or 21: values 21..23 are not in use (three colour channels) -- they need no reset and no fold; their slots of the result hold
+// copies of other totals, which nothing reads.
+template <int NV>
 __device__ __forceinline__ void dpp_fold_rows(float (&v)[24]) {
-
-    asm volatile(
+    static_assert(NV == 24 || NV == 21, "24 values, or 21 with the last three unused");
+    if (NV == 24) {
+        asm volatile(
         "s_nop 1\n"
         // level lane^8, lanes 0-7 of every row: v[k] += v[k] of lane^8 (all lanes written; lanes 8-15 are overwritten next)
         "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
@@ -244,16 +248,54 @@ __device__ __forceinline__ void dpp_fold_rows(float (&v)[24]) {
         "v_add_f32_dpp %4, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n"
         "v_add_f32_dpp %5, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n"
         "s_nop 1\n"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]),
-          "+v"(v[11])
-        : "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]), "v"(v[21]), "v"(v[22]),
-          "v"(v[23]));
-
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11])
+        : "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]), "v"(v[21]), "v"(v[22]), "v"(v[23]));
+    } else {
+        asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %9, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %10, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %11, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %1, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %2, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %3, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %4, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %5, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %6, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %7, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %8, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %2, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %4, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %5, %5, %5 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %0, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %1, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %2, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %3, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %4, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %5, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "s_nop 1\n"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11])
+        : "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]));
+    }
 }
 __device__ __forceinline__ int reduce24_index(int l) { return ((l & 2) ? 2 : ((l >> 4) & 1)) + 3 * ((l >> 5) & 1) + 6 * ((l >> 2) & 1) + 12 * ((l >> 3) & 1); }
 __device__ __forceinline__ bool reduce24_holds_total(int l) { return (l & 1) == 0 && !((l & 2) && (l & 16)); }
+template <int NV = 24>
 __device__ __forceinline__ float wave_reduce24(float (&v)[24], int lane) {
-    dpp_fold_rows(v);                          // v[0..5]: value k + 6 bit2 + 12 bit3, summed over the lanes {l, l^4, l^8, l^12}
+    dpp_fold_rows<NV>(v);                          // v[0..5]: value k + 6 bit2 + 12 bit3, summed over the lanes {l, l^4, l^8, l^12}
 #pragma unroll
     for (int k = 0; k < 3; ++k) fold32(v[k], v[k + 3]);    // + 3 bit5, summed over both halves
     float z = 0.f;

@@ -327,11 +327,12 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
             const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
+            constexpr int NV = NC == 3 ? 21 : 24;   // slots 21..23 carry colour channels 3..5 only
             float v[24];
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
                 v[k] = 0.f;
-                asm volatile("" : "+v"(v[k]));   // opaque zero: every quadrant block accumulates in place (no phi copies of constants)
+                if (k < NV) asm volatile("" : "+v"(v[k]));   // opaque zero: every quadrant block accumulates in place (no phi copies of constants)
             }
             float w6 = 0.f, w7 = 0.f, w8 = 0.f;   // colour channels 6..8 (9-channel variant)
 #pragma unroll
@@ -364,6 +365,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     if (NC == 9) { w6 += w * gc6[q]; w7 += w * gc7[q]; w8 += w * gc8[q]; }
                     v[15] += w * gn0[q]; v[16] += w * gn1[q]; v[17] += w * gn2[q];
                     v[14] += h.G * dL_dalpha;
+                    v[11] += dL_dz;   // (both paths)
                     if (h.use3d) {
                         const float gG = -dL_dG * h.G;
                         const float dpx = (gG * h.sx + dL_dz * Twx) * h.pz_inv, dpy = (gG * h.sy + dL_dz * Twy) * h.pz_inv;
@@ -373,17 +375,16 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                         v[0] += dpx; v[1] += dpy; v[2] += dpz;
                         v[3] = fmaf(xq, dpx, v[3]); v[4] = fmaf(xq, dpy, v[4]); v[5] = fmaf(xq, dpz, v[5]);
                         v[6] = fmaf(yq, dpx, v[6]); v[7] = fmaf(yq, dpy, v[7]); v[8] = fmaf(yq, dpz, v[8]);
-                        v[9] = fmaf(dL_dz, h.sx, v[9]); v[10] = fmaf(dL_dz, h.sy, v[10]); v[11] += dL_dz;
+                        v[9] = fmaf(dL_dz, h.sx, v[9]); v[10] = fmaf(dL_dz, h.sy, v[10]);
                     } else {
                         const float gG = -dL_dG * h.G * kFilterInvSquare;
                         v[12] = fmaf(gG, h.dx, v[12]);
                         v[13] = fmaf(gG, h.dy, v[13]);
-                        v[11] += dL_dz;
                     }
                 }
             }
             {
-                const float tot = wave_reduce24(v, lane);
+                const float tot = wave_reduce24<NV>(v, lane);
                 if (reduce24_holds_total(lane)) s_out[j][reduce24_index(lane)] = tot;
                 if (NC == 9) {
                     const float t3 = wave_reduce3(w6, w7, w8);   // row 0: channel 6, row 1: channel 8, row 2: channel 7
