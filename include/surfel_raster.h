@@ -134,7 +134,7 @@ typedef struct SrGradients {
 
 /* Views into the caller-owned state buffers (for tests / debugging; all device pointers). */
 typedef struct SrGeomView {
-    const float* splats;           /* [P,20] packed record: Tu.xyz Tv.x | Tv.yz Tw.xy | Tw.z xy.x xy.y opacity | n.xyz view-depth | r g b radius */
+    const float* splats;           /* [P,20] packed record: Tu.xyz Tv.x | Tv.yz Tw.xy | Tw.z xy.x xy.y opacity | n.xyz view-depth | r g b radius (zeros where radii == 0) */
     const uint32_t* depth_keys;    /* [P] float bits of view-space depth; 0xFFFFFFFF when culled */
     const uint32_t* tiles_touched; /* [P] */
     const uint8_t* clamped;        /* [P] bit c set when SH colour channel c was clamped at 0 */

@@ -23,6 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # are copied wholesale at every branch join (K7: 62 -> 10 v_mov_b64 in the loop body)
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize",
           "-mllvm", "-disable-promote-alloca-to-vector", "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("SR_EXTRA_HIPCC_FLAGS", "").split()   # A/B experiments (-DSR_...=...); empty for the shipped build
 # (source, extra flags)
 SOURCES = [
     ("preprocess.hip", ["-ffp-contract=off"]),  # op order is part of the bit-exact contract with the oracle

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     rect[i] = out_rect;
     depth_keys[i] = out_key;
     clamped[i] = out_clamped;
-    float4* rec = recs + (size_t)i * kRecQuads;
+    float4* rec = recs + (size_t)i * kRecQuads;   // (also for a culled Gaussian: leaving holes in the wave's record stores costs more -- 0.249 -> 0.260 ms -- than the 34 MB they save)
     rec[0] = q0; rec[1] = q1; rec[2] = q2; rec[3] = q3; rec[4] = q4;
 }
 

@@ -14,21 +14,28 @@
 namespace sr {
 
 constexpr int kRsThreads = 256;
-constexpr int kRsItems = 8;                       // per thread
+constexpr int kRsItems = 8;                       // per thread (the emission-offset scan and the rank test hook)
 constexpr int kRsTile = kRsThreads * kRsItems;    // 2048 items per block
 static_assert(kRsTile == kScanTile, "first_index() divides by the scan's block size");
+// The sort's histogram / scatter kernels take 8 items per thread (2048 per block), or 16 for 8-bit passes over >= 2 M items: half the
+// blocks, digit runs twice as long in the write-out (depth sort at 3 M keys 0.200 -> 0.189 ms; below ~1 M items the 2048-item
+// blocks fill the chip better).
+constexpr int kSortItemsBig = 16;
+constexpr uint32_t kSortBigFrom = 2u << 20;
 constexpr int kRsMaxBins = 256;
 
+template <int kSortItems>
 __global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, int bits,
                                                              uint32_t* __restrict__ hist, int nblocks) {
+    constexpr int kSortTile = kRsThreads * kSortItems;
     __shared__ uint32_t s_h[kRsMaxBins];
     const int tid = threadIdx.x, bins = 1 << bits;
     const uint32_t mask = (uint32_t)bins - 1u;
     if (tid < bins) s_h[tid] = 0;
-    const uint32_t base = blockIdx.x * (uint32_t)kRsTile;
+    const uint32_t base = blockIdx.x * (uint32_t)kSortTile;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kRsItems; ++i) {
+    for (int i = 0; i < kSortItems; ++i) {
         const uint32_t idx = base + (uint32_t)(i * kRsThreads + tid);
         if (idx < n) atomicAdd(&s_h[(keys[idx] >> shift) & mask], 1u);
     }
@@ -61,28 +68,29 @@ __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __re
     if (tid == 0) row_total[blockIdx.x] = s_carry;
 }
 
-template <int kBits, bool kAtomicRank>   // digit width (compile time; 0 = run-time width <= 8), ranking (common.h take_run_slot)
+template <int kBits, bool kAtomicRank, int kSortItems>   // digit width (compile time; 0 = run-time width <= 8), ranking (common.h take_run_slot), items per thread
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                 uint32_t n, int shift, int bits_rt, const uint32_t* __restrict__ hist,
                                                                 const uint32_t* __restrict__ row_total, int nblocks,
                                                                 const uint2* __restrict__ aux_src, uint2* __restrict__ aux_out) {
+    constexpr int kSortTile = kRsThreads * kSortItems;
     __shared__ uint32_t s_run[kRsThreads / 64][kRsMaxBins];    // items of digit b held by wave w; then, in place, the next block-local slot for (wave, digit)
     __shared__ uint32_t s_lstart[kRsMaxBins];                  // block-local start of digit b
     __shared__ uint32_t s_gbase[kRsMaxBins];                   // global position of the block's first item of digit b
     __shared__ uint32_t s_wsum[kRsThreads / 64];
-    __shared__ uint32_t s_key[kRsTile], s_val[kRsTile];        // the tile, stably reordered by digit
+    __shared__ uint32_t s_key[kSortTile], s_val[kSortTile];        // the tile, stably reordered by digit
     const int bits = kBits ? kBits : bits_rt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, bins = 1 << bits;
     const uint32_t mask = (uint32_t)bins - 1u;
     for (int b = tid; b < (kRsThreads / 64) * kRsMaxBins; b += kRsThreads) (&s_run[0][0])[b] = 0;
     __syncthreads();
     // wave w owns items [wbase, wbase + 512), 64 at a time in order -> stable
-    const uint32_t tile_base = blockIdx.x * (uint32_t)kRsTile;
-    const uint32_t wbase = tile_base + (uint32_t)w * (64 * kRsItems);
-    uint32_t key[kRsItems], val[kRsItems];
+    const uint32_t tile_base = blockIdx.x * (uint32_t)kSortTile;
+    const uint32_t wbase = tile_base + (uint32_t)w * (64 * kSortItems);
+    uint32_t key[kSortItems], val[kSortItems];
 #pragma unroll
-    for (int i = 0; i < kRsItems; ++i) {
+    for (int i = 0; i < kSortItems; ++i) {
         const uint32_t idx = wbase + (uint32_t)(i * 64 + lane);
         key[i] = 0; val[i] = 0;
         if (idx < n) {
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kRsItems; ++i) {
+    for (int i = 0; i < kSortItems; ++i) {
         const uint32_t idx = wbase + (uint32_t)(i * 64 + lane);
         const bool live = idx < n;
         const uint32_t d = (key[i] >> shift) & mask;
@@ -133,9 +141,9 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     }
     __syncthreads();
     // coalesced write-out: consecutive local slots of one digit are consecutive in global memory
-    const uint32_t count = min((uint32_t)kRsTile, n - tile_base);
+    const uint32_t count = min((uint32_t)kSortTile, n - tile_base);
 #pragma unroll
-    for (int i = 0; i < kRsItems; ++i) {
+    for (int i = 0; i < kSortItems; ++i) {
         const uint32_t li = (uint32_t)(i * kRsThreads + tid);
         if (li < count) {
             const uint32_t k = s_key[li];
@@ -275,7 +283,8 @@ hipError_t lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t n,
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static inline int rs_blocks(uint32_t n) { return (int)((n + kRsTile - 1) / kRsTile); }
+static inline int rs_blocks(uint32_t n, int items = kRsItems) { return (int)((n + (uint32_t)(kRsThreads * items) - 1) / (uint32_t)(kRsThreads * items)); }
+static inline int scan_blocks(uint32_t n) { return (int)((n + kRsTile - 1) / kRsTile); }
 
 // scratch: ping-pong (keys, vals) + histogram table + row totals
 size_t radix_sort_temp_bytes(uint32_t n) {
@@ -293,11 +302,11 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
     int passes = (total_bits + 7) / 8;
     if (passes < 1) passes = 1;
     if (passes & 1) ++passes;   // even pass count: the ping-pong ends in keys_out/vals_out (an extra pass on zero bits is a stable copy)
-    const int nb = rs_blocks(n);
+    const int nb8 = rs_blocks(n);
     char* t = static_cast<char*>(temp);
     uint32_t* tk = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)n * 4, 256);
     uint32_t* tv = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)n * 4, 256);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)nb * kRsMaxBins * 4, 256);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)nb8 * kRsMaxBins * 4, 256);
     uint32_t* row_total = reinterpret_cast<uint32_t*>(t);
     const uint32_t* ki = keys_in; const uint32_t* vi = vals_in;
     int shift = 0, left = total_bits;
@@ -309,16 +318,19 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         const bool last = p == passes - 1;
         uint32_t* ko = (p & 1) ? keys_out : tk;
         uint32_t* vo = (p & 1) ? vals_out : tv;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
+        const bool big = bits == 8 && n >= kSortBigFrom;
+        const int nb = big ? rs_blocks(n, kSortItemsBig) : nb8;
+        if (big) hipLaunchKernelGGL(rs_hist_kernel<kSortItemsBig>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
+        else hipLaunchKernelGGL(rs_hist_kernel<kRsItems>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
-#define SR_SCATTER_R(B, A) hipLaunchKernelGGL((rs_scatter_kernel<B, A>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
-                                              row_total, nb, last ? aux_src : nullptr, last ? aux_out : nullptr)
-#define SR_SCATTER(B) do { if (rank_mode == kRankAtomic) SR_SCATTER_R(B, true); else SR_SCATTER_R(B, false); } while (0)
+#define SR_SCATTER_R(B, A, I) hipLaunchKernelGGL((rs_scatter_kernel<B, A, I>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
+                                                 row_total, nb, last ? aux_src : nullptr, last ? aux_out : nullptr)
+#define SR_SCATTER(B, I) do { if (rank_mode == kRankAtomic) SR_SCATTER_R(B, true, I); else SR_SCATTER_R(B, false, I); } while (0)
         switch (bits) {
-            case 8: SR_SCATTER(8); break;
-            case 7: SR_SCATTER(7); break;
-            case 6: SR_SCATTER(6); break;
-            default: SR_SCATTER(0); break;
+            case 8: if (big) SR_SCATTER(8, kSortItemsBig); else SR_SCATTER(8, kRsItems); break;
+            case 7: SR_SCATTER(7, kRsItems); break;
+            case 6: SR_SCATTER(6, kRsItems); break;
+            default: SR_SCATTER(0, kRsItems); break;
         }
 #undef SR_SCATTER
 #undef SR_SCATTER_R
@@ -328,14 +340,14 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
     return hipGetLastError();
 }
 
-size_t tile_count_scan_temp_bytes(uint32_t n) { return align_up(((size_t)rs_blocks(n > 0 ? n : 1) + 1) * 4, 256); }
+size_t tile_count_scan_temp_bytes(uint32_t n) { return align_up(((size_t)scan_blocks(n > 0 ? n : 1) + 1) * 4, 256); }
 
 // out[i] = exclusive scan of counts INSIDE block i / 2048; block_base[b] = exclusive scan of the block totals,
 // block_base[nblocks] = total.  (block_base lives in `temp`.)
 hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (temp_bytes < tile_count_scan_temp_bytes(n)) return hipErrorInvalidValue;
-    const int nb = rs_blocks(n);
+    const int nb = scan_blocks(n);
     uint32_t* totals = static_cast<uint32_t*>(temp);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(kRsThreads), 0, s, counts, n, out, totals);
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kRsThreads), 0, s, totals, nb);

@@ -2,8 +2,8 @@
 # (ab/ is git-ignored but travels with gpurun), then: gpurun -- 'bash tools/ab_bench.sh [bench args]'
 L=streetunveiler_amd/lib/libsurfel_raster.so
 cp $L /tmp/lib_keep.so
-for r in 1 2; do for v in A B; do
+for r in 1 2; do for v in ${AB_VARIANTS:-A B}; do
   cp ab/lib$v.so $L
-  timeout 150 python bench.py --no-cpu-baseline "$@" | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], d['stage_ms'])"
+  timeout 150 python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], {k: round(x, 4) for k, x in d['stage_ms'].items()})"
 done; done
 cp /tmp/lib_keep.so $L
