@@ -306,10 +306,10 @@ def main():
         step()
     sync()
     exchange_log.update(ms=0.0, bytes=0, calls=0, early_starts=0)
-    # Timed region: HIP events around the two blend kernels only (the roofline kernels; a pair of events costs a few
-    # microseconds of stream time, all nine stages would add ~1.4 % to the step).  The other stages are timed right after
-    # the timed region, on extra untimed steps.
-    blend_mask = (1 << list(_lib.SR_STAGE_NAMES).index("blend_fwd")) | (1 << list(_lib.SR_STAGE_NAMES).index("blend_bwd"))
+    # Timed region: HIP events (recorded by the library on the launch stream) around the DOMINANT kernel only -- the blend backward,
+    # the kernel of `roofline` -- because every event record costs ~5 us of stream time (tools/step_timeline.py: bracketing both blend
+    # kernels cost 30 us per step, all nine stages ~1.4 %).  Every other stage is timed right after the timed region, on extra steps.
+    blend_mask = 1 << list(_lib.SR_STAGE_NAMES).index("blend_bwd")
     lib.sr_set_stage_timing(2 * blend_mask)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()

@@ -26,7 +26,8 @@ size_t expand_x_hist_bytes(int P, int tiles_x);
 size_t expand_y_hist_bytes(uint32_t D, int tiles_y);
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, uint32_t* sorted_keys,
                           uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, int rank_mode, hipStream_t s);
-hipError_t run_tile_count_scan(int P, const uint32_t* tiles_touched, uint32_t* first, void* block_base, size_t base_bytes, hipStream_t s);
+hipError_t run_tile_count_scan(int P, const uint32_t* tiles_touched, uint32_t* first, void* block_base, size_t base_bytes, uint32_t* total_host,
+                               hipStream_t s);
 hipError_t run_expand_columns(int P, int tiles_x, int n_tiles, const uint2* rect_sorted, const uint32_t* sorted_gid, uint2* columns,
                               uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, int rank_mode, hipStream_t s);
 hipError_t run_expand_rows(uint32_t D, int tiles_x, int tiles_y, const uint2* columns, const uint32_t* n_columns, uint32_t* hist, uint32_t* row_total,
@@ -98,6 +99,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr int kEvRing = 512;
 struct EvRing {
     hipEvent_t ev[kEvRing][2];
+    bool closed[kEvRing];   // the end event of the slot has been recorded (a reader skips a pair whose timer is still open)
     int created = 0, used = 0;
 };
 EvRing g_ring[SR_STAGE_COUNT];
@@ -115,13 +117,13 @@ struct StageTimer {
             ++r.created;
         }
         slot = r.used++;   // reserved here: a timer started meanwhile on another thread (autograd's backward) gets the next one
-        (void)hipEventRecord(r.ev[slot][0], s);
-        (void)hipEventRecord(r.ev[slot][1], s);   // placeholder end, so that a reader never meets a never-recorded event
+        r.closed[slot] = false;
+        (void)hipEventRecord(r.ev[slot][0], s);   // (two records per stage: each costs ~5 us of stream time)
     }
     ~StageTimer() {
         if (slot < 0) return;
         std::lock_guard<std::mutex> lk(g_ring_mu);
-        (void)hipEventRecord(g_ring[stage].ev[slot][1], s);
+        if (hipEventRecord(g_ring[stage].ev[slot][1], s) == hipSuccess) g_ring[stage].closed[slot] = true;
     }
 };
 
@@ -353,19 +355,23 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
                                          at<uint32_t>(geom, L.tiles_touched), at<uint2>(geom, L.rect), at<uint8_t>(geom, L.clamped), radii, s));
     }
     if (int rc = debug_sync(frame, s, "preprocess_forward")) return rc;
-    {
-        StageTimer t(SR_STAGE_SCAN, s);
-        SR_HIP(run_tile_count_scan(P, at<uint32_t>(geom, L.tiles_touched), at<uint32_t>(geom, L.first), at<void>(geom, L.block_base),
-                                   L.base_bytes, s));
-    }
-    if (int rc = debug_sync(frame, s, "emission_scan")) return rc;
-    // the one host read-back of the forward (the reference does the same between scan and duplicateWithKeys)
-    // through a pinned word (one block per host thread; with one event per (thread, device) the only things this library keeps): a DMA
-    // copy instead of the staged pageable path.  The depth sort is queued BEHIND the copy and the host waits for the copy only, so the GPU sorts
-    // while the caller wakes up, sizes the binning buffer from D and queues the second phase.
+    // D, the scan's grand total, is the one word the host reads back (the reference does the same between scan and duplicateWithKeys).
+    // It travels through a pinned host word (one block per host thread; with one event per (thread, device) the only things this library
+    // keeps): the last scan kernel stores it there itself when the word is mapped into the device's address space -- no copy kernel
+    // between the scan and the host's wake-up -- else a DMA copy does.
     int sort_mode = kRankUnknown;
     if (int rc = rank_mode(s, (frame->flags & SR_FLAG_BALLOT_RANKING) != 0, &sort_mode)) return rc;   // (first call on a device: ~20 us self-check)
     uint32_t* pinned = pinned_words();
+    uint32_t* pinned_dev = nullptr;
+    if (pinned && (hipHostGetDevicePointer(reinterpret_cast<void**>(&pinned_dev), pinned, 0) != hipSuccess)) pinned_dev = nullptr;
+    {
+        StageTimer t(SR_STAGE_SCAN, s);
+        SR_HIP(run_tile_count_scan(P, at<uint32_t>(geom, L.tiles_touched), at<uint32_t>(geom, L.first), at<void>(geom, L.block_base),
+                                   L.base_bytes, pinned_dev, s));
+    }
+    if (int rc = debug_sync(frame, s, "emission_scan")) return rc;
+    // The depth sort is queued BEHIND the read-back and the host waits for the read-back only, so the GPU sorts while the caller wakes
+    // up, sizes the binning buffer from D and queues the second phase.
     static thread_local hipEvent_t copied_ev[kMaxDevices] = {};   // one marker per (calling thread, device): an event belongs to its device
     int dev = 0;
     SR_HIP(hipGetDevice(&dev));
@@ -374,8 +380,10 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
         if (!copied_ev[dev] && hipEventCreateWithFlags(&copied_ev[dev], hipEventDisableTiming) != hipSuccess) copied_ev[dev] = nullptr;
         copied = copied_ev[dev];
     }
-    uint32_t* dst = pinned ? pinned : num_rendered_host;
-    SR_HIP(hipMemcpyAsync(dst, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks, 4, hipMemcpyDeviceToHost, s));   // the scan's grand total
+    if (!pinned_dev) {
+        uint32_t* dst = pinned ? pinned : num_rendered_host;
+        SR_HIP(hipMemcpyAsync(dst, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks, 4, hipMemcpyDeviceToHost, s));   // the scan's grand total
+    }
     if (copied && pinned && hipEventRecord(copied, s) != hipSuccess) copied = nullptr;   // (then: wait for the stream instead)
     {
         StageTimer t(SR_STAGE_DEPTH_SORT, s);
@@ -385,7 +393,7 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     if (int rc = debug_sync(frame, s, "depth_sort")) return rc;
     if (copied && pinned) SR_HIP(hipEventSynchronize(copied));
     else SR_HIP(hipStreamSynchronize(s));
-    if (pinned) *num_rendered_host = *pinned;
+    if (pinned) *num_rendered_host = *reinterpret_cast<volatile uint32_t*>(pinned);
     return SR_OK;
 }
 
@@ -750,14 +758,17 @@ int sr_stage_stats(int stage, float* total_ms, int* launches) {
     std::lock_guard<std::mutex> lk(g_ring_mu);
     EvRing& r = g_ring[stage];
     float sum = 0.f;
+    int done = 0;
     for (int i = 0; i < r.used; ++i) {
+        if (!r.closed[i]) continue;
+        ++done;
         float ms = 0.f;
         SR_HIP(hipEventSynchronize(r.ev[i][1]));
         SR_HIP(hipEventElapsedTime(&ms, r.ev[i][0], r.ev[i][1]));
         sum += ms;
     }
     *total_ms = sum;
-    *launches = r.used;
+    *launches = done;
     return SR_OK;
 }
 

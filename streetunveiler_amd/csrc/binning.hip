@@ -21,7 +21,7 @@ size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode);
 size_t tile_count_scan_temp_bytes(uint32_t n);
-hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, uint32_t* total_host, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // K3 + K4: the "expanding partition".  The final list is ordered by (tile row, tile column, depth rank), so an LSD partition runs
@@ -435,9 +435,10 @@ hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, 
 }
 
 // K2: emission offsets = scan of tiles_touched in id order (block-local values in first, block bases + total D in block_base).
-hipError_t run_tile_count_scan(int P, const uint32_t* tiles_touched, uint32_t* first, void* block_base, size_t base_bytes, hipStream_t s) {
+hipError_t run_tile_count_scan(int P, const uint32_t* tiles_touched, uint32_t* first, void* block_base, size_t base_bytes, uint32_t* total_host,
+                               hipStream_t s) {
     if (P == 0) return hipSuccess;
-    return tile_count_scan(tiles_touched, first, (uint32_t)P, block_base, base_bytes, s);
+    return tile_count_scan(tiles_touched, first, (uint32_t)P, block_base, base_bytes, total_host, s);
 }
 
 template <int AXIS, bool kAtomicRank, typename... Args>

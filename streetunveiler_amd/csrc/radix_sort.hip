@@ -197,8 +197,9 @@ __global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t*
     if (tid == kRsThreads - 1) block_total[blockIdx.x] = off + sum;
 }
 
-__global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __restrict__ block_total, int nblocks) {
-    // exclusive scan in place, one block, sequential over chunks of 256; block_total[nblocks] = grand total
+__global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __restrict__ block_total, int nblocks, uint32_t* __restrict__ total_host) {
+    // exclusive scan in place, one block, sequential over chunks of 256; block_total[nblocks] = grand total (also stored straight into
+    // the caller's pinned host word when one is given: no copy kernel between this one and the host's wake-up)
     __shared__ uint32_t s_w[kRsThreads / 64];
     __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __res
         if (tid == kRsThreads - 1) s_carry = carry + wb + incl;
         __syncthreads();
     }
-    if (tid == 0) block_total[nblocks] = s_carry;
+    if (tid == 0) { block_total[nblocks] = s_carry; if (total_host) *total_host = s_carry; }
 }
 
 // Run-time guard of the rank phase (api.hip rank_mode, once per device): 256 rounds of 64 items per wave with alphabets from 1 to 1000
@@ -344,13 +345,13 @@ size_t tile_count_scan_temp_bytes(uint32_t n) { return align_up(((size_t)scan_bl
 
 // out[i] = exclusive scan of counts INSIDE block i / 2048; block_base[b] = exclusive scan of the block totals,
 // block_base[nblocks] = total.  (block_base lives in `temp`.)
-hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s) {
+hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, uint32_t* total_host, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (temp_bytes < tile_count_scan_temp_bytes(n)) return hipErrorInvalidValue;
     const int nb = scan_blocks(n);
     uint32_t* totals = static_cast<uint32_t*>(temp);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(kRsThreads), 0, s, counts, n, out, totals);
-    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kRsThreads), 0, s, totals, nb);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kRsThreads), 0, s, totals, nb, total_host);
     return hipGetLastError();
 }
 
