@@ -259,14 +259,16 @@ def main():
     del radii0
 
     # what the blend kernels execute on this scene (device counters of one forward, outside the timed region)
-    counters = torch.zeros(8, dtype=torch.int64, device=dev)
+    counters = torch.zeros(16, dtype=torch.int64, device=dev)
     with torch.no_grad():
         GaussianRasterizer(settings, blend_counters=counters)(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
                                                               opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
     torch.cuda.synchronize()
     st = counters.tolist()
     blend_counts = {"staged_entries_D_eff": int(st[0]), "entries_after_quadrant_cull": int(st[1]), "quadrant_tests": int(st[2]),
-                    "quadrant_tests_with_a_hit": int(st[3]), "contributing_pairs": int(st[4]), "entries_with_a_hit": int(st[7])}
+                    "quadrant_tests_with_a_hit": int(st[3]), "contributing_pairs": int(st[4]), "entries_with_a_hit": int(st[7]),
+                    "cell_pairs_4x4": int(st[8]), "row_mapping_steps": int(st[9]),
+                    "cell_pairs_4x4_octagon_culling": int(st[10]), "row_mapping_steps_octagon_culling": int(st[11])}
 
     def sync():
         if multi:

@@ -80,11 +80,14 @@ typedef struct SrFrame {
                                * 9-channel passes (SrGaussians.color_channels) and the counter variant exist for 16x16 only */
     int32_t tile_height;      /* 0 = 16 (BLOCK_Y).  Same shape in every call that shares the state buffers */
     uint32_t flags;           /* SR_FLAG_* bits; per call, nothing about a call is process-wide state */
-    uint64_t* blend_counters; /* NULL, or device [8] u64 owned by the caller: selects the COUNTING variant of the forward blend (same
+    uint64_t* blend_counters; /* NULL, or device [16] u64 owned by the caller: selects the COUNTING variant of the forward blend (same
                                * results, slow), which adds to [0] list entries staged, [1] entries kept by the quadrant culling,
                                * [2] (entry, quadrant) tests run, [3] tests with >= 1 contributing pixel, [4] contributing (pixel, entry)
                                * pairs, [5] / [6] tests with a contributing pixel in rows 0-3 / rows 4-7 of the quadrant, [7] entries with a
-                               * contributing pixel anywhere in the tile (= the gradient records the backward writes).  16x16 tile with
+                               * contributing pixel anywhere in the tile (= the gradient records the backward writes), [8] (entry, 4x4 cell) pairs
+                               * with a contributing pixel, [9] the wave steps a 16-lane-row mapping would take (sum over rounds of 64
+                               * entries and quadrants of the busiest cell's pair count), [10] / [11] the same two counting the pairs an octagon-vs-cell
+                               * culling at staging would keep (hits and misses); [12..15] reserved.  16x16 tile with
                                * 3 or 6 colour channels; any other request returns SR_ERR_UNSUPPORTED (never silent zeros) */
 } SrFrame;
 #define SR_FLAG_NO_QUADRANT_CULL 1u  /* forward blend: run every list entry against every 8x8 quadrant instead of dropping entries that

@@ -13,9 +13,11 @@ constexpr float kFN = kFar / (kFar - kNear);
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// counters of the K6 counter variant (SrFrame.blend_counters, caller-owned, 8 x u64): [0] entries staged, [1] entries with a
+// counters of the K6 counter variant (SrFrame.blend_counters, caller-owned, 16 x u64; [12..15] unused): [0] entries staged, [1] entries with a
 // non-zero quadrant mask, [2] quadrant tests executed, [3] quadrant tests with >= 1 valid lane, [4] valid (pixel, entry) pairs,
-// [5] / [6] tests with a valid pixel in rows 0-3 / rows 4-7 of the quadrant, [7] entries with a valid pixel anywhere in the tile
+// [5] / [6] tests with a valid pixel in rows 0-3 / rows 4-7 of the quadrant, [7] entries with a valid pixel anywhere in the tile,
+// [8] (entry, 4x4 cell) pairs with a valid pixel, [9] sum over (round of 64 entries, quadrant) of the busiest cell's pair count,
+// [10] / [11] the same two with the pairs an octagon-vs-cell culling at staging would KEEP (hits and misses) instead of the exact hits
 
 // ---------------------------------------------------------------------------------------------
 // Quadrant culling.  A list entry can only contribute to a pixel if alpha = min(0.99, opacity*G) >= 1/255,
@@ -29,15 +31,15 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // anything is degenerate or NaN.  Inputs are tile-local (origin at
 // the tile centre), which keeps the conic free of cancellation.
 // ---------------------------------------------------------------------------------------------
-template <int QX, int QY>
-__device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my,
-                                                  float opacity, float yshift) {
-    constexpr uint32_t kAll = (1u << (QX * QY)) - 1u;
+// octagon of the entry's footprint in tile-local coordinates: lo / hi of x, y, x + y, x - y.  Returns 0 = empty footprint, 2 = unbounded
+// (the cutoff disc reaches the camera plane, or something is degenerate: keep the entry everywhere), 1 = bounds valid.
+__device__ __forceinline__ int octagon_bounds(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my, float opacity,
+                                              float (&lo)[4], float (&hi)[4]) {
     float thr = 2.f * __logf(255.f * opacity);
     thr = thr * 1.01f + 0.01f;
-    if (thr <= 0.f) return 0u;
+    if (thr <= 0.f) return 0;
     const float c22 = thr * (Tw[0] * Tw[0] + Tw[1] * Tw[1]) - Tw[2] * Tw[2];
-    if (!(c22 < 0.f)) return kAll;  // the cutoff disc reaches the camera plane: unbounded footprint
+    if (!(c22 < 0.f)) return 2;  // the cutoff disc reaches the camera plane: unbounded footprint
     const float c00 = thr * (Tu[0] * Tu[0] + Tu[1] * Tu[1]) - Tu[2] * Tu[2];
     const float c01 = thr * (Tu[0] * Tv[0] + Tu[1] * Tv[1]) - Tu[2] * Tv[2];
     const float c11 = thr * (Tv[0] * Tv[0] + Tv[1] * Tv[1]) - Tv[2] * Tv[2];
@@ -45,7 +47,6 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
     const float c12 = thr * (Tv[0] * Tw[0] + Tv[1] * Tw[1]) - Tv[2] * Tw[2];
     const float inv = fast_rcp(c22);
     const float r = __builtin_amdgcn_sqrtf(0.5f * thr);
-    float lo[4], hi[4];
     const float QA[4] = {c00, c11, c00 + 2.f * c01 + c11, c00 - 2.f * c01 + c11};
     const float QB[4] = {c02, c12, c02 + c12, c02 - c12};
     const float ctr[4] = {mx, my, mx + my, mx - my};
@@ -58,19 +59,46 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
         lo[d] = fminf(dc - half, ctr[d] - rad[d]);
         hi[d] = fmaxf(dc + half, ctr[d] + rad[d]);
     }
+    return 1;
+}
+// does the octagon reach the pixel-centre rectangle [x0, x1] x [y0, y1] (0.3 px of slack for float rounding)?
+__device__ __forceinline__ bool octagon_reaches(const float (&lo)[4], const float (&hi)[4], float x0, float x1, float y0, float y1) {
+    const float m = 0.3f;
+    x0 -= m; y0 -= m; x1 += m; y1 += m;
+    return !(lo[0] > x1 || hi[0] < x0 || lo[1] > y1 || hi[1] < y0 || lo[2] > x1 + y1 || hi[2] < x0 + y0 || lo[3] > x1 - y0 || hi[3] < x0 - y1);
+}
+
+template <int QX, int QY>
+__device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my,
+                                                  float opacity, float yshift) {
+    constexpr uint32_t kAll = (1u << (QX * QY)) - 1u;
+    float lo[4], hi[4];
+    const int kind = octagon_bounds(Tu, Tv, Tw, mx, my, opacity, lo, hi);
+    if (kind != 1) return kind ? kAll : 0u;
     // the wave's quadrants sit `yshift` below the local origin: shift the bounds instead of the (compile-time) rectangles
     lo[1] -= yshift; hi[1] -= yshift; lo[2] -= yshift; hi[2] -= yshift; lo[3] += yshift; hi[3] += yshift;
-    const float m = 0.3f;
     uint32_t mask = 0;
 #pragma unroll
     for (int q = 0; q < QX * QY; ++q) {   // quadrant (q % QX, q / QX) of the tile, coordinates relative to the tile centre
-        const float x0 = (float)((q % QX) * 8 - QX * 4) - m, x1 = (float)((q % QX) * 8 - QX * 4 + 7) + m;
-        const float y0 = (float)((q / QX) * 8 - QY * 4) - m, y1 = (float)((q / QX) * 8 - QY * 4 + 7) + m;
-        const bool out = lo[0] > x1 || hi[0] < x0 || lo[1] > y1 || hi[1] < y0 || lo[2] > x1 + y1 || hi[2] < x0 + y0 ||
-                         lo[3] > x1 - y0 || hi[3] < x0 - y1;
-        if (out) continue;
-        mask |= 1u << q;
+        const float x0 = (float)((q % QX) * 8 - QX * 4), y0 = (float)((q / QX) * 8 - QY * 4);
+        if (octagon_reaches(lo, hi, x0, x0 + 7.f, y0, y0 + 7.f)) mask |= 1u << q;
     }
+    return mask;
+}
+// (counter variant only) the same test against the sixteen 4x4 cells of a 16x16 tile: bit 4 q + c = cell c of quadrant q, cell c at
+// (c & 1, c >> 1) inside its quadrant
+__device__ __forceinline__ uint32_t cell_mask16(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my, float opacity) {
+    float lo[4], hi[4];
+    const int kind = octagon_bounds(Tu, Tv, Tw, mx, my, opacity, lo, hi);
+    if (kind != 1) return kind ? 0xFFFFu : 0u;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float x0 = (float)((q % 2) * 8 + (c & 1) * 4 - 8), y0 = (float)((q / 2) * 8 + (c >> 1) * 4 - 8);
+            if (octagon_reaches(lo, hi, x0, x0 + 3.f, y0, y0 + 3.f)) mask |= 1u << (4 * q + c);
+        }
     return mask;
 }
 
@@ -92,7 +120,7 @@ __device__ __forceinline__ float4 load_extra(const float* __restrict__ colors6, 
 
 template <int QX, int QY, int NC>
 __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], const float4 ex, const float4 ey, float Xc, float Yc, int cull,
-                                                float4 (*s_e)[kWave], int slot, float yshift = 0.f) {
+                                                float4 (*s_e)[kWave], int slot, float yshift = 0.f, uint32_t* cells16 = nullptr) {
     const float Tw[3] = {q[1].z, q[1].w, q[2].x};
     const float Tu[3] = {q[0].x - Xc * Tw[0], q[0].y - Xc * Tw[1], q[0].z - Xc * Tw[2]};
     const float Tv[3] = {q[0].w - Yc * Tw[0], q[1].x - Yc * Tw[1], q[1].y - Yc * Tw[2]};
@@ -107,6 +135,7 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], co
     s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[4].x);
     s_e[5][slot] = make_float4(q[4].y, q[4].z, ex.x, ex.y);
     if (NC == 9) s_e[6][slot] = make_float4(ey.x, ey.y, ey.z, 0.f);
+    if (cells16) *cells16 = cell_mask16(Tu, Tv, Tw, mx, my, opacity);   // (counter variant: what a 4x4-cell culling would keep)
     return cull ? quadrant_mask<QX, QY>(Tu, Tv, Tw, mx, my, opacity, yshift) : (1u << (QX * QY)) - 1u;
 }
 

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __res
     if (tid == 0) { block_total[nblocks] = s_carry; if (total_host) *total_host = s_carry; }
 }
 
-// Run-time guard of the rank phase (api.hip rank_mode, once per device): 256 rounds of 64 items per wave with alphabets from 1 to 1000
+// Run-time guard of the rank phase (api.hip rank_mode, once per device): 64 rounds of 64 items per wave with alphabets from 1 to 1000
 // digits, ranked three ways on running counters -- by LDS atomic returns, by the match-any ballots, and by plain LDS loads / stores
 // (every lane counts the lower lanes holding its digit; the reference).  *result: bit 0 = the atomic returns are the stable ranks,
 // bit 1 = the ballot ranks are.
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kRsThreads) void rank_selfcheck_kernel(uint32_t* __
     if (tid == 0) s_ok = 3u;
     __syncthreads();
     uint32_t ok = 3u;
-    for (int round = 0; round < 256; ++round) {
+    for (int round = 0; round < 64; ++round) {
         const uint32_t alphabets[8] = {1u, 2u, 3u, 16u, 64u, 256u, 700u, 1000u};
         const uint32_t bins = alphabets[round & 7];
         uint32_t h = (uint32_t)(round * 64 + lane) * 2654435761u + (uint32_t)w * 40503u;

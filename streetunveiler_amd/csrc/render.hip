@@ -98,18 +98,23 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats &
         uint32_t m = 0;
         int ys = yshift_px;
         asm volatile("" : "+s"(ys));   // converted again in every round: one v_cvt per 64 entries instead of a register held across the walk
-        if ((uint32_t)lane < n) m = stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, cull & 1, s_e, lane, (float)ys);
+        uint32_t cells16 = 0;
+        if ((uint32_t)lane < n) m = stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, cull & 1, s_e, lane, (float)ys, kStats && QX == 2 && QY == 2 ? &cells16 : nullptr);
         if (base + kWave + lane < n_total) {
             const uint32_t gid = point_list[range.x + base + kWave + lane];
             load_record(recs, gid, nr);
             if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
         }
+        const uint32_t alive_at_round_start = alive;
         unsigned long long bits = ballot64((m & alive) != 0);
         if (kStats && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
         unsigned long long hit[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) hit[q] = 0ull;  // scalar: bit j of hit[q] = entry j reached a pixel of quadrant q
+        uint32_t cell_round[NQ][4];   // (counter variant) entries of this round with a valid pixel in 4x4 cell c of quadrant q
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { cell_round[q][0] = cell_round[q][1] = cell_round[q][2] = cell_round[q][3] = 0u; }
         while (bits) {
             const int j = __ffsll((long long)bits) - 1;
             bits &= bits - 1;
@@ -126,6 +131,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats &
                     const unsigned long long vb = ballot64(valid);
                     if (lane == 0) { atomicAdd(&g_stats[2], 1ull); if (vb) atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)__popcll(vb));
                                      if (vb & 0xFFFFFFFFull) atomicAdd(&g_stats[5], 1ull); if (vb >> 32) atomicAdd(&g_stats[6], 1ull); }
+                    // bit of pixel (x, y) of the quadrant = 8 y + x: the four 4x4 cells
+                    cell_round[q][0] += (vb & 0x000000000F0F0F0Full) != 0; cell_round[q][1] += (vb & 0x00000000F0F0F0F0ull) != 0;
+                    cell_round[q][2] += (vb & 0x0F0F0F0F00000000ull) != 0; cell_round[q][3] += (vb & 0xF0F0F0F000000000ull) != 0;
                 }
                 if (ballot64(valid) == 0) continue;
                 hit[q] |= 1ull << j;
@@ -158,6 +166,29 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats &
 #pragma unroll
             for (int q = 0; q < NQ; ++q) any |= hit[q];
             atomicAdd(&g_stats[7], (unsigned long long)__popcll(any));
+            // what a mapping of 16-lane rows on independent entries (one 4x4 cell per row, four rows = one quadrant per wave, exact
+            // cell culling) would execute for this round of 64 entries: the busiest row of every quadrant sets its wave's step count
+            unsigned long long cells = 0ull, steps = 0ull;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                cells += cell_round[q][0] + cell_round[q][1] + cell_round[q][2] + cell_round[q][3];
+                steps += max(max(cell_round[q][0], cell_round[q][1]), max(cell_round[q][2], cell_round[q][3]));
+            }
+            atomicAdd(&g_stats[8], cells); atomicAdd(&g_stats[9], steps);
+        }
+        if (kStats && NQ == 4) {   // ... and with the (entry, cell) pairs a conservative octagon-vs-cell test at staging would hand to the rows
+            unsigned long long kept = 0ull, steps = 0ull;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t busiest = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t k = (uint32_t)__popcll(ballot64(((cells16 >> (4 * q + c)) & 1u) != 0u && ((m >> q) & 1u) != 0u && ((alive_at_round_start >> q) & 1u) != 0u));
+                    kept += k; busiest = max(busiest, k);
+                }
+                steps += busiest;
+            }
+            if (lane == 0) { atomicAdd(&g_stats[10], kept); atomicAdd(&g_stats[11], steps); }
         }
         // exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel here
         if ((uint32_t)lane < n) {

@@ -13,7 +13,7 @@ cam = synthetic_camera(W, H); g = {k: v.to(dev) for k, v in synthetic_gaussians(
 s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3, device=dev), 1.0,
                                   cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 3, cam.camera_center.to(dev), False, False)
 for cull in (True, False):
-    out = torch.zeros(8, dtype=torch.int64, device=dev)
+    out = torch.zeros(16, dtype=torch.int64, device=dev)
     GaussianRasterizer(s, quadrant_cull=cull, blend_counters=out)(means3D=g["means3D"], means2D=torch.zeros(P, 3, device=dev), shs=g["shs"], opacities=g["opacities"], scales=g["scales"], rotations=g["rotations"])
     torch.cuda.synchronize()
     st = out.tolist()
