@@ -268,7 +268,8 @@ def main():
     blend_counts = {"staged_entries_D_eff": int(st[0]), "entries_after_quadrant_cull": int(st[1]), "quadrant_tests": int(st[2]),
                     "quadrant_tests_with_a_hit": int(st[3]), "contributing_pairs": int(st[4]), "entries_with_a_hit": int(st[7]),
                     "cell_pairs_4x4": int(st[8]), "row_mapping_steps": int(st[9]),
-                    "cell_pairs_4x4_octagon_culling": int(st[10]), "row_mapping_steps_octagon_culling": int(st[11])}
+                    "cell_pairs_4x4_octagon_culling": int(st[10]), "row_mapping_steps_octagon_culling": int(st[11]),
+                    "cell_pairs_4x4_box_culling": int(st[12]), "row_mapping_steps_box_culling": int(st[13]), "box_culling_dropped_hits": int(st[14])}
 
     def sync():
         if multi:

@@ -13,11 +13,12 @@ constexpr float kFN = kFar / (kFar - kNear);
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// counters of the K6 counter variant (SrFrame.blend_counters, caller-owned, 16 x u64; [12..15] unused): [0] entries staged, [1] entries with a
+// counters of the K6 counter variant (SrFrame.blend_counters, caller-owned, 16 x u64): [0] entries staged, [1] entries with a
 // non-zero quadrant mask, [2] quadrant tests executed, [3] quadrant tests with >= 1 valid lane, [4] valid (pixel, entry) pairs,
 // [5] / [6] tests with a valid pixel in rows 0-3 / rows 4-7 of the quadrant, [7] entries with a valid pixel anywhere in the tile,
 // [8] (entry, 4x4 cell) pairs with a valid pixel, [9] sum over (round of 64 entries, quadrant) of the busiest cell's pair count,
-// [10] / [11] the same two with the pairs an octagon-vs-cell culling at staging would KEEP (hits and misses) instead of the exact hits
+// [10] / [11] the same two with the pairs an octagon-vs-cell culling at staging would KEEP (hits and misses) instead of the exact hits,
+// [12] / [13] ... an octagon + oriented-box culling would keep, [14] exact (entry, cell) pairs that the oriented box would DROP (must be 0)
 
 // ---------------------------------------------------------------------------------------------
 // Quadrant culling.  A list entry can only contribute to a pixel if alpha = min(0.99, opacity*G) >= 1/255,
@@ -86,18 +87,46 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
     return mask;
 }
 // (counter variant only) the same test against the sixteen 4x4 cells of a 16x16 tile: bit 4 q + c = cell c of quadrant q, cell c at
-// (c & 1, c >> 1) inside its quadrant
+// (c & 1, c >> 1) inside its quadrant.  Bits 16..31: the same with two more slabs, along the principal axes of the footprint ellipse
+// (an oriented box around ellipse and filter disc): what a tighter -- still conservative -- cell culling would keep.
 __device__ __forceinline__ uint32_t cell_mask16(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my, float opacity) {
     float lo[4], hi[4];
     const int kind = octagon_bounds(Tu, Tv, Tw, mx, my, opacity, lo, hi);
-    if (kind != 1) return kind ? 0xFFFFu : 0u;
+    if (kind != 1) return kind ? 0xFFFFFFFFu : 0u;
+    // oriented box: centre c, axes u / v, half extents E1 / E2 (support of the ellipse {rho3d <= thr} = sqrt(d^T S d), S from the dual conic)
+    float thr = 2.f * __logf(255.f * opacity);
+    thr = thr * 1.01f + 0.01f;
+    const float c22 = thr * (Tw[0] * Tw[0] + Tw[1] * Tw[1]) - Tw[2] * Tw[2];
+    const float c00 = thr * (Tu[0] * Tu[0] + Tu[1] * Tu[1]) - Tu[2] * Tu[2];
+    const float c01 = thr * (Tu[0] * Tv[0] + Tu[1] * Tv[1]) - Tu[2] * Tv[2];
+    const float c11 = thr * (Tv[0] * Tv[0] + Tv[1] * Tv[1]) - Tv[2] * Tv[2];
+    const float c02 = thr * (Tu[0] * Tw[0] + Tu[1] * Tw[1]) - Tu[2] * Tw[2];
+    const float c12 = thr * (Tv[0] * Tw[0] + Tv[1] * Tw[1]) - Tv[2] * Tw[2];
+    const float inv = fast_rcp(c22), inv2 = inv * inv;
+    const float cx = c02 * inv, cy = c12 * inv;
+    const float sxx = (c02 * c02 - c22 * c00) * inv2, syy = (c12 * c12 - c22 * c11) * inv2, sxy = (c02 * c12 - c22 * c01) * inv2;
+    const float a = 0.5f * (sxx - syy), r = __builtin_amdgcn_sqrtf(a * a + sxy * sxy), mid = 0.5f * (sxx + syy);
+    float ux = a >= 0.f ? a + r : sxy, uy = a >= 0.f ? sxy : r - a;
+    const float ul = ux * ux + uy * uy;
+    const float un = ul > 0.f ? __builtin_amdgcn_rsqf(ul) : 0.f;
+    ux = ul > 0.f ? ux * un : 1.f; uy = ul > 0.f ? uy * un : 0.f;
+    const float rd = __builtin_amdgcn_sqrtf(0.5f * thr);
+    const float ox = mx - cx, oy = my - cy;
+    const float E1 = fmaxf(__builtin_amdgcn_sqrtf(fmaxf(mid + r, 0.f)) * 1.01f, fabsf(ox * ux + oy * uy) + rd);
+    const float E2 = fmaxf(__builtin_amdgcn_sqrtf(fmaxf(mid - r, 0.f)) * 1.01f, fabsf(oy * ux - ox * uy) + rd);
+    const bool box_ok = E1 == E1 && E2 == E2;   // anything degenerate: the box says nothing
     uint32_t mask = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float x0 = (float)((q % 2) * 8 + (c & 1) * 4 - 8), y0 = (float)((q / 2) * 8 + (c >> 1) * 4 - 8);
-            if (octagon_reaches(lo, hi, x0, x0 + 3.f, y0, y0 + 3.f)) mask |= 1u << (4 * q + c);
+            if (!octagon_reaches(lo, hi, x0, x0 + 3.f, y0, y0 + 3.f)) continue;
+            mask |= 1u << (4 * q + c);
+            const float rx = x0 + 1.5f - cx, ry = y0 + 1.5f - cy, h = 1.8f;
+            const float R = h * (fabsf(ux) + fabsf(uy));
+            const bool out = fabsf(rx * ux + ry * uy) > E1 + R || fabsf(ry * ux - rx * uy) > E2 + R;
+            if (!(box_ok && out)) mask |= 1u << (16 + 4 * q + c);
         }
     return mask;
 }

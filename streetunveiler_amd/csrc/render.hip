@@ -134,6 +134,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats &
                     // bit of pixel (x, y) of the quadrant = 8 y + x: the four 4x4 cells
                     cell_round[q][0] += (vb & 0x000000000F0F0F0Full) != 0; cell_round[q][1] += (vb & 0x00000000F0F0F0F0ull) != 0;
                     cell_round[q][2] += (vb & 0x0F0F0F0F00000000ull) != 0; cell_round[q][3] += (vb & 0xF0F0F0F000000000ull) != 0;
+                    if (NQ == 4) {   // is the oriented-box cell mask conservative?  an exact hit in a cell whose box bit is clear is counted in [14]
+                        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cells16, j) >> (16 + 4 * q);
+                        const uint32_t exact = ((vb & 0x000000000F0F0F0Full) != 0 ? 1u : 0u) | ((vb & 0x00000000F0F0F0F0ull) != 0 ? 2u : 0u) |
+                                               ((vb & 0x0F0F0F0F00000000ull) != 0 ? 4u : 0u) | ((vb & 0xF0F0F0F000000000ull) != 0 ? 8u : 0u);
+                        if (lane == 0 && (exact & ~cj & 15u)) atomicAdd(&g_stats[14], (unsigned long long)__popc(exact & ~cj & 15u));
+                    }
                 }
                 if (ballot64(valid) == 0) continue;
                 hit[q] |= 1ull << j;
@@ -189,6 +195,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats &
                 steps += busiest;
             }
             if (lane == 0) { atomicAdd(&g_stats[10], kept); atomicAdd(&g_stats[11], steps); }
+            kept = 0ull; steps = 0ull;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t busiest = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t k = (uint32_t)__popcll(ballot64(((cells16 >> (16 + 4 * q + c)) & 1u) != 0u && ((m >> q) & 1u) != 0u && ((alive_at_round_start >> q) & 1u) != 0u));
+                    kept += k; busiest = max(busiest, k);
+                }
+                steps += busiest;
+            }
+            if (lane == 0) { atomicAdd(&g_stats[12], kept); atomicAdd(&g_stats[13], steps); }
         }
         // exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel here
         if ((uint32_t)lane < n) {
