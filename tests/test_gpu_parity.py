@@ -540,3 +540,37 @@ def test_degenerate_parameters():
         assert np.isfinite(np.asarray(a)).all()
     _check_images(out, fwd, "degenerate")
     _check_grads(out, bwd, names, "degenerate")
+
+
+def test_wide_frame_with_few_gaussians_and_counter_variant_errors():
+    """(a) One Gaussian in a frame 750 tile columns wide: pass X's [columns][blocks] histogram lives in the geometry scratch, which is
+    sized for the widest frame the binning accepts (it used to be sized by P alone: BUFFER_TOO_SMALL for P = 1 beyond 640 columns).
+    (b) The counting variant of the forward blend exists for the 16x16 tile with 3 or 6 channels: any other request is refused with
+    SR_ERR_UNSUPPORTED instead of returning zeros that look like measurements."""
+    from streetunveiler_amd import _lib
+    from tests.gpu_util import DEV, run_hip_raw, run_oracle
+    from diff_surfel_rasterization import GaussianRasterizer
+    from tests.gpu_util import settings_for
+    W, H = 12000, 32
+    cam = synthetic_camera(W, H)
+    g = synthetic_gaussians(3, W, H, seed=2, scale_lo=1e-3, scale_hi=2e-3)
+    g = {k: v[:1].contiguous() for k, v in g.items()}
+    g["means3D"][0] = torch.tensor([0.0, 0.0, 5.0])
+    bg = np.zeros(3, np.float32)
+    fwd, _ = run_oracle(g, cam, bg, 3)
+    raw = run_hip_raw(g, cam, bg, 3)
+    assert raw["D"] == fwd["num_rendered"] and raw["D"] >= 1
+    np.testing.assert_array_equal(raw["bin"]["point_list"].view(np.uint32), fwd["point_list"])
+    np.testing.assert_array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])
+    np.testing.assert_allclose(raw["color"], fwd["color"], atol=1e-4)
+    # (b)
+    cam2, g2 = _scene(500, 96, 64, 3, 5e-3, 5e-2)
+    s = settings_for(cam2, [0, 0, 0], 1)
+    d = {k: v.to(DEV) for k, v in g2.items()}
+    counters = torch.zeros(16, dtype=torch.int64, device=DEV)
+    kw = dict(means3D=d["means3D"], means2D=torch.zeros(500, 3, device=DEV), shs=d["shs"], opacities=d["opacities"], scales=d["scales"], rotations=d["rotations"])
+    GaussianRasterizer(s, blend_counters=counters)(**kw)
+    torch.cuda.synchronize()
+    assert counters[0] > 0 and counters[7] <= counters[1] and counters[9] <= counters[8] <= counters[10]
+    with pytest.raises(_lib.SurfelRasterError, match="blend_counters"):
+        GaussianRasterizer(s, tile=(32, 16), blend_counters=counters)(**kw)
