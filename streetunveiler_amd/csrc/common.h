@@ -31,10 +31,11 @@ constexpr int kRecFloats = SR_SPLAT_FLOATS;
 
 // Gradient record written by the blend backward (one per (tile, Gaussian) duplicate, then summed per Gaussian),
 // 6 x float4 = 96 B.  The transMat gradient is kept in "moment" form: with dp = dL/dp of the ray-splat cross
-// product p = k x l at a pixel (x, y) (global pixel coordinates),
+// product p = k x l at a pixel (x, y) (pixel coordinates relative to the Gaussian's own centre (cx, cy): round 3),
 //   S0 = sum dp, Sx = sum x dp, Sy = sum y dp, Z = sum dL/ddepth * (s.x, s.y, 1)
 // are linear in the pixels AND in the tiles, so they can be summed first and turned into dL/dT once per
-// Gaussian (K8):  dTu = Tv x S0 - Tw x Sy,  dTv = S0 x Tu - Sx x Tw,  dTw = Tu x Sy - Tv x Sx + Z.
+// Gaussian (K8):  dTu = Tv' x S0 - Tw x Sy,  dTv = S0 x Tu' - Sx x Tw,  dTw = Tu' x Sy - Tv' x Sx + Z - cx dTu - cy dTv
+// with Tu' = Tu - cx Tw, Tv' = Tv - cy Tw.
 //   slots  0..2 S0 | 3..5 Sx | 6..8 Sy | 9..11 Z | 12,13 d/dxy | 14 d/dopacity | 15..17 d/dnormal | 18..20 d/drgb |
 //          21..23 d/d(colour channels 3..5) in the 6-channel variant, else unused.
 // Next to the records: one `written` byte per slot, zeroed per call, set by K7 where it stored a record.

@@ -522,16 +522,25 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
                 if (NC == 9) { g_col[6] = g[kGQ - 1].x; g_col[7] = g[kGQ - 1].y; g_col[8] = g[kGQ - 1].z; }
             }
             const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
-            // moments -> dL/dT (see common.h): dTu = Tv x S0 - Tw x Sy, dTv = S0 x Tu - Sx x Tw, dTw = Tu x Sy - Tv x Sx + Z
+            // moments -> dL/dT (see common.h).  The records carry the moments about the Gaussian's own centre c = (cx, cy) (K7's flush), i.e.
+            // of the same ray-splat form written in x' = x - cx, y' = y - cy with Tu' = Tu - cx Tw, Tv' = Tv - cy Tw:
+            //   dTu' = Tv' x S0 - Tw x Sy',  dTv' = S0 x Tu' - Sx' x Tw,  dTw' = Tu' x Sy' - Tv' x Sx' + Z
+            // and back through the shift: dTu = dTu', dTv = dTv', dTw = dTw' - cx dTu' - cy dTv'.  Every cross product now multiplies
+            // quantities of the splat's own extent instead of pixel coordinates ~1000 that cancel.
             {
+                const float cx = r2.y, cy = r2.z;
+                const float Tuc[3] = {Tu[0] - cx * Tw[0], Tu[1] - cx * Tw[1], Tu[2] - cx * Tw[2]};
+                const float Tvc[3] = {Tv[0] - cy * Tw[0], Tv[1] - cy * Tw[1], Tv[2] - cy * Tw[2]};
                 const float S0[3] = {g0.x, g0.y, g0.z}, Sx[3] = {g0.w, g1.x, g1.y}, Sy[3] = {g1.z, g1.w, g2.x}, Z[3] = {g2.y, g2.z, g2.w};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-                    dT[0 + c] = (Tv[c1] * S0[c2] - Tv[c2] * S0[c1]) - (Tw[c1] * Sy[c2] - Tw[c2] * Sy[c1]);
-                    dT[3 + c] = (S0[c1] * Tu[c2] - S0[c2] * Tu[c1]) - (Sx[c1] * Tw[c2] - Sx[c2] * Tw[c1]);
-                    dT[6 + c] = (Tu[c1] * Sy[c2] - Tu[c2] * Sy[c1]) - (Tv[c1] * Sx[c2] - Tv[c2] * Sx[c1]) + Z[c];
+                    dT[0 + c] = (Tvc[c1] * S0[c2] - Tvc[c2] * S0[c1]) - (Tw[c1] * Sy[c2] - Tw[c2] * Sy[c1]);
+                    dT[3 + c] = (S0[c1] * Tuc[c2] - S0[c2] * Tuc[c1]) - (Sx[c1] * Tw[c2] - Sx[c2] * Tw[c1]);
+                    dT[6 + c] = (Tuc[c1] * Sy[c2] - Tuc[c2] * Sy[c1]) - (Tvc[c1] * Sx[c2] - Tvc[c2] * Sx[c1]) + Z[c];
                 }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dT[6 + c] = (dT[6 + c] - cx * dT[0 + c]) - cy * dT[3 + c];
             }
             const float gx2 = g3.x, gy2 = g3.y;
             g_opa = g3.z;

@@ -266,8 +266,10 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
             float4 acc[kGQ];
 #pragma unroll
             for (int k = 0; k < kGQ; ++k) acc[k] = accl[k];
-            acc[0].w = fmaf(Xc, acc[0].x, acc[0].w); acc[1].x = fmaf(Xc, acc[0].y, acc[1].x); acc[1].y = fmaf(Xc, acc[0].z, acc[1].y);
-            acc[1].z = fmaf(Yc, acc[0].x, acc[1].z); acc[1].w = fmaf(Yc, acc[0].y, acc[1].w); acc[2].x = fmaf(Yc, acc[0].z, acc[2].x);
+            const float4 centre = s_e[3][lane];   // (mx, my, ..) = the Gaussian's centre relative to the tile centre
+            const float ox = -centre.x, oy = -centre.y;
+            acc[0].w = fmaf(ox, acc[0].x, acc[0].w); acc[1].x = fmaf(ox, acc[0].y, acc[1].x); acc[1].y = fmaf(ox, acc[0].z, acc[1].y);
+            acc[1].z = fmaf(oy, acc[0].x, acc[1].z); acc[1].w = fmaf(oy, acc[0].y, acc[1].w); acc[2].x = fmaf(oy, acc[0].z, acc[2].x);
             float4* o = inst_grads + (size_t)slot * kGQ;
 #pragma unroll
             for (int k = 0; k < kGQ; ++k) o[k] = acc[k];

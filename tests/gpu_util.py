@@ -204,14 +204,15 @@ def gradient_row_errors(hip, bwd64, vis, scene=None):
 
 
 # Gradient bars, per Gaussian row: 99.9 % of the rows / every row.  Reference = the all-float64 backward.  Every tensor sits at the
-# float32 rounding of the blend's sums (measured at C2 / C3, profiles/r03_parity_*.json: p99.9 <= 4e-5, max 3.3e-3), dL_dscales and
-# dL_drotations included once their rows are measured against the terms they sum (p99.9 1.8e-4 / 1.7e-4, max 2.5e-3 / 3.2e-3; the
-# float32 oracle, forced to the same decisions, shows 1.6e-4 / 2.0e-3 against the same arbiter).  Without `scene` (precomputed
-# transMat: no scale / rotation chain) only the plain row metric applies.  dL_dmeans2D (the densification proxy) is ONE element of
-# dL/dT times Tw.z * W / 2 -- a single float32 sum of cancelling terms rather than a row maximum -- and sits at p99.9 4e-5 on the
-# benchmark scenes, 4e-4 under a train.py-style loss that weights the distortion map by 100 (tests/test_gpu_render_api.py).
+# float32 rounding of the blend's sums (measured at C2 / C3, profiles/r03_parity_*.json: p99.9 <= 2.5e-5, max 3.3e-3), dL_dscales and
+# dL_drotations included once their rows are measured against the terms they sum (p99.9 6.0e-5 / 6.6e-5, max 5.2e-4 / 3.6e-3 at C2 since
+# K7's moments are taken about the Gaussian's own centre; the float32 oracle, forced to the same decisions, shows 1.6e-4 / 2.0e-3 against
+# the same arbiter).  Without `scene` (precomputed transMat: no scale / rotation chain) only the plain row metric applies.  dL_dmeans2D
+# (the densification proxy) is ONE element of dL/dT times Tw.z * W / 2 -- a single float32 sum of cancelling terms rather than a row
+# maximum -- and sits at p99.9 4e-5 on the benchmark scenes, 4e-4 under a train.py-style loss that weights the distortion map by 100
+# (tests/test_gpu_render_api.py).
 STRICT_ROW_BARS = {"dL_dmeans3D": (2e-4, 1e-2), "dL_dopacity": (2e-4, 1e-2), "dL_dsh": (2e-4, 1e-2), "dL_dmeans2D": (6e-4, 1e-2),
-                   "dL_dcolors": (2e-4, 1e-2), "dL_dscales": (4e-4, 1e-2), "dL_drotations": (4e-4, 1e-2)}
+                   "dL_dcolors": (2e-4, 1e-2), "dL_dscales": (2e-4, 1e-2), "dL_drotations": (2e-4, 1e-2)}
 
 
 def assert_strict_parity(hip, fwd64, bwd64=None, tag="", report=None, scene=None):
