@@ -304,7 +304,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     const float* __restrict__ colors_precomp, const float* __restrict__ transMat_precomp,
     const uint8_t* __restrict__ mask, float4* __restrict__ recs, uint32_t* __restrict__ depth_keys,
     uint32_t* __restrict__ tiles_touched, uint2* __restrict__ rect, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii) {
-    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? kPreBlock * kShHalfStride : 4];
+    // SH half rows (kShHalfStride floats per Gaussian) while the colour is evaluated, then the outgoing records + sh_jac rows (20 + 9)
+    constexpr int kK1LdsFloats = kPreBlock * (kShHalfStride > kRecFloats + 9 ? kShHalfStride : kRecFloats + 9);
+    __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? kK1LdsFloats : 4];
     const int tid = threadIdx.x, base = blockIdx.x * kPreBlock;
     const int i = base + tid;
     // every per-Gaussian input is requested up front, in front of the SH staging and its barrier: one memory round trip instead of four
@@ -438,22 +440,44 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
         __syncthreads();   // every thread is done with the first halves
         sh_half_store(s_sh, tid, half_b);
         __syncthreads();
+        float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (need_sh) {
-            float rgb[3], J[9];
+            float rgb[3];
             sh_to_rgb_hi(f.sh_degree, row, sdx, sdy, sdz, res, rgb, out_clamped);
             sh_dir_jacobian_hi(f.sh_degree, row, sdx, sdy, sdz, slen, dd, J);
             q4 = make_float4(rgb[0], rgb[1], rgb[2], sradius);
+        }
+        // The 80-B records and the 36-B sh_jac rows leave through LDS: a block's rows are contiguous in memory, so its 128 lanes store
+        // consecutive 16-B chunks instead of five (nine) stores per lane at an 80-B (36-B) stride -- partial sectors that the L2 does not
+        // merge for free: K1 0.245 -> 0.219 ms with the records alone.  The staging buffer is free by now.
+        __syncthreads();
+        float4* s_rec = reinterpret_cast<float4*>(s_sh);
+        float* s_jac = s_sh + kPreBlock * kRecFloats;
+        s_rec[tid * kRecQuads + 0] = q0; s_rec[tid * kRecQuads + 1] = q1; s_rec[tid * kRecQuads + 2] = q2; s_rec[tid * kRecQuads + 3] = q3;
+        s_rec[tid * kRecQuads + 4] = q4;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) f.sh_jac[9 * (size_t)i + k] = J[k];
+        for (int k = 0; k < 9; ++k) s_jac[tid * 9 + k] = J[k];   // (stride 9 words: conflict-free)
+        __syncthreads();
+        {
+            const int nrows = min(kPreBlock, P - base);
+            float4* dst = recs + (size_t)base * kRecQuads;
+            for (int fq = tid; fq < nrows * kRecQuads; fq += kPreBlock) dst[fq] = s_rec[fq];
+            // 9 floats per row: rows * 9 floats are 16-B aligned per block of 128 rows (128 * 36 B) -- whole float4 chunks, plus a scalar tail
+            float* jd = f.sh_jac + (size_t)base * 9;
+            const int nf = nrows * 9, nq = nf / 4;
+            for (int fq = tid; fq < nq; fq += kPreBlock) reinterpret_cast<float4*>(jd)[fq] = reinterpret_cast<const float4*>(s_jac)[fq];
+            for (int fk = nq * 4 + tid; fk < nf; fk += kPreBlock) jd[fk] = s_jac[fk];
         }
         if (!in_range) return;
+        radii[i] = out_radius; tiles_touched[i] = out_tiles; rect[i] = out_rect; depth_keys[i] = out_key; clamped[i] = out_clamped;
+        return;
     }
     radii[i] = out_radius;
     tiles_touched[i] = out_tiles;
     rect[i] = out_rect;
     depth_keys[i] = out_key;
     clamped[i] = out_clamped;
-    float4* rec = recs + (size_t)i * kRecQuads;   // (also for a culled Gaussian: leaving holes in the wave's record stores costs more -- 0.249 -> 0.260 ms -- than the 34 MB they save)
+    float4* rec = recs + (size_t)i * kRecQuads;   // (the path without SH staging: precomputed colours)
     rec[0] = q0; rec[1] = q1; rec[2] = q2; rec[3] = q3; rec[4] = q4;
 }
 
@@ -637,9 +661,14 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
                 for (int k = 0; k < M * 3; ++k) dsh_g[k] = 0.f;
             }
         }
+        // (sending these two 12-B-per-Gaussian outputs through LDS behind the dL_dsh rows, as K1 does with its records, changes nothing here:
+        // 0.345 vs 0.347 ms -- 72 MB of K8's 1.8 GB)
         if (out.dL_dmeans3D) { out.dL_dmeans3D[3 * (size_t)i] = g_means3D[0]; out.dL_dmeans3D[3 * (size_t)i + 1] = g_means3D[1]; out.dL_dmeans3D[3 * (size_t)i + 2] = g_means3D[2]; }
         if (out.dL_dmeans2D) { out.dL_dmeans2D[3 * (size_t)i] = g_m2d[0]; out.dL_dmeans2D[3 * (size_t)i + 1] = g_m2d[1]; out.dL_dmeans2D[3 * (size_t)i + 2] = 0.f; }
-        if (out.dL_dscales) { out.dL_dscales[2 * (size_t)i] = g_scales[0]; out.dL_dscales[2 * (size_t)i + 1] = g_scales[1]; }
+        if (out.dL_dscales) {
+            if ((reinterpret_cast<uintptr_t>(out.dL_dscales) & 7u) == 0) reinterpret_cast<float2*>(out.dL_dscales)[i] = make_float2(g_scales[0], g_scales[1]);
+            else { out.dL_dscales[2 * (size_t)i] = g_scales[0]; out.dL_dscales[2 * (size_t)i + 1] = g_scales[1]; }
+        }
         if (out.dL_drotations) { reinterpret_cast<float4*>(out.dL_drotations)[i] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]); }
         if (out.dL_dopacity) out.dL_dopacity[i] = g_opa;
         if (out.dL_dcolors) {
