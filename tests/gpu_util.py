@@ -150,10 +150,15 @@ def forced_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=No
 
 
 def row_errors(got, ref, vis):
-    """Per Gaussian row: max_j |got - ref| / (max_j |ref| + 1e-3 * max |ref| over the tensor), visible rows only."""
+    """Per Gaussian row: max_j |got - ref| / (max_j |ref| + 1e-3 * max |ref| over the tensor), visible rows only.  (A tensor that is
+    identically zero in the reference -- e.g. the densification proxy of a scene blended by the screen-space filter alone -- must be
+    identically zero: 0 / 0 counts as 0, anything else as inf.)"""
     ref = np.asarray(ref, np.float64); P = ref.shape[0]
     ref = ref.reshape(P, -1); got = np.asarray(got, np.float64).reshape(P, -1)
-    return (np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-3 * np.abs(ref).max()))[vis]
+    num = np.abs(got - ref).max(1); den = np.abs(ref).max(1) + 1e-3 * np.abs(ref).max()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        e = np.where(num == 0, 0.0, num / den)
+    return e[vis]
 
 
 def k8_term_magnitudes(g, cam, dT):
@@ -263,14 +268,16 @@ def free_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None
 
 
 def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report=None, scene=None, pixel_budget=NONROBUST_PIXEL_BUDGET,
-                       gaussian_budget=NONROBUST_GAUSSIAN_BUDGET):
+                       gaussian_budget=NONROBUST_GAUSSIAN_BUDGET, value_slack=1.0):
     """HIP against the free-running float64 reference.
       * every ROBUST pixel: same last contributor, colour and the six summed aux maps within 1e-4 * (1 + |value|) -- no exempt
         fraction; where the median selection is robust too: same median contributor and median depth within the same bar;
       * every ROBUST visible Gaussian (no near-threshold decision anywhere in its footprint): the strict per-row bars against the
         all-float64 backward (blend AND K8 in double: "<name>64");
       * the non-robust remainder is counted against its measured fraction and only has to stay finite and within the loose bars
-        of a flipped contributor (2e-2 per pixel, 5e-2 of the tensor scale per row)."""
+        of a flipped contributor (2e-2 per pixel, 5e-2 of the tensor scale per row).
+    `value_slack` > 1 widens the VALUE bars of the robust elements (never the identical-decision checks): the fuzz sweep uses it for its
+    camera-plane regime, where the ray-splat intersection itself is ill-conditioned in float32."""
     rob_px = margins["pixel"] > 1.0
     rob_med = rob_px & (margins["median"] > 1.0)
     assert (~rob_px).mean() <= pixel_budget, f"{tag}: {(~rob_px).mean():.2e} of the pixels are non-robust"
@@ -286,7 +293,7 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
         rep[f"{tag}{name}"] = dict(robust_max=float(err[m].max()) if m.any() else 0.0, non_robust_max=float(err[~m].max()) if (~m).any() else 0.0,
                                    non_robust_over_1e4=int((err[~m] > 1e-4).sum()))
         assert np.isfinite(a).all(), f"{tag} {name}: non-finite output"
-        assert err[m].max() <= 1e-4, f"{tag} {name}: robust pixel off by {err[m].max():.3e} of (1 + |value|) against the free-running float64 reference"
+        assert err[m].max(initial=0.0) <= 1e-4 * value_slack, f"{tag} {name}: robust pixel off by {err[m].max():.3e} of (1 + |value|) against the free-running float64 reference"
         if name != "allmap[5]":   # (the median depth of a non-robust pixel is another splat's depth: a selection, not a sum)
             assert err[~m].max(initial=0.0) <= 2e-2, f"{tag} {name}: non-robust pixel off by {err[~m].max():.3e}"
     if bwd64 is None:
@@ -304,10 +311,11 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
         r = np.asarray(ref, np.float64).reshape(P, -1); a = np.asarray(hip[key], np.float64).reshape(P, -1)
         loose = np.abs(a - r).max(1) / (np.abs(r).max() + 1e-30)
         er = e[rob_g]
-        rep[f"{tag}{key}"] = dict(robust_rows=int(rob_g.sum()), robust_max=float(er.max()), robust_p999=float(np.quantile(er, 0.999)),
+        rep[f"{tag}{key}"] = dict(robust_rows=int(rob_g.sum()), robust_max=float(er.max(initial=0.0)), robust_p999=float(np.quantile(er, 0.999)) if er.size else 0.0,
                                   non_robust_max_of_tensor_scale=float(loose[vis & ~rob_g].max(initial=0.0)))
         assert np.isfinite(a).all(), f"{tag} {key}: non-finite gradient"
-        assert np.quantile(er, 0.999) <= p999_bar and er.max() <= max_bar, \
-            f"{tag} {key}: robust rows p99.9 {np.quantile(er, 0.999):.2e} (bar {p999_bar:.0e}), max {er.max():.2e} (bar {max_bar:.0e})"
+        if er.size:
+            assert np.quantile(er, 0.999) <= p999_bar * value_slack and er.max() <= max_bar * value_slack, \
+                f"{tag} {key}: robust rows p99.9 {np.quantile(er, 0.999):.2e} (bar {p999_bar:.0e}), max {er.max():.2e} (bar {max_bar:.0e})"
         assert loose[vis & ~rob_g].max(initial=0.0) <= 5e-2, f"{tag} {key}: a non-robust row is off by {loose[vis & ~rob_g].max():.2e} of the tensor scale"
         assert not np.abs(a[~vis]).any(), f"{tag} {key}: gradient on an invisible Gaussian"

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
-from tests.gpu_util import assert_close_frac, check_allmap, run_hip, run_hip_raw, run_oracle
+from tests.gpu_util import assert_close_frac, assert_free_parity, check_allmap, free_f64_reference, run_hip, run_hip_raw, run_oracle
 from tests.test_gpu_parity import _check_binning
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -48,19 +48,30 @@ for k in range(n_scenes):
         for ch, mag in ((0, zmax), (1, 1.0), (2, 1.0), (3, 1.0), (4, 1.0), (6, 1.0)):
             e = np.abs(out["allmap"][ch] - fwd["allmap"][ch]).max()
             assert e <= flip * mag + 1e-3 * max(1.0, mag), f"allmap[{ch}] err {e:.3e} beyond one flipped contributor ({flip * mag:.3e})"
+        # ... and the free-running float64 reference (its own decisions): on every ROBUST pixel the kernels stop at the same entry, pick
+        # the same median and agree within 1e-4; on every robust Gaussian the strict row bars hold.  (Random regimes -- translucent deep
+        # lists, splats around the near plane -- make many pixels non-robust: the fraction is reported, not bounded, here.)
+        xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, colors=colors, tile=tile, base=fwd)
+        rep = {}
+        # regime 3 puts splats around the camera plane: p.z -> 0 inside a footprint makes the VALUE of the ray-splat intersection
+        # ill-conditioned in float32 (not a decision): the value bars get a factor 5 there, the identical-decision checks none
+        assert_free_parity(out, raw["img"]["n_contrib"], xfwd, xbwd, margins, scene=(g, cam), report=rep, pixel_budget=1.0, gaussian_budget=1.0,
+                           value_slack=5.0 if regime == 3 else 1.0)
         names = ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D", "dL_dcolors" if colors is not None else "dL_dsh"]
-        # Per GAUSSIAN: any gradient element off by more than 2e-3 of its tensor's scale marks the Gaussian.  Threshold and
-        # selection flips (alpha >= 1/255, T < 1e-4, rho3d <= rho2d) move the whole gradient of a few-pixel splat, so a handful
-        # of marked Gaussians per scene is inherent; more than max(3, 0.1 %) is a failure.
+        # Per GAUSSIAN, against the float32 oracle: any gradient element of a ROBUST Gaussian off by more than 2e-3 of its tensor's scale
+        # marks it.  (A flipped decision moves the whole gradient of a few-pixel splat: those Gaussians are the non-robust ones, checked
+        # above against the float64 reference's looser bound.)  What is left is the float32 oracle's own conditioning on grazing splats:
+        # more than max(3, 0.1 %) marked Gaussians is a failure.
         marked = np.zeros(P, bool)
         for n in names:
             ref = np.asarray(bwd[n], np.float64).reshape(P, -1); got = np.asarray(out[n], np.float64).reshape(P, -1)
             scale = np.abs(ref).max()
             if scale > 0:
-                marked |= (np.abs(got - ref) / scale > 2e-3).any(axis=1)
+                marked |= (np.abs(got - ref) / scale > 2e-3).any(axis=1) & (margins["gaussian"] > 1.0)   # (float32 oracle; robust Gaussians only)
                 assert np.isfinite(got).all(), n + " not finite"
         assert marked.sum() <= max(3, int(1e-3 * P)), f"{int(marked.sum())} Gaussians with out-of-tolerance gradients: {np.nonzero(marked)[0][:8]}"
-        print("ok  ", tag, f"D={fwd['num_rendered']}", flush=True)
+        vis = fwd["radii"] > 0
+        print("ok  ", tag, f"D={fwd['num_rendered']} robust px {(margins['pixel'] > 1).mean():.4f} gaussians {((margins['gaussian'] > 1) & vis).sum() / max(1, vis.sum()):.3f}", flush=True)
     except AssertionError as e:
         bad += 1
         print("FAIL", tag, "\n     ", str(e).splitlines()[0][:300], flush=True)
