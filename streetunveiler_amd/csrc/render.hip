@@ -397,16 +397,17 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     T[q] *= one_m_inv;                 // transmittance in front of this entry
                     const float w = h.alpha * T[q];
                     // psi = rgb.g + depth g_depth + n.gn + (a2 + m (m a0 - 2 a1)), m = the depth metric; dL/dz = w (2 (m a0 - a1) dm/dz + g_depth),
-                    // dm/dz = kFN kNear / depth^2.  t1 = m a0 - a1 serves both, a2 seeds the fma chain: 7 instructions where the literal
-                    // transcription took 11
+                    // dm/dz = kFN kNear / depth^2.  t1 = m a0 - a1 serves both: 8 instructions where the literal transcription took 11.  (The
+                    // three distortion terms cancel to the variance of m along the ray: they are combined in ONE fma before anything else is
+                    // added -- seeding the colour chain with a2 saves another instruction and costs a digit under a distortion-weighted loss.)
                     float phi = fmaf(e4.w, gr[q], fmaf(e5.x, gg[q], fmaf(e5.y, gb[q], fmaf(h.depth, g_depth[q],
-                                fmaf(e4.x, gn0[q], fmaf(e4.y, gn1[q], fmaf(e4.z, gn2[q], a2[q])))))));
+                                fmaf(e4.x, gn0[q], fmaf(e4.y, gn1[q], e4.z * gn2[q]))))));
                     if (NC >= 6) phi = fmaf(e5.z, gc3[q], fmaf(e5.w, gc4[q], fmaf(e3.w, gc5[q], phi)));
                     if (NC == 9) { const float4 e6 = s_e[6][j]; phi = fmaf(e6.x, gc6[q], fmaf(e6.y, gc7[q], fmaf(e6.z, gc8[q], phi))); }
                     const float inv_depth = fast_rcp(h.depth);
                     const float m_d = fmaf(inv_depth, -kFN * kNear, kFN);
                     const float t1 = fmaf(m_d, a0[q], -a1[q]);
-                    const float psi = fmaf(m_d, t1 - a1[q], phi);
+                    const float psi = phi + fmaf(m_d, t1 - a1[q], a2[q]);
                     const float dL_dalpha = T[q] * psi - one_m_inv * Z[q];
                     Z[q] = fmaf(w, psi, Z[q]);
                     float dL_dz = w * fmaf(t1 * (inv_depth * inv_depth), 2.f * kFN * kNear, g_depth[q]);
