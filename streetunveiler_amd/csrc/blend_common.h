@@ -185,9 +185,10 @@ __device__ __forceinline__ bool intersect(float xl, float yl, const float4 e0, c
     const float rho3d = h.sx * h.sx + h.sy * h.sy;
     h.dx = e3.x - xl; h.dy = e3.y - yl;
     const float rho2d = kFilterInvSquare * (h.dx * h.dx + h.dy * h.dy);
-    h.use3d = rho3d <= rho2d;
+    const bool use2d = !(rho3d <= rho2d);   // (ONE compare serves the depth select here and the path branch of the backward)
+    h.use3d = !use2d;
     const float rho = fminf(rho3d, rho2d);
-    h.depth = h.use3d ? fmaf(h.sx, e2.y, fmaf(h.sy, e2.z, e2.w)) : e2.w;
+    h.depth = use2d ? e2.w : fmaf(h.sx, e2.y, fmaf(h.sy, e2.z, e2.w));
     h.G = __builtin_amdgcn_exp2f(rho * (-0.5f * kLog2e));   // exp(-rho / 2)
     h.alpha = fminf(kAlphaCap, e3.z * h.G);
     // (the reference also skips on `power > 0`: never true -- rho3d and rho2d are sums of squares, fminf drops a NaN operand, and a NaN

@@ -410,8 +410,8 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     const float psi = phi + fmaf(m_d, t1 - a1[q], a2[q]);
                     const float dL_dalpha = T[q] * psi - one_m_inv * Z[q];
                     Z[q] = fmaf(w, psi, Z[q]);
-                    float dL_dz = w * fmaf(t1 * (inv_depth * inv_depth), 2.f * kFN * kNear, g_depth[q]);
-                    if (cidx == medc[q] - 1u) dL_dz += g_median[q];
+                    const float med_add = (cidx == medc[q] - 1u) ? g_median[q] : 0.f;
+                    const float dL_dz = fmaf(w, fmaf(t1 * (inv_depth * inv_depth), 2.f * kFN * kNear, g_depth[q]), med_add);
                     const float dL_dG = e3.z * dL_dalpha;
                     v[18] += w * gr[q]; v[19] += w * gg[q]; v[20] += w * gb[q];
                     if (NC >= 6) { v[21] += w * gc3[q]; v[22] += w * gc4[q]; v[23] += w * gc5[q]; }
