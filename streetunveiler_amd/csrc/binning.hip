@@ -19,7 +19,8 @@ namespace sr {
 // radix_sort.hip
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode);
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode,
+                            int rect_bx = 0, int rect_by = 0);
 size_t tile_count_scan_temp_bytes(uint32_t n);
 hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, uint32_t* total_host, hipStream_t s);
 
@@ -428,10 +429,13 @@ size_t expand_y_hist_bytes(uint32_t D, int tiles_y) { return (size_t)tiles_y * (
 // launchers ---------------------------------------------------------------------------------------
 // K2: stable sort of (depth key, gaussian id) -- ties keep ascending id, culled Gaussians (key 0xFFFFFFFF) end up last.
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, uint32_t* sorted_keys,
-                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, int rank_mode, hipStream_t s) {
+                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, int rank_mode, int tiles_x, int tiles_y, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    // the last pass also gathers the tile rectangles into depth order, so the scan and the partition read sequentially
-    return radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, rect, rect_sorted, rank_mode);
+    // the sort also delivers the tile rectangles in depth order, so the scan and the partition read sequentially: packed into a word that
+    // rides along with the Gaussian's id where its fields (0 .. tiles_x, 0 .. tiles_y) fit into 32 bits -- up to 255 x 255 tiles, or
+    // e.g. 511 x 127 -- and gathered by the last pass for wider frames (radix_sort.hip)
+    const int bx = 32 - __builtin_clz((unsigned)(tiles_x > 0 ? tiles_x : 1)), by = 32 - __builtin_clz((unsigned)(tiles_y > 0 ? tiles_y : 1));
+    return radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, rect, rect_sorted, rank_mode, bx, by);
 }
 
 // K2: emission offsets = scan of tiles_touched in id order (block-local values in first, block bases + total D in block_base).

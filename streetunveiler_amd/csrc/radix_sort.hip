@@ -23,6 +23,9 @@ static_assert(kRsTile == kScanTile, "first_index() divides by the scan's block s
 constexpr int kSortItemsBig = 16;
 constexpr uint32_t kSortBigFrom = 2u << 20;
 constexpr int kRsMaxBins = 256;
+// The payload rides along with the value from this many items up (below, the whole payload table sits in the L2 and the last pass's
+// gather is the cheaper way: 500 k items 69 us gathered / 73 us riding; 3 M: 181 / 167; 6 M: 334 / 295)
+constexpr uint32_t kSortRideFrom = 1u << 20;
 
 template <int kSortItems>
 __global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, int bits,
@@ -71,12 +74,27 @@ __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __re
     if (tid == 0) row_total[blockIdx.x] = s_carry;
 }
 
-template <int kBits, bool kAtomicRank, int kSortItems>   // digit width (compile time; 0 = run-time width <= 8), ranking (common.h take_run_slot), items per thread
+// The 8-B payload of the depth sort (the tile rectangle, preprocess.hip: minx | miny << 16, width | height << 16) as ONE word that
+// travels with the value through every pass: x fields of bx bits, y fields of by bits, 2 (bx + by) <= 32.
+__device__ __forceinline__ uint32_t pack_rect(uint2 r, int bx, int by) {
+    return (r.x & 0xFFFFu) | ((r.y & 0xFFFFu) << bx) | ((r.x >> 16) << (2 * bx)) | ((r.y >> 16) << (2 * bx + by));
+}
+__device__ __forceinline__ uint2 unpack_rect(uint32_t w, int bx, int by) {
+    const uint32_t mx = (1u << bx) - 1u, my = (1u << by) - 1u;
+    return make_uint2((w & mx) | (((w >> (2 * bx)) & my) << 16), ((w >> bx) & mx) | ((w >> (2 * bx + by)) << 16));
+}
+
+// kWide: the value is a pair (vals, ride) of words in two arrays; the first pass packs `ride` from aux_src[i] (read in order), the last
+// unpacks it into aux_out -- instead of the last pass GATHERING aux_src[vals_out[i]]: at 3 M items that gather is 3 M random line fetches,
+// 43 us of a 67 us pass (the other passes take 20), against ~3 us per pass for the extra word.  The ride is reordered through the same LDS
+// buffer as the value, after it (the block keeps its 38 KB of LDS: four blocks per CU).
+template <int kBits, bool kAtomicRank, int kSortItems, bool kWide>   // digit width (compile time; 0 = run-time width <= 8), ranking (common.h take_run_slot), items per thread
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                 uint32_t n, int shift, int bits_rt, const uint32_t* __restrict__ hist,
                                                                 const uint32_t* __restrict__ row_total, int nblocks,
-                                                                const uint2* __restrict__ aux_src, uint2* __restrict__ aux_out) {
+                                                                const uint2* __restrict__ aux_src, uint2* __restrict__ aux_out,
+                                                                const uint32_t* __restrict__ ride_in, uint32_t* __restrict__ ride_out, int bx, int by) {
     constexpr int kSortTile = kRsThreads * kSortItems;
     __shared__ uint32_t s_run[kRsThreads / 64][kRsMaxBins];    // items of digit b held by wave w; then, in place, the next block-local slot for (wave, digit)
     __shared__ uint32_t s_lstart[kRsMaxBins];                  // block-local start of digit b
@@ -91,14 +109,16 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     // wave w owns items [wbase, wbase + 512), 64 at a time in order -> stable
     const uint32_t tile_base = blockIdx.x * (uint32_t)kSortTile;
     const uint32_t wbase = tile_base + (uint32_t)w * (64 * kSortItems);
-    uint32_t key[kSortItems], val[kSortItems];
+    uint32_t key[kSortItems], val[kSortItems], ride[kWide ? kSortItems : 1], slot[kWide ? kSortItems : 1];
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
         const uint32_t idx = wbase + (uint32_t)(i * 64 + lane);
         key[i] = 0; val[i] = 0;
+        if constexpr (kWide) ride[i] = 0;
         if (idx < n) {
             key[i] = keys_in[idx];
             val[i] = vals_in ? vals_in[idx] : idx;   // first pass of an index sort: the value is the position itself
+            if constexpr (kWide) ride[i] = ride_in ? ride_in[idx] : pack_rect(aux_src[idx], bx, by);
             atomicAdd(&s_run[w][(key[i] >> shift) & mask], 1u);
         }
     }
@@ -141,10 +161,12 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         // rank among the wave's items of the same digit, in item order, and the advance of the (wave, digit) run (common.h)
         const uint32_t pos = take_run_slot<kAtomicRank>(s_run[w], d, live, bits);
         if (live) { s_key[pos] = key[i]; s_val[pos] = val[i]; }
+        if constexpr (kWide) slot[i] = pos;
     }
     __syncthreads();
     // coalesced write-out: consecutive local slots of one digit are consecutive in global memory
     const uint32_t count = min((uint32_t)kSortTile, n - tile_base);
+    uint32_t dest[kWide ? kSortItems : 1];
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
         const uint32_t li = (uint32_t)(i * kRsThreads + tid);
@@ -153,9 +175,25 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
             const uint32_t d = (k >> shift) & mask;
             const uint32_t g = s_gbase[d] + (li - s_lstart[d]);
             const uint32_t v = s_val[li];
+            if constexpr (kWide) dest[i] = g;
             keys_out[g] = k;
             vals_out[g] = v;
-            if (aux_out) aux_out[g] = aux_src[v];   // last pass: payload gathered in sorted order (aux_out[i] = aux_src[vals_out[i]])
+            if (!kWide && aux_out) aux_out[g] = aux_src[v];   // last pass: payload gathered in sorted order (aux_out[i] = aux_src[vals_out[i]])
+        }
+    }
+    if constexpr (kWide) {   // the ride, through s_val once the values are out
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kSortItems; ++i)
+            if (wbase + (uint32_t)(i * 64 + lane) < n) s_val[slot[i]] = ride[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kSortItems; ++i) {
+            const uint32_t li = (uint32_t)(i * kRsThreads + tid);
+            if (li < count) {
+                if (ride_out) ride_out[dest[i]] = s_val[li];
+                else aux_out[dest[i]] = unpack_rect(s_val[li], bx, by);   // last pass
+            }
         }
     }
 }
@@ -293,14 +331,16 @@ static inline int scan_blocks(uint32_t n) { return (int)((n + kRsTile - 1) / kRs
 // scratch: ping-pong (keys, vals) + histogram table + row totals
 size_t radix_sort_temp_bytes(uint32_t n) {
     const size_t nb = (size_t)rs_blocks(n > 0 ? n : 1);
-    return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 2 + align_up(nb * kRsMaxBins * 4, 256) + align_up(kRsMaxBins * 4, 256);
+    return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 3 + align_up(nb * kRsMaxBins * 4, 256) + align_up(kRsMaxBins * 4, 256);   // (keys, vals, ride)
 }
 
 // Sorts by key bits [0, total_bits) in passes of <= 8 bits (as even as possible); stable; result in keys_out/vals_out.
-// vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.  If aux_out != nullptr the last pass also
-// writes aux_out[i] = aux_src[vals_out[i]] (an 8-B payload gathered in sorted order, for free).
+// vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.  If aux_out != nullptr the sort also delivers
+// aux_out[i] = aux_src[vals_out[i]] (an 8-B payload in sorted order): packed into a word that rides along with the value when it is
+// a tile rectangle whose fields fit (value = index, fields < 2^rect_bx / 2^rect_by, 2 (bx + by) <= 32), gathered by the last pass otherwise.
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode) {
+                            int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode,
+                            int rect_bx, int rect_by) {
     if (n == 0) return hipSuccess;
     if (temp_bytes < radix_sort_temp_bytes(n) || (rank_mode != kRankAtomic && rank_mode != kRankBallot)) return hipErrorInvalidValue;
     int passes = (total_bits + 7) / 8;
@@ -310,6 +350,9 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
     char* t = static_cast<char*>(temp);
     uint32_t* tk = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)n * 4, 256);
     uint32_t* tv = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)n * 4, 256);
+    uint32_t* tr = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)n * 4, 256);
+    // the ride's other buffer is the first half of aux_out itself: written by odd passes, read by the next one; the last pass reads `tr`
+    const bool wide = aux_out && !vals_in && rect_bx > 0 && rect_by > 0 && 2 * (rect_bx + rect_by) <= 32 && passes >= 2 && n >= kSortRideFrom;
     uint32_t* hist = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)nb8 * kRsMaxBins * 4, 256);
     uint32_t* row_total = reinterpret_cast<uint32_t*>(t);
     const uint32_t* ki = keys_in; const uint32_t* vi = vals_in;
@@ -322,13 +365,16 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         const bool last = p == passes - 1;
         uint32_t* ko = (p & 1) ? keys_out : tk;
         uint32_t* vo = (p & 1) ? vals_out : tv;
+        const uint32_t* ri = p == 0 ? nullptr : ((p & 1) ? tr : reinterpret_cast<const uint32_t*>(aux_out));
+        uint32_t* ro = last ? nullptr : ((p & 1) ? reinterpret_cast<uint32_t*>(aux_out) : tr);
         const bool big = bits == 8 && n >= kSortBigFrom;
         const int nb = big ? rs_blocks(n, kSortItemsBig) : nb8;
         if (big) hipLaunchKernelGGL(rs_hist_kernel<kSortItemsBig>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
         else hipLaunchKernelGGL(rs_hist_kernel<kRsItems>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
-#define SR_SCATTER_R(B, A, I) hipLaunchKernelGGL((rs_scatter_kernel<B, A, I>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
-                                                 row_total, nb, last ? aux_src : nullptr, last ? aux_out : nullptr)
+#define SR_SCATTER_W(B, A, I, Wd) hipLaunchKernelGGL((rs_scatter_kernel<B, A, I, Wd>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
+                                                 row_total, nb, (Wd ? p == 0 : last) ? aux_src : nullptr, last ? aux_out : nullptr, ri, ro, rect_bx, rect_by)
+#define SR_SCATTER_R(B, A, I) do { if (wide) SR_SCATTER_W(B, A, I, true); else SR_SCATTER_W(B, A, I, false); } while (0)
 #define SR_SCATTER(B, I) do { if (rank_mode == kRankAtomic) SR_SCATTER_R(B, true, I); else SR_SCATTER_R(B, false, I); } while (0)
         switch (bits) {
             case 8: if (big) SR_SCATTER(8, kSortItemsBig); else SR_SCATTER(8, kRsItems); break;
@@ -338,6 +384,7 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         }
 #undef SR_SCATTER
 #undef SR_SCATTER_R
+#undef SR_SCATTER_W
         ki = ko; vi = vo;
         shift += bits; left -= bits;
     }

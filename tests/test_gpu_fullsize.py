@@ -54,6 +54,24 @@ def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget):
                        gaussian_budget=gaussian_budget)
 
 
+def test_depth_sort_payload_paths_bit_exact():
+    """From 2^20 Gaussians up the tile rectangle rides along with the Gaussian's id through the depth sort, packed into one word whose
+    field widths follow the tile grid (radix_sort.hip kWide); grids whose four fields do not fit 32 bits keep the last pass's gather.
+    Both paths, with unequal field widths: duplicate count, sorted list and ranges bit-exact against the oracle's 64-bit sort."""
+    from tests.gpu_util import run_hip_raw, run_oracle
+    bg = np.zeros(3, np.float32)
+    for (w, h, tile) in [(520, 200, (8, 8)),        # 65 x 25 tiles: 7 + 5 bits per field pair
+                         (4112, 40, (16, 16)),      # 257 x 3 tiles: 9 + 2 bits
+                         (2408, 2408, (8, 8))]:     # 301 x 301 tiles: 2 (9 + 9) bits > 32 -> gathered
+        cam = synthetic_camera(w, h)
+        g = synthetic_gaussians(1_100_000, w, h, seed=5, scale_lo=2e-4, scale_hi=2e-3)
+        fwd, _ = run_oracle(g, cam, bg, 0, tile=tile)
+        raw = run_hip_raw(g, cam, bg, 0, tile=tile)
+        assert raw["D"] == fwd["num_rendered"] and raw["D"] > 500_000, (w, h, raw["D"])
+        np.testing.assert_array_equal(raw["bin"]["point_list"].view(np.uint32), fwd["point_list"])
+        np.testing.assert_array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])
+
+
 def test_c2_500k_against_oracle():
     """BASELINE config 2: 500 k Gaussians, 1920x1080, SH 3, colour + alpha gradients."""
     _against_oracle(500_000, False, "C2", pixel_budget=2.5e-3, gaussian_budget=0.20)

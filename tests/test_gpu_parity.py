@@ -242,8 +242,17 @@ def test_radix_sort_stability_and_edges():
     lib = _lib.load()
     dev = "cuda:0"
     rng = np.random.default_rng(0)
-    for n, bits in [(1, 32), (63, 5), (64, 13), (65, 8), (2047, 7), (2048, 16), (2049, 9), (100_003, 13), (1_000_001, 32), (777_777, 3)]:
-        keys = rng.integers(0, 2 ** bits, size=n, dtype=np.uint64).astype(np.uint32)
+    cases = [(1, 32), (63, 5), (64, 13), (65, 8), (2047, 7), (2048, 16), (2049, 9), (100_003, 13), (1_000_001, 32), (777_777, 3)]
+    # digits shared by most lanes of a row (the peeled path of common.h take_run_slot / wave_count_digit): one key everywhere, one bit,
+    # and depth keys -- the bits of floats between 0.5 and 50, whose top byte takes four values
+    cases += [(70_001, 0), (300_001, 1), (2_100_000, -1)]
+    for n, bits in cases:
+        if bits == -1:
+            keys, bits = rng.uniform(0.5, 50.0, size=n).astype(np.float32).view(np.uint32), 32
+        elif bits == 0:
+            keys, bits = np.full(n, 0xDEADBEEF, np.uint32), 32
+        else:
+            keys = rng.integers(0, 2 ** bits, size=n, dtype=np.uint64).astype(np.uint32)
         for vals in (None, rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)):
             k = torch.from_numpy(keys.view(np.int32)).to(dev)
             v = None if vals is None else torch.from_numpy(vals.view(np.int32)).to(dev)
