@@ -482,7 +482,10 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     if (int rc = bin_duplicates(frame, g, f, geom, geom_bytes, binning, B, D, s, &recs)) return rc;
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
-        const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0);
+        const bool rows = (frame->flags & SR_FLAG_ROW_MAPPED_FORWARD) != 0;
+        if (rows && (!(f.tile_w == 16 && f.tile_h == 16 && f.colors == 3) || frame->blend_counters || (frame->flags & SR_FLAG_NO_QUADRANT_CULL)))
+            return fail(SR_ERR_UNSUPPORTED, "SR_FLAG_ROW_MAPPED_FORWARD: 16x16 tile, three colour channels, no counters, culling on");
+        const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0) | (rows ? 4 : 0);
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
                                      out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint16_t>(binning, B.hit_mask), flags,
                                      reinterpret_cast<unsigned long long*>(frame->blend_counters), s));

@@ -86,6 +86,28 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float Tu[3], const float
     }
     return mask;
 }
+// The same test against the four 4x4 cells of each of the wave's quadrants: bit 4 q + c = cell c of quadrant q, cell c at (c & 1, c >> 1)
+// inside its quadrant (the row-mapped forward blend: one 16-lane row per cell).  (Two more slabs along the principal axes of the footprint
+// ellipse -- cell_mask16's oriented box -- keep 6 % fewer (entry, cell) pairs and cost as much at staging as they save: measured, not kept.)
+template <int QX, int QY>
+__device__ __forceinline__ uint32_t cell_mask_rows(const float Tu[3], const float Tv[3], const float Tw[3], float mx, float my,
+                                                   float opacity, float yshift) {
+    constexpr uint32_t kAll = (QX * QY >= 8) ? 0xFFFFFFFFu : (1u << (4 * QX * QY)) - 1u;
+    float lo[4], hi[4];
+    const int kind = octagon_bounds(Tu, Tv, Tw, mx, my, opacity, lo, hi);
+    if (kind != 1) return kind ? kAll : 0u;
+    lo[1] -= yshift; hi[1] -= yshift; lo[2] -= yshift; hi[2] -= yshift; lo[3] += yshift; hi[3] += yshift;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < QX * QY; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float x0 = (float)((q % QX) * 8 + (c & 1) * 4 - QX * 4), y0 = (float)((q / QX) * 8 + (c >> 1) * 4 - QY * 4);
+            if (!octagon_reaches(lo, hi, x0, x0 + 3.f, y0, y0 + 3.f)) continue;
+            mask |= 1u << (4 * q + c);
+        }
+    return mask;
+}
 // (counter variant only) the same test against the sixteen 4x4 cells of a 16x16 tile: bit 4 q + c = cell c of quadrant q, cell c at
 // (c & 1, c >> 1) inside its quadrant.  Bits 16..31: the same with two more slabs, along the principal axes of the footprint ellipse
 // (an oriented box around ellipse and filter disc): what a tighter -- still conservative -- cell culling would keep.
@@ -149,7 +171,7 @@ __device__ __forceinline__ float4 load_extra(const float* __restrict__ colors6, 
 
 template <int QX, int QY, int NC>
 __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], const float4 ex, const float4 ey, float Xc, float Yc, int cull,
-                                                float4 (*s_e)[kWave], int slot, float yshift = 0.f, uint32_t* cells16 = nullptr) {
+                                                float4 (*s_e)[kWave], int slot, float yshift = 0.f, uint32_t* cells16 = nullptr, uint32_t* cells_rows = nullptr) {
     const float Tw[3] = {q[1].z, q[1].w, q[2].x};
     const float Tu[3] = {q[0].x - Xc * Tw[0], q[0].y - Xc * Tw[1], q[0].z - Xc * Tw[2]};
     const float Tv[3] = {q[0].w - Yc * Tw[0], q[1].x - Yc * Tw[1], q[1].y - Yc * Tw[2]};
@@ -165,6 +187,13 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], co
     s_e[5][slot] = make_float4(q[4].y, q[4].z, ex.x, ex.y);
     if (NC == 9) s_e[6][slot] = make_float4(ey.x, ey.y, ey.z, 0.f);
     if (cells16) *cells16 = cell_mask16(Tu, Tv, Tw, mx, my, opacity);   // (counter variant: what a 4x4-cell culling would keep)
+    if (cells_rows) {   // (row-mapped forward: per-cell bits; a quadrant is visited if one of its cells is)
+        *cells_rows = cell_mask_rows<QX, QY>(Tu, Tv, Tw, mx, my, opacity, yshift);
+        uint32_t qm = 0;
+#pragma unroll
+        for (int q = 0; q < QX * QY; ++q) qm |= ((*cells_rows >> (4 * q)) & 15u) ? (1u << q) : 0u;
+        return qm;
+    }
     return cull ? quadrant_mask<QX, QY>(Tu, Tv, Tw, mx, my, opacity, yshift) : (1u << (QX * QY)) - 1u;
 }
 

@@ -255,6 +255,144 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats &
 }
 
 // ---------------------------------------------------------------------------------------------
+// K6, row-mapped (three colour channels): the wave's four 16-lane rows are the four 4x4 cells of a quadrant, and every row walks ITS
+// OWN list -- the entries of the round whose octagon reaches its cell -- so a wave step serves four different entries, one per row,
+// instead of one entry on 64 lanes of which a thin splat uses a dozen.  Same staging, same `intersect`, same per-pixel sequence of
+// operations as render_forward_kernel: bit-identical images, state and hit masks.  The rows' entry indices travel packed in one SGPR
+// (next set bit of the row's 64-bit mask: scalar unit), every lane extracts its row's byte and reads the staged entry at ITS address.
+// ---------------------------------------------------------------------------------------------
+template <int QX, int QY, int SPLIT>
+__global__ __launch_bounds__(kWave) void render_forward_rows_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
+                                                                     const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
+                                                                     float* __restrict__ out_color, float* __restrict__ out_allmap,
+                                                                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                                     uint16_t* __restrict__ hit_mask) {
+    constexpr int NC = 3;
+    __shared__ float4 s_e[entry_quads<NC>()][kWave];
+    __shared__ uint8_t s_hit[QX * QY][kWave];   // (entry, quadrant) reached a pixel: the backward's exact visit list
+    const int lane = threadIdx.x;
+    int tile = blockIdx.x, part = 0;
+    if (SPLIT > 1) {
+        const int xcd = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
+        tile = (k / SPLIT) * kXcds + xcd; part = k % SPLIT;
+        if (tile >= f.tiles_x * f.tiles_y) return;
+    }
+    tile = (int)tile_order[tile];
+    constexpr int NQ = QX * QY;
+    const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8 * SPLIT) + part * (QY * 8);
+    const float Xc = (float)(tx0 + QX * 4), Yc = (float)((tile / f.tiles_x) * (QY * 8 * SPLIT) + QY * SPLIT * 4);
+    const int yshift_px = part * (QY * 8) - QY * (SPLIT - 1) * 4;
+    const float yshift = (float)yshift_px;
+    // row r = lane / 16 <-> cell (r & 1, r >> 1) of the quadrant; lane % 16 <-> pixel (l & 3, l >> 2) of the cell
+    const int lx = ((lane >> 4) & 1) * 4 + (lane & 3), ly = (lane >> 5) * 4 + ((lane >> 2) & 3);
+    const uint2 range = ranges[tile];
+    const uint32_t n_total = range.y - range.x;
+
+    const float xl0 = (float)(lx - QX * 4), yl0 = (float)(ly - QY * 4) + yshift;   // quadrant 0; quadrant q adds 8 (q % QX, q / QX)
+    float T[NQ], C0[NQ], C1[NQ], C2[NQ], N0[NQ], N1[NQ], N2[NQ], Dsum[NQ], M1[NQ], M2[NQ], dist[NQ], med[NQ];
+    uint32_t lastc[NQ], medc[NQ];
+    uint32_t alive = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
+        T[q] = (px < f.W && py < f.H) ? 1.f : -1.f; C0[q] = C1[q] = C2[q] = N0[q] = N1[q] = N2[q] = 0.f;
+        Dsum[q] = M1[q] = M2[q] = dist[q] = med[q] = 0.f;
+        lastc[q] = 0; medc[q] = 0xFFFFFFFFu;
+        if (ballot64(T[q] > 0.f) != 0) alive |= 1u << q;
+    }
+    float4 nr[kRecQuads];
+    const float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((uint32_t)lane < n_total) load_record(recs, point_list[range.x + lane], nr);
+    for (uint32_t base = 0; base < n_total && alive; base += kWave) {
+        const uint32_t n = min((uint32_t)kWave, n_total - base);
+        int ys = yshift_px;
+        asm volatile("" : "+s"(ys));
+        uint32_t cm = 0;   // this lane's ENTRY: bit 4 q + c = its octagon reaches cell c of quadrant q
+        if ((uint32_t)lane < n) (void)stage_entry<QX, QY, NC>(nr, nx, nx, Xc, Yc, 1, s_e, lane, (float)ys, nullptr, &cm);
+        if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s_hit[q][lane] = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (!(alive & (1u << q))) continue;
+            const float xq = xl0 + (float)((q % QX) * 8), yq = yl0 + (float)((q / QX) * 8);
+            // this lane's ROW's list for the quadrant: the scalar unit serves four SIMDs and would be the bottleneck of a walk on scalar
+            // masks (measured: 60 scalar instructions per step), so every lane keeps its row's mask in a register pair
+            unsigned long long brow;
+            {
+                const unsigned long long b0 = ballot64(((cm >> (4 * q)) & 1u) != 0u), b1 = ballot64(((cm >> (4 * q + 1)) & 1u) != 0u),
+                                         b2 = ballot64(((cm >> (4 * q + 2)) & 1u) != 0u), b3 = ballot64(((cm >> (4 * q + 3)) & 1u) != 0u);
+                const int row = lane >> 4;
+                brow = row == 0 ? b0 : (row == 1 ? b1 : (row == 2 ? b2 : b3));
+            }
+            while (ballot64(brow != 0ull) != 0ull) {
+                const bool act = brow != 0ull;
+                const uint32_t j = act ? (uint32_t)__builtin_ctzll(brow) : 0u;
+                brow &= brow - 1ull;
+                const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+                Hit h;
+                const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (T[q] > 0.f) & act;
+                if (ballot64(valid) == 0ull) continue;
+                const float4 e4 = s_e[4][j], e5 = s_e[5][j];
+                if (valid) {
+                    s_hit[q][j] = 1;   // (every valid lane of the row stores the same byte)
+                    const uint32_t contributor = base + j + 1u;
+                    const float test_T = T[q] * (1.f - h.alpha);
+                    const bool go = !(test_T < kTStop);
+                    if (go) {
+                        const float w = h.alpha * T[q];
+                        const float A = 1.f - T[q];
+                        const float mm = kFN * (1.f - kNear * fast_rcp(h.depth));
+                        dist[q] += (mm * mm * A + M2[q] - 2.f * mm * M1[q]) * w;
+                        Dsum[q] += h.depth * w;
+                        M1[q] += mm * w;
+                        M2[q] += mm * mm * w;
+                        if (T[q] > 0.5f) { med[q] = h.depth; medc[q] = contributor; }
+                        N0[q] += e4.x * w; N1[q] += e4.y * w; N2[q] += e4.z * w;
+                        C0[q] += e4.w * w; C1[q] += e5.x * w; C2[q] += e5.y * w;
+                        lastc[q] = contributor;
+                    }
+                    T[q] = go ? test_T : -T[q];
+                }
+                // (a row whose sixteen pixels are done could drop the rest of its list: the test costs more per step than the steps it saves)
+                if (ballot64(T[q] > 0.f) == 0ull) { alive &= ~(1u << q); break; }
+            }
+        }
+        if ((uint32_t)lane < n) {
+            uint32_t hm = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) hm |= (uint32_t)s_hit[q][lane] << q;
+            if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base + lane) + part] = (uint8_t)hm;
+            else if (QY == 2) hit_mask[range.x + base + lane] = (uint16_t)((hm & ((1u << QX) - 1u)) | ((hm >> QX) << 8));
+            else hit_mask[range.x + base + lane] = (uint16_t)hm;
+        }
+    }
+    const size_t HW = (size_t)f.H * f.W;
+    const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
+    int lane_again = threadIdx.x;
+    asm volatile("" : "+v"(lane_again));   // the pixel coordinates are recomputed here instead of living in registers across the list walk
+    const int lx2 = ((lane_again >> 4) & 1) * 4 + (lane_again & 3), ly2 = (lane_again >> 5) * 4 + ((lane_again >> 2) & 3);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int px = tx0 + (q % QX) * 8 + lx2, py = ty0 + (q / QX) * 8 + ly2;
+        if (px < f.W && py < f.H) {
+            const size_t pix = (size_t)py * f.W + px;
+            const float Tq = fabsf(T[q]);
+            final_T[pix] = Tq; final_T[HW + pix] = M1[q]; final_T[2 * HW + pix] = M2[q];
+            n_contrib[pix] = lastc[q]; n_contrib[HW + pix] = medc[q];
+            out_color[pix] = C0[q] + Tq * bg0;
+            out_color[HW + pix] = C1[q] + Tq * bg1;
+            out_color[2 * HW + pix] = C2[q] + Tq * bg2;
+            out_allmap[pix] = Dsum[q];
+            out_allmap[HW + pix] = 1.f - Tq;
+            out_allmap[2 * HW + pix] = N0[q]; out_allmap[3 * HW + pix] = N1[q]; out_allmap[4 * HW + pix] = N2[q];
+            out_allmap[5 * HW + pix] = med[q];
+            out_allmap[6 * HW + pix] = dist[q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
 // Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
@@ -517,7 +655,7 @@ __global__ __launch_bounds__(kWave) void pair_decisions_kernel(FrameDev f, const
     else if (f.tile_w == 32 && f.tile_h == 16) { F(4, 2); }                     \
     else return hipErrorInvalidValue;
 
-// flags: bit 0 = quadrant culling on (SR_FLAG_NO_QUADRANT_CULL clear), bit 1 = counter variant (counters != NULL)
+// flags: bit 0 = quadrant culling on (SR_FLAG_NO_QUADRANT_CULL clear), bit 1 = counter variant (counters != NULL), bit 2 = row-mapped kernel
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib,
                                  uint16_t* hit_mask, int flags, unsigned long long* counters, hipStream_t s) {
@@ -535,6 +673,8 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
         if (f.colors == 9) { SR_LAUNCH_FWD(false, 9, 2, 1, 2); }
         else if (f.colors == 6) { if (count) SR_LAUNCH_FWD(true, 6, 2, 2, 1); else SR_LAUNCH_FWD(false, 6, 2, 1, 2); }
         else if (count)         SR_LAUNCH_FWD(true, 3, 2, 2, 1);
+        else if (flags & 4)     hipLaunchKernelGGL((render_forward_rows_kernel<2, 1, 2>), dim3((n_tiles + kXcds - 1) / kXcds * kXcds * 2), block, 0, s, f, ranges,
+                                                   tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);
         else                    SR_LAUNCH_FWD(false, 3, 2, 1, 2);
     } else {
         if (f.colors != 3) return hipErrorInvalidValue;

@@ -33,7 +33,7 @@ def run_oracle(g, cam, bg, deg, dc=None, da=None, mode="sh", colors=None, Tpre=N
     return fwd, bwd
 
 
-def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=False, tile=None, quadrant_cull=True):
+def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=False, tile=None, quadrant_cull=True, row_mapped=False):
     """Returns dict with outputs, internal state views and (if dc given) input gradients, all numpy."""
     dev = DEV
     s = settings_for(cam, bg, deg, debug)
@@ -49,7 +49,7 @@ def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=Fal
         t["Tpre"] = torch.as_tensor(Tpre).to(dev).requires_grad_(); kw["cov3D_precomp"] = t["Tpre"]
     else:
         kw["scales"] = t["scales"]; kw["rotations"] = t["rotations"]
-    color, radii, allmap = GaussianRasterizer(s, tile=tile, quadrant_cull=quadrant_cull)(**kw)
+    color, radii, allmap = GaussianRasterizer(s, tile=tile, quadrant_cull=quadrant_cull, row_mapped=row_mapped)(**kw)
     out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), allmap=allmap.detach().cpu().numpy())
     if dc is not None:
         ((color * dc.to(dev)).sum() + (allmap * da.to(dev)).sum()).backward()
@@ -63,7 +63,7 @@ def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=Fal
     return out
 
 
-def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None, tile=None, quadrant_cull=True, decisions=False):
+def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None, tile=None, quadrant_cull=True, decisions=False, row_mapped=False):
     """Calls _C.rasterize_gaussians directly and returns the state-buffer views as numpy (for bit-exact checks)."""
     dev = DEV
     s = settings_for(cam, bg, deg)
@@ -76,7 +76,7 @@ def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None, tile=None, quadrant_cul
     tp = e if Tpre is None else torch.as_tensor(Tpre).to(dev)
     D, color, allmap, radii, geom, binning, img = _C.rasterize_gaussians(
         s.bg, d("means3D"), col, d("opacities"), sc, ro, 1.0, tp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
-        s.image_height, s.image_width, sh, deg, s.campos, False, False, tile=tile, quadrant_cull=quadrant_cull)
+        s.image_height, s.image_width, sh, deg, s.campos, False, False, tile=tile, quadrant_cull=quadrant_cull, row_mapped=row_mapped)
     dec = None
     if decisions:   # the hard decisions the blend kernels act on, per (list entry, pixel) pair (sr_debug_pair_decisions)
         valid, use3d = _C.pair_decisions(s.bg, d("means3D"), 1.0, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width,

@@ -206,6 +206,28 @@ def test_quadrant_culling_is_exact():
             assert np.abs(out1[k] - out0[k]).max() <= 2e-5 * scale, k
 
 
+def test_row_mapped_forward_is_bit_identical():
+    """SR_FLAG_ROW_MAPPED_FORWARD: the four 16-lane rows of a wave walk the lists of four 4x4 cells instead of one entry on 64 lanes --
+    the same per-pixel sequence of operations, so images, per-pixel state and (through the exact hit masks the backward visits)
+    every gradient equal the default kernel's bit for bit; shapes it does not exist for are refused by name."""
+    from streetunveiler_amd import _lib
+    from tests.gpu_util import run_hip, run_hip_raw
+    for (P, W, H, lo, hi, idx) in [(30000, 384, 216, 5e-4, 5e-3, None), (8000, 200, 150, 5e-3, 8e-2, 6), (3000, 161, 97, 2e-2, 3e-1, 1)]:
+        cam, g = _scene(P, W, H, P + 2, lo, hi, idx)
+        g["opacities"][::11] = 1.0
+        dc, da = synthetic_upstream_grads(W, H, seed=P)
+        raw0, raw1 = (run_hip_raw(g, cam, [0.2, 0.4, 0.6], 3, row_mapped=r) for r in (False, True))
+        out0, out1 = (run_hip(g, cam, [0.2, 0.4, 0.6], 3, dc, da, row_mapped=r) for r in (False, True))
+        for k in ("color", "allmap"):
+            np.testing.assert_array_equal(raw1[k], raw0[k])
+        np.testing.assert_array_equal(raw1["img"]["n_contrib"], raw0["img"]["n_contrib"])
+        np.testing.assert_array_equal(raw1["img"]["final_T"], raw0["img"]["final_T"])
+        for k in ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"]:
+            np.testing.assert_array_equal(out1[k], out0[k], err_msg=k)
+    with pytest.raises(_lib.SurfelRasterError, match="ROW_MAPPED"):
+        run_hip_raw(g, cam, [0.2, 0.4, 0.6], 3, tile=(8, 8), row_mapped=True)
+
+
 def test_lds_atomic_returns_in_lane_order():
     """The rank phase of the sort / partition kernels is ONE LDS atomic per item: it relies on ds_add_rtn_u32 handing its return values
     to the lanes of a wave instruction that hit the same address in ascending lane order (not documented for gfx950).  Checked here
