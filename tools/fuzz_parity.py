@@ -1,62 +1,92 @@
 #!/usr/bin/env python
 """Randomised parity sweep: HIP operator vs CPU oracle over many small random scenes (sizes, cameras, SH degree, tile shape,
-opacity / scale regimes, precomputed colours / transMat).  Exits non-zero on the first scene that misses the parity bars of
-tests/gpu_util.py.  python tools/fuzz_parity.py [n_scenes] [first_seed]"""
+opacity / scale regimes, precomputed colours / transMat).  Exits non-zero if a scene misses the parity bars of
+tests/gpu_util.py.  python tools/fuzz_parity.py [n_scenes] [first_seed]   (FUZZ_SEEDS=a,b,c: exactly these scenes; tools/fuzz_diagnose.py
+prints one scene in detail, the float32 oracle beside the kernels)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
-from tests.gpu_util import assert_close_frac, assert_free_parity, check_allmap, free_f64_reference, run_hip, run_hip_raw, run_oracle
+from tests.gpu_util import (assert_close_frac, assert_free_parity, assert_strict_parity, check_allmap, forced_f64_reference, free_f64_reference, run_hip,
+                            run_hip_raw, run_oracle)
 from tests.test_gpu_parity import _check_binning
 
-n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 big = int(os.environ.get("FUZZ_BIG", "1"))   # FUZZ_BIG=4: images up to 4x wider/higher, 16x the Gaussians
 shapes = [(16, 16)] * 4 + [(8, 8), (16, 8), (32, 8), (32, 16)]
-bad = 0
-for k in range(n_scenes):
-    rng = np.random.default_rng(seed0 + k)
+
+
+def make_scene(seed):
+    rng = np.random.default_rng(seed)
     W, H = int(rng.integers(17, 330 * big)), int(rng.integers(9, 200 * big))
     P = int(rng.integers(1, 9000 * big * big))
     lo = float(10 ** rng.uniform(-3.3, -1.5)); hi = lo * float(10 ** rng.uniform(0.3, 1.5))
     deg = int(rng.integers(0, 4))
     tile = shapes[int(rng.integers(0, len(shapes)))]
     cam = synthetic_camera(W, H, index=int(rng.integers(0, 8)))
-    g = synthetic_gaussians(P, W, H, seed=seed0 + k, scale_lo=lo, scale_hi=hi)
+    g = synthetic_gaussians(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi)
     regime = int(rng.integers(0, 4))
     if regime == 1: g["opacities"] = g["opacities"] * 0.05                       # translucent: deep lists
     if regime == 2: g["opacities"] = (g["opacities"] * 0.2 + 0.8).clamp(max=1.0)  # opaque: early saturation
     if regime == 3: g["means3D"][: P // 3, 2] = torch.rand(P // 3) * 0.5 - 0.1     # around / behind the near plane
     bg = rng.random(3).astype(np.float32)
-    dc, da = synthetic_upstream_grads(W, H, seed=seed0 + k)
+    dc, da = synthetic_upstream_grads(W, H, seed=seed)
     colors = rng.random((P, 3)).astype(np.float32) if rng.random() < 0.25 else None
-    tag = f"scene {k} (seed {seed0 + k}): P={P} {W}x{H} deg={deg} tile={tile} regime={regime} scales[{lo:.1e},{hi:.1e}] colors={'pre' if colors is not None else 'sh'}"
+    tag = f"(seed {seed}): P={P} {W}x{H} deg={deg} tile={tile} regime={regime} scales[{lo:.1e},{hi:.1e}] colors={'pre' if colors is not None else 'sh'}"
+    return dict(g=g, cam=cam, bg=bg, deg=deg, dc=dc, da=da, colors=colors, tile=tile, regime=regime, P=P, tag=tag)
+
+
+def main():
+  n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+  seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+  seeds = [seed0 + k for k in range(n_scenes)]
+  if os.environ.get("FUZZ_SEEDS"):   # exactly these scenes (regressions the sweep found)
+    seeds = [int(x) for x in os.environ["FUZZ_SEEDS"].split(",")]; n_scenes = len(seeds)
+  bad = 0
+  for k in range(n_scenes):
+    sc = make_scene(seeds[k])
+    g, cam, bg, deg, dc, da, colors, tile, regime, P = (sc[x] for x in ("g", "cam", "bg", "deg", "dc", "da", "colors", "tile", "regime", "P"))
+    tag = f"scene {k} " + sc["tag"]
     try:
         fwd, bwd = run_oracle(g, cam, bg, deg, dc, da, colors=colors, tile=tile)
-        raw = run_hip_raw(g, cam, bg, deg, colors=colors, tile=tile if tile != (16, 16) else None)
+        raw = run_hip_raw(g, cam, bg, deg, colors=colors, tile=tile if tile != (16, 16) else None, decisions=True)
         _check_binning(raw, fwd)
         out = run_hip(g, cam, bg, deg, dc, da, colors=colors, tile=tile if tile != (16, 16) else None)
         # images: 1e-4 for all but a small fraction of the pixels; the rest is bounded by what ONE flipped contributor at the
         # alpha = 1/255 threshold can move: 1/255 of the channel's per-splat magnitude (rgb, depth, unit normal, ...)
         assert_close_frac(out["color"], fwd["color"], 1e-4, 1e-4, 1e-3, None, "color")
         check_allmap(out["allmap"], fwd["allmap"], "allmap", max_bad_frac=2e-3, hard=None)
+        # (every pixel, against the float32 oracle OR the free-running float64 reference, whichever is closer: the reference's
+        # `if (p.z == 0) continue` fires where the ORACLE's float32 p.z lands on exactly 0 -- rounding noise of a ray nearly parallel to the
+        # splat's plane -- and there the kernels blend the pair through its 2-D filter footprint like exact arithmetic does: blend_common.h)
+        xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, colors=colors, tile=tile, base=fwd)
         flip = 1.5 / 255.0
         zmax = float(fwd["depths"][fwd["radii"] > 0].max()) if (fwd["radii"] > 0).any() else 1.0
         cmax = max(1.0, float(fwd["rgb"].max()))
-        assert np.abs(out["color"] - fwd["color"]).max() <= flip * cmax + 1e-3, "color beyond one flipped contributor"
+        both = lambda a, r32, r64: np.minimum(np.abs(a - r32), np.abs(a - r64)).max()
+        assert both(out["color"], fwd["color"], xfwd["color"]) <= flip * cmax + 1e-3, "color beyond one flipped contributor"
         for ch, mag in ((0, zmax), (1, 1.0), (2, 1.0), (3, 1.0), (4, 1.0), (6, 1.0)):
-            e = np.abs(out["allmap"][ch] - fwd["allmap"][ch]).max()
+            e = both(out["allmap"][ch], fwd["allmap"][ch], xfwd["allmap"][ch])
             assert e <= flip * mag + 1e-3 * max(1.0, mag), f"allmap[{ch}] err {e:.3e} beyond one flipped contributor ({flip * mag:.3e})"
         # ... and the free-running float64 reference (its own decisions): on every ROBUST pixel the kernels stop at the same entry, pick
         # the same median and agree within 1e-4; on every robust Gaussian the strict row bars hold.  (Random regimes -- translucent deep
         # lists, splats around the near plane -- make many pixels non-robust: the fraction is reported, not bounded, here.)
-        xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, colors=colors, tile=tile, base=fwd)
         rep = {}
         # regime 3 puts splats around the camera plane: p.z -> 0 inside a footprint makes the VALUE of the ray-splat intersection
         # ill-conditioned in float32 (not a decision): the value bars get a factor 5 there, the identical-decision checks none
+        # Non-robust elements (a decision within float32 rounding of its threshold: either implementation may take it either way, and one
+        # flipped contributor moves a few-pixel splat's whole gradient) only have to be finite here -- they are pinned below with the
+        # decisions FORCED.  A robust-row bar reads "within the bar, or at least twice as accurate as the float32 oracle on those rows":
+        # some random scenes (translucent deep lists of large splats) put float32 itself 1e-2 from the float64 reference.
         assert_free_parity(out, raw["img"]["n_contrib"], xfwd, xbwd, margins, scene=(g, cam), report=rep, pixel_budget=1.0, gaussian_budget=1.0,
-                           value_slack=5.0 if regime == 3 else 1.0)
+                           value_slack=5.0 if regime == 3 else 1.0, nonrobust_pixel_cap=None, nonrobust_row_cap=None, oracle32=bwd, oracle32_fwd=fwd)
+        # ... and EVERY element, robust or not, with the kernels' own decisions forced on a float64 evaluation (blend and K8 in double):
+        # 1e-4 (1 + |v|) at every pixel of colour and aux maps, the strict row bars on every visible Gaussian
+        _, sfwd, sbwd = forced_f64_reference(g, cam, bg, deg, dc, da, tile=tile, colors=colors, base=fwd, raw=raw)
+        # (row bars: within the bar, or no worse than the float32 oracle under the same forced decisions -- some random scenes cancel badly)
+        if regime != 3:
+            _, sfwd32, sbwd32 = forced_f64_reference(g, cam, bg, deg, dc, da, tile=tile, colors=colors, base=fwd, raw=raw, f64=False)
+            assert_strict_parity(out, sfwd, sbwd, scene=(g, cam), oracle32=sbwd32, oracle32_fwd=sfwd32)
         names = ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D", "dL_dcolors" if colors is not None else "dL_dsh"]
         # Per GAUSSIAN, against the float32 oracle: any gradient element of a ROBUST Gaussian off by more than 2e-3 of its tensor's scale
         # marks it.  (A flipped decision moves the whole gradient of a few-pixel splat: those Gaussians are the non-robust ones, checked
@@ -75,5 +105,9 @@ for k in range(n_scenes):
     except AssertionError as e:
         bad += 1
         print("FAIL", tag, "\n     ", str(e).splitlines()[0][:300], flush=True)
-print(f"{n_scenes - bad}/{n_scenes} scenes within the parity bars")
-sys.exit(1 if bad else 0)
+  print(f"{n_scenes - bad}/{n_scenes} scenes within the parity bars")
+  sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+  main()
