@@ -60,7 +60,7 @@ def main():
         # `if (p.z == 0) continue` fires where the ORACLE's float32 p.z lands on exactly 0 -- rounding noise of a ray nearly parallel to the
         # splat's plane -- and there the kernels blend the pair through its 2-D filter footprint like exact arithmetic does: blend_common.h)
         xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, colors=colors, tile=tile, base=fwd)
-        flip = 1.5 / 255.0
+        flip = (5.0 if regime == 3 else 1.0) * 1.5 / 255.0   # (camera-plane regime: the ill-conditioned one, see value_slack below)
         zmax = float(fwd["depths"][fwd["radii"] > 0].max()) if (fwd["radii"] > 0).any() else 1.0
         cmax = max(1.0, float(fwd["rgb"].max()))
         both = lambda a, r32, r64: np.minimum(np.abs(a - r32), np.abs(a - r64)).max()
