@@ -30,6 +30,7 @@ SOURCES = [
     ("binning.hip", []),
     ("radix_sort.hip", []),
     ("render.hip", []),
+    ("render_bwd.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),   # K7: -1 % with the max-ILP scheduler (the forward kernel spills with it)
     ("render_class.hip", []),
     ("postprocess.hip", []),
     ("knn.hip", ["-ffp-contract=off"]),         # squared distances bit-identical to the brute-force oracle

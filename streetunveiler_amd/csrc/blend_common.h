@@ -1,4 +1,4 @@
-// blend_common.h -- device helpers shared by the blend kernels (render.hip: K6 / K7 / decision dump; render_class.hip: the
+// blend_common.h -- device helpers shared by the blend kernels (render.hip: K6 / decision dump, render_bwd.hip: K7; render_class.hip: the
 // per-class distortion pass): staging of list entries into the tile-local form, exact quadrant culling, the ray-splat test,
 // the emission index of a duplicate, and the wave-level transpose-reduction of the per-entry gradient sums.
 #pragma once

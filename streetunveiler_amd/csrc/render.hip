@@ -1,4 +1,4 @@
-// render.hip -- K6 (per-tile front-to-back blend) and K7 (per-tile back-to-front backward), gfx950.
+// render.hip -- K6 (per-tile front-to-back blend); K7 (per-tile back-to-front backward) lives in render_bwd.hip; gfx950.
 //
 // Mapping: a wave64 owns QX x QY quadrants of 8x8 pixels, one pixel of each per lane -- lane l is pixel (l&7, l>>3) of every
 // quadrant.  For the reference's 16x16 tile K7 is ONE wave per tile (2 x 2 quadrants, four pixels per lane: the gradient
@@ -393,219 +393,6 @@ __global__ __launch_bounds__(kWave) void render_forward_rows_kernel(FrameDev f, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K7
-// ---------------------------------------------------------------------------------------------
-// Output: one 96-B gradient record per (tile, Gaussian) duplicate, stored at the duplicate's EMISSION index
-// (first[gid] + its index inside the Gaussian's tile rectangle; first[] = FrameDev.first, fetched next to the record), where the
-// records of one Gaussian are contiguous; K8 sums them.  Only entries with a contributing pixel get a record, and a 1 in
-// `written[]` at the same index (zeroed per call).  Gradient record slots: see common.h.
-// Register budget: three waves per SIMD (<= 168 VGPRs) wherever the per-pixel state allows it -- the loop is latency-bound
-// at two -- i.e. up to four pixels per lane with three colour channels.
-template <int NC, int QX, int QY>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(QX * QY <= 4 && NC == 3 ? 3 : 1, QX * QY <= 4 && NC == 3 ? 3 : 8)))
-void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
-                                                                 const uint32_t* __restrict__ point_list,
-                                                                 const float4* __restrict__ recs,
-                                                                 const float* __restrict__ extra,
-                                                                 const float* __restrict__ final_T,
-                                                                 const uint32_t* __restrict__ n_contrib,
-                                                                 const float* __restrict__ dL_dcolor,
-                                                                 const float* __restrict__ dL_dallmap,
-                                                                 const uint16_t* __restrict__ hit_mask,
-                                                                 float4* __restrict__ inst_grads, uint8_t* __restrict__ written) {
-    constexpr int kGQ = NC == 9 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record (27 values with 9 channels)
-    __shared__ float4 s_e[entry_quads<NC>()][kWave];
-    __shared__ __attribute__((aligned(16))) float s_out[kWave][kGQ * 4];
-    const int lane = threadIdx.x;
-    const int tile = (int)tile_order[blockIdx.x];   // longest lists first
-    constexpr int NQ = QX * QY;   // 8x8 quadrants per tile = pixels per lane
-    const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8);
-    const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
-    const int lx = lane & 7, ly = lane >> 3;
-    const uint2 range = ranges[tile];
-    const uint32_t count = range.y - range.x;
-    const size_t HW = (size_t)f.H * f.W;
-    const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
-
-    // per-pixel constants (upstream gradients folded with the forward's final accumulators) and state
-    const float xl0 = (float)(lx - QX * 4), yl0 = (float)(ly - QY * 4);   // tile-local pixel of quadrant 0; quadrant q adds 8*(q%QX, q/QX)
-    float gr[NQ], gg[NQ], gb[NQ], gn0[NQ], gn1[NQ], gn2[NQ], g_depth[NQ], g_median[NQ], a0[NQ], a1[NQ], a2[NQ];
-    float gc3[NQ], gc4[NQ], gc5[NQ], gc6[NQ], gc7[NQ], gc8[NQ];   // only live in the 6- / 9-channel variants
-    uint32_t lastc[NQ], medc[NQ], quad_last[NQ];
-    float T[NQ], Z[NQ];
-    uint32_t total = 0;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
-        const bool inside = px < f.W && py < f.H;
-        const size_t pix = inside ? (size_t)py * f.W + px : 0;
-        const float T_final = inside ? final_T[pix] : 0.f;
-        const float fin_D = inside ? final_T[HW + pix] : 0.f, fin_D2 = inside ? final_T[2 * HW + pix] : 0.f;
-        lastc[q] = inside ? n_contrib[pix] : 0u;
-        medc[q] = inside ? n_contrib[HW + pix] : 0u;
-        gr[q] = inside ? dL_dcolor[pix] : 0.f; gg[q] = inside ? dL_dcolor[HW + pix] : 0.f; gb[q] = inside ? dL_dcolor[2 * HW + pix] : 0.f;
-        g_depth[q] = inside ? dL_dallmap[pix] : 0.f;
-        const float g_accum = inside ? dL_dallmap[HW + pix] : 0.f;
-        gn0[q] = inside ? dL_dallmap[2 * HW + pix] : 0.f; gn1[q] = inside ? dL_dallmap[3 * HW + pix] : 0.f; gn2[q] = inside ? dL_dallmap[4 * HW + pix] : 0.f;
-        g_median[q] = inside ? dL_dallmap[5 * HW + pix] : 0.f;
-        const float g_reg = inside ? dL_dallmap[6 * HW + pix] : 0.f;
-        float bg_dot = bg0 * gr[q] + bg1 * gg[q] + bg2 * gb[q];
-        gc3[q] = gc4[q] = gc5[q] = gc6[q] = gc7[q] = gc8[q] = 0.f;
-        if (NC >= 6) {
-            gc3[q] = inside ? dL_dcolor[3 * HW + pix] : 0.f; gc4[q] = inside ? dL_dcolor[4 * HW + pix] : 0.f; gc5[q] = inside ? dL_dcolor[5 * HW + pix] : 0.f;
-            bg_dot += f.bg[3] * gc3[q] + f.bg[4] * gc4[q] + f.bg[5] * gc5[q];
-        }
-        if (NC == 9) {
-            gc6[q] = inside ? dL_dcolor[6 * HW + pix] : 0.f; gc7[q] = inside ? dL_dcolor[7 * HW + pix] : 0.f; gc8[q] = inside ? dL_dcolor[8 * HW + pix] : 0.f;
-            bg_dot += f.bg[6] * gc6[q] + f.bg[7] * gc7[q] + f.bg[8] * gc8[q];
-        }
-        a0[q] = (1.f - T_final) * g_reg; a1[q] = fin_D * g_reg; a2[q] = fin_D2 * g_reg;
-        T[q] = T_final; Z[q] = -T_final * (g_accum - bg_dot);   // the background / alpha term rides in the suffix sum
-        quad_last[q] = wave_max_u32(lastc[q]);  // deepest entry any pixel of quadrant q needs (uniform)
-        total = max(total, quad_last[q]);
-    }
-
-    // entries behind the deepest contributor of the tile are never looked at: they get no record and keep a clear `written` flag
-    const int rounds = (int)((total + kWave - 1) / kWave);
-    float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f), ny = nx;
-    uint32_t nhit = 0;
-    if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
-        const uint32_t pos = range.x + (rounds - 1) * kWave + lane;
-        const uint32_t gid = point_list[pos];
-        load_record(recs, gid, nr); nr[3].w = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
-        if (NC == 6) nx = load_extra(extra, gid, 3);
-            if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
-        nhit = decode_hits<QX, QY>(hit_mask[pos]);
-    }
-    for (int rd = rounds - 1; rd >= 0; --rd) {
-        const uint32_t rbase = (uint32_t)rd * kWave;
-        const uint32_t n = min((uint32_t)kWave, total - rbase);
-        uint32_t m = 0, slot = 0;
-        if ((uint32_t)lane < n) {
-            (void)stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, 0, s_e, lane);
-            m = nhit;   // (entry, quadrant) pairs that reached a pixel in the forward: exact, no culling test needed here
-            slot = emission_index(nr, __float_as_uint(nr[3].w), tile % f.tiles_x, tile / f.tiles_x, f);
-            uint32_t need = 0;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
-            m &= need;
-        }
-        {
-            float4* z = reinterpret_cast<float4*>(&s_out[lane][0]);
-#pragma unroll
-            for (int k = 0; k < kGQ; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (rd > 0) {  // next round is always full
-            const uint32_t pos = range.x + rbase - kWave + lane;
-            const uint32_t gid = point_list[pos];
-            load_record(recs, gid, nr); nr[3].w = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
-            if (NC == 6) nx = load_extra(extra, gid, 3);
-            if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
-            nhit = decode_hits<QX, QY>(hit_mask[pos]);
-        }
-        unsigned long long bits = ballot64(m != 0);
-        // entries of this round that get a record: those with an (entry, quadrant) pair that reached a pixel in the forward.  (Such a
-        // pair has a valid lane here too -- same decisions, bit for bit -- unless every pixel it reached stopped at the transmittance
-        // floor instead of blending: that rare entry gets a record of zeros rather than a wave-wide `any lane valid` test per pair.)
-        const unsigned long long wrote = bits;
-        while (bits) {
-            const int j = 63 - __clzll((long long)bits);
-            bits &= ~(1ull << j);
-            const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
-            const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
-            const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
-            constexpr int NV = NC == 3 ? 21 : 24;   // slots 21..23 carry colour channels 3..5 only
-            float v[24];
-#pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                v[k] = 0.f;
-                if (k < NV) asm volatile("" : "+v"(v[k]));   // opaque zero: every quadrant block accumulates in place (no phi copies of constants)
-            }
-            float w6 = 0.f, w7 = 0.f, w8 = 0.f;   // colour channels 6..8 (9-channel variant)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (!(mj & (1u << q))) continue;  // wave-uniform
-                Hit h;
-                const float xq = xl0 + (float)((q % QX) * 8), yq = yl0 + (float)((q / QX) * 8);
-                const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc[q]);
-                if (valid) {
-                    const float4 e4 = s_e[4][j], e5 = s_e[5][j];
-                    const float Twx = e2.y, Twy = e2.z;
-                    const float one_m_inv = fast_rcp(1.f - h.alpha);
-                    T[q] *= one_m_inv;                 // transmittance in front of this entry
-                    const float w = h.alpha * T[q];
-                    // psi = rgb.g + depth g_depth + n.gn + (a2 + m (m a0 - 2 a1)), m = the depth metric; dL/dz = w (2 (m a0 - a1) dm/dz + g_depth),
-                    // dm/dz = kFN kNear / depth^2.  t1 = m a0 - a1 serves both: 8 instructions where the literal transcription took 11.  (The
-                    // three distortion terms cancel to the variance of m along the ray: they are combined in ONE fma before anything else is
-                    // added -- seeding the colour chain with a2 saves another instruction and costs a digit under a distortion-weighted loss.)
-                    float phi = fmaf(e4.w, gr[q], fmaf(e5.x, gg[q], fmaf(e5.y, gb[q], fmaf(h.depth, g_depth[q],
-                                fmaf(e4.x, gn0[q], fmaf(e4.y, gn1[q], e4.z * gn2[q]))))));
-                    if (NC >= 6) phi = fmaf(e5.z, gc3[q], fmaf(e5.w, gc4[q], fmaf(e3.w, gc5[q], phi)));
-                    if (NC == 9) { const float4 e6 = s_e[6][j]; phi = fmaf(e6.x, gc6[q], fmaf(e6.y, gc7[q], fmaf(e6.z, gc8[q], phi))); }
-                    const float inv_depth = fast_rcp(h.depth);
-                    const float m_d = fmaf(inv_depth, -kFN * kNear, kFN);
-                    const float t1 = fmaf(m_d, a0[q], -a1[q]);
-                    const float psi = phi + fmaf(m_d, t1 - a1[q], a2[q]);
-                    const float dL_dalpha = T[q] * psi - one_m_inv * Z[q];
-                    Z[q] = fmaf(w, psi, Z[q]);
-                    const float med_add = (cidx == medc[q] - 1u) ? g_median[q] : 0.f;
-                    const float dL_dz = fmaf(w, fmaf(t1 * (inv_depth * inv_depth), 2.f * kFN * kNear, g_depth[q]), med_add);
-                    const float dL_dG = e3.z * dL_dalpha;
-                    v[18] += w * gr[q]; v[19] += w * gg[q]; v[20] += w * gb[q];
-                    if (NC >= 6) { v[21] += w * gc3[q]; v[22] += w * gc4[q]; v[23] += w * gc5[q]; }
-                    if (NC == 9) { w6 += w * gc6[q]; w7 += w * gc7[q]; w8 += w * gc8[q]; }
-                    v[15] += w * gn0[q]; v[16] += w * gn1[q]; v[17] += w * gn2[q];
-                    v[14] += h.G * dL_dalpha;
-                    v[11] += dL_dz;   // (both paths)
-                    if (h.use3d) {
-                        const float gG = -dL_dG * h.G;
-                        const float dpx = (gG * h.sx + dL_dz * Twx) * h.pz_inv, dpy = (gG * h.sy + dL_dz * Twy) * h.pz_inv;
-                        const float dpz = -(dpx * h.sx + dpy * h.sy);
-                        // moments of dL/dp in tile-local pixel coordinates (shifted to global ones when the record is written);
-                        // the cross products happen once per Gaussian in K8
-                        v[0] += dpx; v[1] += dpy; v[2] += dpz;
-                        v[3] = fmaf(xq, dpx, v[3]); v[4] = fmaf(xq, dpy, v[4]); v[5] = fmaf(xq, dpz, v[5]);
-                        v[6] = fmaf(yq, dpx, v[6]); v[7] = fmaf(yq, dpy, v[7]); v[8] = fmaf(yq, dpz, v[8]);
-                        v[9] = fmaf(dL_dz, h.sx, v[9]); v[10] = fmaf(dL_dz, h.sy, v[10]);
-                    } else {
-                        const float gG = -dL_dG * h.G * kFilterInvSquare;
-                        v[12] = fmaf(gG, h.dx, v[12]);
-                        v[13] = fmaf(gG, h.dy, v[13]);
-                    }
-                }
-            }
-            {
-                const float tot = wave_reduce24<NV>(v, lane);
-                if (reduce24_holds_total(lane)) s_out[j][reduce24_index(lane)] = tot;
-                if (NC == 9) {
-                    const float t3 = wave_reduce3(w6, w7, w8);   // row 0: channel 6, row 1: channel 8, row 2: channel 7
-                    if ((lane & 15) == 0 && lane < 48) s_out[j][24 + (lane == 0 ? 0 : (lane == 16 ? 2 : 1))] = t3;
-                }
-            }
-        }
-        // flush this round's records: one 96-B store per lane whose entry got a contribution
-        if ((wrote >> lane) & 1ull) {
-            const float4* accl = reinterpret_cast<const float4*>(&s_out[lane][0]);
-            float4 acc[kGQ];
-#pragma unroll
-            for (int k = 0; k < kGQ; ++k) acc[k] = accl[k];
-            // Sx, Sy from tile-local coordinates to coordinates relative to the Gaussian's OWN centre (cx, cy): sum (xl - mx) dp = sum xl dp -
-            // mx S0 with mx = cx - Xc.  K8 sums these over the Gaussian's tiles and works with Tu - cx Tw, Tv - cy Tw: the same dL/dT as
-            // with moments about the image origin, without the cancellation of pixel coordinates ~1000 against extents of a few pixels
-            const float4 centre = s_e[3][lane];   // (mx, my, ..) = the Gaussian's centre relative to the tile centre
-            // (clamped into the image: the moments of a splat whose centre projects far off-screen are taken about the nearest image point)
-            const float ox = -fminf(fmaxf(centre.x, -Xc), (float)(f.W - 1) - Xc), oy = -fminf(fmaxf(centre.y, -Yc), (float)(f.H - 1) - Yc);
-            acc[0].w = fmaf(ox, acc[0].x, acc[0].w); acc[1].x = fmaf(ox, acc[0].y, acc[1].x); acc[1].y = fmaf(ox, acc[0].z, acc[1].y);
-            acc[1].z = fmaf(oy, acc[0].x, acc[1].z); acc[1].w = fmaf(oy, acc[0].y, acc[1].w); acc[2].x = fmaf(oy, acc[0].z, acc[2].x);
-            float4* o = inst_grads + (size_t)slot * kGQ;
-#pragma unroll
-            for (int k = 0; k < kGQ; ++k) o[k] = acc[k];
-            written[slot] = 1;   // K8 reads this 1-B flag (zeroed per call) before it touches the record
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Decision dump (test infrastructure of the parity bars, not part of the operator): for every list entry of every tile and
 // every pixel of the tile, whether the ray-splat test of K6 / K7 accepts the pair (`valid`: the chain of skips of Appendix A.4
 // up to alpha >= 1/255, WITHOUT the pixel's saturation state) and which path it takes (`use3d`: rho3d <= rho2d).  Same staging,
@@ -687,26 +474,6 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
         }
     }
 #undef SR_LAUNCH_FWD
-    return hipGetLastError();
-}
-
-hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
-                                  const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s) {
-    const int n_tiles = f.tiles_x * f.tiles_y;
-    if (n_tiles == 0) return hipSuccess;
-#define SR_LAUNCH_BWD(NCH, QX, QY)                                                                                                          \
-    hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, extra, final_T, \
-                       n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written)
-    if (f.tile_w == 16 && f.tile_h == 16) {
-        if (f.colors == 9) SR_LAUNCH_BWD(9, 2, 2); else if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
-    } else {
-        if (f.colors != 3) return hipErrorInvalidValue;
-#define SR_BWD_SHAPE(QX, QY) SR_LAUNCH_BWD(3, QX, QY)
-        SR_FOR_TILE_SHAPE(SR_BWD_SHAPE)
-#undef SR_BWD_SHAPE
-    }
-#undef SR_LAUNCH_BWD
     return hipGetLastError();
 }
 
