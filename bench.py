@@ -51,7 +51,8 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-aux", action="store_true", help="only colour + alpha gradients live (as in C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--row-mapped", action="store_true", help="A/B switch: the row-mapped forward blend (SR_FLAG_ROW_MAPPED_FORWARD; bit-identical results)")
+    ap.add_argument("--row-mapped", action="store_true", help="A/B switch: force the row-mapped forward blend (SR_FLAG_ROW_MAPPED_FORWARD; bit-identical results)")
+    ap.add_argument("--quadrant-mapped", action="store_true", help="A/B switch: force the quadrant-mapped forward blend (default: picked per frame on the device)")
     ap.add_argument("--exchange", choices=["factored", "allreduce"], default="factored",
                     help="N > 1 gradient exchange: factored = all-gather 12-B colour gradients + local SH expansion + all-reduce of "
                          "the other 40 B/Gaussian; allreduce = plain all-reduce of all 232 B/Gaussian")
@@ -206,7 +207,7 @@ def main():
                                                             1.0, c.world_view_transform.to(dev), c.full_proj_transform.to(dev), deg,
                                                             c.camera_center.to(dev), False, False)
     settings = make_settings(cam)
-    rasterizers = [GaussianRasterizer(settings if j == 0 else make_settings(cams[j]), row_mapped=args.row_mapped) for j in range(K)]
+    rasterizers = [GaussianRasterizer(settings if j == 0 else make_settings(cams[j]), row_mapped=True if args.row_mapped else (False if args.quadrant_mapped else None)) for j in range(K)]
     # the camera list is replicated: every rank knows every rank's camera positions ([world, 3], or [world, K, 3] with accumulation)
     all_campos = None
     if multi:

@@ -45,14 +45,14 @@ def _stream(device):
 
 
 def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile=None,
-           quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=False):
+           quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=None):
     keep = [_f32c(bg, "bg"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos"), blend_counters]
     if blend_counters is not None and (blend_counters.dtype != torch.int64 or blend_counters.numel() < 16 or not blend_counters.is_cuda):
         raise L.SurfelRasterError("blend_counters must be a CUDA (ROCm) int64 tensor with 16 entries")
     fr = L.SrFrame(int(H), int(W), float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree),
                    int(bool(prefiltered)), int(bool(debug)), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
                    int(tile[0]) if tile else 0, int(tile[1]) if tile else 0, (0 if quadrant_cull else L.SR_FLAG_NO_QUADRANT_CULL) | (L.SR_FLAG_BALLOT_RANKING if ballot_ranking else 0) |
-                   (L.SR_FLAG_ROW_MAPPED_FORWARD if row_mapped else 0),
+                   (0 if row_mapped is None else (L.SR_FLAG_ROW_MAPPED_FORWARD if row_mapped else L.SR_FLAG_QUADRANT_MAPPED_FORWARD)),
                    _ptr(blend_counters))
     return fr, keep
 
@@ -94,12 +94,13 @@ def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transM
 def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, activations=0, tile=None, mask=None, quadrant_cull=True, blend_counters=None,
-                        ballot_ranking=False, row_mapped=False):
+                        ballot_ranking=False, row_mapped=None):
     """`tile` = (width, height) of the binning tile, default the reference's 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
     16x16, 32x8, 32x16); the backward must be given the same shape.  `quadrant_cull=False` / `blend_counters` (int64[8], device):
     per-call SrFrame.flags / SrFrame.blend_counters (tests and profiling; results are identical).  `ballot_ranking=True`
     (SR_FLAG_BALLOT_RANKING): the binning of this call ranks with match-any ballots, the fallback of the LDS-atomic ranking.
-    `row_mapped=True` (SR_FLAG_ROW_MAPPED_FORWARD): the row-mapped forward blend, bit-identical results."""
+    `row_mapped=True` / `False` (SR_FLAG_ROW_MAPPED_FORWARD / SR_FLAG_QUADRANT_MAPPED_FORWARD): force one of the two forward blend kernels
+    (bit-identical results); None: the device picks per frame."""
     lib = L.load()
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise L.SurfelRasterError("means3D must have dimensions (num_points, 3)")

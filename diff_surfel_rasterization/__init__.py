@@ -155,7 +155,7 @@ class _ClassDistortions(torch.autograd.Function):
 
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False, tile=None, quadrant_cull: bool = True,
-                 blend_counters=None, ballot_ranking: bool = False, row_mapped: bool = False):
+                 blend_counters=None, ballot_ranking: bool = False, row_mapped=None):
         """`fused_activations=True` (extension): `opacities`, `scales`, `rotations` are the RAW parameters
         (`_opacity`, `_scaling`, `_rotation` of the reference's GaussianModel); sigmoid / exp / normalize run inside the
         preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values.
@@ -163,8 +163,8 @@ class GaussianRasterizer(nn.Module):
         16x16, 32x8, 32x16); images and gradients do not depend on it beyond float summation order.
         `quadrant_cull=False` / `blend_counters` (int64[8] device tensor): this call's SrFrame.flags / SrFrame.blend_counters --
         test and profiling switches with identical results (include/surfel_raster.h); `ballot_ranking=True`: SR_FLAG_BALLOT_RANKING,
-        the binning's fallback ranking (identical lists); `row_mapped=True`: SR_FLAG_ROW_MAPPED_FORWARD, the row-mapped forward blend
-        (16x16 tile, three channels; bit-identical results)."""
+        the binning's fallback ranking (identical lists); `row_mapped=True` / `False`: force the row-mapped / the quadrant-mapped
+        forward blend (SR_FLAG_ROW_MAPPED_FORWARD / SR_FLAG_QUADRANT_MAPPED_FORWARD; bit-identical results; None = picked per frame on the device)."""
         super().__init__()
         self.raster_settings = raster_settings
         self.activations = 7 if fused_activations else 0
@@ -176,8 +176,8 @@ class GaussianRasterizer(nn.Module):
             self.probe["blend_counters"] = blend_counters
         if ballot_ranking:
             self.probe["ballot_ranking"] = True
-        if row_mapped:
-            self.probe["row_mapped"] = True
+        if row_mapped is not None:
+            self.probe["row_mapped"] = bool(row_mapped)
 
     def markVisible(self, positions):
         with torch.no_grad():

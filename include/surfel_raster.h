@@ -98,11 +98,14 @@ typedef struct SrFrame {
                                       * the library checks that property on every device before its first sort (sr_rank_mode) and falls
                                       * back to the ballots by itself; this flag forces the fallback for one call (tests, A/B timing).
                                       * The lists are bit-identical either way */
-#define SR_FLAG_ROW_MAPPED_FORWARD 4u /* forward blend, 16x16 tile with three colour channels: the row-mapped kernel (the four 16-lane rows of a
-                                      * wave are the four 4x4 cells of a quadrant, every row walks its own list of entries) instead of one
-                                      * entry on all 64 lanes.  Bit-identical images, state and hit masks (a test requires it); measured at
-                                      * par with the default, kept as the reproducible form of that measurement.  Any other
-                                      * tile shape / channel count / blend_counters with this flag: SR_ERR_UNSUPPORTED */
+#define SR_FLAG_ROW_MAPPED_FORWARD 4u /* forward blend, 16x16 tile with three colour channels: force the row-mapped kernel (the four 16-lane rows
+                                      * of a wave are the four 4x4 cells of a quadrant, every row walks its own list of entries) ... */
+#define SR_FLAG_QUADRANT_MAPPED_FORWARD 8u /* ... or the quadrant-mapped one (one entry on all 64 lanes).  Bit-identical images, state and hit
+                                      * masks (a test requires it).  Without either flag the DEVICE picks per frame from the duplicates per
+                                      * visible Gaussian the emission scan leaves in the geometry state: rows below 6.5 (small footprints:
+                                      * -3 % at 1920x1080 / 3 M, -11 % at 1280x720), quadrants above (+10 % for the rows at 3840x2160):
+                                      * DESIGN.md 4.  The flags exist for the A/B and the test.  SR_FLAG_ROW_MAPPED_FORWARD with any other
+                                      * tile shape / channel count / blend_counters / SR_FLAG_NO_QUADRANT_CULL: SR_ERR_UNSUPPORTED */
 
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
  * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp

@@ -14,6 +14,7 @@ SR_ACT_EXP_SCALES, SR_ACT_SIGMOID_OPACITY, SR_ACT_NORMALIZE_ROTATIONS = 1, 2, 4
 SR_FLAG_NO_QUADRANT_CULL = 1
 SR_FLAG_BALLOT_RANKING = 2
 SR_FLAG_ROW_MAPPED_FORWARD = 4
+SR_FLAG_QUADRANT_MAPPED_FORWARD = 8
 SR_ABI_VERSION = 6
 SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "expand_x", "expand_y", "ranges", "blend_fwd", "blend_bwd",
                   "preprocess_bwd"]

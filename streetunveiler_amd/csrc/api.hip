@@ -36,7 +36,7 @@ hipError_t run_tile_ranges_order(int n_tiles, const uint32_t* tile_counts, uint2
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint16_t* hit_mask, int flags,
-                                 unsigned long long* counters, hipStream_t s);
+                                 unsigned long long* counters, const uint32_t* frame_counts, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                   const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s);
@@ -482,13 +482,15 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
     if (int rc = bin_duplicates(frame, g, f, geom, geom_bytes, binning, B, D, s, &recs)) return rc;
     {
         StageTimer t(SR_STAGE_BLEND_FWD, s);
-        const bool rows = (frame->flags & SR_FLAG_ROW_MAPPED_FORWARD) != 0;
+        const bool rows = (frame->flags & SR_FLAG_ROW_MAPPED_FORWARD) != 0, quads = (frame->flags & SR_FLAG_QUADRANT_MAPPED_FORWARD) != 0;
+        if (rows && quads) return fail(SR_ERR_INVALID_ARGUMENT, "SR_FLAG_ROW_MAPPED_FORWARD and SR_FLAG_QUADRANT_MAPPED_FORWARD exclude each other");
         if (rows && (!(f.tile_w == 16 && f.tile_h == 16 && f.colors == 3) || frame->blend_counters || (frame->flags & SR_FLAG_NO_QUADRANT_CULL)))
             return fail(SR_ERR_UNSUPPORTED, "SR_FLAG_ROW_MAPPED_FORWARD: 16x16 tile, three colour channels, no counters, culling on");
-        const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0) | (rows ? 4 : 0);
+        const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0) | (rows ? 4 : 0) | (quads ? 8 : 0);
+        const GeomLayout GL = geom_layout(g->P);   // (D and the visible count, left in the geometry state by the emission scan)
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
                                      out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint16_t>(binning, B.hit_mask), flags,
-                                     reinterpret_cast<unsigned long long*>(frame->blend_counters), s));
+                                     reinterpret_cast<unsigned long long*>(frame->blend_counters), at<uint32_t>(geom, GL.block_base) + GL.n_scan_blocks, s));
     }
     return debug_sync(frame, s, "render_forward");
 }

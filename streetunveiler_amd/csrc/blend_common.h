@@ -248,6 +248,11 @@ __device__ __forceinline__ uint32_t emission_index(const float4 (&q)[kRecQuads],
     return first + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
 }
 
+__device__ __forceinline__ void load_record4(const float4* __restrict__ recs, uint32_t gid, float4 (&q)[kRecQuads]) {
+    const float4* r = recs + (size_t)gid * kRecQuads;
+#pragma unroll
+    for (int k = 0; k < kRecQuads - 1; ++k) q[k] = r[k];
+}
 __device__ __forceinline__ void load_record(const float4* __restrict__ recs, uint32_t gid, float4 (&q)[kRecQuads]) {
     const float4* r = recs + (size_t)gid * kRecQuads;
 #pragma unroll

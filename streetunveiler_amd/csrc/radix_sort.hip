@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ out,
                                                                  uint32_t* __restrict__ block_total) {
-    __shared__ uint32_t s_w[kRsThreads / 64];
+    __shared__ uint32_t s_w[kRsThreads / 64], s_nz[kRsThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t base = blockIdx.x * (uint32_t)kRsTile + (uint32_t)tid * kRsItems;   // 8 consecutive items per thread
     uint32_t c[kRsItems];
@@ -217,14 +217,16 @@ __global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t*
 #pragma unroll
         for (int i = 0; i < kRsItems; ++i) c[i] = base + i < n ? counts[base + i] : 0u;
     }
-    uint32_t v[kRsItems], sum = 0;
+    uint32_t v[kRsItems], sum = 0, nz = 0;
 #pragma unroll
     for (int i = 0; i < kRsItems; ++i) {
         v[i] = sum;   // exclusive within the thread
         sum += c[i];
+        nz += c[i] != 0u;
     }
     uint32_t incl = wave_inclusive_scan(sum);
-    if (lane == 63) s_w[w] = incl;
+    const uint32_t nz_incl = wave_inclusive_scan(nz);
+    if (lane == 63) { s_w[w] = incl; s_nz[w] = nz_incl; }
     __syncthreads();
     uint32_t off = incl - sum;
     for (int k = 0; k < w; ++k) off += s_w[k];
@@ -235,17 +237,31 @@ __global__ __launch_bounds__(kRsThreads) void scan_blocks_kernel(const uint32_t*
 #pragma unroll
         for (int i = 0; i < kRsItems; ++i) if (base + i < n) out[base + i] = off + v[i];
     }
-    if (tid == kRsThreads - 1) block_total[blockIdx.x] = off + sum;
+    if (tid == kRsThreads - 1) {
+        block_total[blockIdx.x] = off + sum;
+        // side product: the Gaussians of this block with at least one tile -- their total, the frame's VISIBLE count, travels to the host
+        // with D and picks the forward blend kernel (api.hip: duplicates per visible Gaussian)
+        uint32_t n_vis = 0;
+        for (int k = 0; k < kRsThreads / 64; ++k) n_vis += s_nz[k];
+        block_total[gridDim.x + 2 + blockIdx.x] = n_vis;
+    }
 }
 
 __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __restrict__ block_total, int nblocks, uint32_t* __restrict__ total_host) {
     // exclusive scan in place, one block, sequential over chunks of 256; block_total[nblocks] = grand total (also stored straight into
-    // the caller's pinned host word when one is given: no copy kernel between this one and the host's wake-up)
+    // the caller's pinned host words when given: no copy kernel between this one and the host's wake-up); block_total[nblocks + 1] /
+    // total_host[1] = the sum of the blocks' non-zero counts (scan_blocks_kernel), i.e. the number of items with a non-zero count
     __shared__ uint32_t s_w[kRsThreads / 64];
-    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_carry, s_vis;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_carry = 0;
+    if (tid == 0) { s_carry = 0; s_vis = 0; }
     __syncthreads();
+    {
+        uint32_t mine = 0;
+        for (int i = tid; i < nblocks; i += kRsThreads) mine += block_total[nblocks + 2 + i];
+        const uint32_t tot = wave_inclusive_scan(mine);
+        if (lane == 63 && tot) atomicAdd(&s_vis, tot);
+    }
     for (int c = 0; c < nblocks; c += kRsThreads) {
         const int i = c + tid;
         const uint32_t x = i < nblocks ? block_total[i] : 0u;
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __res
         if (tid == kRsThreads - 1) s_carry = carry + wb + incl;
         __syncthreads();
     }
-    if (tid == 0) { block_total[nblocks] = s_carry; if (total_host) *total_host = s_carry; }
+    if (tid == 0) { block_total[nblocks] = s_carry; block_total[nblocks + 1] = s_vis; if (total_host) { total_host[0] = s_carry; total_host[1] = s_vis; } }
 }
 
 // Run-time guard of the rank phase (api.hip rank_mode, once per device): 64 rounds of 64 items per wave with alphabets from 1 to 1000
@@ -391,7 +407,7 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
     return hipGetLastError();
 }
 
-size_t tile_count_scan_temp_bytes(uint32_t n) { return align_up(((size_t)scan_blocks(n > 0 ? n : 1) + 1) * 4, 256); }
+size_t tile_count_scan_temp_bytes(uint32_t n) { return align_up((2 * (size_t)scan_blocks(n > 0 ? n : 1) + 2) * 4, 256); }   // bases, D, visible, per-block visible
 
 // out[i] = exclusive scan of counts INSIDE block i / 2048; block_base[b] = exclusive scan of the block totals,
 // block_base[nblocks] = total.  (block_base lives in `temp`.)

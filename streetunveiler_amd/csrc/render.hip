@@ -40,14 +40,10 @@ namespace sr {
 // each, all walking the parent's list: fewer pixels per lane -> fewer registers -> more waves per SIMD, which is what these
 // latency-bound loops want, at the price of staging every entry SPLIT times.
 template <bool kStats, int NC, int QX, int QY, int SPLIT>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats && NC == 3 && QX == 2 && QY == 1 && SPLIT == 2 ? 6 : 1, !kStats && NC == 3 && QX == 2 && QY == 1 && SPLIT == 2 ? 6 : 8))) void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
-                                                                const uint32_t* __restrict__ point_list,
-                                                                const float4* __restrict__ recs,
-                                                                const float* __restrict__ extra,
-                                                                float* __restrict__ out_color, float* __restrict__ out_allmap,
-                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                                uint16_t* __restrict__ hit_mask, int cull, unsigned long long* __restrict__ g_stats) {
-    __shared__ float4 s_e[entry_quads<NC>()][kWave];
+__device__ __forceinline__ void render_forward_body(float4 (*s_e)[kWave], const FrameDev& f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
+                                                    const uint32_t* __restrict__ point_list, const float4* __restrict__ recs, const float* __restrict__ extra,
+                                                    float* __restrict__ out_color, float* __restrict__ out_allmap, float* __restrict__ final_T,
+                                                    uint32_t* __restrict__ n_contrib, uint16_t* __restrict__ hit_mask, int cull, unsigned long long* __restrict__ g_stats) {
     const int lane = threadIdx.x;
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: the SPLIT bands of one tile take consecutive
     // slots of the SAME XCD so that the second band finds the tile's records in that L2 instead of fetching them again.
@@ -254,6 +250,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats &
     }
 }
 
+template <bool kStats, int NC, int QX, int QY, int SPLIT>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats && NC == 3 && QX == 2 && QY == 1 && SPLIT == 2 ? 6 : 1, !kStats && NC == 3 && QX == 2 && QY == 1 && SPLIT == 2 ? 6 : 8)))
+void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list,
+                           const float4* __restrict__ recs, const float* __restrict__ extra, float* __restrict__ out_color, float* __restrict__ out_allmap,
+                           float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint16_t* __restrict__ hit_mask, int cull,
+                           unsigned long long* __restrict__ g_stats) {
+    __shared__ float4 s_e[entry_quads<NC>()][kWave];
+    render_forward_body<kStats, NC, QX, QY, SPLIT>(s_e, f, ranges, tile_order, point_list, recs, extra, out_color, out_allmap, final_T, n_contrib, hit_mask, cull, g_stats);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6, row-mapped (three colour channels): the wave's four 16-lane rows are the four 4x4 cells of a quadrant, and every row walks ITS
 // OWN list -- the entries of the round whose octagon reaches its cell -- so a wave step serves four different entries, one per row,
@@ -262,14 +268,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(!kStats &
 // (next set bit of the row's 64-bit mask: scalar unit), every lane extracts its row's byte and reads the staged entry at ITS address.
 // ---------------------------------------------------------------------------------------------
 template <int QX, int QY, int SPLIT>
-__global__ __launch_bounds__(kWave) void render_forward_rows_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
-                                                                     const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
-                                                                     float* __restrict__ out_color, float* __restrict__ out_allmap,
-                                                                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                                     uint16_t* __restrict__ hit_mask) {
+__device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], uint8_t (*s_hit)[kWave], const FrameDev& f, const uint2* __restrict__ ranges,
+                                                         const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list,
+                                                         const float4* __restrict__ recs, float* __restrict__ out_color, float* __restrict__ out_allmap,
+                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint16_t* __restrict__ hit_mask) {
     constexpr int NC = 3;
-    __shared__ float4 s_e[entry_quads<NC>()][kWave];
-    __shared__ uint8_t s_hit[QX * QY][kWave];   // (entry, quadrant) reached a pixel: the backward's exact visit list
     const int lane = threadIdx.x;
     int tile = blockIdx.x, part = 0;
     if (SPLIT > 1) {
@@ -302,14 +305,17 @@ __global__ __launch_bounds__(kWave) void render_forward_rows_kernel(FrameDev f, 
     }
     float4 nr[kRecQuads];
     const float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((uint32_t)lane < n_total) load_record(recs, point_list[range.x + lane], nr);
+    // (four of the record's five quads are prefetched a round ahead; the fifth -- two colour components and the radius -- is fetched when the
+    // round is staged: four registers less across the walk, which is what separates five waves per SIMD from six)
+    uint32_t ngid = 0;
+    if ((uint32_t)lane < n_total) { ngid = point_list[range.x + lane]; load_record4(recs, ngid, nr); }
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         int ys = yshift_px;
         asm volatile("" : "+s"(ys));
         uint32_t cm = 0;   // this lane's ENTRY: bit 4 q + c = its octagon reaches cell c of quadrant q
-        if ((uint32_t)lane < n) (void)stage_entry<QX, QY, NC>(nr, nx, nx, Xc, Yc, 1, s_e, lane, (float)ys, nullptr, &cm);
-        if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
+        if ((uint32_t)lane < n) { nr[4] = recs[(size_t)ngid * kRecQuads + 4]; (void)stage_entry<QX, QY, NC>(nr, nx, nx, Xc, Yc, 1, s_e, lane, (float)ys, nullptr, &cm); }
+        if (base + kWave + lane < n_total) { ngid = point_list[range.x + base + kWave + lane]; load_record4(recs, ngid, nr); }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) s_hit[q][lane] = 0;
 #pragma unroll
@@ -392,6 +398,35 @@ __global__ __launch_bounds__(kWave) void render_forward_rows_kernel(FrameDev f, 
     }
 }
 
+template <int QX, int QY, int SPLIT>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(QX * QY <= 2 ? 6 : 1, QX * QY <= 2 ? 6 : 8)))
+void render_forward_rows_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list,
+                                const float4* __restrict__ recs, float* __restrict__ out_color, float* __restrict__ out_allmap, float* __restrict__ final_T,
+                                uint32_t* __restrict__ n_contrib, uint16_t* __restrict__ hit_mask) {
+    __shared__ float4 s_e[entry_quads<3>()][kWave];
+    __shared__ uint8_t s_hit[QX * QY][kWave];   // (entry, quadrant) reached a pixel: the backward's exact visit list
+    render_forward_rows_body<QX, QY, SPLIT>(s_e, s_hit, f, ranges, tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);
+}
+
+// The reference's 16x16 tile with three colour channels picks its mapping per FRAME, on the device: counts[0] = D, the frame's duplicates,
+// counts[1] = its visible Gaussians (both fall out of the emission scan, radix_sort.hip).  Splats that touch few tiles touch few 4x4 cells
+// of a quadrant, and the rows win; large splats fill quadrants, and one entry on all 64 lanes wins (3 M Gaussians: 1280x720, D / visible
+// = 3.4: 0.620 vs 0.696 ms; 1920x1080, 5.2: 0.858 vs 0.885; 2560x1440, 7.4: 1.182 vs 1.164; 3840x2160, 13: 2.13 vs 1.94).  Both bodies
+// produce the same bits, so the choice is invisible in the results.
+constexpr uint32_t kRowsBelowDuplicatesPerVisibleX2 = 13;   // rows if D / visible < 6.5
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void render_forward_auto_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list,
+                                const float4* __restrict__ recs, float* __restrict__ out_color, float* __restrict__ out_allmap, float* __restrict__ final_T,
+                                uint32_t* __restrict__ n_contrib, uint16_t* __restrict__ hit_mask, const uint32_t* __restrict__ counts) {
+    __shared__ float4 s_e[entry_quads<3>()][kWave];
+    __shared__ uint8_t s_hit[2][kWave];
+    const unsigned long long D = counts[0], V = counts[1];
+    if (2ull * D < (unsigned long long)kRowsBelowDuplicatesPerVisibleX2 * V)
+        render_forward_rows_body<2, 1, 2>(s_e, s_hit, f, ranges, tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);
+    else
+        render_forward_body<false, 3, 2, 1, 2>(s_e, f, ranges, tile_order, point_list, recs, nullptr, out_color, out_allmap, final_T, n_contrib, hit_mask, 1, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Decision dump (test infrastructure of the parity bars, not part of the operator): for every list entry of every tile and
 // every pixel of the tile, whether the ray-splat test of K6 / K7 accepts the pair (`valid`: the chain of skips of Appendix A.4
@@ -443,10 +478,11 @@ __global__ __launch_bounds__(kWave) void pair_decisions_kernel(FrameDev f, const
     else if (f.tile_w == 32 && f.tile_h == 16) { F(4, 2); }                     \
     else return hipErrorInvalidValue;
 
-// flags: bit 0 = quadrant culling on (SR_FLAG_NO_QUADRANT_CULL clear), bit 1 = counter variant (counters != NULL), bit 2 = row-mapped kernel
+// flags: bit 0 = quadrant culling on (SR_FLAG_NO_QUADRANT_CULL clear), bit 1 = counter variant (counters != NULL), bit 2 / bit 3 = the row-mapped /
+// the quadrant-mapped kernel forced (else, for the 16x16 tile with three channels and culling on, the device picks per frame: frame_counts)
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib,
-                                 uint16_t* hit_mask, int flags, unsigned long long* counters, hipStream_t s) {
+                                 uint16_t* hit_mask, int flags, unsigned long long* counters, const uint32_t* frame_counts, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     const dim3 block(kWave);
@@ -463,6 +499,9 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
         else if (count)         SR_LAUNCH_FWD(true, 3, 2, 2, 1);
         else if (flags & 4)     hipLaunchKernelGGL((render_forward_rows_kernel<2, 1, 2>), dim3((n_tiles + kXcds - 1) / kXcds * kXcds * 2), block, 0, s, f, ranges,
                                                    tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);
+        else if (cull && !(flags & 8) && frame_counts)
+                                hipLaunchKernelGGL(render_forward_auto_kernel, dim3((n_tiles + kXcds - 1) / kXcds * kXcds * 2), block, 0, s, f, ranges,
+                                                   tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask, frame_counts);
         else                    SR_LAUNCH_FWD(false, 3, 2, 1, 2);
     } else {
         if (f.colors != 3) return hipErrorInvalidValue;

@@ -33,7 +33,7 @@ def run_oracle(g, cam, bg, deg, dc=None, da=None, mode="sh", colors=None, Tpre=N
     return fwd, bwd
 
 
-def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=False, tile=None, quadrant_cull=True, row_mapped=False):
+def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=False, tile=None, quadrant_cull=True, row_mapped=None):
     """Returns dict with outputs, internal state views and (if dc given) input gradients, all numpy."""
     dev = DEV
     s = settings_for(cam, bg, deg, debug)
@@ -63,7 +63,7 @@ def run_hip(g, cam, bg, deg, dc=None, da=None, colors=None, Tpre=None, debug=Fal
     return out
 
 
-def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None, tile=None, quadrant_cull=True, decisions=False, row_mapped=False):
+def run_hip_raw(g, cam, bg, deg, colors=None, Tpre=None, tile=None, quadrant_cull=True, decisions=False, row_mapped=None):
     """Calls _C.rasterize_gaussians directly and returns the state-buffer views as numpy (for bit-exact checks)."""
     dev = DEV
     s = settings_for(cam, bg, deg)

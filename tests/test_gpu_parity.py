@@ -207,7 +207,8 @@ def test_quadrant_culling_is_exact():
 
 
 def test_row_mapped_forward_is_bit_identical():
-    """SR_FLAG_ROW_MAPPED_FORWARD: the four 16-lane rows of a wave walk the lists of four 4x4 cells instead of one entry on 64 lanes --
+    """The two forward blend kernels of the 16x16 tile (the device picks one per frame; SR_FLAG_ROW_MAPPED_FORWARD /
+    SR_FLAG_QUADRANT_MAPPED_FORWARD force one): the four 16-lane rows of a wave walk the lists of four 4x4 cells instead of one entry on 64 lanes --
     the same per-pixel sequence of operations, so images, per-pixel state and (through the exact hit masks the backward visits)
     every gradient equal the default kernel's bit for bit; shapes it does not exist for are refused by name."""
     from streetunveiler_amd import _lib
@@ -216,8 +217,10 @@ def test_row_mapped_forward_is_bit_identical():
         cam, g = _scene(P, W, H, P + 2, lo, hi, idx)
         g["opacities"][::11] = 1.0
         dc, da = synthetic_upstream_grads(W, H, seed=P)
-        raw0, raw1 = (run_hip_raw(g, cam, [0.2, 0.4, 0.6], 3, row_mapped=r) for r in (False, True))
-        out0, out1 = (run_hip(g, cam, [0.2, 0.4, 0.6], 3, dc, da, row_mapped=r) for r in (False, True))
+        raw0, raw1, raw2 = (run_hip_raw(g, cam, [0.2, 0.4, 0.6], 3, row_mapped=r) for r in (False, True, None))   # quadrants, rows, the device's pick
+        out0, out1, out2 = (run_hip(g, cam, [0.2, 0.4, 0.6], 3, dc, da, row_mapped=r) for r in (False, True, None))
+        np.testing.assert_array_equal(raw2["color"], raw0["color"]); np.testing.assert_array_equal(raw2["img"]["n_contrib"], raw0["img"]["n_contrib"])
+        np.testing.assert_array_equal(out2["dL_dmeans3D"], out0["dL_dmeans3D"])
         for k in ("color", "allmap"):
             np.testing.assert_array_equal(raw1[k], raw0[k])
         np.testing.assert_array_equal(raw1["img"]["n_contrib"], raw0["img"]["n_contrib"])

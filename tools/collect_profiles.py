@@ -29,6 +29,8 @@ def short(name, pool=True):
     n = n.replace("void ", "")
     if "render_forward_kernel<true" in n:
         return "sr::render_forward_kernel[counter variant, 1 untimed launch]"   # bench.py's blend_counts pass (device atomics)
+    if pool:   # (K6 is whichever forward blend kernel the frame ran: the per-frame pick, or a forced mapping)
+        n = n.replace("render_forward_auto_kernel", "render_forward_kernel").replace("render_forward_rows_kernel", "render_forward_kernel")
     return re.sub(r"<[^<>]*>", "", n) if pool else n   # template arguments dropped: variants of one kernel are pooled
 
 
