@@ -320,7 +320,8 @@ def geom_view(geom: torch.Tensor, P: int):
     L.check(L.load().sr_geom_view(_ptr(geom), geom.numel(), P, C.byref(v)), "sr_geom_view")
     return dict(splats=_view(geom, v.splats, P * 80, torch.float32).view(P, 20),
                 depth_keys=_view(geom, v.depth_keys, P * 4, torch.int32), tiles_touched=_view(geom, v.tiles_touched, P * 4, torch.int32),
-                clamped=_view(geom, v.clamped, P, torch.uint8), sorted_gid=_view(geom, v.sorted_gid, P * 4, torch.int32))
+                clamped=_view(geom, v.clamped, P, torch.uint8), sorted_gid=_view(geom, v.sorted_gid, P * 4, torch.int32),
+                frame_counts=_view(geom, v.frame_counts, 8, torch.int32))
 
 
 def binning_view(binning: torch.Tensor, P: int, D: int, W: int, H: int, tile=(16, 16)):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 6
+#define SR_ABI_VERSION 7
 #define SR_TILE 16            /* default 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y); see SrFrame.tile_width */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
 #define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
@@ -150,6 +150,8 @@ typedef struct SrGeomView {
     const uint32_t* tiles_touched; /* [P] */
     const uint8_t* clamped;        /* [P] bit c set when SH colour channel c was clamped at 0 */
     const uint32_t* sorted_gid;    /* [P] Gaussian ids in ascending (depth bits, id) order; culled last */
+    const uint32_t* frame_counts;  /* [2] D (= *num_rendered_host of sr_forward_plan) and the number of Gaussians with at least one tile: what
+                                    * the forward blend picks its mapping by (SR_FLAG_ROW_MAPPED_FORWARD) */
 } SrGeomView;
 
 typedef struct SrBinningView {

@@ -15,7 +15,7 @@ SR_FLAG_NO_QUADRANT_CULL = 1
 SR_FLAG_BALLOT_RANKING = 2
 SR_FLAG_ROW_MAPPED_FORWARD = 4
 SR_FLAG_QUADRANT_MAPPED_FORWARD = 8
-SR_ABI_VERSION = 6
+SR_ABI_VERSION = 7
 SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "expand_x", "expand_y", "ranges", "blend_fwd", "blend_bwd",
                   "preprocess_bwd"]
 
@@ -42,7 +42,7 @@ class SrGradients(C.Structure):
 
 class SrGeomView(C.Structure):
     _fields_ = [("splats", C.c_void_p), ("depth_keys", C.c_void_p), ("tiles_touched", C.c_void_p), ("clamped", C.c_void_p),
-                ("sorted_gid", C.c_void_p)]
+                ("sorted_gid", C.c_void_p), ("frame_counts", C.c_void_p)]
 
 
 class SrBinningView(C.Structure):

@@ -316,6 +316,7 @@ int sr_geom_view(void* geom, size_t geom_bytes, int32_t P, SrGeomView* out) {
     out->splats = at<float>(geom, L.recs); out->depth_keys = at<uint32_t>(geom, L.depth_keys);
     out->tiles_touched = at<uint32_t>(geom, L.tiles_touched); out->clamped = at<uint8_t>(geom, L.clamped);
     out->sorted_gid = at<uint32_t>(geom, L.sorted_gid);
+    out->frame_counts = at<uint32_t>(geom, L.block_base) + L.n_scan_blocks;
     return SR_OK;
 }
 

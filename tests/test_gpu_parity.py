@@ -107,6 +107,8 @@ def test_forward_backward_vs_oracle(P, W, H, deg, lo, hi, cam_index):
     assert fwd["num_rendered"] > P // 2
     raw = run_hip_raw(g, cam, bg, deg)
     _check_binning(raw, fwd)
+    # the two words the emission scan leaves for the forward blend's choice of mapping: D and the Gaussians with at least one tile
+    assert raw["geom"]["frame_counts"].view(np.uint32).tolist() == [fwd["num_rendered"], int((fwd["tiles_touched"] > 0).sum())]
     nc = raw["img"]["n_contrib"].view(np.uint32)
     assert (nc != fwd["n_contrib"]).mean() < 1e-3   # contributor counts: equal up to rare threshold flips
     out = run_hip(g, cam, bg, deg, dc, da)
