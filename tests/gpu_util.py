@@ -351,7 +351,7 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
             p999_eff, max_eff = p999_bar * value_slack, max_bar * value_slack
             if key in errs32 and errs32[key][rob_g].size:
                 o = errs32[key][rob_g]
-                p999_eff, max_eff = max(p999_eff, 0.5 * float(np.quantile(o, 0.999))), max(max_eff, 0.5 * float(o.max()))
+                p999_eff, max_eff = max(p999_eff, 0.5 * float(np.quantile(o, 0.999))), max(max_eff, float(o.max()))   # (worst row: no worse than the oracle's)
             assert rows_within(er, p999_eff, max_eff), \
                 f"{tag} {key}: robust rows p99.9 {np.quantile(er, 0.999):.2e} (bar {p999_eff:.1e}), max {er.max():.2e} (bar {max_eff:.1e})"
         if nonrobust_row_cap is not None:
