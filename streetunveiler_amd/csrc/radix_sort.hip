@@ -256,15 +256,11 @@ __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __res
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) { s_carry = 0; s_vis = 0; }
     __syncthreads();
-    {
-        uint32_t mine = 0;
-        for (int i = tid; i < nblocks; i += kRsThreads) mine += block_total[nblocks + 2 + i];
-        const uint32_t tot = wave_inclusive_scan(mine);
-        if (lane == 63 && tot) atomicAdd(&s_vis, tot);
-    }
+    uint32_t vis_mine = 0;   // (this thread's share of the blocks' non-zero counts, fetched next to the totals)
     for (int c = 0; c < nblocks; c += kRsThreads) {
         const int i = c + tid;
         const uint32_t x = i < nblocks ? block_total[i] : 0u;
+        vis_mine += i < nblocks ? block_total[nblocks + 2 + i] : 0u;
         uint32_t incl = wave_inclusive_scan(x);
         if (lane == 63) s_w[w] = incl;
         __syncthreads();
@@ -274,6 +270,11 @@ __global__ __launch_bounds__(kRsThreads) void scan_totals_kernel(uint32_t* __res
         if (i < nblocks) block_total[i] = carry + wb + incl - x;
         __syncthreads();
         if (tid == kRsThreads - 1) s_carry = carry + wb + incl;
+        __syncthreads();
+    }
+    {
+        const uint32_t tot = wave_inclusive_scan(vis_mine);
+        if (lane == 63 && tot) atomicAdd(&s_vis, tot);
         __syncthreads();
     }
     if (tid == 0) { block_total[nblocks] = s_carry; block_total[nblocks + 1] = s_vis; if (total_host) { total_host[0] = s_carry; total_host[1] = s_vis; } }
