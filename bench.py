@@ -361,8 +361,16 @@ def main():
         lane_tests = blend_counts["quadrant_tests"] * 64
         useful = blend_counts["contributing_pairs"] * 260 / (blend_ms * 1e-3) / 1e12 if blend_ms else None
         issued = lane_tests * 260 / (blend_ms * 1e-3) / 1e12 if blend_ms else None
+        # which mapping the forward blend ran (the device's rule, csrc/render.hip render_forward_auto_kernel: rows below 6.5 duplicates per
+        # visible Gaussian; the A/B switches force one) and the lanes IT issued: 64 per wave step of the row mapping (counted with the
+        # octagon-vs-cell culling the kernel uses), 64 per quadrant test otherwise.  K7 always walks quadrants.
+        rows_run = True if args.row_mapped else (False if args.quadrant_mapped else 2 * D < 13 * V)
+        fwd_lane_tests = (blend_counts["row_mapping_steps_octagon_culling"] if rows_run else blend_counts["quadrant_tests"]) * 64
         valu = {"peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_pair": 260, **blend_counts, "lane_tests": lane_tests,
                 "lane_utilisation": round(blend_counts["contributing_pairs"] / lane_tests, 4) if lane_tests else None,
+                "forward_mapping": "16-lane rows on independent entries" if rows_run else "one entry on 64 lanes (8x8 quadrants)",
+                "forward_lane_utilisation": round(blend_counts["contributing_pairs"] / fwd_lane_tests, 4) if fwd_lane_tests else None,
+                "backward_lane_utilisation": round(blend_counts["contributing_pairs"] / (blend_counts["quadrant_tests_with_a_hit"] * 64), 4) if blend_counts["quadrant_tests_with_a_hit"] else None,
                 "issued": None if issued is None else round(issued, 2), "issued_frac": None if issued is None else round(issued / FP32_VALU_PEAK_TFLOPS, 4),
                 "useful": None if useful is None else round(useful, 2), "useful_frac": None if useful is None else round(useful / FP32_VALU_PEAK_TFLOPS, 4),
                 "issue_roof": {"render_forward_kernel": valu_issue_roof("render_forward_kernel", group_ms["blend_fwd"], args),
