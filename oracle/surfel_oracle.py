@@ -208,10 +208,11 @@ def render_margins(fwd: Dict[str, np.ndarray], eps: Optional[Dict[str, float]] =
     L.so_set_tile(*i["tile"])
     e = dict(DEFAULT_EPS); e.update(eps or {})
     ev = np.array([e["alpha"], e["T"], e["path"], e["near"], e["median"]], np.float32)
-    pm = np.zeros((H, W), np.float32); mm = np.zeros((H, W), np.float32); gm = np.zeros(P, np.float32)
+    pm = np.zeros((H, W), np.float32); mm = np.zeros((H, W), np.float32); gm = np.zeros(P, np.float32); vn = np.zeros((H, W), np.float32)
     (L.so_render_margins_f64 if f64 else L.so_render_margins)(P, W, H, _p(fwd["ranges"], C.c_uint32), _p(i["vals_buf"], C.c_uint32), _p(fwd["means2D"]),
-                        _p(fwd["transMat"]), _p(fwd["normal_opacity"]), _p(ev), _p(pm), _p(mm), _p(gm))
-    return dict(pixel=pm, median=mm, gaussian=gm, eps=e)
+                        _p(fwd["transMat"]), _p(fwd["normal_opacity"]), _p(ev), _p(pm), _p(mm), _p(gm), _p(vn))
+    # `value_noise`[H,W]: relative noise float32 rounding of the ray-splat intersections can put into the pixel's transmittance and weights
+    return dict(pixel=pm, median=mm, gaussian=gm, value_noise=vn, eps=e)
 
 
 def mark_visible(means3D, viewmatrix) -> np.ndarray:

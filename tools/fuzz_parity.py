@@ -88,7 +88,7 @@ def main():
         # (row bars: within the bar, or no worse than the float32 oracle under the same forced decisions -- some random scenes cancel badly)
         if regime != 3:
             _, sfwd32, sbwd32 = forced_f64_reference(g, cam, bg, deg, dc, da, tile=tile, colors=colors, base=fwd, raw=raw, f64=False)
-            assert_strict_parity(out, sfwd, sbwd, scene=(g, cam), oracle32=sbwd32, oracle32_fwd=sfwd32)
+            assert_strict_parity(out, sfwd, sbwd, scene=(g, cam), oracle32=sbwd32, oracle32_fwd=sfwd32, value_noise=margins["value_noise"])
         names = ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D", "dL_dcolors" if colors is not None else "dL_dsh"]
         # Per GAUSSIAN, against the float32 oracle: any gradient element of a ROBUST Gaussian off by more than 2e-3 of its tensor's scale
         # marks it.  (A flipped decision moves the whole gradient of a few-pixel splat: those Gaussians are the non-robust ones, checked
