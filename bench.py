@@ -176,11 +176,30 @@ def cpu_baseline(args, g, cam, dc, da):
                        + f" at {args.width}x{args.height} (D={D}), {dt:.1f} s wall, OpenMP {threads} threads")}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N workers ourselves -- one process per GPU under
+    torch.distributed.run on the loopback address, same flags -- and hand their output through.  (The driver wraps its N > 1 runs in
+    torch.distributed.run itself; this makes the bare command line of the 1-GPU run work for any N.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a torchrun environment: launching {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     from streetunveiler_amd.parallel import allreduce_gradients, factored_sh_exchange, init_distributed
     rank, world, local_rank = init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: start {args.gpus} ranks "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or drop the environment")
     # SURFEL_EXCHANGE_SINGLE_RANK=1 (with torchrun --nproc-per-node 1): take the frame-parallel branches on a one-rank RCCL group -- the
     # same calls an N-GPU run makes, exercised on a single GPU (functional check; the JSON line then reports n_gpus 1 with an exchange)
     multi = world > 1 or os.environ.get("SURFEL_EXCHANGE_SINGLE_RANK") == "1"
@@ -290,8 +309,11 @@ def main():
         dist.all_gather_into_tensor(seen, mine)
         worlds_seen = [int(x) for x in seen.tolist()]
         if args.exchange == "factored":
-            # one untimed trial step of the factored exchange; should it raise (it would on every rank alike: same code, same
-            # arguments), fall back to the plain all-reduce instead of losing the run -- the JSON line says which one ran
+            # one untimed trial step of the factored exchange.  Only a failure of the COLLECTIVE LAYER (a backend that lacks
+            # all_gather_into_tensor, a communicator error: torch.distributed raises DistBackendError / NotImplementedError, on every
+            # rank alike) falls back to the plain all-reduce, and the JSON line carries the message; anything else -- a wrong result
+            # included -- is a bug and ends the run.
+            fallback_errors = (NotImplementedError,) + ((dist.DistBackendError,) if hasattr(dist, "DistBackendError") else ())
             try:
                 step()
                 sync()
@@ -303,9 +325,10 @@ def main():
                 exchange_check = {"factored_vs_allreduce_max_rel_err": worst, "ok": bool(worst < 1e-4)}
                 if not exchange_check["ok"]:
                     raise RuntimeError(f"factored exchange disagrees with the plain all-reduce ({worst:.2e})")
-            except Exception as e:   # noqa: BLE001
+            except fallback_errors as e:
                 print(f"[rank {rank}] factored exchange unavailable ({type(e).__name__}: {e}); using all-reduce", file=sys.stderr, flush=True)
                 args.exchange = "allreduce"
+                exchange_check = {"ok": False, "fell_back_to": "allreduce", "error": f"{type(e).__name__}: {e}"[:300]}
 
     for _ in range(args.warmup):
         step()

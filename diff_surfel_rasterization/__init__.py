@@ -83,6 +83,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         # (Only when the SHs are the sole colour source: the 9-channel pass keeps its SH gradient local, as _C does.)
         from streetunveiler_amd.parallel import active_sh_exchange
         ctx.sh_exchange = active_sh_exchange() if sh.numel() and not colors_precomp.numel() else None
+        # which of the step's frames this call is (row of all_campos[rank]): drawn now, in forward order -- autograd may run the backward
+        # nodes of several frames in any order (one summed loss: reverse creation order)
+        ctx.sh_frame = ctx.sh_exchange.attach() if ctx.sh_exchange is not None and hasattr(ctx.sh_exchange, "attach") else None
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -104,7 +107,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         kwargs = {"defer_sh": True} if exchange is not None else {}
         if exchange is not None and hasattr(exchange, "start"):
             # the 12-B colour gradients are final right after the blend backward: their all-gather goes on the wire while K8 runs
-            kwargs["after_blend"] = exchange.start
+            kwargs["after_blend"] = (lambda gc, _ex=exchange, _j=ctx.sh_frame: _ex.start(gc, _j)) if ctx.sh_frame is not None else exchange.start
         if ctx.activations:
             kwargs["activations"] = ctx.activations
         if ctx.tile:
@@ -122,7 +125,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations = out
         if exchange is not None:   # grad_colors_precomp holds the clamp-masked dL/drgb; dL_dsh comes back summed over ranks
             rest = [grad_means3D, grad_opacities, grad_scales, grad_rotations] if exchange.reduce_all else []
-            grad_sh = exchange.run(grad_colors_precomp, means3D, s.campos, int(sh.shape[1]), s.sh_degree, also_reduce=rest)
+            extra = {"frame": ctx.sh_frame} if ctx.sh_frame is not None else {}
+            grad_sh = exchange.run(grad_colors_precomp, means3D, s.campos, int(sh.shape[1]), s.sh_degree, also_reduce=rest, **extra)
         none_if_empty = lambda g, ref: g if ref.numel() else None
         return (grad_means3D, grad_means2D, none_if_empty(grad_sh, sh), none_if_empty(grad_colors_precomp, colors_precomp),
                 grad_opacities, none_if_empty(grad_scales, scales), none_if_empty(grad_rotations, rotations),

@@ -128,8 +128,18 @@ class ShExchange:
         self.bytes_sent = 0     # payload bytes this rank contributed to the collectives
         self.early_starts = 0   # all-gathers put on the wire between K7 and K8 (sr_backward_colors)
         self.exchange_ms = 0.0  # host-side wall time spent waiting on the collectives (diagnostic; bench.py reports it)
-        self._early = None
-        self._held = []         # (gathered [world,P,3] buffer, handle, this frame's camera position) of the frames accumulated so far
+        self.attached = 0       # forward calls that attached themselves to this exchange (`attach`): frame j = the j-th forward
+        self._early = {}        # frame -> (gc, gathered buffer, handle) of an all-gather started between K7 and K8
+        # frame -> (gathered [world,P,3] buffer, handle, that frame's camera position).  Indexed by the frame number the FORWARD
+        # drew, not by backward order: one loss over K frames runs the K backward nodes in reverse creation order.
+        self._held = {}
+
+    def attach(self) -> int:
+        """Called by the operator's forward: this call is frame `attached` (mod frames_per_rank) of the step -- the row of
+        `all_campos[rank]` that holds its camera.  The number rides on the autograd node to `start` / `run`."""
+        j = self.attached % self.frames_per_rank
+        self.attached += 1
+        return j
 
     def _gather(self, gc: torch.Tensor):
         world = dist.get_world_size(self.group)
@@ -138,13 +148,13 @@ class ShExchange:
         self.bytes_sent += gc.numel() * gc.element_size()
         return flat, h
 
-    def start(self, gc: torch.Tensor) -> None:
+    def start(self, gc: torch.Tensor, frame: int = 0) -> None:
         """Called by the operator's backward BETWEEN its two halves (sr_backward_blend / sr_backward_colors done, sr_backward_geometry
         not yet launched): `gc` [P,3] is final, so its all-gather goes on the wire now and overlaps K8.  `run` picks it up."""
         if not gc.is_contiguous():
             return
         flat, h = self._gather(gc)
-        self._early = (gc, flat, h)
+        self._early[frame] = (gc, flat, h)
         self.early_starts += 1
 
     def _cameras(self, frames, device) -> torch.Tensor:
@@ -152,6 +162,12 @@ class ShExchange:
         world, K = dist.get_world_size(self.group), len(frames)
         if self.all_campos is not None:      # every rank knows the camera list: [world, 3] or [world, frames_per_rank, 3]
             cams = self.all_campos.to(device=device, dtype=torch.float32).reshape(world, K, 3)
+            # the replicated list must agree with the cameras the frames were rendered with (row j = the j-th FORWARD of the step)
+            rank = dist.get_rank(self.group)
+            mine = torch.stack([f[2] for f in frames]).to(device=device, dtype=torch.float32)
+            if not torch.allclose(cams[rank], mine, rtol=1e-5, atol=1e-6):
+                raise RuntimeError("factored_sh_exchange: all_campos[rank] does not list this rank's cameras in the order of its forward "
+                                   "calls (row j must be the camera of the j-th rasterizer call inside the block)")
             return cams.transpose(0, 1).reshape(K * world, 3).contiguous()
         mine = torch.stack([f[2] for f in frames]).to(device=device, dtype=torch.float32).reshape(K * 3).contiguous()
         cams = torch.empty(world * K * 3, dtype=torch.float32, device=device)
@@ -159,25 +175,34 @@ class ShExchange:
         return cams.view(world, K, 3).transpose(0, 1).reshape(K * world, 3).contiguous()
 
     def run(self, gc: torch.Tensor, means3D: torch.Tensor, campos: torch.Tensor, sh_coeffs: int, degree: int,
-            also_reduce: Sequence[torch.Tensor] = ()) -> Optional[torch.Tensor]:
+            also_reduce: Sequence[torch.Tensor] = (), frame: Optional[int] = None) -> Optional[torch.Tensor]:
         """gc: this rank's clamp-masked dL/drgb [P,3] of one frame.  Returns dL_dsh [P,M,3] summed over all ranks' frames -- or, while
         fewer than `frames_per_rank` frames have been handed in, None (autograd: no contribution yet): that frame's all-gather is
         already on the wire and runs under the next frame's kernels; the LAST frame's call expands all world * frames_per_rank views.
 
         `also_reduce`: further gradient tensors to SUM all-reduce in place (frames_per_rank == 1 only); their collective is queued
-        right behind the all-gather, so it runs on the communication stream while the expansion kernel runs on the compute stream."""
+        right behind the all-gather, so it runs on the communication stream while the expansion kernel runs on the compute stream.
+        `frame`: the number the forward drew from `attach` (None: the next free slot, i.e. backward order = forward order) -- the
+        gathered gradient is filed under it, so that view (frame j, rank r) meets camera all_campos[r, j] whatever order autograd
+        runs the K backward nodes in.  Every rank must run its backward nodes in the same order (the all-gathers pair up by issue
+        order): same graph on every rank, as in DDP."""
         import time
         world = dist.get_world_size(self.group)
         gc = gc.contiguous()
-        if self._early is not None and self._early[0] is gc:     # started by `start` between the two halves of the backward
-            _, flat, h = self._early
+        if frame is None:   # a direct call (no operator forward drew a number): frames in the order of the calls
+            frame = next(j for j in range(self.frames_per_rank) if j not in self._held)
+            self.attached += 1
+        if frame in self._held:
+            raise RuntimeError(f"factored_sh_exchange: frame {frame} handed in twice before the step's {self.frames_per_rank} frames were complete")
+        early = self._early.pop(frame, None)
+        if early is not None and early[0] is gc:     # started by `start` between the two halves of the backward
+            _, flat, h = early
         else:
             flat, h = self._gather(gc)
-        self._early = None
-        self._held.append((flat, h, campos.detach().reshape(3)))
+        self._held[frame] = (flat, h, campos.detach().reshape(3))
         if len(self._held) < self.frames_per_rank:
             return None
-        frames, self._held = self._held, []
+        frames, self._held = [self._held[j] for j in range(self.frames_per_rank)], {}
         cams = self._cameras(frames, gc.device)
         pending = []
         groups, singles = _storage_groups([t for t in also_reduce if t is not None and t.numel() > 0])
@@ -242,6 +267,11 @@ def factored_sh_exchange(group=None, expand: Optional[Callable] = None, all_camp
         yield ex
     finally:
         _ACTIVE_SH_EXCHANGE.reset(token)
+        if ex is not None and ex.attached == 0:
+            # the binding happens at FORWARD time: a block around loss.backward() alone exchanges nothing and the ranks diverge silently
+            import warnings
+            warnings.warn("factored_sh_exchange: no rasterizer forward ran inside the block -- wrap the render call (the forward), not only "
+                          "loss.backward(); this step's SH gradients were NOT exchanged", RuntimeWarning, stacklevel=3)
 
 
 def active_sh_exchange() -> Optional[ShExchange]:
@@ -254,17 +284,30 @@ def reduce_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor
     """Per-rank contribution of one rendered view, then cross-rank SUM / SUM / MAX.
 
     Mirrors GaussianModel.add_densification_stats + the max_radii2D update for this rank's frame and makes
-    the three statistics identical on every rank."""
+    the three statistics identical on every rank [REF /root/reference/scene/gaussian_model.py:555-557; train.py:168-169].
+    ONE packed buffer per rank -- (|viewspace grad|, radius) = 8 B per Gaussian, 0 / 0 where the view does not see it; `denom`'s
+    contribution is radius > 0 and needs no slot -- and no boolean-index kernels.  Up to three ranks it travels as ONE all-gather
+    (every rank then sums / counts / maximises the `world` rows locally: (N - 1) * 8 B received per Gaussian, against 12 B for
+    reducing three arrays); from four ranks on as ONE all-reduce pair issued together, SUM over the (norm, visible) columns and MAX
+    over the radii (2 (N - 1) / N * 12 B, which the all-gather's (N - 1) * 8 B exceeds)."""
     vis = radii > 0
-    local_accum = torch.zeros_like(xyz_gradient_accum)
-    local_denom = torch.zeros_like(denom)
-    local_accum[vis] = torch.norm(viewspace_grad[vis], dim=-1, keepdim=True)
-    local_denom[vis] = 1
-    local_max = torch.where(vis, radii.to(max_radii2D.dtype), torch.zeros_like(max_radii2D))
-    if _exchange_wanted(group):
-        dist.all_reduce(local_accum, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(local_denom, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(local_max, op=dist.ReduceOp.MAX, group=group)
-    xyz_gradient_accum += local_accum
-    denom += local_denom
-    torch.maximum(max_radii2D, local_max, out=max_radii2D)
+    norm = torch.where(vis, torch.norm(viewspace_grad, dim=-1), torch.zeros((), dtype=viewspace_grad.dtype, device=viewspace_grad.device))
+    rad = torch.where(vis, radii, torch.zeros_like(radii)).to(torch.float32)   # radii are small integers: exact in float32
+    if not _exchange_wanted(group):
+        acc, cnt, mx = norm, vis.to(norm.dtype), rad
+    elif dist.get_world_size(group) <= 3:
+        world = dist.get_world_size(group)
+        mine = torch.stack([norm.to(torch.float32), rad]).contiguous()            # [2, P]
+        rows = torch.empty(world * mine.numel(), dtype=torch.float32, device=mine.device)
+        dist.all_gather_into_tensor(rows, mine.reshape(-1), group=group)
+        rows = rows.view(world, 2, -1)
+        acc, cnt, mx = rows[:, 0].sum(0), (rows[:, 1] > 0).sum(0).to(torch.float32), rows[:, 1].max(0).values
+    else:
+        sums = torch.stack([norm.to(torch.float32), vis.to(torch.float32)]).contiguous()   # [2, P]: ONE SUM collective for both
+        h1 = dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        h2 = dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=group, async_op=True)
+        h1.wait(); h2.wait()
+        acc, cnt, mx = sums[0], sums[1], rad
+    xyz_gradient_accum += acc.to(xyz_gradient_accum.dtype).view_as(xyz_gradient_accum)
+    denom += cnt.to(denom.dtype).view_as(denom)
+    torch.maximum(max_radii2D, mx.to(max_radii2D.dtype).view_as(max_radii2D), out=max_radii2D)

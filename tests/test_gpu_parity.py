@@ -484,6 +484,37 @@ def test_factored_sh_exchange_over_rccl_with_one_rank():
     assert "factored exchange OK (world 1, backend nccl)" in r.stdout
 
 
+def _bare_env():
+    """The environment of a plain `python bench.py` call: no torchrun variables (the test process may itself run under a launcher)."""
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_PORT",
+                                                              "TORCHELASTIC_RUN_ID", "SURFEL_EXCHANGE_SINGLE_RANK")}
+
+
+@pytest.mark.parametrize("extra", [[], ["--frames-per-rank", "2"], ["--exchange", "allreduce"]])
+def test_bench_gpus_2_launches_itself_and_exchanges(extra):
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the shape of the driver's 1-GPU command line): bench.py starts its two
+    ranks itself; here they share this box's one GPU over gloo.  The JSON line must report two ranks that both see a world of two, and
+    the factored exchange must have reproduced the plain all-reduce (exchange_selfcheck) -- BASELINE configs[3], SURVEY 8(e)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(_bare_env(), SURFEL_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "200000",
+                        "--no-cpu-baseline"] + extra, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "without a torchrun environment: launching" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_seen_by_each_rank"] == [2, 2] and d["config"]["backend"] == "gloo"
+    assert d["config"]["frames_per_step"] == 2 * (2 if "--frames-per-rank" in extra else 1)
+    if "--exchange" in extra:
+        assert d["config"]["gradient_exchange"].startswith("all-reduce of 232")
+    else:
+        assert d["config"]["exchange_selfcheck"]["ok"] and d["config"]["exchange_selfcheck"]["factored_vs_allreduce_max_rel_err"] < 1e-4
+        assert d["config"]["gradient_exchange"].startswith("all-gather")
+    assert d["value"] > 0 and d["scaling"] == "weak"
+
+
 @pytest.mark.parametrize("tile", [(8, 8), (16, 8), (32, 8), (32, 16)])
 def test_tile_shape_sweep(tile):
     """BASELINE config 5's tile-size sweep: every shape bins bit-exactly like the oracle run with the same BLOCK_X x BLOCK_Y,
