@@ -167,6 +167,9 @@ typedef struct SrImageView {
 } SrImageView;
 
 int sr_abi_version(void);
+/* Which of the named compile-time switches (include/surfel_switches.h: SURVEY.md Appendix A's (!) items) this library was built with
+ * at a NON-default value: SR_SWITCH_BITS, 0 for the shipped configuration. */
+uint32_t sr_build_switches(void);
 const char* sr_last_error(void);
 
 /* Sizes of the three state buffers (bytes). num_rendered = D from sr_forward_plan. */

@@ -21,7 +21,8 @@ from typing import Dict, Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsurfel_oracle.so")
+# SURFEL_ORACLE_LIB: the oracle compiled with a non-default named switch (include/surfel_switches.h; streetunveiler_amd/build.py --variant)
+_LIB_PATH = os.environ.get("SURFEL_ORACLE_LIB") or os.path.join(_HERE, "libsurfel_oracle.so")
 _lib = None
 
 TILE = 16
@@ -29,7 +30,9 @@ TILE = 16
 
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (idempotent)."""
-    srcs = [os.path.join(_HERE, f) for f in ("surfel_oracle.c", "surfel_blend.inc", "surfel_k8.inc", "knn_oracle.c")]
+    if os.environ.get("SURFEL_ORACLE_LIB"):
+        return _LIB_PATH   # a variant: built by streetunveiler_amd/build.py --variant
+    srcs = [os.path.join(_HERE, f) for f in ("surfel_oracle.c", "surfel_blend.inc", "surfel_k8.inc", "knn_oracle.c", "../include/surfel_switches.h")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libsurfel_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -43,7 +46,21 @@ def lib():
         _lib.so_count_duplicates.restype = C.c_uint64
         _lib.so_bin.restype = C.c_int
         _lib.so_num_threads.restype = C.c_int
+        _lib.so_build_switches.restype = C.c_uint32
+        _lib.so_set_tanfov.argtypes = [C.c_float, C.c_float]
     return _lib
+
+
+def build_switches() -> int:
+    """SR_SWITCH_BITS the oracle was compiled with (include/surfel_switches.h); 0 = the shipped configuration."""
+    return int(lib().so_build_switches())
+
+
+def quat_to_R(q) -> np.ndarray:
+    """The oracle's quaternion (r, x, y, z) -> rotation restatement, [n,4] -> [n,3,3] (used as given, no normalisation)."""
+    q = _f32(q); out = np.zeros((q.shape[0], 3, 3), np.float32)
+    lib().so_quat_to_R(q.shape[0], _p(q), _p(out))
+    return out
 
 
 def num_threads() -> int:
@@ -95,7 +112,8 @@ def _preprocess_and_bin(L, P, deg, M, means3D, scales, rotations, opacities, shs
 def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None, colors_precomp=None,
                       transMat_precomp=None, *, viewmatrix, projmatrix, campos, bg, image_width: int,
                       image_height: int, sh_degree: int = 0, scale_modifier: float = 1.0,
-                      stages: bool = True, tile=(16, 16), forced=None, f64: bool = False, reuse=None) -> Dict[str, np.ndarray]:
+                      stages: bool = True, tile=(16, 16), forced=None, f64: bool = False, reuse=None,
+                      tanfovx: Optional[float] = None, tanfovy: Optional[float] = None) -> Dict[str, np.ndarray]:
     """K1..K6. Returns every stage's outputs (dict of numpy arrays).  `tile` = (BLOCK_X, BLOCK_Y), 16x16 in the reference.
     `forced` = dict(valid=u64[D,nq], use3d=u64[D,nq], n_contrib=u32[2,H,W]): blend with the hard decisions of another
     implementation (sr_debug_pair_decisions + its n_contrib) -- see so_render_forward; the backward then uses them too.
@@ -141,7 +159,8 @@ def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None,
     o["_inputs"] = dict(means3D=means3D, opacities=opacities, scales=scales, rotations=rotations, shs=shs,
                         colors_precomp=colors_precomp, transMat_precomp=transMat_precomp, view=view, proj=proj,
                         cam=cam, bg=bgc, W=W, H=H, deg=int(sh_degree), M=M, scale_modifier=float(scale_modifier),
-                        vals_buf=vals_buf, tile=(int(tile[0]), int(tile[1])), forced=(fv, fu), f64=bool(f64))
+                        vals_buf=vals_buf, tile=(int(tile[0]), int(tile[1])), forced=(fv, fu), f64=bool(f64),
+                        tanfov=(tanfovx, tanfovy))   # only read by a SR_BACKWARD_WH_FROM_FOCAL build
     return o
 
 
@@ -150,6 +169,10 @@ def rasterize_backward(fwd: Dict[str, np.ndarray], dL_dcolor, dL_dallmap) -> Dic
     L = lib()
     i = fwd["_inputs"]; P = i["means3D"].shape[0]; W, H, M = i["W"], i["H"], i["M"]
     L.so_set_tile(*i["tile"])
+    if i.get("tanfov", (None, None))[0] is not None:
+        L.so_set_tanfov(float(i["tanfov"][0]), float(i["tanfov"][1]))
+    elif build_switches() & 32:
+        raise ValueError("this oracle was built with SR_BACKWARD_WH_FROM_FOCAL=1: pass tanfovx / tanfovy to rasterize_forward")
     dL_dcolor = _f32(dL_dcolor).reshape(3, H, W); dL_dallmap = _f32(dL_dallmap).reshape(7, H, W)
     f64 = i.get("f64", False)
     rt, ct = (np.float64, C.c_double) if f64 else (np.float32, C.c_float)

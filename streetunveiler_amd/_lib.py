@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsurfel_raster.so")
+# SURFEL_RASTER_LIB: another BUILD of the same library -- one of the named-switch variants of include/surfel_switches.h
+# (`python -m streetunveiler_amd.build --variant <name>` -> lib/variants/<name>/libsurfel_raster.so).  Same ABI, still no CPU path.
+LIB_PATH = os.environ.get("SURFEL_RASTER_LIB") or os.path.join(HERE, "lib", "libsurfel_raster.so")
 
 SR_ACT_EXP_SCALES, SR_ACT_SIGMOID_OPACITY, SR_ACT_NORMALIZE_ROTATIONS = 1, 2, 4
 SR_FLAG_NO_QUADRANT_CULL = 1
@@ -54,7 +56,7 @@ class SrImageView(C.Structure):
 
 
 # every symbol include/surfel_raster.h declares (checked by tests/test_abi.py)
-EXPORTS = ["sr_abi_version", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
+EXPORTS = ["sr_abi_version", "sr_build_switches", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
            "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan", "sr_sh_gradient_expand", "sr_knn_workspace_bytes", "sr_knn_mean_dist2",
            "sr_forward_render", "sr_backward", "sr_backward_blend", "sr_backward_colors", "sr_backward_geometry", "sr_debug_pair_decisions", "sr_class_image_bytes", "sr_class_forward_render", "sr_class_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_debug_radix_sort", "sr_debug_radix_sort_temp_bytes", "sr_debug_lds_atomic_ranks", "sr_rank_mode", "sr_postprocess_forward",
            "sr_postprocess_backward"]
@@ -77,6 +79,7 @@ def load():
             "(or __graft_entry__.build()). There is no CPU fallback for the rasterizer.")
     lib = C.CDLL(LIB_PATH)
     lib.sr_abi_version.restype = C.c_int
+    lib.sr_build_switches.restype = C.c_uint32
     lib.sr_last_error.restype = C.c_char_p
     for name in ("sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes", "sr_backward_workspace_bytes"):
         getattr(lib, name).restype = C.c_size_t
@@ -128,6 +131,17 @@ def load():
         raise SurfelRasterError(f"ABI version mismatch: library reports {lib.sr_abi_version()}, binding expects {SR_ABI_VERSION}")
     _lib = lib
     return lib
+
+
+# include/surfel_switches.h: bit -> the switch that is NOT at its default in a library reporting that bit (sr_build_switches)
+SWITCH_BITS = {1: "SR_TIGHTBBOX=1", 2: "SR_DETACH_WEIGHT=1", 4: "SR_RADIUS_FILTER_FLOOR=0", 8: "SR_MEDIAN_CONTRIBUTOR_MINUS_ONE=0",
+               16: "SR_PROXY_DEPTH_VIEW_Z=1", 32: "SR_BACKWARD_WH_FROM_FOCAL=1", 64: "SR_REFERENCE_PZ_SKIP=1"}
+
+
+def build_switches():
+    """Non-default named switches of the loaded library, e.g. ['SR_DETACH_WEIGHT=1']; [] for the shipped configuration."""
+    bits = int(load().sr_build_switches())
+    return [name for bit, name in SWITCH_BITS.items() if bits & bit]
 
 
 def check(rc: int, what: str):

@@ -278,6 +278,13 @@ int check_common(const SrFrame* frame, const SrGaussians* g) {
 FrameDev make_frame(const SrFrame* frame, const SrGaussians* g) {
     FrameDev f{};
     f.W = frame->image_width; f.H = frame->image_height;
+    f.bw_W = f.W; f.bw_H = f.H;
+#if SR_BACKWARD_WH_FROM_FOCAL
+    {   // upstream's backward: focal = size / (2 tanfov) (rasterizer_impl), then W = int(focal_x * tan_fovx * 2) in float32
+        const float focal_x = (float)f.W / (2.0f * frame->tanfovx), focal_y = (float)f.H / (2.0f * frame->tanfovy);
+        f.bw_W = (int)(focal_x * frame->tanfovx * 2); f.bw_H = (int)(focal_y * frame->tanfovy * 2);
+    }
+#endif
     f.tile_w = frame->tile_width > 0 ? frame->tile_width : kTile; f.tile_h = frame->tile_height > 0 ? frame->tile_height : kTile;
     f.inv_tile_w = 1.f / (float)f.tile_w; f.inv_tile_h = 1.f / (float)f.tile_h;
     f.tiles_x = (f.W + f.tile_w - 1) / f.tile_w; f.tiles_y = (f.H + f.tile_h - 1) / f.tile_h;
@@ -296,6 +303,7 @@ template <class T> T* at(void* base, size_t off) { return reinterpret_cast<T*>(s
 extern "C" {
 
 int sr_abi_version(void) { return SR_ABI_VERSION; }
+uint32_t sr_build_switches(void) { return SR_SWITCH_BITS; }
 const char* sr_last_error(void) { return g_err; }
 
 size_t sr_geom_bytes(int32_t P) { return geom_layout(P).total; }

@@ -234,7 +234,11 @@ __device__ __forceinline__ bool intersect(float xl, float yl, const float4 e0, c
     // float32 oracle both blend.)  With ppz = 0, rcp gives inf, rho3d is inf or NaN, the comparison above takes the screen-space
     // path and fminf drops rho3d: the pair is blended through its 2-D filter footprint, exactly what exact arithmetic does with the
     // astronomically large rho3d of a nearly parallel ray.  sx, sy, pz_inv are only read on the ray-splat path.
+#if SR_REFERENCE_PZ_SKIP
+    return !(h.depth < kNear) & !(h.alpha < kAlphaFloor) & !(ppz == 0.f);   // upstream's per-pair `if (p.z == 0) continue`, on THIS cross product
+#else
     return !(h.depth < kNear) & !(h.alpha < kAlphaFloor);
+#endif
 }
 
 // Emission index of the duplicate (tile tx,ty ; Gaussian gid): duplicates are emitted per Gaussian, y-major /

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/surfel_raster.h"
+#include "../../include/surfel_switches.h"   // the named Appendix-A switches, shared with the oracle
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "these kernels are written for gfx950 (MI355X): wave64, v_permlane16/32_swap, DPP row controls, and the LDS-atomic lane order the sort kernels rank by (checked at run time, api.hip rank_mode)"
@@ -44,6 +45,7 @@ constexpr int kGradFloats = SR_GRAD_FLOATS;
 
 struct FrameDev {
     int W, H, tiles_x, tiles_y;
+    int bw_W, bw_H;               // image size as the per-Gaussian backward sees it (SR_BACKWARD_WH_FROM_FOCAL; = W, H by default)
     int tile_w, tile_h;           // pixels per tile: powers of two, multiples of 8 (8x8 quadrant = 1 pixel per lane)
     float inv_tile_w, inv_tile_h; // exact reciprocals
     int sh_degree, sh_coeffs;

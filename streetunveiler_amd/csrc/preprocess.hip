@@ -378,7 +378,13 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
         nrm[0] *= mult; nrm[1] *= mult; nrm[2] *= mult;
 
         const float* Tu = Tm; const float* Tv = Tm + 3; const float* Tw = Tm + 6;
-        const float c2 = kCutoff * kCutoff;
+#if SR_TIGHTBBOX   // upstream config.h TIGHTBBOX: the extent follows the opacity
+        const float act_opacity = (f.activations & SR_ACT_SIGMOID_OPACITY) ? sigmoidf(raw_opacity) : raw_opacity;
+        const float cutoff = sqrtf(fmaxf(9.f + 2.f * logf(act_opacity), 0.000001f));
+#else
+        const float cutoff = kCutoff;
+#endif
+        const float c2 = cutoff * cutoff;
         const float t0 = c2, t1 = c2, t2 = -1.f;
         const float dist = ((Tw[0] * Tw[0]) * t0 + (Tw[1] * Tw[1]) * t1) + (Tw[2] * Tw[2]) * t2;
         alive = alive && (dist != 0.f);
@@ -391,7 +397,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
             const float ty = ((f0 * Tv[0]) * Tv[0] + (f1 * Tv[1]) * Tv[1]) + (f2 * Tv[2]) * Tv[2];
             const float hx = cx * cx - tx, hy = cy * cy - ty;
             const float ex = sqrtf(fmaxf(1e-4f, hx)), ey = sqrtf(fmaxf(1e-4f, hy));
-            const float radius = ceilf(fmaxf(fmaxf(ex, ey), kCutoff * kFilterSize));
+#if SR_RADIUS_FILTER_FLOOR
+            const float radius = ceilf(fmaxf(fmaxf(ex, ey), cutoff * kFilterSize));
+#else
+            const float radius = ceilf(fmaxf(ex, ey));   // older upstream revisions: no low-pass floor on the radius
+#endif
             // tile sizes are powers of two: multiplying by the exact reciprocal == the reference's division
             int minx = (int)((cx - radius) * f.inv_tile_w), miny = (int)((cy - radius) * f.inv_tile_h);
             int maxx = (int)((cx + radius + (float)(f.tile_w - 1)) * f.inv_tile_w);
@@ -575,8 +585,13 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
             g_col[0] = g4.z; g_col[1] = g4.w; g_col[2] = g5.x;
             if (NC >= 6) { g_col[3] = g5.y; g_col[4] = g5.z; g_col[5] = g5.w; }
             // densification proxy from the blend-only dL/dT (Appendix A.6, last paragraph)
-            g_m2d[0] = dT[2] * Tw[2] * 0.5f * (float)f.W;
-            g_m2d[1] = dT[5] * Tw[2] * 0.5f * (float)f.H;
+#if SR_PROXY_DEPTH_VIEW_Z
+            const float depth_c = rec[3].w;   // view-space depth of the centre (record slot `depth`)
+#else
+            const float depth_c = Tw[2];      // upstream: transMat[8]
+#endif
+            g_m2d[0] = dT[2] * depth_c * 0.5f * (float)f.bw_W;
+            g_m2d[1] = dT[5] * depth_c * 0.5f * (float)f.bw_H;
 #pragma unroll
             for (int k = 0; k < 9; ++k) dTr[k] = dT[k];
             if (gx2 != 0.f || gy2 != 0.f) {
@@ -596,7 +611,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
             const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
             if (!transMat_precomp) {
                 float B[12], R[9];
-                build_B(f.proj, f.W, f.H, B);
+                build_B(f.proj, f.bw_W, f.bw_H, B);   // (SR_BACKWARD_WH_FROM_FOCAL: upstream's backward derives the size from focal * tanfov)
                 float qn;
                 const float4 q = load_rotation(rotations, i, f.activations, qn);
                 quat_to_R(q, R);

@@ -158,10 +158,14 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     const float inv_depth = fast_rcp(h.depth);
                     const float m_d = fmaf(inv_depth, -kFN * kNear, kFN);
                     const float t1 = fmaf(m_d, a0[q], -a1[q]);
+#if SR_DETACH_WEIGHT
+                    const float psi = phi;   // upstream DETACH_WEIGHT: the distortion does not differentiate through the blend weights
+#else
                     const float psi = phi + fmaf(m_d, t1 - a1[q], a2[q]);
+#endif
                     const float dL_dalpha = T[q] * psi - one_m_inv * Z[q];
                     Z[q] = fmaf(w, psi, Z[q]);
-                    const float med_add = (cidx == medc[q] - 1u) ? g_median[q] : 0.f;
+                    const float med_add = (cidx == medc[q] - (SR_MEDIAN_CONTRIBUTOR_MINUS_ONE ? 1u : 0u)) ? g_median[q] : 0.f;
                     const float dL_dz = fmaf(w, fmaf(t1 * (inv_depth * inv_depth), 2.f * kFN * kNear, g_depth[q]), med_add);
                     const float dL_dG = e3.z * dL_dalpha;
                     v[18] += w * gr[q]; v[19] += w * gg[q]; v[20] += w * gb[q];

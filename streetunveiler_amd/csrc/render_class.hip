@@ -234,7 +234,11 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
                     const float inv_depth = fast_rcp(h.depth);
                     const float m_d = kFN * (1.f - kNear * inv_depth);
                     const float dmd_dd = kFN * kNear * inv_depth * inv_depth;
+#if SR_DETACH_WEIGHT
+                    const float psi = 0.f;   // upstream DETACH_WEIGHT: no gradient through the blend weights (a distortion-only pass keeps d/dm)
+#else
                     const float psi = a2[q] + m_d * (m_d * a0[q] - 2.f * a1[q]);
+#endif
                     const float dL_dalpha = T[q] * psi - one_m_inv * Z[q];
                     Z[q] = fmaf(w, psi, Z[q]);
                     const float dL_dz = 2.f * w * (m_d * a0[q] - a1[q]) * dmd_dd;

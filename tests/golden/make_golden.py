@@ -267,14 +267,128 @@ def g5_g6_reference_render():
                 sys.modules.pop(k, None)
 
 
+# ---------------------------------------------------------------------------------------------------
+# G7 / G8: the remaining pins the reference's python offers for the path (round-3 review, item 2).
+#   G7  utils/general_utils.py build_rotation / build_scaling_rotation (:78-110) -- the quaternion -> rotation formula and
+#       L = R diag(s) that K1 / the oracle's quat_to_R restate -- and inverse_sigmoid; their hard-coded device='cuda' is stripped
+#       for the duration of the call, as G5/G6 do for torch.zeros_like.
+#   G8  scene/gaussian_model.py: GaussianModel.construct_list_of_attributes + save_ply + load_ply (:226-259, :338-382) and the
+#       activation getters (:31-39, :101-123) executed on seeded raw parameters.  plyfile (a third-party library the image lacks)
+#       is replaced by a CAPTURING stand-in: what is recorded is the structured array the reference hands to PlyElement.describe
+#       (property names, order, dtypes, the packed bytes) and the tensors its load_ply builds from the same element -- i.e. the
+#       reference's half of the format; the PLY container syntax itself is plyfile's published format.
+# ---------------------------------------------------------------------------------------------------
+def g7_g8_rotation_and_checkpoint():
+    import importlib.util
+    import types
+    saved = {k: sys.modules.get(k) for k in ("plyfile", "simple_knn", "simple_knn._C")}
+    for k in list(sys.modules):
+        if k == "utils" or k.startswith("utils."):
+            del sys.modules[k]
+    captured = {}
+
+    class _Prop:
+        def __init__(self, name): self.name = name
+
+    class _Element:
+        def __init__(self, data): self.data = data; self.properties = [_Prop(n) for n in data.dtype.names]
+        def __getitem__(self, k): return self.data[k]
+
+    class PlyElement:
+        @staticmethod
+        def describe(data, name):
+            assert name == "vertex"
+            return _Element(data)
+
+    class PlyData:
+        def __init__(self, elements): self.elements = elements
+        def write(self, path): captured[path] = self.elements[0]
+        @staticmethod
+        def read(path): return PlyData([captured[path]])
+
+    ply = types.ModuleType("plyfile"); ply.PlyData, ply.PlyElement = PlyData, PlyElement
+    knn, knnc = types.ModuleType("simple_knn"), types.ModuleType("simple_knn._C")
+    knnc.dist3knn = knnc.dist10knn = None
+    sys.modules.update({"plyfile": ply, "simple_knn": knn, "simple_knn._C": knnc})
+    orig = (torch.zeros, torch.tensor, torch.Tensor.cuda)
+    strip = lambda f: (lambda *a, **k: f(*a, **{kk: vv for kk, vv in k.items() if kk != "device"}))
+    torch.zeros, torch.tensor = strip(orig[0]), strip(orig[1])
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, "/root/reference")
+    try:
+        from utils.general_utils import build_rotation, build_scaling_rotation, inverse_sigmoid   # the reference's real functions
+        spec = importlib.util.spec_from_file_location("ref_gaussian_model", "/root/reference/scene/gaussian_model.py")
+        gm = importlib.util.module_from_spec(spec); spec.loader.exec_module(gm)
+        gm.mkdir_p = lambda path: None
+        out = {}
+        # G7
+        g = torch.Generator().manual_seed(70)
+        q = torch.randn(96, 4, generator=g)
+        q[:8] = torch.eye(4).repeat(2, 1); q[8:16] = -torch.eye(4).repeat(2, 1) * 3.0     # axis quaternions, un-normalised ones
+        s3 = torch.cat([torch.exp(torch.randn(96, 2, generator=g)), torch.ones(96, 1)], 1)   # 2DGS: two scales, third axis = normal
+        out["g7_quat"] = q.numpy(); out["g7_scale3"] = s3.numpy()
+        out["g7_R"] = build_rotation(q).numpy()                                   # normalises internally (:79-81)
+        out["g7_L"] = build_scaling_rotation(s3, q).numpy()                       # R @ diag(s) (:101-110)
+        x = torch.rand(64, generator=g) * 0.98 + 0.01
+        out["g7_inverse_sigmoid_in"] = x.numpy(); out["g7_inverse_sigmoid_out"] = inverse_sigmoid(x).numpy()
+        # G8
+        P, deg = 29, 3
+        pc = gm.GaussianModel(deg)
+        g = torch.Generator().manual_seed(80)
+        raw = dict(_xyz=torch.randn(P, 3, generator=g), _features_dc=torch.randn(P, 1, 3, generator=g),
+                   _features_rest=torch.randn(P, (deg + 1) ** 2 - 1, 3, generator=g), _opacity=torch.randn(P, 1, generator=g) * 2,
+                   _scaling=torch.randn(P, 2, generator=g) - 3, _rotation=torch.randn(P, 4, generator=g) * 2)
+        raw["_rotation"][0] = torch.tensor([0.0, 0.0, 0.0, 1e-20])    # normalize()'s eps matters here
+        sem = torch.randint(0, 6, (P, 1), generator=g)
+        for k, v in raw.items():
+            setattr(pc, k, v)
+            out["g8_raw" + k] = v.numpy()
+        pc._semantics = sem
+        out["g8_semantics"] = sem.numpy()
+        names = pc.construct_list_of_attributes()
+        out["g8_attribute_names"] = np.array(names)
+        # the activation getters [REF scene/gaussian_model.py:31-39, 101-123]
+        out["g8_get_scaling"] = pc.get_scaling.numpy(); out["g8_get_opacity"] = pc.get_opacity.numpy()
+        out["g8_get_rotation"] = pc.get_rotation.numpy(); out["g8_get_features"] = pc.get_features.numpy()
+        out["g8_get_semantics_32bit"] = pc.get_semantics_32bit.numpy()
+        pc.save_ply("/nonexistent/point_cloud.ply")
+        el = captured["/nonexistent/point_cloud.ply"]
+        out["g8_element_names"] = np.array(el.data.dtype.names)
+        out["g8_element_formats"] = np.array([el.data.dtype[n].str for n in el.data.dtype.names])
+        packed = np.empty(P, dtype=np.dtype([(n, el.data.dtype[n].newbyteorder("<")) for n in el.data.dtype.names]))   # little-endian, no padding
+        for n in el.data.dtype.names:
+            packed[n] = el.data[n]
+        out["g8_element_bytes"] = np.frombuffer(packed.tobytes(), np.uint8).copy()
+        pc2 = gm.GaussianModel(deg)
+        pc2.load_ply("/nonexistent/point_cloud.ply")
+        for k in raw:
+            out["g8_loaded" + k] = getattr(pc2, k).detach().numpy()
+        out["g8_loaded_semantics"] = pc2._semantics.numpy()
+        out["g8_loaded_active_sh_degree"] = np.array(pc2.active_sh_degree)
+        np.savez_compressed(os.path.join(HERE, "rotation_checkpoint_golden.npz"), **out)
+    finally:
+        sys.path.remove("/root/reference")
+        torch.zeros, torch.tensor, torch.Tensor.cuda = orig
+        for k in list(sys.modules):
+            if k == "utils" or k.startswith("utils.") or k == "ref_gaussian_model":
+                del sys.modules[k]
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+            else:
+                sys.modules.pop(k, None)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g12", "g34", "g56"]
+    which = sys.argv[1:] or ["g12", "g34", "g56", "g78"]
     if "g12" in which:
         g1_g2_from_reference()
     if "g34" in which:
         g3_g4_from_oracle()
     if "g56" in which:
         g5_g6_reference_render()
+    if "g78" in which:
+        g7_g8_rotation_and_checkpoint()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

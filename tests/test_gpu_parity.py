@@ -484,6 +484,55 @@ def test_factored_sh_exchange_over_rccl_with_one_rank():
     assert "factored exchange OK (world 1, backend nccl)" in r.stdout
 
 
+def test_k1_rotation_scaling_and_fused_activations_match_reference_fixtures(golden_dir):
+    """G7 / G8 on the GPU: K1's splat -> screen transform carries L = R diag(s) of the reference's build_scaling_rotation
+    [REF utils/general_utils.py:78-110], and the activations K1 fuses (SR_ACT_*) are the reference GaussianModel's getters
+    [REF scene/gaussian_model.py:31-39, 101-123] -- both from fixtures the reference's own python produced (tests/golden/make_golden.py)."""
+    import math
+    from diff_surfel_rasterization import GaussianRasterizer
+    from streetunveiler_amd.camera import make_camera
+    from tests.gpu_util import run_hip_raw, settings_for
+    z = np.load(os.path.join(golden_dir, "rotation_checkpoint_golden.npz"))
+    q = torch.tensor(z["g7_quat"])
+    qn = q / torch.sqrt((q * q).sum(1))[:, None]
+    n = qn.shape[0]
+    W, H = 64, 48
+    cam = synthetic_camera(W, H, index=2)
+    g = dict(means3D=torch.tensor([[0.1, -0.2, 6.0]]).repeat(n, 1), opacities=torch.full((n, 1), 0.5),
+             scales=torch.tensor(z["g7_scale3"][:, :2]) * 0.05, rotations=qn.float().contiguous(), shs=torch.zeros(n, 16, 3))
+    raw = run_hip_raw(g, cam, [0, 0, 0], 0)
+    rec = raw["geom"]["splats"].reshape(n, 20)
+    Tm = rec[:, :9].reshape(n, 3, 3)
+    proj = cam.full_proj_transform.numpy().astype(np.float64).reshape(16)
+    B = np.zeros((3, 4))
+    for k in range(4):
+        a0, a1, a3 = proj[4 * k], proj[4 * k + 1], proj[4 * k + 3]
+        B[0, k] = 0.5 * W * a0 + 0.5 * (W - 1) * a3; B[1, k] = 0.5 * H * a1 + 0.5 * (H - 1) * a3; B[2, k] = a3
+    expect = np.einsum("rk,nkc->nrc", B[:, :3], z["g7_L"].astype(np.float64)[:, :, :2] * 0.05)
+    vis = raw["radii"] > 0
+    assert vis.sum() > n // 2
+    np.testing.assert_allclose(Tm[vis][:, :, :2], expect[vis], rtol=2e-5, atol=2e-5 * np.abs(expect).max())
+    # G8: raw checkpoint parameters through the FUSED activations == the reference's activated getters fed to the plain operator
+    P = z["g8_raw_xyz"].shape[0]
+    cam2 = make_camera(W, H, cam.FoVx, cam.FoVy, t=np.array([0.0, 0.0, 6.0]))
+    feats = torch.tensor(z["g8_get_features"])
+    common = dict(means3D=torch.tensor(z["g8_raw_xyz"]), shs=feats)
+    act = dict(common, opacities=torch.tensor(z["g8_get_opacity"]), scales=torch.tensor(z["g8_get_scaling"]) * 8, rotations=torch.tensor(z["g8_get_rotation"]))
+    dev = "cuda:0"
+    s = settings_for(cam2, [0.1, 0.2, 0.3], 3)
+    plain = GaussianRasterizer(s)(means3D=act["means3D"].to(dev), means2D=torch.zeros(P, 3, device=dev), shs=act["shs"].to(dev),
+                                  opacities=act["opacities"].to(dev), scales=act["scales"].to(dev), rotations=act["rotations"].to(dev))
+    fused = GaussianRasterizer(s, fused_activations=True)(
+        means3D=act["means3D"].to(dev), means2D=torch.zeros(P, 3, device=dev), shs=act["shs"].to(dev), opacities=torch.tensor(z["g8_raw_opacity"]).to(dev),
+        scales=(torch.tensor(z["g8_raw_scaling"]) + math.log(8.0)).to(dev), rotations=torch.tensor(z["g8_raw_rotation"]).to(dev))
+    assert (plain[1] > 0).sum() >= P // 3
+    same = (plain[1] == fused[1]).float().mean().item()
+    assert same >= 1 - 1.5 / P, f"radii equal on {same:.3f}"       # (an ulp of exp can cross a ceil)
+    if same == 1.0:
+        torch.testing.assert_close(fused[0], plain[0], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(fused[2], plain[2], rtol=1e-4, atol=1e-4)
+
+
 def _bare_env():
     """The environment of a plain `python bench.py` call: no torchrun variables (the test process may itself run under a launcher)."""
     return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_PORT",

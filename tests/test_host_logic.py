@@ -346,3 +346,38 @@ def test_bench_self_launches_its_ranks_without_a_launcher():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], cwd=root,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "--gpus 4 but the launcher's WORLD_SIZE is 1" in r.stderr
+
+
+def test_checkpoint_layout_and_activations_match_reference_gaussian_model(tmp_path, golden_dir):
+    """G8: the reference's OWN GaussianModel (construct_list_of_attributes, save_ply, load_ply, the activation getters
+    [REF scene/gaussian_model.py:31-39, 101-123, 226-259, 338-382]) was run on seeded raw parameters by tests/golden/make_golden.py
+    with a capturing stand-in for plyfile; what it handed to PlyElement.describe and what its load_ply built are the fixture.
+    ply.py must write those very bytes and read those very tensors; SurfelModel's getters must equal the reference's."""
+    from streetunveiler_amd import gaussian_renderer as gr
+    from streetunveiler_amd.ply import attribute_names, load_ply, save_ply
+    z = np.load(os.path.join(golden_dir, "rotation_checkpoint_golden.npz"))
+    raw = {k: z["g8_raw_" + k] for k in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")}
+    P = raw["xyz"].shape[0]
+    names = [str(n) for n in z["g8_attribute_names"]]
+    assert attribute_names() == names
+    assert [str(n) for n in z["g8_element_names"]] == names + ["semantics"]
+    assert [str(f) for f in z["g8_element_formats"]] == ["<f4"] * len(names) + ["<i4"]
+    path = os.path.join(tmp_path, "pc.ply")
+    save_ply(path, raw["xyz"], raw["features_dc"], raw["features_rest"], raw["opacity"], raw["scaling"], raw["rotation"], z["g8_semantics"])
+    body = open(path, "rb").read().split(b"end_header\n", 1)[1]
+    assert body == z["g8_element_bytes"].tobytes(), "the vertex rows differ from what the reference hands to plyfile"
+    assert len(body) == P * (len(names) * 4 + 4)
+    back = load_ply(path)
+    for k in raw:
+        np.testing.assert_array_equal(back[k], z["g8_loaded_" + k]), k
+        np.testing.assert_array_equal(back[k], raw[k])
+    np.testing.assert_array_equal(back["semantics"], z["g8_loaded_semantics"][:, 0])
+    assert int(z["g8_loaded_active_sh_degree"]) == 3
+    # the activations: exp / sigmoid / normalize (eps 1e-12: row 0 is a quaternion of norm 1e-20) == SR_ACT_* of the C-ABI
+    pc = gr.SurfelModel.from_ply(path, device="cpu")
+    np.testing.assert_array_equal(pc.get_scaling.detach().numpy(), z["g8_get_scaling"])
+    np.testing.assert_array_equal(pc.get_opacity.detach().numpy(), z["g8_get_opacity"])
+    np.testing.assert_array_equal(pc.get_rotation.detach().numpy(), z["g8_get_rotation"])
+    np.testing.assert_array_equal(pc.get_features.detach().numpy(), z["g8_get_features"])
+    np.testing.assert_array_equal(pc.get_semantics_32bit.numpy().reshape(-1), z["g8_get_semantics_32bit"].reshape(-1))
+    assert np.abs(z["g8_get_rotation"][0]).max() < 1e-6     # |q| = 1e-20 < eps: normalize() divides by eps, not by the norm

@@ -159,3 +159,39 @@ def test_knn_oracle_against_kdtree():
     d, _ = cKDTree(ref.astype(np.float64)).query(pts.astype(np.float64), k=3)
     np.testing.assert_allclose(knn_mean_dist2(pts, 3, reference=ref), (d ** 2).mean(axis=1), rtol=1e-5)
     np.testing.assert_allclose(knn_mean_dist2(pts, 3, reference=ref, take_sqrt=True), np.sqrt((d ** 2).mean(axis=1)), rtol=1e-5)
+
+
+def test_quaternion_and_scaling_rotation_match_reference(golden_dir):
+    """G7: the oracle's quaternion -> rotation (so_quat_to_R) and K1's L = R diag(s) against the reference's OWN build_rotation /
+    build_scaling_rotation [REF utils/general_utils.py:78-110], executed by tests/golden/make_golden.py (device kwarg stripped)."""
+    z = np.load(os.path.join(golden_dir, "rotation_checkpoint_golden.npz"))
+    q = torch.tensor(z["g7_quat"])
+    # the reference normalises inside build_rotation (:79-81); the operator receives get_rotation = normalize(_rotation) and uses it as given
+    norm = torch.sqrt(q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2] + q[:, 3] * q[:, 3])
+    qn = (q / norm[:, None]).numpy()
+    R = so.quat_to_R(qn)
+    np.testing.assert_allclose(R, z["g7_R"], rtol=0, atol=3e-7)
+    assert np.abs(z["g7_R"]).max() > 0.99 and np.abs(np.linalg.det(z["g7_R"].astype(np.float64)) - 1).max() < 1e-5
+    # K1: transMat columns 0 / 1 are B[:, :3] @ L[:, 0 / 1] with L = R diag(s_u, s_v, 1) -- the reference's build_scaling_rotation
+    W, H = 64, 48
+    cam = synthetic_camera(W, H, index=2)
+    n = qn.shape[0]
+    means = np.tile(np.array([[0.1, -0.2, 6.0]], np.float32), (n, 1))
+    s2 = np.ascontiguousarray(z["g7_scale3"][:, :2]) * 0.05
+    fwd = so.rasterize_forward(means, np.full((n, 1), 0.5, np.float32), s2, qn, colors_precomp=np.zeros((n, 3), np.float32),
+                               viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
+                               campos=cam.camera_center.numpy(), bg=np.zeros(3, np.float32), image_width=W, image_height=H)
+    proj = cam.full_proj_transform.numpy().astype(np.float64).reshape(16)
+    B = np.zeros((3, 4))
+    for k in range(4):
+        a0, a1, a3 = proj[4 * k], proj[4 * k + 1], proj[4 * k + 3]
+        B[0, k] = 0.5 * W * a0 + 0.5 * (W - 1) * a3; B[1, k] = 0.5 * H * a1 + 0.5 * (H - 1) * a3; B[2, k] = a3
+    L = z["g7_L"].astype(np.float64) * 0.05            # R @ diag(s): columns scale with s
+    expect = np.einsum("rk,nkc->nrc", B[:, :3], L[:, :, :2])
+    vis = fwd["radii"] > 0
+    assert vis.sum() > n // 2
+    got = fwd["transMat"].reshape(n, 3, 3)[:, :, :2]
+    np.testing.assert_allclose(got[vis], expect[vis], rtol=2e-5, atol=2e-5 * np.abs(expect).max())
+    # inverse_sigmoid [REF utils/general_utils.py:21-22] is the inverse of the opacity activation the operator fuses (SR_ACT_SIGMOID_OPACITY)
+    x = torch.tensor(z["g7_inverse_sigmoid_out"])
+    np.testing.assert_allclose(torch.sigmoid(x).numpy(), z["g7_inverse_sigmoid_in"], rtol=1e-6, atol=1e-7)
