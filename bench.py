@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-aux", action="store_true", help="only colour + alpha gradients live (as in C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the untimed `train_step` section (the reference's 8 rasterizations of a late training iteration vs 2)")
     ap.add_argument("--row-mapped", action="store_true", help="A/B switch: force the row-mapped forward blend (SR_FLAG_ROW_MAPPED_FORWARD; bit-identical results)")
     ap.add_argument("--quadrant-mapped", action="store_true", help="A/B switch: force the quadrant-mapped forward blend (default: picked per frame on the device)")
     ap.add_argument("--exchange", choices=["factored", "allreduce"], default="factored",
@@ -174,6 +175,26 @@ def cpu_baseline(args, g, cam, dc, da):
     return {"value": n / dt / 1e6, "unit": "Msplats/s", "cores": threads, "kind": "port",
             "sample": (f"oracle/surfel_oracle.c fwd+bwd, " + ("the whole scene" if n == args.gaussians else f"first {n} Gaussians of the same scene")
                        + f" at {args.width}x{args.height} (D={D}), {dt:.1f} s wall, OpenMP {threads} threads")}
+
+
+def train_step_section(args, params, cam, dev):
+    """Untimed extra (like stage_ms): one late training iteration's rasterizer calls on this scene, the reference's way -- render +
+    render_semantic (two passes) + five class-filtered renders = 8 operator calls [REF train.py:84-109] -- and as this build's two
+    rasterizations (render_and_semantic + render_class_distortions); ms per fwd+bwd and how far the resulting maps are apart."""
+    from streetunveiler_amd.gaussian_renderer import SurfelModel
+    from streetunveiler_amd.train_pattern import compare_and_time
+    sem = torch.randint(0, 6, (args.gaussians,), generator=torch.Generator().manual_seed(0)).to(dev)
+    sem[sem == 4] = 2   # the reference prunes the sky Gaussians before training
+    for t in params.values():
+        t.grad = None
+    pc = SurfelModel(params["means3D"], params["scales"], params["rotations"], params["opacities"], params["shs"], sem, args.sh_degree, 3)
+    try:
+        res = compare_and_time(cam.to(dev), pc, torch.zeros(3, device=dev), list(params.values()))
+    finally:
+        for t in params.values():
+            t.grad = None
+        torch.cuda.empty_cache()
+    return res
 
 
 def self_launch(args):
@@ -442,6 +463,8 @@ def main():
                                       "frac": round(sum(ab.values()) / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kernels_ms else None}},
             "stage_ms": {k: (None if v is None else round(v, 4)) for k, v in stage_ms.items()},
         }
+        if world == 1 and not multi and not args.no_train_step:
+            out["train_step"] = train_step_section(args, params, cam, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g_cpu, cam, dc_cpu, da_cpu)
         print(json.dumps(out), flush=True)

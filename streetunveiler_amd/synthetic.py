@@ -47,6 +47,26 @@ def synthetic_gaussians(P: int, width: int, height: int, seed: int = 0, sh_coeff
                 opacities=opacities.float(), shs=shs.float().contiguous())
 
 
+def clustered_gaussians(P: int, width: int, height: int, fraction: float = 0.5, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """A street-like, NON-uniform variant of the benchmark scene: `fraction` of the Gaussians is squeezed into four screen regions
+    (dense facades / vegetation) and made translucent, so the tile lists are heavy-tailed (1920x1080, 3 M Gaussians: list length
+    p50 ~830, p99 ~27 k, max ~41 k against a uniform ~1 640) and walked deep.  One blend wave per tile makes the longest lists the
+    tail of K6 / K7: tools/clustered_scene.py times it, tests/test_gpu_fullsize.py checks it against the oracle."""
+    g = synthetic_gaussians(P, width, height, seed=seed)
+    cam = synthetic_camera(width, height)
+    gen = torch.Generator().manual_seed(9)
+    n = int(P * fraction)
+    tx, ty = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    centres = torch.tensor([[-0.6, 0.1], [0.1, -0.3], [0.55, 0.4], [0.8, -0.5]])
+    which = torch.randint(0, 4, (n,), generator=gen)
+    z = g["means3D"][:n, 2]
+    off = torch.randn(n, 2, generator=gen) * 0.06
+    g["means3D"][:n, 0] = (centres[which, 0] + off[:, 0]) * z * tx
+    g["means3D"][:n, 1] = (centres[which, 1] + off[:, 1]) * z * ty
+    g["opacities"][:n] *= 0.3      # translucent clutter: lists are walked deep
+    return g
+
+
 def synthetic_upstream_grads(width: int, height: int, seed: int = 1, aux: bool = True):
     """dL_dcolor ~ N(0,1)[3,H,W], dL_dallmap ~ N(0,1)[7,H,W]; aux=False keeps colour + alpha only (C2)."""
     g = torch.Generator().manual_seed(seed)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 W, H = 1920, 1080
 
 
-def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget):
+def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, report=None):
     """One BASELINE configuration in full against the CPU oracle [REF gaussian_renderer/__init__.py:129-165: the operator call and the
     meaning of its outputs]:
       1. integers bit-exact: D, radii, the sorted duplicate list, the tile ranges (the float32 oracle's 64-bit stable sort);
@@ -27,7 +27,7 @@ def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget):
     from tests.gpu_util import (assert_close_frac, assert_free_parity, assert_grads_close, assert_strict_parity, check_allmap,
                                 forced_f64_reference, free_f64_reference, run_hip, run_hip_raw, run_oracle)
     cam = synthetic_camera(W, H)
-    g = synthetic_gaussians(P, W, H, seed=0)
+    g = synthetic_gaussians(P, W, H, seed=0) if scene is None else scene(P, W, H)
     bg = np.zeros(3, np.float32)
     dc, da = synthetic_upstream_grads(W, H, seed=1, aux=aux)
     fwd, bwd = run_oracle(g, cam, bg, 3, dc, da)
@@ -45,13 +45,21 @@ def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget):
     for k in ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"]:
         # (no per-element cap here: with 3 M rows the float32 oracle's own worst rows -- global-coordinate cancellation of grazing
         # splats, 0.3 of a row against the float64 arbiter in profiles/r03_parity_c3.json -- exceed any; steps 3 and 4 are the tight ones)
-        assert_grads_close(out[k], bwd[k], 2e-3, f"{tag} {k}", hard=None)
+        # ... but a loose one stays: no element may be off by a quarter of its tensor's scale, whatever its row's conditioning
+        assert_grads_close(out[k], bwd[k], 2e-3, f"{tag} {k}", hard=0.25)
     _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da, base=fwd, raw=raw)
     assert_strict_parity(out, fwd64, bwd64, tag=tag + " ", scene=(g, cam))
     del fwd64, bwd64
     xfwd, xbwd, margins = free_f64_reference(g, cam, bg, 3, dc, da, base=fwd)
     assert_free_parity(out, raw["img"]["n_contrib"], xfwd, xbwd, margins, tag=tag + " ", scene=(g, cam), pixel_budget=pixel_budget,
-                       gaussian_budget=gaussian_budget)
+                       gaussian_budget=gaussian_budget, report=report)
+    if report is not None:
+        vis = fwd["radii"] > 0
+        report["non_robust_pixels"] = float((margins["pixel"] <= 1.0).mean())
+        report["non_robust_visible_gaussians"] = float(1.0 - (vis & (margins["gaussian"] > 1.0)).sum() / max(1, vis.sum()))
+        lens = (fwd["ranges"][:, 1].astype(np.int64) - fwd["ranges"][:, 0])
+        report["list_length"] = dict(mean=float(lens.mean()), p50=float(np.percentile(lens, 50)), p99=float(np.percentile(lens, 99)), max=int(lens.max()))
+        report["deepest_contributor"] = dict(mean=float(fwd["n_contrib"][0].mean()), max=int(fwd["n_contrib"][0].max()))
 
 
 def test_depth_sort_payload_paths_bit_exact():
@@ -81,6 +89,23 @@ def test_c3_3m_against_oracle():
     """BASELINE config 3 -- the configuration the metric is quoted on: 3 M Gaussians, 1920x1080, all seven aux-map gradients live.
     The oracle needs ~12 s per free-running pass on the GPU box's host (128 threads) and ~3 s per forced pass."""
     _against_oracle(3_000_000, True, "C3", pixel_budget=8e-3, gaussian_budget=0.25)
+
+
+def test_clustered_street_scene_against_oracle():
+    """Heavy-tailed tile lists -- what a Waymo segment looks like, unlike the uniform benchmark scene: half of the C3 scene's 3 M Gaussians squeezed
+    into four screen regions and made translucent (streetunveiler_amd.synthetic.clustered_gaussians; list length p99 >> mean, pixels
+    thousands of contributors deep).  The same four-way check as C2 / C3: bit-exact lists, the float32 oracle, the strict float64 bar on
+    the kernels' own decisions, and the free-running float64 reference.  The measured fractions go to gpurun_out/ for the budgets."""
+    import json, os
+    from streetunveiler_amd.synthetic import clustered_gaussians
+    rep = {}
+    try:
+        # budgets = the measured non-robust fractions plus a margin (1.5 M Gaussians: 0.38 % of the pixels, 24 % of the visible Gaussians)
+        _against_oracle(3_000_000, True, "clustered", pixel_budget=1e-2, gaussian_budget=0.32, scene=lambda P, W, H: clustered_gaussians(P, W, H, 0.5), report=rep)
+    finally:
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(rep, open("gpurun_out/clustered_parity.json", "w"), indent=1, default=float)
+    assert rep["list_length"]["p99"] > 6 * rep["list_length"]["p50"] and rep["deepest_contributor"]["max"] > 1500
 
 
 def _properties(P, W, H, check_linearity=True):

@@ -459,3 +459,24 @@ def test_class_distortions_one_pass_equals_the_per_class_renders():
     loss.backward()
     for key in ("means3D", "opacities", "scales", "rotations"):
         assert_grads_close(t1[key].grad.cpu().numpy(), t2[key].grad.cpu().numpy(), 2e-5, "one pass vs five renders d" + key, max_bad_frac=0.0, hard=2e-5)
+
+
+def test_training_iteration_eight_calls_equal_two_rasterizations():
+    """The reference's late training iteration rasterizes one view eight times [REF train.py:84-109]: render_semantic (two 3-channel
+    passes), five class-filtered renders on boolean-indexed copies, render.  streetunveiler_amd.train_pattern issues those eight calls
+    through the drop-in operator and, beside them, this build's two rasterizations (render_and_semantic + render_class_distortions):
+    same maps, same parameter gradients -- what bench.py's `train_step` section times at the C3 size."""
+    from streetunveiler_amd.gaussian_renderer import SurfelModel
+    from streetunveiler_amd.train_pattern import compare_and_time
+    W, H, P = 208, 128, 6000
+    cam = synthetic_camera(W, H, index=2).to(DEV)
+    g = {k: v.to(DEV).requires_grad_() for k, v in synthetic_gaussians(P, W, H, seed=21, scale_lo=2e-3, scale_hi=3e-2).items()}
+    sem = torch.randint(0, 6, (P,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    sem[sem == 4] = 2
+    pc = SurfelModel(g["means3D"], g["scales"], g["rotations"], g["opacities"], g["shs"], sem, 3, 3)
+    r = compare_and_time(cam, pc, torch.tensor([0.1, 0.2, 0.3], device=DEV), list(g.values()), iters=1, warmup=1)
+    d = r["max_abs_difference_of_maps"]
+    assert d["render"] == 0.0 and d["render_semantics"] == 0.0 and d["rend_dist"] == 0.0 and d["rend_normal"] == 0.0, d   # same blend, bit for bit
+    assert d["class_dist"] <= 2e-6, d
+    assert r["max_gradient_difference_of_tensor_scale"] <= 5e-5, r
+    assert r["reference_8_calls_ms"] > 0 and r["fused_2_calls_ms"] > 0

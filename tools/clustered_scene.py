@@ -8,22 +8,13 @@ import numpy as np
 import torch
 from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
 from streetunveiler_amd import _lib
-from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
+from streetunveiler_amd.synthetic import clustered_gaussians, synthetic_camera, synthetic_upstream_grads
 P, W, H, dev = 3_000_000, 1920, 1080, "cuda:0"
 frac = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 lib = _lib.load()
 cam = synthetic_camera(W, H)
-g = synthetic_gaussians(P, W, H)
-gen = torch.Generator().manual_seed(9)
-n = int(P * frac)
+g = clustered_gaussians(P, W, H, frac)
 tx, ty = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
-centres = torch.tensor([[-0.6, 0.1], [0.1, -0.3], [0.55, 0.4], [0.8, -0.5]])
-which = torch.randint(0, 4, (n,), generator=gen)
-z = g["means3D"][:n, 2]
-off = torch.randn(n, 2, generator=gen) * 0.06
-g["means3D"][:n, 0] = (centres[which, 0] + off[:, 0]) * z * tx
-g["means3D"][:n, 1] = (centres[which, 1] + off[:, 1]) * z * ty
-g["opacities"][:n] *= 0.3      # translucent clutter: lists are walked deep
 t = {k: v.to(dev).requires_grad_() for k, v in g.items()}
 dc, da = [x.to(dev) for x in synthetic_upstream_grads(W, H)]
 s = GaussianRasterizationSettings(H, W, tx, ty, torch.zeros(3, device=dev), 1.0, cam.world_view_transform.to(dev),
