@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 7
+#define SR_ABI_VERSION 8
 #define SR_TILE 16            /* default 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y); see SrFrame.tile_width */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
 #define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
@@ -145,7 +145,7 @@ typedef struct SrGradients {
 
 /* Views into the caller-owned state buffers (for tests / debugging; all device pointers). */
 typedef struct SrGeomView {
-    const float* splats;           /* [P,20] packed record: Tu.xyz Tv.x | Tv.yz Tw.xy | Tw.z xy.x xy.y opacity | n.xyz view-depth | r g b radius (zeros where radii == 0) */
+    const float* splats;           /* [P,20] packed record: Tu.xyz Tv.x | Tv.yz Tw.xy | Tw.z xy.x xy.y opacity | n.xyz r | g b view-depth radius (zeros where radii == 0) */
     const uint32_t* depth_keys;    /* [P] float bits of view-space depth; 0xFFFFFFFF when culled */
     const uint32_t* tiles_touched; /* [P] */
     const uint8_t* clamped;        /* [P] bit c set when SH colour channel c was clamped at 0 */

@@ -17,7 +17,7 @@ SR_FLAG_NO_QUADRANT_CULL = 1
 SR_FLAG_BALLOT_RANKING = 2
 SR_FLAG_ROW_MAPPED_FORWARD = 4
 SR_FLAG_QUADRANT_MAPPED_FORWARD = 8
-SR_ABI_VERSION = 7
+SR_ABI_VERSION = 8
 SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "expand_x", "expand_y", "ranges", "blend_fwd", "blend_bwd",
                   "preprocess_bwd"]
 

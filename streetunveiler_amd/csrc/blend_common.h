@@ -187,8 +187,8 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], co
     // with opacity 0 and never passes the alpha test.  (An isolated p.z == 0 of a healthy splat is rounding noise: see intersect().)
     const bool plane_degenerate = A[2] == 0.f && B[2] == 0.f && C[2] == 0.f;
     s_e[3][slot] = make_float4(mx, my, plane_degenerate ? 0.f : opacity, ex.z);
-    s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[4].x);
-    s_e[5][slot] = make_float4(q[4].y, q[4].z, ex.x, ex.y);
+    s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[3].w);   // n.xyz, c0  (component-wise: a whole-quad copy of an array element keeps the array in scratch)
+    s_e[5][slot] = make_float4(q[4].x, q[4].y, ex.x, ex.y);   // c1, c2 | c3, c4
     if (NC == 9) s_e[6][slot] = make_float4(ey.x, ey.y, ey.z, 0.f);
     if (cells16) *cells16 = cell_mask16(Tu, Tv, Tw, mx, my, opacity);   // (counter variant: what a 4x4-cell culling would keep)
     if (cells_rows) {   // (row-mapped forward: per-cell bits; a quadrant is visited if one of its cells is)
@@ -252,10 +252,13 @@ __device__ __forceinline__ uint32_t emission_index(const float4 (&q)[kRecQuads],
     return first + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
 }
 
-__device__ __forceinline__ void load_record4(const float4* __restrict__ recs, uint32_t gid, float4 (&q)[kRecQuads]) {
+// the 18 floats the forward blend stages (everything but depth and radius): four dwordx4 + one dwordx2
+__device__ __forceinline__ void load_record18(const float4* __restrict__ recs, uint32_t gid, float4 (&q)[kRecQuads]) {
     const float4* r = recs + (size_t)gid * kRecQuads;
 #pragma unroll
     for (int k = 0; k < kRecQuads - 1; ++k) q[k] = r[k];
+    const float2 t = *reinterpret_cast<const float2*>(r + (kRecQuads - 1));
+    q[kRecQuads - 1].x = t.x; q[kRecQuads - 1].y = t.y;
 }
 __device__ __forceinline__ void load_record(const float4* __restrict__ recs, uint32_t gid, float4 (&q)[kRecQuads]) {
     const float4* r = recs + (size_t)gid * kRecQuads;

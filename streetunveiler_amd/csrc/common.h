@@ -26,7 +26,8 @@ constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
 
 // Packed per-Gaussian record, 5 x float4 = 80 B, 16-B aligned (one gather = five dwordx4 loads):
 //   q0 = Tu.x Tu.y Tu.z Tv.x | q1 = Tv.y Tv.z Tw.x Tw.y | q2 = Tw.z xy.x xy.y opacity
-//   q3 = n.x n.y n.z depth   | q4 = r g b radius      (depth = view-space depth; not read by the blend kernels)
+//   q3 = n.x n.y n.z r       | q4 = g b depth radius  (depth = view-space depth; depth and radius are not read by the forward blend:
+//   everything K6 stages sits in the first 18 floats -- four dwordx4 + one dwordx2 per entry)
 constexpr int kRecQuads = 5;
 constexpr int kRecFloats = SR_SPLAT_FLOATS;
 

@@ -435,8 +435,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
                 q0 = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
                 q1 = make_float4(Tv[1], Tv[2], Tw[0], Tw[1]);
                 q2 = make_float4(Tw[2], cx, cy, (f.activations & SR_ACT_SIGMOID_OPACITY) ? sigmoidf(raw_opacity) : raw_opacity);
-                q3 = make_float4(nrm[0], nrm[1], nrm[2], vz);
-                q4 = make_float4(rgb[0], rgb[1], rgb[2], radius);
+                q3 = make_float4(nrm[0], nrm[1], nrm[2], rgb[0]);
+                q4 = make_float4(rgb[1], rgb[2], vz, radius);
             }
         }
     }
@@ -455,7 +455,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
             float rgb[3];
             sh_to_rgb_hi(f.sh_degree, row, sdx, sdy, sdz, res, rgb, out_clamped);
             sh_dir_jacobian_hi(f.sh_degree, row, sdx, sdy, sdz, slen, dd, J);
-            q4 = make_float4(rgb[0], rgb[1], rgb[2], sradius);
+            q3.w = rgb[0];
+            q4 = make_float4(rgb[1], rgb[2], q4.z, sradius);
         }
         // The 80-B records and the 36-B sh_jac rows leave through LDS: a block's rows are contiguous in memory, so its 128 lanes store
         // consecutive 16-B chunks instead of five (nine) stores per lane at an 80-B (36-B) stride -- partial sectors that the L2 does not
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
             if (NC >= 6) { g_col[3] = g5.y; g_col[4] = g5.z; g_col[5] = g5.w; }
             // densification proxy from the blend-only dL/dT (Appendix A.6, last paragraph)
 #if SR_PROXY_DEPTH_VIEW_Z
-            const float depth_c = rec[3].w;   // view-space depth of the centre (record slot `depth`)
+            const float depth_c = rec[4].z;   // view-space depth of the centre (record slot `depth`)
 #else
             const float depth_c = Tw[2];      // upstream: transMat[8]
 #endif

@@ -305,17 +305,18 @@ __device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], u
     }
     float4 nr[kRecQuads];
     const float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
-    // (four of the record's five quads are prefetched a round ahead; the fifth -- two colour components and the radius -- is fetched when the
-    // round is staged: four registers less across the walk, which is what separates five waves per SIMD from six)
-    uint32_t ngid = 0;
-    if ((uint32_t)lane < n_total) { ngid = point_list[range.x + lane]; load_record4(recs, ngid, nr); }
+    // (the 18 floats this kernel stages -- everything of the record but depth and radius, which sit in its last two slots -- are prefetched a
+    // round ahead: 18 registers across the walk keep the kernel at 80 VGPRs = six waves per SIMD.  Round 3 prefetched four quads and fetched
+    // the fifth at staging time, a round later: by then its line had left the L1 and often the L2 -- 13.7 M extra L1->L2 requests and
+    // +0.33 GB of raw FETCH_SIZE per launch, tools/notes_round4_measured.md)
+    if ((uint32_t)lane < n_total) load_record18(recs, point_list[range.x + lane], nr);
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         int ys = yshift_px;
         asm volatile("" : "+s"(ys));
         uint32_t cm = 0;   // this lane's ENTRY: bit 4 q + c = its octagon reaches cell c of quadrant q
-        if ((uint32_t)lane < n) { nr[4] = recs[(size_t)ngid * kRecQuads + 4]; (void)stage_entry<QX, QY, NC>(nr, nx, nx, Xc, Yc, 1, s_e, lane, (float)ys, nullptr, &cm); }
-        if (base + kWave + lane < n_total) { ngid = point_list[range.x + base + kWave + lane]; load_record4(recs, ngid, nr); }
+        if ((uint32_t)lane < n) (void)stage_entry<QX, QY, NC>(nr, nx, nx, Xc, Yc, 1, s_e, lane, (float)ys, nullptr, &cm);
+        if (base + kWave + lane < n_total) load_record18(recs, point_list[range.x + base + kWave + lane], nr);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) s_hit[q][lane] = 0;
 #pragma unroll

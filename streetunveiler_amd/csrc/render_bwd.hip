@@ -85,7 +85,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
     if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
         const uint32_t pos = range.x + (rounds - 1) * kWave + lane;
         const uint32_t gid = point_list[pos];
-        load_record(recs, gid, nr); nr[3].w = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
+        load_record(recs, gid, nr); nr[4].z = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
         if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
         nhit = decode_hits<QX, QY>(hit_mask[pos]);
@@ -97,7 +97,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
         if ((uint32_t)lane < n) {
             (void)stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, 0, s_e, lane);
             m = nhit;   // (entry, quadrant) pairs that reached a pixel in the forward: exact, no culling test needed here
-            slot = emission_index(nr, __float_as_uint(nr[3].w), tile % f.tiles_x, tile / f.tiles_x, f);
+            slot = emission_index(nr, __float_as_uint(nr[4].z), tile % f.tiles_x, tile / f.tiles_x, f);
             uint32_t need = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
@@ -111,7 +111,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
         if (rd > 0) {  // next round is always full
             const uint32_t pos = range.x + rbase - kWave + lane;
             const uint32_t gid = point_list[pos];
-            load_record(recs, gid, nr); nr[3].w = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
+            load_record(recs, gid, nr); nr[4].z = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
             if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
             nhit = decode_hits<QX, QY>(hit_mask[pos]);

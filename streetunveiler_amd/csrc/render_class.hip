@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
         uint32_t m = 0;
         bool has_class = false;
         if ((uint32_t)lane < n) {
-            const float cls_f = nr[4].x;            // class id (colors_precomp[:, 0])
+            const float cls_f = nr[3].w;            // class id (colors_precomp[:, 0])
             const int ci = (int)cls_f;
             has_class = cls_f >= 0.f && ci < NCLS;
             m = stage_entry<QX, QY, 3>(nr, make_float4(0.f, 0.f, has_class ? (float)ci : -1.f, 0.f), zero4, Xc, Yc, cull & 1, s_e, lane, yshift);
@@ -184,7 +184,7 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 nr[kRecQuads];
     uint32_t nhit = 0;
-    auto fetch = [&](uint32_t pos) { const uint32_t gid = point_list[pos]; load_record(recs, gid, nr); nr[3].w = __uint_as_float(first_index(f, gid)); nhit = decode_hits<QX, QY>(hit_mask[pos]); };
+    auto fetch = [&](uint32_t pos) { const uint32_t gid = point_list[pos]; load_record(recs, gid, nr); nr[4].z = __uint_as_float(first_index(f, gid)); nhit = decode_hits<QX, QY>(hit_mask[pos]); };
     if ((uint32_t)((rounds - 1) * kWave + lane) < total) fetch(range.x + (rounds - 1) * kWave + lane);
     for (int rd = rounds - 1; rd >= 0; --rd) {
         const uint32_t rbase = (uint32_t)rd * kWave;
@@ -192,8 +192,8 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
         uint32_t m = 0, slot = 0;
         if ((uint32_t)lane < n) {
             (void)stage_entry<QX, QY, 3>(nr, zero4, zero4, Xc, Yc, 0, s_e, lane);
-            if (nr[4].x == (float)cls) {            // the other classes' entries are not there for this chain
-                slot = emission_index(nr, __float_as_uint(nr[3].w), tile % f.tiles_x, tile / f.tiles_x, f);
+            if (nr[3].w == (float)cls) {            // the other classes' entries are not there for this chain
+                slot = emission_index(nr, __float_as_uint(nr[4].z), tile % f.tiles_x, tile / f.tiles_x, f);
                 uint32_t need = 0;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;

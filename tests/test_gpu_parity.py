@@ -41,7 +41,7 @@ def _check_binning(raw, fwd):
     np.testing.assert_array_equal(rec[vis][:, 0:9], fwd["transMat"][vis])
     np.testing.assert_array_equal(rec[vis][:, 9:11], fwd["means2D"][vis])
     np.testing.assert_array_equal(rec[vis][:, 12:15], fwd["normal_opacity"][vis][:, :3])
-    np.testing.assert_allclose(rec[vis][:, 16:19], fwd["rgb"][vis], atol=2e-6)
+    np.testing.assert_allclose(rec[vis][:, 15:18], fwd["rgb"][vis], atol=2e-6)
     # the sorted duplicate list == the reference's 64-bit (tile<<32 | depth) stable sort, bit for bit
     pl = raw["bin"]["point_list"].view(np.uint32)
     np.testing.assert_array_equal(pl, fwd["point_list"])

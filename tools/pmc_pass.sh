@@ -8,4 +8,4 @@ CTRS=""; while [ $# -gt 0 ] && [ "$1" != "--" ]; do CTRS="$CTRS $1"; shift; done
 [ "$1" = "--" ] && shift
 mkdir -p $D
 cd $R
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $D -o $NAME -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $D/$NAME.log 2>&1
+rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $D -o $NAME -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-step "$@" > $D/$NAME.log 2>&1

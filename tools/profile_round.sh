@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 D=$R/gpurun_out/${TAG}_${CFG}
 mkdir -p $D
 cd $R
-B="python bench.py --config $CFG --no-cpu-baseline"
+B="python bench.py --config $CFG --no-cpu-baseline --no-train-step"
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o trace -- $B --steps 20 --warmup 5 > $D/trace_bench.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D -o fetch -- $B --steps 3 --warmup 1 > $D/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D -o write -- $B --steps 3 --warmup 1 > $D/write.log 2>&1
