@@ -57,9 +57,20 @@ json.dump({**META, "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two 
                   "stream on gfx950 -- confirmed on preprocess_forward_kernel: 2*FETCH = the 232 B x 3 M it reads; WRITE_SIZE is exact on streaming "
                   "stores; for the 16-B record gathers of the blend kernels the 2x is an upper bound)",
            "kernels": out}, open(f"{dst}/{tag}_hbm_traffic.json", "w"), indent=1)
+def durations(fn):
+    """average kernel duration (ns) of one profiling pass, from its own kernel trace"""
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fn)):
+        agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
 passes = {"sq": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY"],
           "sq2": ["SQ_INSTS_VALU_TRANS_F32", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_BRANCH",
-                  "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_SCA"]}
+                  "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_SCA"],
+          "sq3": ["SQ_WAIT_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_DATA_FIFO_FULL", "SQ_INST_CYCLES_VMEM", "SQ_INSTS_SMEM",
+                  "SQ_INSTS_VMEM", "SQ_INSTS_FLAT"],
+          "l2": ["TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"]}
 sq = {}
 for run, names in passes.items():
     fn = f"{src}/{run}_counter_collection.csv"
@@ -68,9 +79,20 @@ for run, names in passes.items():
             for k, v in per_kernel(fn, n).items():
                 if k.startswith("sr::"):
                     sq.setdefault(k, {})[n] = round(v)
+# effective shader clock of every kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the kernel's duration in the SAME pass -- the chip
+# clocks to its power budget (MI355X_MICROARCH.md "DVFS give-back"): the VALU-heavy blend kernels run slower than the streaming ones
+fn = f"{src}/grbm_counter_collection.csv"
+if os.path.exists(fn):
+    act, dur = per_kernel(fn, "GRBM_GUI_ACTIVE"), durations(f"{src}/grbm_kernel_trace.csv")
+    for k, v in act.items():
+        if k.startswith("sr::") and dur.get(k):
+            sq.setdefault(k, {})["GRBM_GUI_ACTIVE"] = round(v)
+            sq[k]["clock_ghz"] = round(v / 8.0 / dur[k], 4)
+            sq[k]["duration_ns_in_clock_pass"] = round(dur[k])
 if sq:
     json.dump({**META, "how": "rocprofv3 --pmc <8 SQ counters> --kernel-trace in separate passes (" + " | ".join(" ".join(v) for v in passes.values()) +
-                      "), bench.py --config <cfg> --steps 3 --warmup 1; averages per launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles",
+                      " | GRBM_GUI_ACTIVE), bench.py --config <cfg> --steps 3 --warmup 1; averages per launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles "
+                      "(one issue slot of a SIMD); clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / the kernel's duration in that pass",
                "kernels": sq}, open(f"{dst}/{tag}_sq_counters.json", "w"), indent=1)
 if os.path.exists(f"{src}/bench.json") and os.path.getsize(f"{src}/bench.json") > 10:
     json.dump(json.load(open(f"{src}/bench.json")), open(f"{dst}/{tag}_bench.json", "w"), indent=1)

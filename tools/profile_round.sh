@@ -13,6 +13,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D -o fetch -- 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D -o write -- $B --steps 3 --warmup 1 > $D/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $D -o sq -- $B --steps 3 --warmup 1 > $D/sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $D -o sq2 -- $B --steps 3 --warmup 1 > $D/sq2.log 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_FLAT --kernel-trace --output-format csv -d $D -o sq3 -- $B --steps 3 --warmup 1 > $D/sq3.log 2>&1 || true
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D -o grbm -- $B --steps 3 --warmup 1 > $D/grbm.log 2>&1
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $D -o l2 -- $B --steps 3 --warmup 1 > $D/l2.log 2>&1 || true
 python bench.py --config $CFG 2>$D/bench.err | tail -1 > $D/bench.json
 python tools/collect_profiles.py $D ${TAG}_${CFG} $D/out
 ls $D/out
