@@ -294,6 +294,46 @@ __device__ __forceinline__ void sh_basis_adjoint(int deg, int M, RowOut dsh, flo
     for (int k = used * 3; k < M * 3; ++k) dsh[k] = 0.f;
 }
 
+// The splat -> pixel transform (Appendix A.2 step 3) and the AABB centre (step 5), as K1 evaluates them.  K8 calls the SAME functions on the
+// same inputs instead of reading them back from the 80-B record (this translation unit is compiled with -ffp-contract=off, so the same
+// expressions give the same bits): 205 MB less to fetch per frame at C3.
+__device__ __forceinline__ void splat_transform(const float B[12], float px, float py, float pz, const float R[9], float su, float sv, float Tm[9]) {
+    const float L0[3] = {R[0] * su, R[3] * su, R[6] * su};
+    const float L1[3] = {R[1] * sv, R[4] * sv, R[7] * sv};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float* b = B + 4 * r;
+        Tm[3 * r + 0] = dot3(b, L0[0], L0[1], L0[2]);
+        Tm[3 * r + 1] = dot3(b, L1[0], L1[1], L1[2]);
+        Tm[3 * r + 2] = dot3(b, px, py, pz) + b[3];
+    }
+}
+__device__ __forceinline__ float bbox_cutoff(float act_opacity) {
+#if SR_TIGHTBBOX   // upstream config.h TIGHTBBOX: the extent follows the opacity
+    return sqrtf(fmaxf(9.f + 2.f * logf(act_opacity), 0.000001f));
+#else
+    (void)act_opacity;
+    return kCutoff;
+#endif
+}
+struct SplatBox { float dist, cx, cy, ex, ey; };
+__device__ __forceinline__ SplatBox splat_box(const float Tm[9], float cutoff) {
+    const float* Tu = Tm; const float* Tv = Tm + 3; const float* Tw = Tm + 6;
+    const float c2 = cutoff * cutoff;
+    const float t0 = c2, t1 = c2, t2 = -1.f;
+    SplatBox b;
+    b.dist = ((Tw[0] * Tw[0]) * t0 + (Tw[1] * Tw[1]) * t1) + (Tw[2] * Tw[2]) * t2;
+    const float inv = 1.f / b.dist;
+    const float f0 = inv * t0, f1 = inv * t1, f2 = inv * t2;
+    b.cx = ((f0 * Tu[0]) * Tw[0] + (f1 * Tu[1]) * Tw[1]) + (f2 * Tu[2]) * Tw[2];
+    b.cy = ((f0 * Tv[0]) * Tw[0] + (f1 * Tv[1]) * Tw[1]) + (f2 * Tv[2]) * Tw[2];
+    const float tx = ((f0 * Tu[0]) * Tu[0] + (f1 * Tu[1]) * Tu[1]) + (f2 * Tu[2]) * Tu[2];
+    const float ty = ((f0 * Tv[0]) * Tv[0] + (f1 * Tv[1]) * Tv[1]) + (f2 * Tv[2]) * Tv[2];
+    const float hx = b.cx * b.cx - tx, hy = b.cy * b.cy - ty;
+    b.ex = sqrtf(fmaxf(1e-4f, hx)); b.ey = sqrtf(fmaxf(1e-4f, hy));
+    return b;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------
@@ -357,16 +397,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
             float qn;
             quat_to_R(activate_rotation(raw_rot, f.activations, qn), R);
             const float2 s = activate_scales(raw_scales, f.activations);
-            const float su = f.scale_modifier * s.x, sv = f.scale_modifier * s.y;
-            const float L0[3] = {R[0] * su, R[3] * su, R[6] * su};
-            const float L1[3] = {R[1] * sv, R[4] * sv, R[7] * sv};
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const float* b = B + 4 * r;
-                Tm[3 * r + 0] = dot3(b, L0[0], L0[1], L0[2]);
-                Tm[3 * r + 1] = dot3(b, L1[0], L1[1], L1[2]);
-                Tm[3 * r + 2] = dot3(b, px, py, pz) + b[3];
-            }
+            splat_transform(B, px, py, pz, R, f.scale_modifier * s.x, f.scale_modifier * s.y, Tm);
             const float nx = R[2], ny = R[5], nz = R[8];
             nrm[0] = (v[0] * nx + v[4] * ny) + v[8] * nz;
             nrm[1] = (v[1] * nx + v[5] * ny) + v[9] * nz;
@@ -378,25 +409,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
         nrm[0] *= mult; nrm[1] *= mult; nrm[2] *= mult;
 
         const float* Tu = Tm; const float* Tv = Tm + 3; const float* Tw = Tm + 6;
-#if SR_TIGHTBBOX   // upstream config.h TIGHTBBOX: the extent follows the opacity
-        const float act_opacity = (f.activations & SR_ACT_SIGMOID_OPACITY) ? sigmoidf(raw_opacity) : raw_opacity;
-        const float cutoff = sqrtf(fmaxf(9.f + 2.f * logf(act_opacity), 0.000001f));
-#else
-        const float cutoff = kCutoff;
-#endif
-        const float c2 = cutoff * cutoff;
-        const float t0 = c2, t1 = c2, t2 = -1.f;
-        const float dist = ((Tw[0] * Tw[0]) * t0 + (Tw[1] * Tw[1]) * t1) + (Tw[2] * Tw[2]) * t2;
-        alive = alive && (dist != 0.f);
+        const float cutoff = bbox_cutoff((f.activations & SR_ACT_SIGMOID_OPACITY) ? sigmoidf(raw_opacity) : raw_opacity);
+        const SplatBox box = splat_box(Tm, cutoff);
+        alive = alive && (box.dist != 0.f);
         if (alive) {
-            const float inv = 1.f / dist;
-            const float f0 = inv * t0, f1 = inv * t1, f2 = inv * t2;
-            const float cx = ((f0 * Tu[0]) * Tw[0] + (f1 * Tu[1]) * Tw[1]) + (f2 * Tu[2]) * Tw[2];
-            const float cy = ((f0 * Tv[0]) * Tw[0] + (f1 * Tv[1]) * Tw[1]) + (f2 * Tv[2]) * Tw[2];
-            const float tx = ((f0 * Tu[0]) * Tu[0] + (f1 * Tu[1]) * Tu[1]) + (f2 * Tu[2]) * Tu[2];
-            const float ty = ((f0 * Tv[0]) * Tv[0] + (f1 * Tv[1]) * Tv[1]) + (f2 * Tv[2]) * Tv[2];
-            const float hx = cx * cx - tx, hy = cy * cy - ty;
-            const float ex = sqrtf(fmaxf(1e-4f, hx)), ey = sqrtf(fmaxf(1e-4f, hy));
+            const float cx = box.cx, cy = box.cy, ex = box.ex, ey = box.ey;
 #if SR_RADIUS_FILTER_FLOOR
             const float radius = ceilf(fmaxf(fmaxf(ex, ey), cutoff * kFilterSize));
 #else
@@ -516,8 +533,30 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
         float* dsh_g = (!kLdsSH && out.dL_dsh) ? out.dL_dsh + (size_t)i * M * 3 : nullptr;
         float* row = s_sh + tid * kShLdsStride;
         if (vis) {
-            const float4* rec = recs + (size_t)i * kRecQuads;
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            // the splat's transform, centre and (activated) opacity: recomputed from the inputs with K1's own functions -- the same bits as
+            // the record holds (asserted by the parity tests: every gradient is unchanged), without fetching 80 B per visible Gaussian
+            const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+            // (the backward's arguments do not include the opacities -- the reference's rasterize_gaussians_backward has none: the activated
+            // value is the one float still taken from the record, and only where it is needed: the sigmoid adjoint, or a TIGHTBBOX build)
+            float act_opacity = 1.f;
+            if (SR_TIGHTBBOX || (f.activations & SR_ACT_SIGMOID_OPACITY)) act_opacity = reinterpret_cast<const float*>(recs)[(size_t)i * kRecFloats + 11];
+            float Tm[9];
+            float qn = 1.f;
+            float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+            float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+            float2 sc = make_float2(1.f, 1.f);
+            if (transMat_precomp) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Tm[k] = transMat_precomp[9 * (size_t)i + k];
+            } else {
+                float Bf[12];
+                build_B(f.proj, f.W, f.H, Bf);   // (the forward's viewport: K1's transMat)
+                q = load_rotation(rotations, i, f.activations, qn);
+                quat_to_R(q, R);
+                sc = load_scales(scales, i, f.activations);
+                splat_transform(Bf, px, py, pz, R, f.scale_modifier * sc.x, f.scale_modifier * sc.y, Tm);
+            }
+            const SplatBox box = splat_box(Tm, bbox_cutoff(act_opacity));
             float4 g0, g1, g2, g3, g4, g5;
             {
                 constexpr int kGQ = NC == 9 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record
@@ -556,7 +595,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
                 g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3]; g4 = g[4]; g5 = g[5];
                 if (NC == 9) { g_col[6] = g[kGQ - 1].x; g_col[7] = g[kGQ - 1].y; g_col[8] = g[kGQ - 1].z; }
             }
-            const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
+            const float Tu[3] = {Tm[0], Tm[1], Tm[2]}, Tv[3] = {Tm[3], Tm[4], Tm[5]}, Tw[3] = {Tm[6], Tm[7], Tm[8]};
             // moments -> dL/dT (see common.h).  The records carry the moments about the Gaussian's own centre c = (cx, cy) (K7's flush), i.e.
             // of the same ray-splat form written in x' = x - cx, y' = y - cy with Tu' = Tu - cx Tw, Tv' = Tv - cy Tw:
             //   dTu' = Tv' x S0 - Tw x Sy',  dTv' = S0 x Tu' - Sx' x Tw,  dTw' = Tu' x Sy' - Tv' x Sx' + Z
@@ -565,7 +604,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
             {
                 // (the reference point is the centre CLAMPED INTO THE IMAGE, like K7's flush: a splat whose centre projects thousands of pixels
                 // off-screen would otherwise cancel lever arms of that length)
-                const float cx = fminf(fmaxf(r2.y, 0.f), (float)(f.W - 1)), cy = fminf(fmaxf(r2.z, 0.f), (float)(f.H - 1));
+                const float cx = fminf(fmaxf(box.cx, 0.f), (float)(f.W - 1)), cy = fminf(fmaxf(box.cy, 0.f), (float)(f.H - 1));
                 const float Tuc[3] = {Tu[0] - cx * Tw[0], Tu[1] - cx * Tw[1], Tu[2] - cx * Tw[2]};
                 const float Tvc[3] = {Tv[0] - cy * Tw[0], Tv[1] - cy * Tw[1], Tv[2] - cy * Tw[2]};
                 const float S0[3] = {g0.x, g0.y, g0.z}, Sx[3] = {g0.w, g1.x, g1.y}, Sy[3] = {g1.z, g1.w, g2.x}, Z[3] = {g2.y, g2.z, g2.w};
@@ -581,13 +620,13 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
             }
             const float gx2 = g3.x, gy2 = g3.y;
             g_opa = g3.z;
-            if (f.activations & SR_ACT_SIGMOID_OPACITY) { const float o = r2.w; g_opa *= o * (1.f - o); }
+            if (f.activations & SR_ACT_SIGMOID_OPACITY) { const float o = act_opacity; g_opa *= o * (1.f - o); }
             const float gn[3] = {g3.w, g4.x, g4.y};
             g_col[0] = g4.z; g_col[1] = g4.w; g_col[2] = g5.x;
             if (NC >= 6) { g_col[3] = g5.y; g_col[4] = g5.z; g_col[5] = g5.w; }
             // densification proxy from the blend-only dL/dT (Appendix A.6, last paragraph)
 #if SR_PROXY_DEPTH_VIEW_Z
-            const float depth_c = rec[4].z;   // view-space depth of the centre (record slot `depth`)
+            const float depth_c = ((f.view[2] * px + f.view[6] * py) + f.view[10] * pz) + f.view[14];   // view-space depth of the centre, as K1 computes it
 #else
             const float depth_c = Tw[2];      // upstream: transMat[8]
 #endif
@@ -609,14 +648,10 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
                     dT[6 + c] += gx2 * fv[c] * Tu[c] + gy2 * fv[c] * Tv[c] + dLdd * (t[c] * Tw[c] * 2.f);
                 }
             }
-            const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
             if (!transMat_precomp) {
-                float B[12], R[9];
+                float B[12];
                 build_B(f.proj, f.bw_W, f.bw_H, B);   // (SR_BACKWARD_WH_FROM_FOCAL: upstream's backward derives the size from focal * tanfov)
-                float qn;
-                const float4 q = load_rotation(rotations, i, f.activations, qn);
-                quat_to_R(q, R);
-                const float2 sc = load_scales(scales, i, f.activations);  // modifier 1.0 (upstream quirk, A.6)
+                // q, R, sc from above; the chain below uses the scales WITHOUT the modifier (upstream quirk, A.6)
                 float dL0[3], dL1[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
