@@ -96,7 +96,7 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
                         prefiltered, debug, activations=0, tile=None, mask=None, quadrant_cull=True, blend_counters=None,
                         ballot_ranking=False, row_mapped=None):
     """`tile` = (width, height) of the binning tile, default the reference's 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
-    16x16, 32x8, 32x16); the backward must be given the same shape.  `quadrant_cull=False` / `blend_counters` (int64[8], device):
+    16x16, 32x8, 32x16); the backward must be given the same shape.  `quadrant_cull=False` / `blend_counters` (int64[16], device):
     per-call SrFrame.flags / SrFrame.blend_counters (tests and profiling; results are identical).  `ballot_ranking=True`
     (SR_FLAG_BALLOT_RANKING): the binning of this call ranks with match-any ballots, the fallback of the LDS-atomic ranking.
     `row_mapped=True` / `False` (SR_FLAG_ROW_MAPPED_FORWARD / SR_FLAG_QUADRANT_MAPPED_FORWARD): force one of the two forward blend kernels

@@ -60,7 +60,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             fused["tile"] = ctx.tile
         if mask is not None:   # only the forward looks at it: masked-out Gaussians get radius 0 and, with that, zero gradients
             fused["mask"] = mask
-        if probe:              # tests / profiling: {"quadrant_cull": bool, "blend_counters": int64[8] device tensor, "ballot_ranking": bool}
+        if probe:              # tests / profiling: {"quadrant_cull": bool, "blend_counters": int64[16] device tensor, "ballot_ranking": bool}
             fused.update(probe)
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
@@ -165,7 +165,7 @@ class GaussianRasterizer(nn.Module):
         preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values.
         `tile=(w, h)`: binning tile shape, default the reference's compile-time 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
         16x16, 32x8, 32x16); images and gradients do not depend on it beyond float summation order.
-        `quadrant_cull=False` / `blend_counters` (int64[8] device tensor): this call's SrFrame.flags / SrFrame.blend_counters --
+        `quadrant_cull=False` / `blend_counters` (int64[16] device tensor): this call's SrFrame.flags / SrFrame.blend_counters --
         test and profiling switches with identical results (include/surfel_raster.h); `ballot_ranking=True`: SR_FLAG_BALLOT_RANKING,
         the binning's fallback ranking (identical lists); `row_mapped=True` / `False`: force the row-mapped / the quadrant-mapped
         forward blend (SR_FLAG_ROW_MAPPED_FORWARD / SR_FLAG_QUADRANT_MAPPED_FORWARD; bit-identical results; None = picked per frame on the device)."""

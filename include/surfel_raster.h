@@ -87,7 +87,7 @@ typedef struct SrFrame {
                                * contributing pixel anywhere in the tile (= the gradient records the backward writes), [8] (entry, 4x4 cell) pairs
                                * with a contributing pixel, [9] the wave steps a 16-lane-row mapping would take (sum over rounds of 64
                                * entries and quadrants of the busiest cell's pair count), [10] / [11] the same two counting the pairs an octagon-vs-cell
-                               * culling at staging would keep (hits and misses); [12..15] reserved.  16x16 tile with
+                               * culling at staging would keep (hits and misses), [12] / [13] the same two with an octagon + oriented-box culling, [14] exact (entry, cell) hits that box would DROP (must be 0); [15] reserved.  16x16 tile with
                                * 3 or 6 colour channels; any other request returns SR_ERR_UNSUPPORTED (never silent zeros) */
 } SrFrame;
 #define SR_FLAG_NO_QUADRANT_CULL 1u  /* forward blend: run every list entry against every 8x8 quadrant instead of dropping entries that

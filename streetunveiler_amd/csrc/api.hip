@@ -138,10 +138,21 @@ int debug_sync(const SrFrame* frame, hipStream_t s, const char* what) {
 
 // One 64-B pinned host block per calling thread (with one event per (thread, device) the only things this library keeps): word 0 =
 // the DMA target of the num_rendered read-back, word 8 = the result word of the rank self-check.
+// (portable + mapped: valid on every device of the process, whichever is current when the thread first calls in.  Never freed: 64 B per
+// calling thread, and a destructor at thread / process exit could run after the HIP runtime has been torn down.)
 uint32_t* pinned_words() {
     static thread_local uint32_t* pinned = nullptr;
-    if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
+    if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { pinned = nullptr; (void)hipGetLastError(); }
     return pinned;
+}
+
+// The device a stream belongs to (the cache below is per device: the CURRENT device may be another one); the null stream -> current device.
+int stream_device(hipStream_t s, int* dev) {
+    hipDevice_t d = 0;
+    if (s && hipStreamGetDevice(s, &d) == hipSuccess) { *dev = (int)d; return SR_OK; }
+    (void)hipGetLastError();
+    SR_HIP(hipGetDevice(dev));
+    return SR_OK;
 }
 
 // How the sort / partition kernels rank items inside a wave (common.h take_run_slot).  The fast path relies on the lane order of LDS
@@ -152,18 +163,24 @@ constexpr int kMaxDevices = 64;
 std::atomic<int> g_rank_mode[kMaxDevices];
 int rank_mode(hipStream_t s, bool force_ballot, int* mode) {
     int dev = 0;
-    SR_HIP(hipGetDevice(&dev));
+    { const int rc = stream_device(s, &dev); if (rc != SR_OK) return rc; }
     if (dev < 0 || dev >= kMaxDevices) return fail(SR_ERR_UNSUPPORTED, "device index %d beyond %d", dev, kMaxDevices);
     int m = g_rank_mode[dev].load(std::memory_order_acquire);
     if (m == kRankUnknown) {
+        // the self-check waits on the stream: not possible while the stream is being captured into a graph -- warm up first
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(SR_ERR_UNSUPPORTED, "the stream is capturing and device %d has not run the rank self-check yet: call sr_rank_mode(stream) once before the capture", dev);
+        (void)hipGetLastError();
+        struct Scratch { uint32_t* p = nullptr; ~Scratch() { if (p) (void)hipFree(p); } } scratch;   // freed on every path out of here
         uint32_t* host = pinned_words();
         uint32_t* result = nullptr;
-        bool temp = false;
-        if (host && hipHostGetDevicePointer(reinterpret_cast<void**>(&result), host + 8, 0) == hipSuccess && result) host[8] = 0;
-        else { SR_HIP(hipMalloc(reinterpret_cast<void**>(&result), 4)); SR_HIP(hipMemsetAsync(result, 0, 4, s)); temp = true; }
+        const bool temp = !(host && hipHostGetDevicePointer(reinterpret_cast<void**>(&result), host + 8, 0) == hipSuccess && result);
+        if (!temp) host[8] = 0;
+        else { (void)hipGetLastError(); SR_HIP(hipMalloc(reinterpret_cast<void**>(&scratch.p), 4)); result = scratch.p; SR_HIP(hipMemsetAsync(result, 0, 4, s)); }
         SR_HIP(launch_rank_selfcheck(result, s));
         uint32_t r = 0;
-        if (temp) { SR_HIP(hipMemcpyAsync(&r, result, 4, hipMemcpyDeviceToHost, s)); SR_HIP(hipStreamSynchronize(s)); (void)hipFree(result); }
+        if (temp) { SR_HIP(hipMemcpyAsync(&r, result, 4, hipMemcpyDeviceToHost, s)); SR_HIP(hipStreamSynchronize(s)); }
         else { SR_HIP(hipStreamSynchronize(s)); r = *reinterpret_cast<volatile uint32_t*>(host + 8); }
         if (!(r & 0x100u)) return fail(SR_ERR_HIP, "the rank self-check kernel did not report back");
         m = (r & 1u) ? kRankAtomic : ((r & 2u) ? kRankBallot : kRankNone);

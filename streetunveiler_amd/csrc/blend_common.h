@@ -313,6 +313,9 @@ __device__ __forceinline__ float row_sum16(float x) {
 // s_nop in front covers whatever wrote the inputs.
 // NV = 24, or 21: values 21..23 are not in use (three colour channels) -- they need no reset and no fold; their slots of the result hold
 // copies of other totals, which nothing reads.
+// Preconditions: ALL 64 lanes active (DPP without bound_ctrl leaves the destination of a lane whose source is disabled untouched: the
+// callers run the fold outside any divergent region -- K7's entry loop is wave-uniform); the twelve outputs are early-clobber ("+&v"):
+// they are overwritten while the input-only registers are still to be read, so no input may share a register with an output.
 template <int NV>
 __device__ __forceinline__ void dpp_fold_rows(float (&v)[24]) {
     static_assert(NV == 24 || NV == 21, "24 values, or 21 with the last three unused");
@@ -360,7 +363,7 @@ __device__ __forceinline__ void dpp_fold_rows(float (&v)[24]) {
         "v_add_f32_dpp %4, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n"
         "v_add_f32_dpp %5, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n"
         "s_nop 1\n"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11])
+        : "+&v"(v[0]), "+&v"(v[1]), "+&v"(v[2]), "+&v"(v[3]), "+&v"(v[4]), "+&v"(v[5]), "+&v"(v[6]), "+&v"(v[7]), "+&v"(v[8]), "+&v"(v[9]), "+&v"(v[10]), "+&v"(v[11])
         : "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]), "v"(v[21]), "v"(v[22]), "v"(v[23]));
     } else {
         asm volatile(
@@ -399,7 +402,7 @@ __device__ __forceinline__ void dpp_fold_rows(float (&v)[24]) {
         "v_add_f32_dpp %4, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n"
         "v_add_f32_dpp %5, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n"
         "s_nop 1\n"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11])
+        : "+&v"(v[0]), "+&v"(v[1]), "+&v"(v[2]), "+&v"(v[3]), "+&v"(v[4]), "+&v"(v[5]), "+&v"(v[6]), "+&v"(v[7]), "+&v"(v[8]), "+&v"(v[9]), "+&v"(v[10]), "+&v"(v[11])
         : "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]));
     }
 }

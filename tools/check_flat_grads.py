@@ -1,5 +1,5 @@
 import sys, math, torch
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 from streetunveiler_amd.synthetic import *
 from streetunveiler_amd.parallel import _storage_groups

@@ -1,5 +1,5 @@
 import math, os, sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 from streetunveiler_amd import _lib

@@ -1,5 +1,5 @@
 import sys, time, torch, math
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from streetunveiler_amd.gaussian_renderer import postprocess_allmap, PipelineParams
 from streetunveiler_amd.synthetic import synthetic_camera
 W,H=1920,1080; dev='cuda:0'
