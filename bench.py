@@ -466,7 +466,7 @@ def main():
             "metric": f"Msplats/s fwd+bwd @{W}x{H}, {P / 1e6:g}M Gaussians", "value": round(value, 3), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "timed_region_ms": round(elapsed * 1e3, 3),
-            "step_ms_percentiles": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9)},
+            "step_ms_percentiles": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9), "max": round(per_step[-1], 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.label, "baseline_config": args.tag,
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D, "visible_per_P": round(V / P, 4), "D_per_P": round(D / P, 3),
