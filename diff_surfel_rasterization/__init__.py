@@ -216,12 +216,12 @@ class GaussianRasterizer(nn.Module):
             if shs is None or colors_precomp is not None or extra_colors.ndim != 2 or extra_colors.shape[1] != 6:
                 raise Exception("extra_colors needs SHs as the colour source and must have dimensions (num_points, 6)")
             colors_precomp = extra_colors
-        # the shared-geometry extensions (6 / 9 colour channels) are instantiated for the reference's 16x16 tile only: refuse the
-        # combination here, by name, instead of letting the C call answer SR_ERR_UNSUPPORTED (INTEGRATION.md "Tile shapes")
-        if self.tile is not None and tuple(int(t) for t in self.tile) != (16, 16) and colors_precomp is not None and colors_precomp.ndim == 2 \
+        # the shared-geometry extensions (6 / 9 colour channels) are instantiated for tiles of up to four 8x8 quadrants (8x8, 16x8, 16x16,
+        # 32x8): refuse 32x16 here, by name, instead of letting the C call answer SR_ERR_UNSUPPORTED (INTEGRATION.md "Tile shapes")
+        if self.tile is not None and tuple(int(t) for t in self.tile) == (32, 16) and colors_precomp is not None and colors_precomp.ndim == 2 \
                 and colors_precomp.shape[1] == 6:
             raise ValueError(f"tile={tuple(self.tile)} and the multi-colour passes (colors_precomp[P,6] / extra_colors: render_semantic, "
-                             "render_and_semantic) are mutually exclusive: those passes exist for the 16x16 tile only -- drop tile= for them")
+                             "render_and_semantic) are mutually exclusive: those passes exist for 8x8, 16x8, 16x16 and 32x8 tiles -- pick one of them")
         empty = torch.Tensor([]).to(means3D.device)
         shs = empty if shs is None else shs
         colors_precomp = empty if colors_precomp is None else colors_precomp

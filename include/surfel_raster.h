@@ -77,7 +77,8 @@ typedef struct SrFrame {
     const float* projmatrix;  /* device [16] = full_proj_transform ((P*W2C)^T), row-major */
     const float* campos;      /* device [3] */
     int32_t tile_width;       /* 0 = 16 (the reference's BLOCK_X); BASELINE config 5 sweeps 8x8, 16x8, 16x16, 32x8, 32x16.  The 6- and
-                               * 9-channel passes (SrGaussians.color_channels) and the counter variant exist for 16x16 only */
+                               * 9-channel passes (SrGaussians.color_channels) exist for every shape but 32x16, the per-class pass and the
+                               * counter variant for 16x16 only */
     int32_t tile_height;      /* 0 = 16 (BLOCK_Y).  Same shape in every call that shares the state buffers */
     uint32_t flags;           /* SR_FLAG_* bits; per call, nothing about a call is process-wide state */
     uint64_t* blend_counters; /* NULL, or device [16] u64 owned by the caller: selects the COUNTING variant of the forward blend (same

@@ -270,7 +270,8 @@ int check_common(const SrFrame* frame, const SrGaussians* g) {
         const int tw = frame->tile_width > 0 ? frame->tile_width : kTile, th = frame->tile_height > 0 ? frame->tile_height : kTile;
         const bool known = (tw == 16 && th == 16) || (tw == 8 && th == 8) || (tw == 16 && th == 8) || (tw == 32 && th == 8) || (tw == 32 && th == 16);
         if (!known) return fail(SR_ERR_UNSUPPORTED, "tile shape %dx%d not in {8x8, 16x8, 16x16, 32x8, 32x16}", tw, th);
-        if (!(tw == 16 && th == 16) && (g->color_channels == 6 || g->color_channels == 9)) return fail(SR_ERR_UNSUPPORTED, "6 / 9 colour channels are built for the 16x16 tile only");
+        if (tw == 32 && th == 16 && (g->color_channels == 6 || g->color_channels == 9))
+            return fail(SR_ERR_UNSUPPORTED, "6 / 9 colour channels are built for tiles of up to four 8x8 quadrants (8x8, 16x8, 16x16, 32x8), not 32x16");
     }
     if (!frame->bg || !frame->viewmatrix || !frame->projmatrix || !frame->campos) return fail(SR_ERR_INVALID_ARGUMENT, "bg / viewmatrix / projmatrix / campos must be non-NULL device pointers");
     if (g->P > 0) {

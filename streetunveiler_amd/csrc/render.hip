@@ -504,8 +504,15 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
                                 hipLaunchKernelGGL(render_forward_auto_kernel, dim3((n_tiles + kXcds - 1) / kXcds * kXcds * 2), block, 0, s, f, ranges,
                                                    tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask, frame_counts);
         else                    SR_LAUNCH_FWD(false, 3, 2, 1, 2);
+    } else if (f.colors != 3) {
+        // the shared-geometry passes on the other shapes with up to four pixels per lane: 8x8, 16x8, 32x8.  (32x16 keeps eight
+        // pixels per lane in K7 -- 234 VGPRs with three channels already -- and stays 3-channel: api.hip refuses it by name.)
+        if (f.tile_h != 8) return hipErrorInvalidValue;
+#define SR_FWD_NC(QX)                                                                                        \
+        { if (f.colors == 9) { SR_LAUNCH_FWD(false, 9, QX, 1, 1); } else { SR_LAUNCH_FWD(false, 6, QX, 1, 1); } }
+        if (f.tile_w == 8) SR_FWD_NC(1) else if (f.tile_w == 16) SR_FWD_NC(2) else if (f.tile_w == 32) SR_FWD_NC(4) else return hipErrorInvalidValue;
+#undef SR_FWD_NC
     } else {
-        if (f.colors != 3) return hipErrorInvalidValue;
         if (f.tile_w == 32 && f.tile_h == 16) { SR_LAUNCH_FWD(false, 3, 4, 1, 2); }   // two 32x8 band waves per tile
         else {
 #define SR_FWD_SHAPE(QX, QY) SR_LAUNCH_FWD(false, 3, QX, QY, 1)

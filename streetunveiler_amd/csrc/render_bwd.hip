@@ -241,8 +241,12 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
                        n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written)
     if (f.tile_w == 16 && f.tile_h == 16) {
         if (f.colors == 9) SR_LAUNCH_BWD(9, 2, 2); else if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
+    } else if (f.colors != 3) {   // 6 / 9 channels on the shapes with up to four pixels per lane (render.hip launch_render_forward)
+        if (f.tile_h != 8) return hipErrorInvalidValue;
+#define SR_BWD_NC(QX) { if (f.colors == 9) SR_LAUNCH_BWD(9, QX, 1); else SR_LAUNCH_BWD(6, QX, 1); }
+        if (f.tile_w == 8) SR_BWD_NC(1) else if (f.tile_w == 16) SR_BWD_NC(2) else if (f.tile_w == 32) SR_BWD_NC(4) else return hipErrorInvalidValue;
+#undef SR_BWD_NC
     } else {
-        if (f.colors != 3) return hipErrorInvalidValue;
 #define SR_BWD_SHAPE(QX, QY) SR_LAUNCH_BWD(3, QX, QY)
         SR_FOR_TILE_SHAPE(SR_BWD_SHAPE)
 #undef SR_BWD_SHAPE

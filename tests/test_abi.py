@@ -73,8 +73,8 @@ def test_cpu_tensors_are_rejected_loudly():
 
 
 def test_tile_option_and_multi_colour_passes_exclude_each_other():
-    """The 6 / 9-channel passes and the per-class pass are built for the reference's 16x16 tile: asking for them together with another
-    tile shape is refused in python, by name, before any C call (INTEGRATION.md "Tile shapes")."""
+    """The 6 / 9-channel passes are built for tiles of up to four 8x8 quadrants (not 32x16), the per-class pass for the reference's 16x16
+    tile: asking for them together with another tile shape is refused in python, by name, before any C call (INTEGRATION.md "Tile shapes")."""
     import torch
     from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     s = GaussianRasterizationSettings(8, 8, 1.0, 1.0, torch.zeros(9), 1.0, torch.eye(4), torch.eye(4), 0, torch.zeros(3), False, False)
@@ -83,6 +83,8 @@ def test_tile_option_and_multi_colour_passes_exclude_each_other():
     with pytest.raises(ValueError, match="mutually exclusive"):
         GaussianRasterizer(s, tile=(32, 16))(colors_precomp=z(4, 6), **geo)
     with pytest.raises(ValueError, match="mutually exclusive"):
+        GaussianRasterizer(s, tile=(32, 16))(shs=z(4, 16, 3), extra_colors=z(4, 6), **geo)
+    with pytest.raises(_lib.SurfelRasterError, match="no CPU path"):   # 8x8 with the 9-channel pass is built: accepted, fails later for the usual reason
         GaussianRasterizer(s, tile=(8, 8))(shs=z(4, 16, 3), extra_colors=z(4, 6), **geo)
     with pytest.raises(ValueError, match="mutually exclusive"):
         GaussianRasterizer(s, tile=(32, 16)).class_distortions(z(4, 3), z(4, 3), torch.ones(4, 1), torch.ones(4, 2), torch.ones(4, 4), torch.zeros(4, dtype=torch.int32), 5)

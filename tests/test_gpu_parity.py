@@ -413,6 +413,42 @@ def test_six_colour_channels_equal_two_three_channel_passes(use_tpre):
     np.testing.assert_array_equal(out["allmap"], out3["allmap"])
 
 
+@pytest.mark.parametrize("tile", [(8, 8), (16, 8), (32, 8)])
+def test_multi_colour_passes_on_other_tile_shapes(tile):
+    """The shared-geometry passes on the tile shapes of BASELINE config 5's sweep that keep up to four pixels per lane: the
+    6-channel pass == two 3-channel oracle passes run with the same tile; the 9-channel pass (SH colour + six channels) reproduces the
+    3-channel SH render bit for bit in its first three channels and the 6-channel pass in the other six; 32x16 is refused by name."""
+    from diff_surfel_rasterization import GaussianRasterizer
+    from tests.gpu_util import DEV, run_hip, run_oracle, settings_for
+    P, W, H = 2500, 208, 120
+    cam, g = _scene(P, W, H, 23, 5e-3, 6e-2, 4)
+    rng = np.random.default_rng(6)
+    colors = rng.random((P, 6)).astype(np.float32)
+    bg = np.array([0.0, 0.25, 0.0, 0.0, 1.0, 0.5], np.float32)
+    dcA, da = synthetic_upstream_grads(W, H, seed=6)
+    dcB, _ = synthetic_upstream_grads(W, H, seed=7)
+    fA, bA = run_oracle(g, cam, bg[:3], 0, dcA, da, colors=colors[:, :3].copy(), tile=tile)
+    fB, bB = run_oracle(g, cam, bg[3:], 0, dcB, torch.zeros_like(da), colors=colors[:, 3:].copy(), tile=tile)
+    out = run_hip(g, cam, bg, 0, torch.cat([dcA, dcB], 0), da, colors=colors, tile=tile)
+    assert out["color"].shape == (6, H, W)
+    np.testing.assert_array_equal(out["radii"], fA["radii"])
+    _check_images(out, dict(color=np.concatenate([fA["color"], fB["color"]], 0), allmap=fA["allmap"]), f"six channels {tile}")
+    names = ["dL_dmeans3D", "dL_dopacity", "dL_dmeans2D", "dL_dscales", "dL_drotations"]
+    bwd = {k: bA[k] + bB[k] for k in names}
+    bwd["dL_dcolors"] = np.concatenate([bA["dL_dcolors"], bB["dL_dcolors"]], 1)
+    _check_grads(out, bwd, names + ["dL_dcolors"], f"six channels {tile}")
+    # nine channels: SH colour + the six precomputed ones in one pass, against the separate calls of the SAME build and tile
+    t = {k: v.to(DEV) for k, v in g.items()}
+    geo = dict(means3D=t["means3D"], means2D=torch.zeros(P, 3, device=DEV), opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+    bg9 = np.concatenate([[0.1, 0.2, 0.3], bg]).astype(np.float32)
+    c9, r9, a9 = GaussianRasterizer(settings_for(cam, bg9, 3), tile=tile)(shs=t["shs"], extra_colors=torch.as_tensor(colors).to(DEV), **geo)
+    c3, r3, a3 = GaussianRasterizer(settings_for(cam, bg9[:3], 3), tile=tile)(shs=t["shs"], **geo)
+    c6, _, _ = GaussianRasterizer(settings_for(cam, bg, 0), tile=tile)(colors_precomp=torch.as_tensor(colors).to(DEV), **geo)
+    assert torch.equal(c9[:3], c3) and torch.equal(c9[3:], c6) and torch.equal(a9, a3) and torch.equal(r9, r3)
+    with pytest.raises(ValueError, match="mutually exclusive"):
+        GaussianRasterizer(settings_for(cam, bg, 0), tile=(32, 16))(colors_precomp=torch.as_tensor(colors).to(DEV), **geo)
+
+
 def test_sh_gradient_expand_matches_backward():
     """Frame-parallel SH gradient: K8 with a deferred SH expansion + sr_sh_gradient_expand == K8's own dL_dsh
     (bit for bit with one view), and the expansion of two views == the sum of their dL_dsh."""
