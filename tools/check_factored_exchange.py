@@ -6,7 +6,7 @@ import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
-from streetunveiler_amd.parallel import allreduce_gradients, factored_sh_exchange, init_distributed
+from streetunveiler_amd.parallel import allreduce_gradients, factored_sh_exchange, init_distributed, reduce_densification_stats
 
 rank, world, local_rank = init_distributed()
 dev = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -57,6 +57,26 @@ for reduce_all in (False, True):
         scale = float(expect[n].abs().max())
         err = float((got[n] - expect[n]).abs().max())
         assert scale > 0 and err <= 2e-5 * scale, f"rank {rank} reduce_all={reduce_all} {n}: max err {err:.3e} vs scale {scale:.3e}"
+# the densification statistics of the ranks' views (one packed exchange) against the per-view values computed locally
+def view_stats(index):
+    cam = synthetic_camera(W, H, index=index, n_cams=world)
+    s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3, device=dev), 1.0,
+                                      cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), deg, cam.camera_center.to(dev), False, False)
+    m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+    color, radii, allmap = GaussianRasterizer(s)(means3D=g["means3D"].to(dev), means2D=m2d, shs=g["shs"].to(dev), opacities=g["opacities"].to(dev),
+                                                 scales=g["scales"].to(dev), rotations=g["rotations"].to(dev))
+    torch.autograd.backward([color, allmap], [dc, da])
+    return m2d.grad, radii
+accum, denom, maxr = torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev), torch.zeros(P, device=dev)
+reduce_densification_stats(*view_stats(rank), accum, denom, maxr)
+e_acc, e_den, e_max = torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev), torch.zeros(P, device=dev)
+for k in range(world):
+    vg, rad = view_stats(k)
+    vis = rad > 0
+    e_acc += torch.where(vis[:, None], vg.norm(dim=-1, keepdim=True), torch.zeros((), device=dev)); e_den += vis[:, None].float()
+    e_max = torch.maximum(e_max, torch.where(vis, rad.float(), torch.zeros((), device=dev)))
+torch.testing.assert_close(accum, e_acc, rtol=1e-6, atol=1e-6 * float(e_acc.abs().max()))
+assert torch.equal(denom, e_den) and torch.equal(maxr, e_max) and float(e_den.max()) >= 1
 dist.barrier()
 if rank == 0:
     print(f"factored exchange OK (world {world}, backend {dist.get_backend()})")
