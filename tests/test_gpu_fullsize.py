@@ -51,8 +51,11 @@ def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, repo
     assert_strict_parity(out, fwd64, bwd64, tag=tag + " ", scene=(g, cam))
     del fwd64, bwd64
     xfwd, xbwd, margins = free_f64_reference(g, cam, bg, 3, dc, da, base=fwd)
+    # the non-robust remainder is not only counted: measured at full size (tools/nonrobust_report.py: C2 / C3 / clustered) its pixels stay
+    # within 2.1e-3 of (1 + |value|) and its gradient rows within 1.5e-3 of the tensor's scale -- the caps are three times that, not the
+    # 2e-2 / 5e-2 a flipped contributor could in principle cost
     assert_free_parity(out, raw["img"]["n_contrib"], xfwd, xbwd, margins, tag=tag + " ", scene=(g, cam), pixel_budget=pixel_budget,
-                       gaussian_budget=gaussian_budget, report=report)
+                       gaussian_budget=gaussian_budget, report=report, nonrobust_pixel_cap=6e-3, nonrobust_row_cap=5e-3)
     if report is not None:
         vis = fwd["radii"] > 0
         report["non_robust_pixels"] = float((margins["pixel"] <= 1.0).mean())
@@ -100,8 +103,8 @@ def test_clustered_street_scene_against_oracle():
     from streetunveiler_amd.synthetic import clustered_gaussians
     rep = {}
     try:
-        # budgets = the measured non-robust fractions plus a margin (1.5 M Gaussians: 0.38 % of the pixels, 24 % of the visible Gaussians)
-        _against_oracle(3_000_000, True, "clustered", pixel_budget=1e-2, gaussian_budget=0.32, scene=lambda P, W, H: clustered_gaussians(P, W, H, 0.5), report=rep)
+        # budgets = the measured non-robust fractions plus a margin (0.63 % of the pixels, 21.2 % of the visible Gaussians)
+        _against_oracle(3_000_000, True, "clustered", pixel_budget=1e-2, gaussian_budget=0.26, scene=lambda P, W, H: clustered_gaussians(P, W, H, 0.5), report=rep)
     finally:
         os.makedirs("gpurun_out", exist_ok=True)
         json.dump(rep, open("gpurun_out/clustered_parity.json", "w"), indent=1, default=float)
