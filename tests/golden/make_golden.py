@@ -365,6 +365,26 @@ def g7_g8_rotation_and_checkpoint():
             out["g8_loaded" + k] = getattr(pc2, k).detach().numpy()
         out["g8_loaded_semantics"] = pc2._semantics.numpy()
         out["g8_loaded_active_sh_degree"] = np.array(pc2.active_sh_degree)
+        # G9: the densification statistics of TWO views, as the reference accumulates them -- its own add_densification_stats
+        # [REF scene/gaussian_model.py:555-557] and the max_radii2D update of train.py:168 (that one line is restated here: train.py is a
+        # script) -- what streetunveiler_amd.parallel.reduce_densification_stats must reproduce view by view and, summed / maximised over
+        # the ranks' views, across ranks
+        P9 = 41
+        pc9 = gm.GaussianModel(deg)
+        pc9.xyz_gradient_accum = torch.zeros(P9, 1); pc9.denom = torch.zeros(P9, 1); pc9.max_radii2D = torch.zeros(P9)
+        g = torch.Generator().manual_seed(90)
+        for v in range(2):
+            vs = torch.zeros(P9, 3, requires_grad=True)
+            grad = torch.randn(P9, 3, generator=g); grad[:, 2] = 0.0          # the operator's proxy gradient has z = 0
+            vs.grad = grad
+            radii = torch.randint(0, 7, (P9,), generator=g, dtype=torch.int32)
+            radii[torch.rand(P9, generator=g) < 0.3] = 0
+            visibility_filter = radii > 0
+            pc9.max_radii2D[visibility_filter] = torch.max(pc9.max_radii2D[visibility_filter], radii[visibility_filter])   # train.py:168
+            pc9.add_densification_stats(vs, visibility_filter)                                                           # train.py:169
+            out[f"g9_view{v}_grad"] = grad.numpy(); out[f"g9_view{v}_radii"] = radii.numpy()
+            out[f"g9_after{v}_accum"] = pc9.xyz_gradient_accum.numpy().copy(); out[f"g9_after{v}_denom"] = pc9.denom.numpy().copy()
+            out[f"g9_after{v}_max_radii2D"] = pc9.max_radii2D.numpy().copy()
         np.savez_compressed(os.path.join(HERE, "rotation_checkpoint_golden.npz"), **out)
     finally:
         sys.path.remove("/root/reference")

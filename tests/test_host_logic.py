@@ -381,3 +381,19 @@ def test_checkpoint_layout_and_activations_match_reference_gaussian_model(tmp_pa
     np.testing.assert_array_equal(pc.get_features.detach().numpy(), z["g8_get_features"])
     np.testing.assert_array_equal(pc.get_semantics_32bit.numpy().reshape(-1), z["g8_get_semantics_32bit"].reshape(-1))
     assert np.abs(z["g8_get_rotation"][0]).max() < 1e-6     # |q| = 1e-20 < eps: normalize() divides by eps, not by the norm
+
+
+def test_densification_statistics_match_reference_gaussian_model(golden_dir):
+    """G9: the reference's own `GaussianModel.add_densification_stats` [REF scene/gaussian_model.py:555-557] and train.py:168's
+    max_radii2D update, run on two seeded views by tests/golden/make_golden.py.  `reduce_densification_stats` (one process: no
+    exchange) must leave the same three arrays after every view -- the per-view semantics the multi-rank exchange then sums / maximises."""
+    from streetunveiler_amd.parallel import reduce_densification_stats
+    z = np.load(os.path.join(golden_dir, "rotation_checkpoint_golden.npz"))
+    P = z["g9_view0_radii"].shape[0]
+    accum, denom, maxr = torch.zeros(P, 1), torch.zeros(P, 1), torch.zeros(P)
+    for v in range(2):
+        reduce_densification_stats(torch.tensor(z[f"g9_view{v}_grad"]), torch.tensor(z[f"g9_view{v}_radii"]), accum, denom, maxr)
+        np.testing.assert_array_equal(accum.numpy(), z[f"g9_after{v}_accum"])
+        np.testing.assert_array_equal(denom.numpy(), z[f"g9_after{v}_denom"])
+        np.testing.assert_array_equal(maxr.numpy(), z[f"g9_after{v}_max_radii2D"])
+    assert denom.max() == 2 and (denom == 0).any()
