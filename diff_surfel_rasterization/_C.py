@@ -207,7 +207,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
 
 
 def class_distortions(bg, means3D, classes, opacities, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
-                      image_height, image_width, campos, n_classes, debug=False, activations=0, mask=None):
+                      image_height, image_width, campos, n_classes, debug=False, activations=0, mask=None, tile=None):
     """Per-class distortion pass, forward (sr_forward_plan + sr_class_forward_render): `classes` [P] integer class of every
     Gaussian (negative or >= n_classes: in no class).  -> (num_rendered, dist[n_classes,H,W], radii, class_cols, geom, binning, class_image)."""
     lib = L.load()
@@ -221,7 +221,7 @@ def class_distortions(bg, means3D, classes, opacities, scales, rotations, scale_
     cols = torch.zeros((P, 3), dtype=torch.float32, device=dev)     # class id in the first colour slot of the splat record
     cols[:, 0] = classes.to(device=dev, dtype=torch.float32).reshape(P)
     with torch.cuda.device(dev):
-        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, 0, campos, False, debug)
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, 0, campos, False, debug, tile)
         mask = _mask(mask, P, dev)
         g = _gaussians(means3D, opacities, scales, rotations, None, cols, None, activations, mask)
         dist = torch.empty((int(n_classes), H, W), dtype=torch.float32, device=dev)
@@ -240,7 +240,7 @@ def class_distortions(bg, means3D, classes, opacities, scales, rotations, scale_
 
 
 def class_distortions_backward(bg, means3D, radii, cols, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
-                               dL_ddist, campos, n_classes, geom, num_rendered, binning, cimg, debug=False, activations=0):
+                               dL_ddist, campos, n_classes, geom, num_rendered, binning, cimg, debug=False, activations=0, tile=None):
     """-> (dL_dmeans2D[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dscales[P,2], dL_drotations[P,4]) of the per-class pass."""
     lib = L.load()
     means3D = _f32c(means3D, "means3D"); scales = _f32c(scales, "scales"); rotations = _f32c(rotations, "rotations")
@@ -249,7 +249,7 @@ def class_distortions_backward(bg, means3D, radii, cols, scales, rotations, scal
     P = int(means3D.shape[0])
     H, W = int(dL_ddist.shape[1]), int(dL_ddist.shape[2])
     with torch.cuda.device(dev):
-        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, 0, campos, False, debug)
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, 0, campos, False, debug, tile)
         g = _gaussians(means3D, means3D, scales, rotations, None, cols, None, activations)
         flat = torch.empty(P * 10, dtype=torch.float32, device=dev)     # means3D | opacity | scales | rotations: one buffer, one all-reduce
         dL_dmeans3D, dL_dopacity = flat[:3 * P].view(P, 3), flat[3 * P:4 * P].view(P, 1)

@@ -137,12 +137,12 @@ class _ClassDistortions(torch.autograd.Function):
     """The per-class distortion pass (include/surfel_raster.h, sr_class_forward_render / sr_class_backward)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, opacities, scales, rotations, classes, n_classes, raster_settings, activations, mask):
+    def forward(ctx, means3D, means2D, opacities, scales, rotations, classes, n_classes, raster_settings, activations, mask, tile=None):
         s = raster_settings
         num_rendered, dist, radii, cols, geom, binning, cimg = _C.class_distortions(
             s.bg, means3D, classes, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
-            s.image_height, s.image_width, s.campos, n_classes, s.debug, activations, mask)
-        ctx.raster_settings, ctx.num_rendered, ctx.n_classes, ctx.activations = s, num_rendered, int(n_classes), int(activations)
+            s.image_height, s.image_width, s.campos, n_classes, s.debug, activations, mask, tile=tile)
+        ctx.raster_settings, ctx.num_rendered, ctx.n_classes, ctx.activations, ctx.tile = s, num_rendered, int(n_classes), int(activations), tile
         ctx.save_for_backward(means3D, scales, rotations, radii, cols, geom, binning, cimg)
         ctx.mark_non_differentiable(radii)
         return dist, radii
@@ -153,8 +153,8 @@ class _ClassDistortions(torch.autograd.Function):
         means3D, scales, rotations, radii, cols, geom, binning, cimg = ctx.saved_tensors
         g2d, gop, g3d, gsc, grot = _C.class_distortions_backward(
             s.bg, means3D, radii, cols, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
-            grad_dist, s.campos, ctx.n_classes, geom, ctx.num_rendered, binning, cimg, s.debug, ctx.activations)
-        return g3d, g2d, gop, gsc, grot, None, None, None, None, None
+            grad_dist, s.campos, ctx.n_classes, geom, ctx.num_rendered, binning, cimg, s.debug, ctx.activations, tile=ctx.tile)
+        return g3d, g2d, gop, gsc, grot, None, None, None, None, None, None
 
 
 class GaussianRasterizer(nn.Module):
@@ -192,12 +192,12 @@ class GaussianRasterizer(nn.Module):
         """Extension: the distortion maps of the class-filtered renders of ONE view in one pass.
         `classes` [P] integer class per Gaussian (negative / >= n_classes: in no class).  Returns (dist[n_classes,H,W], radii[P]);
         dist[k] == allmap[6] of this operator called on the Gaussians of class k only, differentiable w.r.t. means3D, means2D
-        (densification proxy), opacities, scales, rotations.  16x16 tile, n_classes <= 6."""
-        if self.tile is not None and tuple(int(t) for t in self.tile) != (16, 16):
+        (densification proxy), opacities, scales, rotations.  Tiles of up to four 8x8 quadrants (not 32x16), n_classes <= 6."""
+        if self.tile is not None and tuple(int(t) for t in self.tile) == (32, 16):
             raise ValueError(f"tile={tuple(self.tile)} and class_distortions (render_class_distortions) are mutually exclusive: the per-class "
-                             "pass exists for the 16x16 tile only -- use a rasterizer without tile= for it")
+                             "pass exists for 8x8, 16x8, 16x16 and 32x8 tiles -- pick one of them")
         return _ClassDistortions.apply(means3D, means2D, opacities, scales, rotations, classes, int(n_classes), self.raster_settings,
-                                       self.activations, mask)
+                                       self.activations, mask, tuple(int(t) for t in self.tile) if self.tile else None)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, mask=None, extra_colors=None):

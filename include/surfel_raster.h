@@ -232,7 +232,7 @@ int sr_backward_geometry(const SrFrame* frame, const SrGaussians* g, const int32
  *     in no class, contributes nowhere); shs must be NULL.  sr_forward_plan is called first, exactly as for a render.
  *   - class_image: sr_class_image_bytes(W, H, n_classes) bytes of caller-owned state between forward and backward.
  *   - out_dist / dL_ddist: [n_classes, H, W].  grads: as sr_backward (dL_dcolors / dL_dsh are not produced: pass NULL).
- *   - 16x16 tile only; 1 <= n_classes <= 6. */
+ *   - tiles of up to four 8x8 quadrants (16x16, 8x8, 16x8, 32x8; not 32x16); 1 <= n_classes <= 6. */
 size_t sr_class_image_bytes(int32_t image_width, int32_t image_height, int32_t n_classes);
 int sr_class_forward_render(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, void* geom, size_t geom_bytes, void* binning,
                             size_t binning_bytes, void* class_image, size_t class_image_bytes, uint32_t num_rendered, float* out_dist,

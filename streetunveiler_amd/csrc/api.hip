@@ -472,7 +472,7 @@ struct ClassLayout { size_t state, last, tile_total, total; };
 ClassLayout class_layout(int W, int H, int n_classes) {
     ClassLayout L{};
     const size_t hw = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1), n = (size_t)(n_classes > 0 ? n_classes : 1);
-    const size_t tiles = (size_t)((W + kTile - 1) / kTile) * (size_t)((H + kTile - 1) / kTile);
+    const size_t tiles = (size_t)((W + 7) / 8) * (size_t)((H + 7) / 8);   // (sized for the smallest tile of the sweep, 8x8)
     L.state = 0;
     L.last = align_up(n * 3 * hw * 4, 256);
     L.tile_total = L.last + align_up(n * hw * 4, 256);
@@ -484,7 +484,8 @@ int check_class_pass(const SrFrame* frame, const SrGaussians* g, int n_classes) 
     if (int rc = check_common(frame, g)) return rc;
     if (n_classes < 1 || n_classes > 6) return fail(SR_ERR_UNSUPPORTED, "n_classes %d not in 1..6", n_classes);
     const int tw = frame->tile_width > 0 ? frame->tile_width : kTile, th = frame->tile_height > 0 ? frame->tile_height : kTile;
-    if (tw != 16 || th != 16) return fail(SR_ERR_UNSUPPORTED, "the per-class distortion pass is built for the 16x16 tile");
+    if (!((tw == 16 && th == 16) || (th == 8 && (tw == 8 || tw == 16 || tw == 32))))
+        return fail(SR_ERR_UNSUPPORTED, "the per-class distortion pass is built for the 16x16, 8x8, 16x8 and 32x8 tiles (not %dx%d)", tw, th);
     if (g->P > 0 && (g->shs || !g->colors_precomp || (g->color_channels != 0 && g->color_channels != 3)))
         return fail(SR_ERR_INVALID_ARGUMENT, "the per-class distortion pass takes the class ids in colors_precomp[P,3] (column 0), no SHs");
     return SR_OK;

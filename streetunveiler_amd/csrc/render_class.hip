@@ -14,7 +14,9 @@ namespace sr {
 
 constexpr int kClassMax = 8;
 
-template <int NCLS>
+// QX x 1 quadrants per wave; SPLIT = 2: the reference's 16x16 tile as two 16x8 band waves (two pixels per lane), SPLIT = 1: the 8x8 /
+// 16x8 / 32x8 tiles of BASELINE config 5's sweep, one wave per tile.
+template <int NCLS, int QX, int SPLIT>
 __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
                                                               const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
                                                               float* __restrict__ out_dist,       // [NCLS, H, W]
@@ -22,11 +24,12 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
                                                               uint32_t* __restrict__ cls_last,    // [NCLS, H, W]: last contributor
                                                               uint32_t* __restrict__ tile_total,  // [tiles, NCLS]: deepest contributor of the class in the tile (zeroed by the caller)
                                                               uint16_t* __restrict__ hit_mask, int cull) {
-    constexpr int QX = 2, QY = 1, SPLIT = 2, NQ = 2;   // the reference's 16x16 tile as two 16x8 band waves, two pixels per lane
+    constexpr int QY = 1, NQ = QX;
+    constexpr uint32_t kQuadMask = (1u << NQ) - 1u;
     __shared__ float4 s_e[entry_quads<3>()][kWave];
     const int lane = threadIdx.x;
-    int tile, part;
-    {
+    int tile = blockIdx.x, part = 0;
+    if (SPLIT > 1) {   // the bands of a tile on one XCD (render.hip)
         const int xcd = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
         tile = (k / SPLIT) * kXcds + xcd; part = k % SPLIT;
         if (tile >= f.tiles_x * f.tiles_y) return;
@@ -70,17 +73,19 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
             const int ci = (int)cls_f;
             has_class = cls_f >= 0.f && ci < NCLS;
             m = stage_entry<QX, QY, 3>(nr, make_float4(0.f, 0.f, has_class ? (float)ci : -1.f, 0.f), zero4, Xc, Yc, cull & 1, s_e, lane, yshift);
-            m = has_class ? (m & (alive >> (ci * NQ)) & 3u) : 0u;
+            m = has_class ? (m & (alive >> (ci * NQ)) & kQuadMask) : 0u;
         }
         if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
         unsigned long long bits = ballot64(m != 0);
-        unsigned long long hit[NQ] = {0ull, 0ull};
+        unsigned long long hit[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) hit[q] = 0ull;
         while (bits) {
             const int j = __ffsll((long long)bits) - 1;
             bits &= bits - 1;
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
             const int cj = __builtin_amdgcn_readfirstlane((int)e3.w);
-            const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & (alive >> (cj * NQ)) & 3u;
+            const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & (alive >> (cj * NQ)) & kQuadMask;
             if (!mj) continue;
             const uint32_t contributor = base + (uint32_t)j + 1u;
 #pragma unroll
@@ -119,7 +124,8 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
             uint32_t hm = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
-            reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base + lane) + part] = (uint8_t)hm;
+            if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base + lane) + part] = (uint8_t)hm;
+            else hit_mask[range.x + base + lane] = (uint16_t)hm;
         }
     }
     // entries behind the point where every chain of the band had closed keep whatever hit byte they had: the backward never gets
@@ -146,13 +152,13 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
 
 // One wave per (tile, class): the blend backward of the class-filtered render with the distortion gradient as the only upstream
 // gradient (no colour, depth, normal, alpha, median terms): psi = dLw, Z = sum_{k>i} w_k dLw_k  (render.hip, K7).
-template <int NCLS>
+template <int NCLS, int QX, int QY>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list,
                            const float4* __restrict__ recs, const float* __restrict__ cls_state, const uint32_t* __restrict__ cls_last,
                            const uint32_t* __restrict__ tile_total, const float* __restrict__ dL_ddist, const uint16_t* __restrict__ hit_mask,
                            float4* __restrict__ inst_grads, uint8_t* __restrict__ written) {
-    constexpr int QX = 2, QY = 2, NQ = 4, kGQ = kGradQuads;
+    constexpr int NQ = QX * QY, kGQ = kGradQuads;
     __shared__ float4 s_e[entry_quads<3>()][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGQ * 4];
     const int lane = threadIdx.x;
@@ -288,14 +294,17 @@ hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* r
                                 int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    if (f.tile_w != 16 || f.tile_h != 16) return hipErrorInvalidValue;
+    const bool ref_tile = f.tile_w == 16 && f.tile_h == 16;
+    if (!ref_tile && !(f.tile_h == 8 && (f.tile_w == 8 || f.tile_w == 16 || f.tile_w == 32))) return hipErrorInvalidValue;   // (32x16: eight pixels per lane)
     hipError_t e = hipMemsetAsync(tile_total, 0, sizeof(uint32_t) * (size_t)n_tiles * n_classes, s);
     if (e != hipSuccess) return e;
-    const dim3 grid((n_tiles + kXcds - 1) / kXcds * kXcds * 2);
-#define SR_CF(N) hipLaunchKernelGGL(class_forward_kernel<N>, grid, dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, out_dist, cls_state, cls_last, tile_total, hit_mask, cull)
+    const dim3 grid(ref_tile ? (n_tiles + kXcds - 1) / kXcds * kXcds * 2 : n_tiles);
+#define SR_CF_SHAPE(N, QX, SPLIT) hipLaunchKernelGGL((class_forward_kernel<N, QX, SPLIT>), grid, dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, out_dist, cls_state, cls_last, tile_total, hit_mask, cull)
+#define SR_CF(N) { if (ref_tile) SR_CF_SHAPE(N, 2, 2); else if (f.tile_w == 8) SR_CF_SHAPE(N, 1, 1); else if (f.tile_w == 16) SR_CF_SHAPE(N, 2, 1); else SR_CF_SHAPE(N, 4, 1); }
     switch (n_classes) { case 1: SR_CF(1); break; case 2: SR_CF(2); break; case 3: SR_CF(3); break; case 4: SR_CF(4); break;
                          case 5: SR_CF(5); break; case 6: SR_CF(6); break; default: return hipErrorInvalidValue; }
 #undef SR_CF
+#undef SR_CF_SHAPE
     return hipGetLastError();
 }
 
@@ -304,11 +313,14 @@ hipError_t launch_class_backward(const FrameDev& f, int n_classes, const uint2* 
                                  const float* dL_ddist, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    if (f.tile_w != 16 || f.tile_h != 16) return hipErrorInvalidValue;
-#define SR_CB(N) hipLaunchKernelGGL(class_backward_kernel<N>, dim3(n_tiles * N), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, cls_state, cls_last, tile_total, dL_ddist, hit_mask, inst_grads, written)
+    const bool ref_tile = f.tile_w == 16 && f.tile_h == 16;
+    if (!ref_tile && !(f.tile_h == 8 && (f.tile_w == 8 || f.tile_w == 16 || f.tile_w == 32))) return hipErrorInvalidValue;
+#define SR_CB_SHAPE(N, QX, QY) hipLaunchKernelGGL((class_backward_kernel<N, QX, QY>), dim3(n_tiles * N), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, cls_state, cls_last, tile_total, dL_ddist, hit_mask, inst_grads, written)
+#define SR_CB(N) { if (ref_tile) SR_CB_SHAPE(N, 2, 2); else if (f.tile_w == 8) SR_CB_SHAPE(N, 1, 1); else if (f.tile_w == 16) SR_CB_SHAPE(N, 2, 1); else SR_CB_SHAPE(N, 4, 1); }
     switch (n_classes) { case 1: SR_CB(1); break; case 2: SR_CB(2); break; case 3: SR_CB(3); break; case 4: SR_CB(4); break;
                          case 5: SR_CB(5); break; case 6: SR_CB(6); break; default: return hipErrorInvalidValue; }
 #undef SR_CB
+#undef SR_CB_SHAPE
     return hipGetLastError();
 }
 

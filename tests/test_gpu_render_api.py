@@ -461,6 +461,66 @@ def test_class_distortions_one_pass_equals_the_per_class_renders():
         assert_grads_close(t1[key].grad.cpu().numpy(), t2[key].grad.cpu().numpy(), 2e-5, "one pass vs five renders d" + key, max_bad_frac=0.0, hard=2e-5)
 
 
+@pytest.mark.parametrize("tile", [(8, 8), (16, 8), (32, 8)])
+def test_class_distortions_on_other_tile_shapes(tile):
+    """The per-class pass on the other tile shapes of BASELINE config 5's sweep with up to four pixels per lane: every class map equals
+    `allmap[6]` of the operator called WITH THE SAME TILE on the class subset (the reference's call pattern), its gradients the sum of those
+    calls' gradients, and both agree with the 16x16 pass (oracle-checked above) to float summation order; 32x16 is refused by name."""
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from tests.gpu_util import assert_close_frac, assert_grads_close, settings_for
+    P, W, H = 7000, 232, 136
+    cam = synthetic_camera(W, H, index=1)
+    g = synthetic_gaussians(P, W, H, seed=57, scale_lo=3e-3, scale_hi=6e-2)
+    n_cls = 5
+    cls = torch.randint(-1, n_cls + 1, (P,), generator=torch.Generator().manual_seed(3))    # -1 and n_cls: in no class
+    g_dist = (torch.rand(n_cls, H, W, generator=torch.Generator().manual_seed(4)) + 0.5).to(DEV)
+    s = settings_for(cam, np.zeros(3, np.float32), 0)
+    names = ("means3D", "opacities", "scales", "rotations")
+
+    def one_pass(tl):
+        t = {k: g[k].to(DEV).requires_grad_() for k in names}
+        m2d = torch.zeros(P, 3, device=DEV, requires_grad=True)
+        dist, radii = GaussianRasterizer(s, tile=tl).class_distortions(t["means3D"], m2d, t["opacities"], t["scales"], t["rotations"], cls.to(DEV), n_cls)
+        (dist * g_dist).sum().backward()
+        return dist.detach(), radii, {k: t[k].grad for k in names}, m2d.grad
+
+    dist, radii, grads, g2d = one_pass(tile)
+    assert dist.shape == (n_cls, H, W)
+    # (a) the subset renders with the same tile
+    sums = {k: torch.zeros_like(grads[k]) for k in names}
+    sum2d = torch.zeros_like(g2d)
+    for k in range(n_cls):
+        idx = (cls == k).to(DEV)
+        t = {n: g[n].to(DEV)[idx].clone().requires_grad_() for n in names}
+        m2d = torch.zeros(int(idx.sum()), 3, device=DEV, requires_grad=True)
+        cols = torch.zeros(int(idx.sum()), 3, device=DEV)
+        _, r, allmap = GaussianRasterizer(s, tile=tile)(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], colors_precomp=cols,
+                                                         scales=t["scales"], rotations=t["rotations"])
+        d = allmap[6]
+        assert float((d.detach() - dist[k]).abs().max()) <= 1e-6 * max(1.0, float(d.detach().abs().max())), k
+        assert torch.equal(r, radii[idx])
+        (d * g_dist[k]).sum().backward()
+        for n in names:
+            sums[n][idx] += t[n].grad
+        sum2d[idx] += m2d.grad
+    for n in names:
+        assert float(sums[n].abs().max()) > 0
+        assert_grads_close(grads[n].cpu().numpy(), sums[n].cpu().numpy(), 2e-5, f"class pass {tile} vs subset renders d{n}", max_bad_frac=0.0, hard=2e-5)
+    assert_grads_close(g2d.cpu().numpy(), sum2d.cpu().numpy(), 2e-5, f"class pass {tile} vs subset renders dmeans2D", max_bad_frac=0.0, hard=2e-5)
+    assert not grads["means3D"][(cls < 0) | (cls >= n_cls)].any()
+    # (b) the 16x16 pass
+    dist16, radii16, grads16, g2d16 = one_pass(None)
+    both = (radii > 0) & (radii16 > 0)   # (a splat beyond the image's last pixel can still reach the padding of the coarser tile grid)
+    assert torch.equal(radii[both], radii16[both]) and float(both.float().mean()) > 0.5
+    # (another tiling = other tile-local coordinates: a pair at the alpha >= 1/255 threshold can fall the other way, SURVEY 7(d))
+    assert_close_frac(dist.cpu().numpy(), dist16.cpu().numpy(), 2e-6, 1e-3, 1e-3, 2e-2, f"class pass {tile} vs 16x16 rend_dist")   # (a cancelling sum: m^2 A + M2 - 2 m M1)
+    for n in names:
+        assert_grads_close(grads[n].cpu().numpy(), grads16[n].cpu().numpy(), 1e-3, f"class pass {tile} vs 16x16 d{n}")
+    with pytest.raises(ValueError, match="mutually exclusive"):
+        GaussianRasterizer(s, tile=(32, 16)).class_distortions(g["means3D"].to(DEV), torch.zeros(P, 3, device=DEV), g["opacities"].to(DEV), g["scales"].to(DEV),
+                                                               g["rotations"].to(DEV), cls.to(DEV), n_cls)
+
+
 def test_training_iteration_eight_calls_equal_two_rasterizations():
     """The reference's late training iteration rasterizes one view eight times [REF train.py:84-109]: render_semantic (two 3-channel
     passes), five class-filtered renders on boolean-indexed copies, render.  streetunveiler_amd.train_pattern issues those eight calls
