@@ -222,20 +222,33 @@ def rasterize_backward(fwd: Dict[str, np.ndarray], dL_dcolor, dL_dallmap) -> Dic
 DEFAULT_EPS = dict(alpha=2e-5, T=1e-4, path=1e-3, near=1e-5, median=2e-5)
 
 
-def render_margins(fwd: Dict[str, np.ndarray], eps: Optional[Dict[str, float]] = None, f64: bool = False) -> Dict[str, np.ndarray]:
+def render_margins(fwd: Dict[str, np.ndarray], eps: Optional[Dict[str, float]] = None, f64: bool = False,
+                   kernel_decisions: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, np.ndarray]:
     """Decision margins of the forward blend (so_render_margins): `pixel`[H,W], `median`[H,W], `gaussian`[P]; > 1 = robust.
     `f64=True`: the deciding quantities are evaluated in double precision on the float32 per-Gaussian state (so_render_margins_f64),
-    i.e. the margins are distances of the TRUE decisions from their thresholds, free of this oracle's own float32 noise."""
+    i.e. the margins are distances of the TRUE decisions from their thresholds, free of this oracle's own float32 noise.
+    `kernel_decisions` = dict(valid=u64[D,nq], use3d=u64[D,nq]) (sr_debug_pair_decisions): adds `disagree`[H,W], the number of pairs of
+    each pixel -- up to where this walk stops -- whose contribute / path decision differs from the walk's own."""
     L = lib()
     i = fwd["_inputs"]; P = i["means3D"].shape[0]; W, H = i["W"], i["H"]
     L.so_set_tile(*i["tile"])
     e = dict(DEFAULT_EPS); e.update(eps or {})
     ev = np.array([e["alpha"], e["T"], e["path"], e["near"], e["median"]], np.float32)
     pm = np.zeros((H, W), np.float32); mm = np.zeros((H, W), np.float32); gm = np.zeros(P, np.float32); vn = np.zeros((H, W), np.float32)
+    kv = ku = dis = None
+    if kernel_decisions is not None:
+        nq = (i["tile"][0] // 8) * (i["tile"][1] // 8); D = int(fwd["num_rendered"])
+        kv = np.ascontiguousarray(kernel_decisions["valid"], dtype=np.uint64).reshape(-1); ku = np.ascontiguousarray(kernel_decisions["use3d"], dtype=np.uint64).reshape(-1)
+        assert kv.size == D * nq and ku.size == D * nq, "kernel decisions must cover every (list position, quadrant)"
+        dis = np.zeros((H, W), np.uint32)
     (L.so_render_margins_f64 if f64 else L.so_render_margins)(P, W, H, _p(fwd["ranges"], C.c_uint32), _p(i["vals_buf"], C.c_uint32), _p(fwd["means2D"]),
-                        _p(fwd["transMat"]), _p(fwd["normal_opacity"]), _p(ev), _p(pm), _p(mm), _p(gm), _p(vn))
+                        _p(fwd["transMat"]), _p(fwd["normal_opacity"]), _p(ev), _p(pm), _p(mm), _p(gm), _p(vn), _p(kv, C.c_uint64), _p(ku, C.c_uint64),
+                        _p(dis, C.c_uint32))
     # `value_noise`[H,W]: relative noise float32 rounding of the ray-splat intersections can put into the pixel's transmittance and weights
-    return dict(pixel=pm, median=mm, gaussian=gm, value_noise=vn, eps=e)
+    out = dict(pixel=pm, median=mm, gaussian=gm, value_noise=vn, eps=e)
+    if dis is not None:
+        out["disagree"] = dis
+    return out
 
 
 def mark_visible(means3D, viewmatrix) -> np.ndarray:

@@ -270,11 +270,13 @@ NONROBUST_PIXEL_BUDGET = 1.5e-2
 NONROBUST_GAUSSIAN_BUDGET = 0.40
 
 
-def free_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None, base=None):
+def free_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None, base=None, kernel_decisions=None):
     """The float64 blend + float64 K8 running FREE on the oracle's float32 per-Gaussian state: every hard decision (contribute,
     path, stop, median) is the checker's own, taken on exactly evaluated quantities -- nothing comes from the HIP kernels.  With the
     float64 decision margins (so_render_margins_f64) it says where two correct implementations MUST agree to rounding (robust
-    pixels / Gaussians) and where a decision sits within float32 noise of its threshold.  -> (fwd64, bwd64 or None, margins)."""
+    pixels / Gaussians) and where a decision sits within float32 noise of its threshold.  -> (fwd64, bwd64 or None, margins).
+    `kernel_decisions` = run_hip_raw(..., decisions=True)["decisions"]: the margins then carry `disagree`[H,W], the per-pixel number of
+    pairs whose contribute / path decision in the kernels differs from the checker's own (assert_free_parity demands 0 at robust pixels)."""
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
               bg=np.asarray(bg, np.float32), image_width=cam.image_width, image_height=cam.image_height, sh_degree=deg, tile=tile or (16, 16),
               f64=True, reuse=base)
@@ -284,7 +286,7 @@ def free_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None
     else:
         fwd = so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), shs=n("shs"), **kw)
     bwd = so.rasterize_backward(fwd, dc.numpy(), da.numpy()) if dc is not None else None
-    return fwd, bwd, so.render_margins(fwd, f64=True)
+    return fwd, bwd, so.render_margins(fwd, f64=True, kernel_decisions=kernel_decisions)
 
 
 def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report=None, scene=None, pixel_budget=NONROBUST_PIXEL_BUDGET,
@@ -312,6 +314,14 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
         nc = np.asarray(hip_n_contrib).view(np.uint32).reshape(2, *rob_px.shape)
         assert np.array_equal(nc[0][rob_px], fwd64["n_contrib"][0][rob_px]), f"{tag}: a robust pixel stops at a different entry"
         assert np.array_equal(nc[1][rob_med], fwd64["n_contrib"][1][rob_med]), f"{tag}: a robust pixel picks a different median"
+    if "disagree" in margins:
+        # every single (pixel, splat) decision of the kernels at a robust pixel -- contribute or not, ray-splat or screen-space path -- is the
+        # float64 checker's own: the "forced decisions" of the strict bar are, at these pixels, not the kernels' word but the arbiter's
+        dis = margins["disagree"]
+        if report is not None:
+            report[f"{tag}pair_decisions"] = dict(differing_pairs_at_robust_pixels=int(dis[rob_px].sum()), differing_pairs_at_non_robust_pixels=int(dis[~rob_px].sum()),
+                                                  non_robust_pixels_with_a_differing_pair=int((dis[~rob_px] > 0).sum()))
+        assert not dis[rob_px].any(), f"{tag}: {int((dis[rob_px] > 0).sum())} robust pixels hold a pair the kernels decided differently from the float64 checker"
     rep = {} if report is None else report
     for name, a, b, mask in [("color", hip["color"], fwd64["color"], rob_px)] + \
                             [(f"allmap[{c}]", hip["allmap"][c], fwd64["allmap"][c], rob_med if c == 5 else rob_px) for c in range(7)]:

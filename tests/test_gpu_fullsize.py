@@ -50,7 +50,8 @@ def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, repo
     _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da, base=fwd, raw=raw)
     assert_strict_parity(out, fwd64, bwd64, tag=tag + " ", scene=(g, cam))
     del fwd64, bwd64
-    xfwd, xbwd, margins = free_f64_reference(g, cam, bg, 3, dc, da, base=fwd)
+    # (with the kernels' per-pair decision dump: every one of them at a robust pixel must be the float64 checker's own)
+    xfwd, xbwd, margins = free_f64_reference(g, cam, bg, 3, dc, da, base=fwd, kernel_decisions=raw["decisions"])
     # the non-robust remainder is not only counted: measured at full size (tools/nonrobust_report.py: C2 / C3 / clustered) its pixels stay
     # within 2.1e-3 of (1 + |value|) and its gradient rows within 1.5e-3 of the tensor's scale -- the caps are three times that, not the
     # 2e-2 / 5e-2 a flipped contributor could in principle cost

@@ -105,7 +105,7 @@ def test_forward_backward_vs_oracle(P, W, H, deg, lo, hi, cam_index):
     dc, da = synthetic_upstream_grads(W, H, seed=P)
     fwd, bwd = run_oracle(g, cam, bg, deg, dc, da)
     assert fwd["num_rendered"] > P // 2
-    raw = run_hip_raw(g, cam, bg, deg)
+    raw = run_hip_raw(g, cam, bg, deg, decisions=True)
     _check_binning(raw, fwd)
     # the two words the emission scan leaves for the forward blend's choice of mapping: D and the Gaussians with at least one tile
     assert raw["geom"]["frame_counts"].view(np.uint32).tolist() == [fwd["num_rendered"], int((fwd["tiles_touched"] > 0).sum())]
@@ -121,7 +121,7 @@ def test_forward_backward_vs_oracle(P, W, H, deg, lo, hi, cam_index):
     # ... and against the free-running float64 reference (its own decisions): 1e-4 and identical stop / median positions at EVERY
     # robust pixel, strict rows on every robust Gaussian, the non-robust remainder counted (tests/gpu_util.py)
     from tests.gpu_util import assert_free_parity, free_f64_reference
-    xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, base=fwd)
+    xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, base=fwd, kernel_decisions=raw["decisions"])
     assert_free_parity(out, nc, xfwd, xbwd, margins, tag=f"P{P} ", scene=(g, cam))
 
 

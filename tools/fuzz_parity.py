@@ -59,7 +59,7 @@ def main():
         # (every pixel, against the float32 oracle OR the free-running float64 reference, whichever is closer: the reference's
         # `if (p.z == 0) continue` fires where the ORACLE's float32 p.z lands on exactly 0 -- rounding noise of a ray nearly parallel to the
         # splat's plane -- and there the kernels blend the pair through its 2-D filter footprint like exact arithmetic does: blend_common.h)
-        xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, colors=colors, tile=tile, base=fwd)
+        xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, colors=colors, tile=tile, base=fwd, kernel_decisions=raw["decisions"])
         flip = 1.5 / 255.0
         zmax = float(fwd["depths"][fwd["radii"] > 0].max()) if (fwd["radii"] > 0).any() else 1.0
         cmax = max(1.0, float(fwd["rgb"].max()))

@@ -54,7 +54,7 @@ def report(P, W, H, seed=0, deg=3, aux=True, scale_lo=5e-4, scale_hi=5e-3, eps=N
     forced = dict(valid=raw["decisions"]["valid"], use3d=raw["decisions"]["use3d"], n_contrib=raw["img"]["n_contrib"].view(np.uint32))
     t = time.time(); ffwd = orc(forced=forced, reuse=fwd); fbwd = so.rasterize_backward(ffwd, dc.numpy(), da.numpy()); sec["forced_f32"] = round(time.time() - t, 2)
     t = time.time(); dfwd = orc(forced=forced, f64=True, reuse=fwd); dbwd = so.rasterize_backward(dfwd, dc.numpy(), da.numpy()); sec["forced_f64"] = round(time.time() - t, 2)
-    t = time.time(); xfwd = orc(f64=True, reuse=fwd); xbwd = so.rasterize_backward(xfwd, dc.numpy(), da.numpy()); m64 = so.render_margins(xfwd, eps, f64=True); sec["free_f64"] = round(time.time() - t, 2)
+    t = time.time(); xfwd = orc(f64=True, reuse=fwd); xbwd = so.rasterize_backward(xfwd, dc.numpy(), da.numpy()); m64 = so.render_margins(xfwd, eps, f64=True, kernel_decisions=raw["decisions"]); sec["free_f64"] = round(time.time() - t, 2)
     assert np.array_equal(ffwd["n_contrib"], forced["n_contrib"]) and np.array_equal(dfwd["n_contrib"], forced["n_contrib"])
     hip_nc = raw["img"]["n_contrib"].view(np.uint32)
     vis = fwd["radii"] > 0
@@ -65,6 +65,11 @@ def report(P, W, H, seed=0, deg=3, aux=True, scale_lo=5e-4, scale_hi=5e-3, eps=N
                                      and np.array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])),
            "definition": "image error = |a - b| / (1 + |b|) per element; gradient error = max_j |a - b|[row, j] / (max_j |b|[row, j] + 1e-3 * tensor max) "
                          "per visible Gaussian row; '64' references run K8 in float64 as well as the blend"}
+    # every per-pair decision of the kernels (contribute or not, which path), pixel by pixel up to where the float64 walk stops, against the
+    # float64 checker's own: at robust pixels the "forced decisions" of section 1 are the arbiter's own decisions
+    dis = m64["disagree"]
+    out["pair_decisions_vs_free_f64"] = dict(pairs_differing_at_robust_pixels=int(dis[rob_px].sum()), pairs_differing_at_non_robust_pixels=int(dis[~rob_px].sum()),
+                                             non_robust_pixels=int((~rob_px).sum()), non_robust_pixels_with_a_differing_pair=int((dis[~rob_px] > 0).sum()))
     # ---- 1. forced decisions vs the float64 arbiter (blend AND K8 in double) ----
     fz = {"images": {}, "gradients": {}}
     for name, a, b, d in [("color", hip["color"], ffwd["color"], dfwd["color"])] + [(f"allmap[{c}]", hip["allmap"][c], ffwd["allmap"][c], dfwd["allmap"][c]) for c in range(7)]:
