@@ -289,6 +289,51 @@ def free_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None
     return fwd, bwd, so.render_margins(fwd, f64=True, kernel_decisions=kernel_decisions)
 
 
+def _assert_everything_but_the_differing_pixels(hip, nc, fwd64, bwd64, margins, tag, rep, scene, value_slack, lenient):
+    """The robust / non-robust split PREDICTS where two correct float32 implementations may decide differently; this is the check on what
+    actually happened.  A pixel DIFFERS if one of its pair decisions, its stopping entry or its median entry in the kernels is not the
+    free-running float64 checker's.  Every other pixel -- robust or not -- saw the same contributor set on both sides and must meet the value
+    bar; every visible Gaussian that is not in the list of a differing pixel (up to that pixel's deeper stop) must meet the strict row bars
+    against the FREE float64 backward.  The differing pixels themselves are few: at most 1e-4 of the frame (measured: 32 of 2 M at C3)."""
+    dis = margins["disagree"]
+    H, W = dis.shape
+    differs = (dis > 0) | (nc[0] != fwd64["n_contrib"][0]) | (nc[1] != fwd64["n_contrib"][1])
+    frac = float(differs.mean())
+    tw, th = fwd64["_inputs"]["tile"]
+    gx = (W + tw - 1) // tw
+    P = fwd64["radii"].shape[0]
+    affected = np.zeros(P, bool)
+    ranges = np.asarray(fwd64["ranges"]).reshape(-1, 2); plist = np.asarray(fwd64["point_list"])
+    for py, px in zip(*np.nonzero(differs)):
+        r0 = int(ranges[(py // th) * gx + px // tw][0]); r1 = int(ranges[(py // th) * gx + px // tw][1])
+        deep = min(r1 - r0, int(max(nc[0][py, px], fwd64["n_contrib"][0][py, px])) + 1)
+        affected[plist[r0:r0 + deep]] = True
+    vis = fwd64["radii"] > 0
+    if rep is not None:
+        rep[f"{tag}differing_pixels"] = dict(pixels=int(differs.sum()), fraction=frac, gaussians_in_their_lists=int((affected & vis).sum()),
+                                             fraction_of_visible=float((affected & vis).sum() / max(1, vis.sum())))
+    assert frac <= 1e-4 or differs.sum() <= 3, f"{tag}: {int(differs.sum())} pixels ({frac:.2e}) hold a decision that differs from the float64 checker's"
+    if lenient:   # (fuzz sweep on ill-conditioned random scenes: its value bars are relative to the float32 oracle -- the robust-element checks carry them)
+        return
+    keep = ~differs
+    for name, a, b in [("color", hip["color"], fwd64["color"])] + [(f"allmap[{c}]", hip["allmap"][c], fwd64["allmap"][c]) for c in range(7)]:
+        err = np.abs(np.asarray(a, np.float64) - b) / (1.0 + np.abs(b)) - np.broadcast_to(margins.get("value_noise", 0.0), np.shape(b))
+        m = np.broadcast_to(keep, err.shape)
+        assert err[m].max(initial=0.0) <= 1e-4 * value_slack, \
+            f"{tag} {name}: a pixel with the checker's own decisions is off by {err[m].max():.3e} of (1 + |value|) against the free-running float64 reference"
+    rows = vis & ~affected
+    for key, e in gradient_row_errors(hip, bwd64, np.ones_like(vis), scene).items():
+        p999_bar, max_bar = STRICT_ROW_BARS[key]
+        if scene is None and key in ("dL_dscales", "dL_drotations"):
+            p999_bar, max_bar = 2e-3, 6e-2
+        er = e[rows]
+        if rep is not None:
+            rep[f"{tag}{key} rows outside the differing pixels"] = dict(rows=int(rows.sum()), max=float(er.max(initial=0.0)), p999=float(np.quantile(er, 0.999)) if er.size else 0.0)
+        if er.size:
+            assert rows_within(er, p999_bar * value_slack, max_bar * value_slack), \
+                f"{tag} {key}: rows outside the differing pixels' lists p99.9 {np.quantile(er, 0.999):.2e} (bar {p999_bar:.1e}), max {er.max():.2e} (bar {max_bar:.1e})"
+
+
 def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report=None, scene=None, pixel_budget=NONROBUST_PIXEL_BUDGET,
                        gaussian_budget=NONROBUST_GAUSSIAN_BUDGET, value_slack=1.0, nonrobust_pixel_cap=2e-2, nonrobust_row_cap=5e-2,
                        oracle32=None, oracle32_fwd=None):
@@ -309,6 +354,7 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
     rule for the value bar of the robust pixels."""
     rob_px = margins["pixel"] > 1.0
     rob_med = rob_px & (margins["median"] > 1.0)
+    rep = {} if report is None else report
     assert (~rob_px).mean() <= pixel_budget, f"{tag}: {(~rob_px).mean():.2e} of the pixels are non-robust"
     if hip_n_contrib is not None:   # (the render()-level tests do not see the image state)
         nc = np.asarray(hip_n_contrib).view(np.uint32).reshape(2, *rob_px.shape)
@@ -322,7 +368,9 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
             report[f"{tag}pair_decisions"] = dict(differing_pairs_at_robust_pixels=int(dis[rob_px].sum()), differing_pairs_at_non_robust_pixels=int(dis[~rob_px].sum()),
                                                   non_robust_pixels_with_a_differing_pair=int((dis[~rob_px] > 0).sum()))
         assert not dis[rob_px].any(), f"{tag}: {int((dis[rob_px] > 0).sum())} robust pixels hold a pair the kernels decided differently from the float64 checker"
-    rep = {} if report is None else report
+        if hip_n_contrib is not None and bwd64 is not None:
+            _assert_everything_but_the_differing_pixels(hip, nc, fwd64, bwd64, margins, tag, rep if report is not None else None, scene, value_slack,
+                                                        oracle32 is not None or oracle32_fwd is not None)
     for name, a, b, mask in [("color", hip["color"], fwd64["color"], rob_px)] + \
                             [(f"allmap[{c}]", hip["allmap"][c], fwd64["allmap"][c], rob_med if c == 5 else rob_px) for c in range(7)]:
         err = np.abs(np.asarray(a, np.float64) - b) / (1.0 + np.abs(b))
