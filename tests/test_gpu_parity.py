@@ -694,6 +694,20 @@ def test_randomised_scenes_short_sweep():
     assert r.returncode == 0 and "5/5 scenes within the parity bars" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_extensions_short_sweep():
+    """tools/fuzz_extensions.py on a dozen random scenes + the seeds a 1 000-scene sweep needed its float64 fallback for: the 9-channel
+    pass, the per-class pass, mask= and the fused activations against the plain operator calls of this build they replace (forward bit
+    for bit where the arithmetic is the same, gradients as the sum of the replaced calls' gradients), over random sizes, tile shapes and
+    regimes."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_extensions.py"), "12", "5000"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "12/12 scenes consistent" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    for seed in ("3427", "3574"):   # distortion-only gradients that are float32 cancellation noise: held against the float64 backward instead
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_extensions.py"), "1", seed], cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "1/1 scenes consistent" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_degenerate_parameters():
     """Zero / sub-denormal / gigantic scales, zero quaternions, opacity exactly 0 and 1: same radii, no NaN or Inf on either
     side, images and gradients within the usual bars (scales underflow in training; nothing here may poison a frame)."""
