@@ -451,9 +451,10 @@ def main():
                 "issue_roof": {"render_forward_kernel": valu_issue_roof("render_forward_kernel", group_ms["blend_fwd"], args),
                                "render_backward_kernel": valu_issue_roof("render_backward_kernel", group_ms["blend_bwd"], args, blend_counts["entries_with_a_hit"])},
                 "note": "issued = 64 lanes x quadrant tests, useful = pairs that contribute.  Neither memory (traffic ~ algorithmic bytes at a fifth "
-                        "of the HBM rate) nor the vector unit alone bounds the blend kernels: they issue at issue_roof.*.datasheet_issue_frac of the "
-                        "datasheet VALU rate because too few waves are ready per quad-cycle -- registers and LDS cap the resident waves, and a wave "
-                        "spends wave_time.stalled_at_issue + waiting of its time not issuing (DESIGN.md 4)",
+                        "of the HBM rate) nor the number of resident waves bounds the blend kernels (a fourth wave per SIMD, built for the two-pixel K7, "
+                        "changes nothing): they run at issue_roof.*.datasheet_issue_frac of the rate the vector unit would reach if every instruction "
+                        "were a two-cycle VOP2 and at issue_roof.*.fitted_issue_cost_frac of the rate their actual instruction forms allow (DPP, "
+                        "transcendentals, lane swaps, three-source / SGPR-source VOP3 at their measured throughput costs) -- the second binds (DESIGN.md 4)",
                 "D_eff_blend_bytes": blend_counts["staged_entries_D_eff"] * 296 + npx * 160}
         # The same fractions with the list entries the blend kernels actually stage (D_eff: what lies behind a tile's saturation
         # point is never loaded) in place of all D duplicates: the D-based figures count bytes no kernel touches -- a factor of two
@@ -497,7 +498,10 @@ def main():
             "stage_ms": {k: (None if v is None else round(v, 4)) for k, v in stage_ms.items()},
         }
         if world == 1 and not multi and not args.no_train_step:
-            out["train_step"] = train_step_section(args, params, cam, dev)
+            try:
+                out["train_step"] = train_step_section(args, params, cam, dev)
+            except Exception as e:   # an untimed extra must never cost the line
+                out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g_cpu, cam, dc_cpu, da_cpu)
         print(json.dumps(out), flush=True)
