@@ -109,6 +109,26 @@ def profiled(kind, args):
         return None, None
 
 
+def measured_ceiling():
+    """What simple streaming kernels reach on an MI355X of this pool (tools/ubench/hbm_ceiling.hip -> profiles/rNN_hbm_ceiling.txt: read-only,
+    write-only, copy, triad with 16-B accesses, hipMemcpyDtoD; best over grid sizes) -- the practical ceiling next to the 8 TB/s vendor peak."""
+    import glob, re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_ceiling.txt")))
+    if not files:
+        return None
+    try:
+        txt = open(files[-1]).read()
+        rows = re.findall(r"read ([0-9.]+) TB/s\s+write ([0-9.]+)\s+copy ([0-9.]+)\s+triad ([0-9.]+)", txt)
+        out = {k: max(float(r[i]) for r in rows) for i, k in enumerate(("read", "write", "copy", "triad"))}
+        m = re.search(r"hipMemcpyDtoD[^:]*:\s*([0-9.]+)", txt)
+        if m:
+            out["hipMemcpyDtoD"] = float(m.group(1))
+        out.update(unit="TB/s", source=os.path.relpath(files[-1], ROOT), quoted="committed micro-benchmark run, not measured in this run")
+        return out
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel`: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, corrected as MI355X_MICROARCH.md
     prescribes (tools/collect_profiles.py)."""
@@ -431,6 +451,15 @@ def main():
         kernels_ms = sum(group_ms.values())
         dom_kernel = "render_backward_kernel" if dominant == "blend_bwd" else "render_forward_kernel"
         traffic, traffic_src = pmc_traffic(dom_kernel, args)
+        # the streaming kernels against what streaming kernels reach on this pool's boxes (read 6.5, copy 5.0-5.9 TB/s measured; 8 is the vendor peak)
+        ceiling = measured_ceiling()
+        hbm_bound = {}
+        for stage, kern in (("preprocess", "preprocess_forward_kernel"), ("preprocess_bwd", "preprocess_backward_kernel")):
+            t, _ = pmc_traffic(kern, args)
+            if t and group_ms[stage]:
+                gbs = t / (group_ms[stage] * 1e-3) / 1e9
+                hbm_bound[kern] = {"traffic_bytes_per_launch": int(t), "ms": round(group_ms[stage], 4), "achieved_GBs": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                   "frac_of_measured_copy_ceiling": None if not ceiling else round(gbs / 1e3 / ceiling["copy"], 4)}
         # FP32-VALU view of the same two kernels (SURVEY 8d "algorithmic flops": 60 fwd + 200 bwd per tested pair).  K7 walks
         # exactly the (entry, quadrant) pairs K6 recorded, so one set of counters serves both.
         lane_tests = blend_counts["quadrant_tests"] * 64
@@ -487,6 +516,7 @@ def main():
                          "algorithmic_bytes_per_launch": ab[dominant], "algorithmic_bytes_per_launch_D_eff": ab_eff[dominant],
                          "avg_launch_ms": round(group_ms[dominant], 4),
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "measured_streaming_ceiling": ceiling, "hbm_bound_kernels": hbm_bound,
                          "note": "HBM fraction as BASELINE.json defines it; the blend kernels are instruction-issue / latency-bound, not HBM-bound (valu.issue_roof, DESIGN.md 4)",
                          "north_star_blend_fwd_bwd": {"algorithmic_bytes": ab["blend_fwd"] + ab["blend_bwd"], "ms": round(blend_ms, 4),
                                                       "achieved": None if blend_gbs is None else round(blend_gbs, 2),
