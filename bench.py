@@ -102,9 +102,16 @@ def profiled(kind, args):
         d = json.load(open(files[-1]))
         rel = os.path.relpath(files[-1], ROOT)
         # which build the counters were taken from: PMC passes cannot run inside the timed run, so this is a QUOTE of a committed
-        # profile of the same command -- round and HEAD of that profile are part of the citation
-        return d["kernels"], {"file": rel, "round": d.get("round", os.path.basename(rel).split("_")[0]), "head": d.get("head"),
-                              "quoted": "committed rocprofv3 counter pass of the same bench.py command, not measured in this run"}
+        # profile of the same command -- round, HEAD and source digest of that profile are part of the citation.  A profile of OTHER
+        # kernel sources is not quoted at all: csrc/, include/ or the build flags changed since (streetunveiler_amd.build.source_digest)
+        from streetunveiler_amd.build import source_digest
+        now = source_digest()
+        src = {"file": rel, "round": d.get("round", os.path.basename(rel).split("_")[0]), "head": d.get("head"), "source_digest": d.get("source_digest"),
+               "quoted": "committed rocprofv3 counter pass of the same bench.py command, not measured in this run"}
+        if d.get("source_digest") != now:
+            src["stale"] = f"the kernels' sources changed since this profile was taken (digest now {now}): counters not quoted -- re-run tools/profile_round.sh"
+            return None, src
+        return d["kernels"], src
     except Exception:
         return None, None
 
@@ -136,7 +143,7 @@ def pmc_traffic(kernel, args):
     try:
         return d["sr::" + kernel]["traffic_bytes_per_launch"], src
     except Exception:
-        return None, None
+        return None, src if src and "stale" in src else None
 
 
 # Per-instruction issue costs FITTED to a micro-benchmark (tools/ubench/valu_issue_ubench.hip, >= 2 waves per SIMD,
@@ -197,17 +204,19 @@ def valu_issue_roof(kernel, ms, args, entries_with_record=0):
                            "profiles/r02_valu_issue_ubench.txt), NOT a speed-of-light figure"})
         return out
     except Exception:
-        return None
+        return {"source": src} if src and "stale" in src else None
 
 
 def cpu_baseline(args, g, cam, dc, da):
     """The CPU oracle (a port: the reference has no CPU rasterizer) timed on a bounded sub-sample of the
     same scene, forward + backward, OpenMP over all host threads."""
     from oracle import surfel_oracle as so
+    native = so.use_native_build()   # -O3 -march=native, compiled on THIS machine (BASELINE.md 3); False: no compiler here, the portable -O3 build
     threads = so.num_threads()
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
               campos=cam.camera_center.numpy(), bg=np.zeros(3, np.float32), image_width=args.width,
-              image_height=args.height, sh_degree=args.sh_degree)
+              image_height=args.height, sh_degree=args.sh_degree,
+              tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     best = None
     spent = 0.0
     for n in (25_000, 100_000, 400_000, 1_600_000, args.gaussians):
@@ -225,7 +234,19 @@ def cpu_baseline(args, g, cam, dc, da):
     n, dt, D = best
     return {"value": n / dt / 1e6, "unit": "Msplats/s", "cores": threads, "kind": "port",
             "sample": (f"oracle/surfel_oracle.c fwd+bwd, " + ("the whole scene" if n == args.gaussians else f"first {n} Gaussians of the same scene")
-                       + f" at {args.width}x{args.height} (D={D}), {dt:.1f} s wall, OpenMP {threads} threads")}
+                       + f" at {args.width}x{args.height} (D={D}), {dt:.1f} s wall, OpenMP {threads} threads, gcc -O3 "
+                       + ("-march=native built on this host" if native else "(portable x86-64 build: no compiler on this host)")),
+            "cpu_model": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def train_step_section(args, params, cam, dev):
@@ -492,6 +513,14 @@ def main():
         ab_eff = {"blend_fwd": d_eff * 76 + npx * 60, "blend_bwd": d_eff * 76 + d_eff * 72 * 2 + npx * (60 + 40)}
         frac_eff = ab_eff[dominant] / (group_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS if group_ms[dominant] else None
         blend_frac_eff = (ab_eff["blend_fwd"] + ab_eff["blend_bwd"]) / (blend_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if blend_ms else None
+        # counter traffic of BOTH blend kernels against the algorithmic bytes -- the D-based figure of SURVEY 8(d) and the one computed on
+        # the entries the kernels actually stage (D_eff): the second is the honest "how many bytes per byte needed" ratio
+        traffic_ratios = {}
+        for stage, kern in (("blend_fwd", "render_forward_kernel"), ("blend_bwd", "render_backward_kernel")):
+            t, _ = pmc_traffic(kern, args)
+            if t:
+                traffic_ratios[kern] = {"traffic_bytes_per_launch": int(t), "traffic_over_D_bytes": round(t / ab[stage], 3),
+                                        "traffic_over_D_eff_bytes": round(t / ab_eff[stage], 3)}
         out = {
             "metric": f"Msplats/s fwd+bwd @{W}x{H}, {P / 1e6:g}M Gaussians", "value": round(value, 3), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -516,6 +545,7 @@ def main():
                          "algorithmic_bytes_per_launch": ab[dominant], "algorithmic_bytes_per_launch_D_eff": ab_eff[dominant],
                          "avg_launch_ms": round(group_ms[dominant], 4),
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_D_eff_bytes": traffic_ratios.get(dom_kernel, {}).get("traffic_over_D_eff_bytes"), "blend_traffic_ratios": traffic_ratios,
                          "measured_streaming_ceiling": ceiling, "hbm_bound_kernels": hbm_bound,
                          "note": "HBM fraction as BASELINE.json defines it; the blend kernels are instruction-issue / latency-bound, not HBM-bound (valu.issue_roof, DESIGN.md 4)",
                          "north_star_blend_fwd_bwd": {"algorithmic_bytes": ab["blend_fwd"] + ab["blend_bwd"], "ms": round(blend_ms, 4),

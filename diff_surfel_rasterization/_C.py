@@ -45,14 +45,15 @@ def _stream(device):
 
 
 def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile=None,
-           quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=None):
+           quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=None, forward_only=False):
     keep = [_f32c(bg, "bg"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos"), blend_counters]
     if blend_counters is not None and (blend_counters.dtype != torch.int64 or blend_counters.numel() < 16 or not blend_counters.is_cuda):
         raise L.SurfelRasterError("blend_counters must be a CUDA (ROCm) int64 tensor with 16 entries")
     fr = L.SrFrame(int(H), int(W), float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree),
                    int(bool(prefiltered)), int(bool(debug)), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
                    int(tile[0]) if tile else 0, int(tile[1]) if tile else 0, (0 if quadrant_cull else L.SR_FLAG_NO_QUADRANT_CULL) | (L.SR_FLAG_BALLOT_RANKING if ballot_ranking else 0) |
-                   (0 if row_mapped is None else (L.SR_FLAG_ROW_MAPPED_FORWARD if row_mapped else L.SR_FLAG_QUADRANT_MAPPED_FORWARD)),
+                   (0 if row_mapped is None else (L.SR_FLAG_ROW_MAPPED_FORWARD if row_mapped else L.SR_FLAG_QUADRANT_MAPPED_FORWARD)) |
+                   (L.SR_FLAG_FORWARD_ONLY if forward_only else 0),
                    _ptr(blend_counters))
     return fr, keep
 
@@ -94,8 +95,12 @@ def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transM
 def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, activations=0, tile=None, mask=None, quadrant_cull=True, blend_counters=None,
-                        ballot_ranking=False, row_mapped=None):
-    """`tile` = (width, height) of the binning tile, default the reference's 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
+                        ballot_ranking=False, row_mapped=None, forward_only=False):
+    """`forward_only=True` (SR_FLAG_FORWARD_ONLY): no backward will follow -- what the reference's inference callers do under
+    torch.no_grad() [REF /root/reference/render.py:68; utils/mesh_utils.py:82-100].  color / allmap / radii are bit-identical; the state
+    only a backward reads is not written (imgBuffer comes back empty, the SH direction Jacobian and the hit masks stay unwritten), so the
+    returned buffers must not be handed to rasterize_gaussians_backward.
+    `tile` = (width, height) of the binning tile, default the reference's 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
     16x16, 32x8, 32x16); the backward must be given the same shape.  `quadrant_cull=False` / `blend_counters` (int64[16], device):
     per-call SrFrame.flags / SrFrame.blend_counters (tests and profiling; results are identical).  `ballot_ranking=True`
     (SR_FLAG_BALLOT_RANKING): the binning of this call ranks with match-any ballots, the fallback of the LDS-atomic ranking.
@@ -112,7 +117,7 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
     P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
     with torch.cuda.device(dev):
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile,
-                          quadrant_cull, blend_counters, ballot_ranking, row_mapped)
+                          quadrant_cull, blend_counters, ballot_ranking, row_mapped, forward_only)
         mask = _mask(mask, P, dev)
         g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations, mask)
         if keep[0].numel() != g.color_channels:
@@ -121,7 +126,7 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
         allmap = torch.empty((7, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         geom = torch.empty((lib.sr_geom_bytes(P),), dtype=torch.uint8, device=dev)
-        img = torch.empty((lib.sr_image_bytes(W, H),), dtype=torch.uint8, device=dev)
+        img = torch.empty((0 if forward_only else lib.sr_image_bytes(W, H),), dtype=torch.uint8, device=dev)
         stream = _stream(dev)
         D = C.c_uint32(0)
         L.check(lib.sr_forward_plan(C.byref(fr), C.byref(g), _ptr(geom), geom.numel(), _ptr(radii), C.byref(D), stream),

@@ -44,14 +44,19 @@ def _cpu_snapshot(args):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                         activations=0, tile=None, mask=None, probe=None):
+    # Will this call be backpropagated?  Decided HERE, on the caller's thread: inside an autograd.Function's forward grad mode is always off
+    # and ctx.needs_input_grad ignores torch.no_grad().  The inference callers of the operator all run under no_grad
+    # [REF /root/reference/render.py:68; /root/reference/utils/mesh_utils.py:82-100]: the forward then skips the state only a backward reads.
+    forward_only = not (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in
+                                                        (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)))
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, activations, tile, mask, probe)
+                                     raster_settings, activations, tile, mask, probe, forward_only)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                activations=0, tile=None, mask=None, probe=None):
+                activations=0, tile=None, mask=None, probe=None, forward_only=False):
         s = raster_settings
         ctx.activations = int(activations)
         ctx.tile = tuple(int(t) for t in tile) if tile else None
@@ -62,6 +67,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             fused["mask"] = mask
         if probe:              # tests / profiling: {"quadrant_cull": bool, "blend_counters": int64[16] device tensor, "ballot_ranking": bool}
             fused.update(probe)
+        if forward_only:       # SR_FLAG_FORWARD_ONLY: no backward will follow -- images bit-identical, backward state not written
+            fused["forward_only"] = True
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
                 s.debug)
@@ -82,7 +89,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         # `factored_sh_exchange` block rides on this node -- the backward runs on autograd's thread and consults no global state.
         # (Only when the SHs are the sole colour source: the 9-channel pass keeps its SH gradient local, as _C does.)
         from streetunveiler_amd.parallel import active_sh_exchange
-        ctx.sh_exchange = active_sh_exchange() if sh.numel() and not colors_precomp.numel() else None
+        # ... and only for a call that WILL be backpropagated: a no_grad / eval render inside the block must not draw a frame number (it
+        # would shift the frame -> camera pairing of the calls that follow it)
+        ctx.sh_exchange = active_sh_exchange() if sh.numel() and not colors_precomp.numel() and not forward_only else None
         # which of the step's frames this call is (row of all_campos[rank]): drawn now, in forward order -- autograd may run the backward
         # nodes of several frames in any order (one summed loss: reverse creation order)
         ctx.sh_frame = ctx.sh_exchange.attach() if ctx.sh_exchange is not None and hasattr(ctx.sh_exchange, "attach") else None
@@ -130,7 +139,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         none_if_empty = lambda g, ref: g if ref.numel() else None
         return (grad_means3D, grad_means2D, none_if_empty(grad_sh, sh), none_if_empty(grad_colors_precomp, colors_precomp),
                 grad_opacities, none_if_empty(grad_scales, scales), none_if_empty(grad_rotations, rotations),
-                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None, None, None)
+                none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None, None, None, None)
 
 
 class _ClassDistortions(torch.autograd.Function):

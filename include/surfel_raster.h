@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 8
+#define SR_ABI_VERSION 9
 #define SR_TILE 16            /* default 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y); see SrFrame.tile_width */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
 #define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
@@ -77,8 +77,8 @@ typedef struct SrFrame {
     const float* projmatrix;  /* device [16] = full_proj_transform ((P*W2C)^T), row-major */
     const float* campos;      /* device [3] */
     int32_t tile_width;       /* 0 = 16 (the reference's BLOCK_X); BASELINE config 5 sweeps 8x8, 16x8, 16x16, 32x8, 32x16.  The 6- and
-                               * 9-channel passes (SrGaussians.color_channels) exist for every shape but 32x16, the per-class pass and the
-                               * counter variant for 16x16 only */
+                               * 9-channel passes (SrGaussians.color_channels) and the per-class pass exist for every shape but 32x16, the
+                               * counter variant (blend_counters) for 16x16 only */
     int32_t tile_height;      /* 0 = 16 (BLOCK_Y).  Same shape in every call that shares the state buffers */
     uint32_t flags;           /* SR_FLAG_* bits; per call, nothing about a call is process-wide state */
     uint64_t* blend_counters; /* NULL, or device [16] u64 owned by the caller: selects the COUNTING variant of the forward blend (same
@@ -107,6 +107,14 @@ typedef struct SrFrame {
                                       * -3 % at 1920x1080 / 3 M, -11 % at 1280x720), quadrants above (+10 % for the rows at 3840x2160):
                                       * DESIGN.md 4.  The flags exist for the A/B and the test.  SR_FLAG_ROW_MAPPED_FORWARD with any other
                                       * tile shape / channel count / blend_counters / SR_FLAG_NO_QUADRANT_CULL: SR_ERR_UNSUPPORTED */
+
+#define SR_FLAG_FORWARD_ONLY 16u      /* no backward will follow this forward (the reference's inference callers run the operator under
+                                      * torch.no_grad(): /root/reference/render.py:68, /root/reference/utils/mesh_utils.py:82-100): K1 does not
+                                      * compute or write the 36-B/Gaussian SH direction Jacobian, K6 does not write the backward's state
+                                      * (final_T / M1 / M2, last and median contributor: 20 B/pixel; the 2-B/duplicate hit masks).  Set in
+                                      * BOTH sr_forward_plan and sr_forward_render; `image` may then be NULL / 0 bytes.  out_color, out_allmap
+                                      * and radii are bit-identical to the training forward (a test requires it); calling a backward on the
+                                      * state of such a forward is undefined */
 
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
  * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp
@@ -206,6 +214,12 @@ int sr_backward(const SrFrame* frame, const SrGaussians* g, const int32_t* radii
                 void* binning, size_t binning_bytes, void* image, size_t image_bytes, uint32_t num_rendered,
                 const float* dL_dcolor, const float* dL_dallmap, void* workspace, size_t workspace_bytes,
                 const SrGradients* grads, void* stream);
+
+/* CONTRACT of every backward entry point (sr_backward, sr_backward_geometry, sr_class_backward): `frame` and the geometry inputs of `g`
+ * (means3D, scales, rotations or transMat_precomp, activations, mask) must be BIT-IDENTICAL to those of the forward that filled the state
+ * buffers.  K8 does not read Tu / Tv / Tw / the centre back from the 80-B record: it recomputes them from these inputs (the same device
+ * functions as K1, hence the same bits) -- with other values the reference centre of K7's moment flush and K8's chain would silently
+ * disagree.  The autograd shim saves and passes the forward's own tensors. */
 
 /* The same backward in two halves, for callers that want to start a gradient exchange in between:
  *   sr_backward_blend     K7: per-(tile, Gaussian) gradient records into `workspace`;

@@ -49,24 +49,28 @@
 #define SR_PROXY_DEPTH_VIEW_Z 0
 #endif
 
-/* Image size inside the per-Gaussian backward (viewport of the dL/dT chain, and the proxy above): the operator's image_width /
- * image_height (0), or upstream's int(focal * tanfov * 2) with focal = size / (2 tanfov) in float32 (1) -- which truncates to
- * size - 1 for some (size, fov) pairs.  Appendix A.6 / DESIGN.md 3. */
+/* Image size inside the per-Gaussian backward (viewport of the dL/dT chain, and the proxy above): upstream's
+ * int(focal * tanfov * 2) with focal = size / (2 tanfov), all in float32 (1, upstream: for some (size, fov) pairs the product lands
+ * just below the integer and truncates to size - 1 -- the proxy gradient that drives densification is then scaled by (W - 1) / W),
+ * or the operator's image_width / image_height (0: what exact arithmetic gives).  Appendix A.6 / DESIGN.md 3. */
 #ifndef SR_BACKWARD_WH_FROM_FOCAL
-#define SR_BACKWARD_WH_FROM_FOCAL 0
+#define SR_BACKWARD_WH_FROM_FOCAL 1
 #endif
 
-/* Upstream's per-pair `if (p.z == 0) continue` in the forward and backward blend (1), or this build's rule (0): a pair whose p.z
- * vanishes is blended through its 2-D filter footprint like in exact arithmetic (rho3d = inf), and a splat whose p.z vanishes at
- * EVERY pixel (a zero scale) contributes nowhere.  Which healthy pairs land on exactly 0 in float32 depends on the operation order
- * (INTEGRATION.md "Differences"); with 1 the test is evaluated on this build's own cross product.  Appendix A.4. */
+/* Upstream's per-pair `if (p.z == 0) continue` in the forward and backward blend (1, upstream: Appendix A.4), or (0) the
+ * exact-arithmetic rule: a pair whose p.z vanishes is blended through its 2-D filter footprint (rho3d = inf), and a splat whose p.z
+ * vanishes at EVERY pixel (a zero scale) contributes nowhere.  For a healthy splat p.z == 0 is rounding noise of the cross product
+ * -- which pairs land on exactly 0 in float32 depends on the operation order, so with 1 the kernels evaluate the test on their own
+ * staged cross product and the oracle on k x l (the margin walk of the oracle flags every pair within that noise as non-robust;
+ * profiles/r05_parity_c3.json counts them).  Appendix A.4 / INTEGRATION.md "Differences". */
 #ifndef SR_REFERENCE_PZ_SKIP
-#define SR_REFERENCE_PZ_SKIP 0
+#define SR_REFERENCE_PZ_SKIP 1
 #endif
 
-/* one bit per switch that is NOT at its default: what sr_build_switches() / so_build_switches() return */
+/* one bit per switch that is NOT at its default; every default is upstream's behaviour as SURVEY.md Appendix A states it, so
+ * sr_build_switches() == 0 / so_build_switches() == 0 reads "upstream semantics" */
 #define SR_SWITCH_BITS ((SR_TIGHTBBOX ? 1u : 0u) | (SR_DETACH_WEIGHT ? 2u : 0u) | (SR_RADIUS_FILTER_FLOOR ? 0u : 4u) | \
                         (SR_MEDIAN_CONTRIBUTOR_MINUS_ONE ? 0u : 8u) | (SR_PROXY_DEPTH_VIEW_Z ? 16u : 0u) | \
-                        (SR_BACKWARD_WH_FROM_FOCAL ? 32u : 0u) | (SR_REFERENCE_PZ_SKIP ? 64u : 0u))
+                        (SR_BACKWARD_WH_FROM_FOCAL ? 0u : 32u) | (SR_REFERENCE_PZ_SKIP ? 0u : 64u))
 
 #endif /* SURFEL_SWITCHES_H */

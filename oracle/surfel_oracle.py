@@ -21,21 +21,56 @@ from typing import Dict, Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SURFEL_ORACLE_LIB: the oracle compiled with a non-default named switch (include/surfel_switches.h; streetunveiler_amd/build.py --variant)
+# SURFEL_ORACLE_LIB: the oracle compiled with a non-default named switch (include/surfel_switches.h; build_variant() below)
 _LIB_PATH = os.environ.get("SURFEL_ORACLE_LIB") or os.path.join(_HERE, "libsurfel_oracle.so")
 _lib = None
 
 TILE = 16
 
 
+_SOURCES = ("surfel_oracle.c", "surfel_blend.inc", "surfel_k8.inc", "knn_oracle.c", "../include/surfel_switches.h")
+
+
+def _make(out: str, defines=(), force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in _SOURCES + ("Makefile",)]
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in srcs):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        r = subprocess.run(["make", "-C", _HERE, "-B", "OUT=" + out, "CFLAGS_EXTRA=" + " ".join(defines)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    return out
+
+
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (idempotent)."""
     if os.environ.get("SURFEL_ORACLE_LIB"):
-        return _LIB_PATH   # a variant: built by streetunveiler_amd/build.py --variant
-    srcs = [os.path.join(_HERE, f) for f in ("surfel_oracle.c", "surfel_blend.inc", "surfel_k8.inc", "knn_oracle.c", "../include/surfel_switches.h")]
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libsurfel_oracle.so"], stdout=subprocess.DEVNULL)
-    return _LIB_PATH
+        return _LIB_PATH   # a variant: built by build_variant()
+    return _make(_LIB_PATH, force=force)
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(_HERE, "variants", name, "libsurfel_oracle.so")
+
+
+def build_variant(name: str, force: bool = False) -> str:
+    """The oracle with one named switch of include/surfel_switches.h flipped (the same -D as the kernels' variant of that name:
+    streetunveiler_amd.build.VARIANTS) -> oracle/variants/<name>/libsurfel_oracle.so.  Selected with SURFEL_ORACLE_LIB=<path>."""
+    from streetunveiler_amd.build import VARIANTS
+    return _make(variant_path(name), VARIANTS[name], force)
+
+
+def use_native_build() -> bool:
+    """bench.py's cpu_baseline leg: switch this process to oracle/_native/libsurfel_oracle.so, compiled here and now with -O3 -march=native
+    (make native: BASELINE.md 3's flags; the default build must stay portable because it travels to the GPU box as a file).  Call before the
+    first use of the library.  False (and the portable build stays) if it cannot be compiled on this machine."""
+    global _LIB_PATH, _lib
+    assert _lib is None, "use_native_build() must come before the first oracle call of the process"
+    r = subprocess.run(["make", "-C", _HERE, "-B", "native"], capture_output=True, text=True)
+    out = os.path.join(_HERE, "_native", "libsurfel_oracle.so")
+    if r.returncode != 0 or not os.path.exists(out):
+        return False
+    _LIB_PATH = out
+    return True
 
 
 def lib():
@@ -160,7 +195,7 @@ def rasterize_forward(means3D, opacities, scales=None, rotations=None, shs=None,
                         colors_precomp=colors_precomp, transMat_precomp=transMat_precomp, view=view, proj=proj,
                         cam=cam, bg=bgc, W=W, H=H, deg=int(sh_degree), M=M, scale_modifier=float(scale_modifier),
                         vals_buf=vals_buf, tile=(int(tile[0]), int(tile[1])), forced=(fv, fu), f64=bool(f64),
-                        tanfov=(tanfovx, tanfovy))   # only read by a SR_BACKWARD_WH_FROM_FOCAL build
+                        tanfov=(tanfovx, tanfovy))   # K8's image size (SR_BACKWARD_WH_FROM_FOCAL, the default)
     return o
 
 
@@ -171,8 +206,9 @@ def rasterize_backward(fwd: Dict[str, np.ndarray], dL_dcolor, dL_dallmap) -> Dic
     L.so_set_tile(*i["tile"])
     if i.get("tanfov", (None, None))[0] is not None:
         L.so_set_tanfov(float(i["tanfov"][0]), float(i["tanfov"][1]))
-    elif build_switches() & 32:
-        raise ValueError("this oracle was built with SR_BACKWARD_WH_FROM_FOCAL=1: pass tanfovx / tanfovy to rasterize_forward")
+    elif not (build_switches() & 32):
+        raise ValueError("upstream's backward derives the image size from int(focal * tanfov * 2) (SR_BACKWARD_WH_FROM_FOCAL=1, the default): "
+                         "pass the operator's tanfovx / tanfovy to rasterize_forward")
     dL_dcolor = _f32(dL_dcolor).reshape(3, H, W); dL_dallmap = _f32(dL_dallmap).reshape(7, H, W)
     f64 = i.get("f64", False)
     rt, ct = (np.float64, C.c_double) if f64 else (np.float32, C.c_float)
@@ -249,6 +285,20 @@ def render_margins(fwd: Dict[str, np.ndarray], eps: Optional[Dict[str, float]] =
     if dis is not None:
         out["disagree"] = dis
     return out
+
+
+def pz_zero_census(fwd: Dict[str, np.ndarray], n_contrib=None) -> Dict[str, int]:
+    """Upstream's per-pair `if (p.z == 0) continue` on a forward's lists (so_pz_zero_census): how many (pixel, splat) pairs have a float32
+    (k x l).z of exactly 0 up to each pixel's last contributor, how many of them would be visible through their 2-D filter footprint, the
+    pixels holding one, and the pairs of identically-degenerate splats.  `n_contrib` = another implementation's [2,H,W] (default: this forward's)."""
+    i = fwd["_inputs"]; W, H = i["W"], i["H"]
+    L = lib(); L.so_set_tile(*i["tile"])
+    nc = np.ascontiguousarray(fwd["n_contrib"] if n_contrib is None else n_contrib, dtype=np.uint32).reshape(2, H, W)
+    out = np.zeros(4, np.uint64)
+    L.so_pz_zero_census(W, H, _p(fwd["ranges"], C.c_uint32), _p(i["vals_buf"], C.c_uint32), _p(fwd["means2D"]), _p(fwd["transMat"]),
+                        _p(fwd["normal_opacity"]), _p(nc, C.c_uint32), _p(out, C.c_uint64))
+    return dict(pairs_with_pz_exactly_zero=int(out[0]), of_them_visible_through_the_2d_footprint=int(out[1]), pixels_holding_one=int(out[2]),
+                pairs_of_identically_degenerate_splats=int(out[3]))
 
 
 def mark_visible(means3D, viewmatrix) -> np.ndarray:

@@ -17,7 +17,8 @@ SR_FLAG_NO_QUADRANT_CULL = 1
 SR_FLAG_BALLOT_RANKING = 2
 SR_FLAG_ROW_MAPPED_FORWARD = 4
 SR_FLAG_QUADRANT_MAPPED_FORWARD = 8
-SR_ABI_VERSION = 8
+SR_FLAG_FORWARD_ONLY = 16
+SR_ABI_VERSION = 9
 SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "expand_x", "expand_y", "ranges", "blend_fwd", "blend_bwd",
                   "preprocess_bwd"]
 
@@ -135,11 +136,12 @@ def load():
 
 # include/surfel_switches.h: bit -> the switch that is NOT at its default in a library reporting that bit (sr_build_switches)
 SWITCH_BITS = {1: "SR_TIGHTBBOX=1", 2: "SR_DETACH_WEIGHT=1", 4: "SR_RADIUS_FILTER_FLOOR=0", 8: "SR_MEDIAN_CONTRIBUTOR_MINUS_ONE=0",
-               16: "SR_PROXY_DEPTH_VIEW_Z=1", 32: "SR_BACKWARD_WH_FROM_FOCAL=1", 64: "SR_REFERENCE_PZ_SKIP=1"}
+               16: "SR_PROXY_DEPTH_VIEW_Z=1", 32: "SR_BACKWARD_WH_FROM_FOCAL=0", 64: "SR_REFERENCE_PZ_SKIP=0"}
 
 
 def build_switches():
-    """Non-default named switches of the loaded library, e.g. ['SR_DETACH_WEIGHT=1']; [] for the shipped configuration."""
+    """Non-default named switches of the loaded library, e.g. ['SR_DETACH_WEIGHT=1']; [] for the shipped configuration (= upstream's
+    semantics as SURVEY.md Appendix A states them)."""
     bits = int(load().sr_build_switches())
     return [name for bit, name in SWITCH_BITS.items() if bits & bit]
 

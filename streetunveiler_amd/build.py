@@ -40,17 +40,33 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "blend_common.h"),
            os.path.join(os.path.dirname(HERE), "include", "surfel_switches.h")]
 
 # The named switches of include/surfel_switches.h at their non-default values (SURVEY.md Appendix A's (!) items): each is a complete
-# build of kernels AND oracle with the same -D, in lib/variants/<name>/ (libsurfel_raster.so + libsurfel_oracle.so); a maintainer
-# holding the real CUDA fork ships the one that matches it (SURFEL_RASTER_LIB=...), tests/test_gpu_switches.py checks every one of them.
+# build of the kernels with that -D in lib/variants/<name>/libsurfel_raster.so; a maintainer holding the real CUDA fork ships the one
+# that matches it (SURFEL_RASTER_LIB=...).  The CPU oracle of the same switch is test infrastructure and lives under oracle/variants/
+# (oracle.surfel_oracle.build_variant); tests/test_gpu_switches.py builds both on demand and checks every one of them.
 VARIANTS = {
     "tightbbox": ["-DSR_TIGHTBBOX=1"],
     "detach_weight": ["-DSR_DETACH_WEIGHT=1"],
     "no_radius_floor": ["-DSR_RADIUS_FILTER_FLOOR=0"],
     "median_plain_index": ["-DSR_MEDIAN_CONTRIBUTOR_MINUS_ONE=0"],
     "proxy_view_depth": ["-DSR_PROXY_DEPTH_VIEW_Z=1"],
-    "backward_wh_from_focal": ["-DSR_BACKWARD_WH_FROM_FOCAL=1"],
-    "reference_pz_skip": ["-DSR_REFERENCE_PZ_SKIP=1"],
+    "backward_wh_from_size": ["-DSR_BACKWARD_WH_FROM_FOCAL=0"],      # the exact image size instead of upstream's int(focal * tanfov * 2)
+    "pz_zero_through_filter": ["-DSR_REFERENCE_PZ_SKIP=0"],          # the exact-arithmetic rule instead of upstream's per-pair p.z == 0 skip
 }
+
+
+def source_digest() -> str:
+    """sha256 over everything that determines the shipped kernels: csrc/*, include/*.h and this script (flags).  tools/collect_profiles.py
+    stores it with every rocprofv3 summary; bench.py quotes a committed counter profile only if the digest still matches (there is no
+    .git on the GPU box, so the check is on content, not on commits)."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + \
+        sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")) + [os.path.abspath(__file__)]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _stale(target: str, deps) -> bool:
@@ -64,19 +80,9 @@ def variant_dir(name: str) -> str:
     return os.path.join(LIBDIR, "variants", name)
 
 
-def build_variant(name: str, force: bool = False, verbose: bool = False):
-    """Kernels + oracle with one named switch flipped -> (libsurfel_raster.so, libsurfel_oracle.so) in lib/variants/<name>/."""
-    defines = VARIANTS[name]
-    d = variant_dir(name)
-    lib = build(force, verbose, libdir=d, defines=defines)
-    oracle_dir = os.path.join(os.path.dirname(HERE), "oracle")
-    out = os.path.join(d, "libsurfel_oracle.so")
-    srcs = [os.path.join(oracle_dir, f) for f in ("surfel_oracle.c", "surfel_blend.inc", "surfel_k8.inc", "knn_oracle.c")] + [HEADERS[-1]]
-    if force or _stale(out, srcs):
-        r = subprocess.run(["make", "-C", oracle_dir, "-B", "OUT=" + out, "CFLAGS_EXTRA=" + " ".join(defines)], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("oracle variant build failed:\n" + r.stdout + r.stderr)
-    return lib, out
+def build_variant(name: str, force: bool = False, verbose: bool = False) -> str:
+    """The kernels with one named switch flipped -> lib/variants/<name>/libsurfel_raster.so."""
+    return build(force, verbose, libdir=variant_dir(name), defines=VARIANTS[name])
 
 
 def build(force: bool = False, verbose: bool = False, libdir: str = LIBDIR, defines=()) -> str:
@@ -97,7 +103,7 @@ def build(force: bool = False, verbose: bool = False, libdir: str = LIBDIR, defi
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         return r
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=max(4, (os.cpu_count() or 4))) as ex:
         list(ex.map(run, jobs))
     lib = os.path.join(libdir, "libsurfel_raster.so")
     if force or jobs or _stale(lib, objs):
@@ -109,6 +115,6 @@ if __name__ == "__main__":
     if "--variant" in sys.argv:
         which = sys.argv[sys.argv.index("--variant") + 1]
         for name in (sorted(VARIANTS) if which == "all" else [which]):
-            print(name, *build_variant(name, force="--force" in sys.argv, verbose=True))
+            print(name, build_variant(name, force="--force" in sys.argv, verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

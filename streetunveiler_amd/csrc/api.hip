@@ -376,7 +376,7 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
     hipStream_t s = static_cast<hipStream_t>(stream);
     FrameDev f = make_frame(frame, g);
-    f.sh_jac = at<float>(geom, L.sh_jac);
+    f.sh_jac = (frame->flags & SR_FLAG_FORWARD_ONLY) ? nullptr : at<float>(geom, L.sh_jac);   // (forward only: K8, its one reader, will not run)
     {
         StageTimer t(SR_STAGE_PREPROCESS, s);
         SR_HIP(launch_preprocess_forward(P, f, *g, at<float4>(geom, L.recs), at<uint32_t>(geom, L.depth_keys),
@@ -496,12 +496,14 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
                       size_t binning_bytes, void* image, size_t image_bytes, uint32_t D, float* out_color,
                       float* out_allmap, void* stream) {
     if (int rc = check_common(frame, g)) return rc;
-    if (!binning || !image || !out_color || !out_allmap) return fail(SR_ERR_INVALID_ARGUMENT, "binning / image / out_color / out_allmap is NULL");
+    const bool fwd_only = (frame->flags & SR_FLAG_FORWARD_ONLY) != 0;   // no backward follows: its state (image buffer, hit masks) is not written
+    if (!binning || (!image && !fwd_only) || !out_color || !out_allmap) return fail(SR_ERR_INVALID_ARGUMENT, "binning / image / out_color / out_allmap is NULL");
     const int W = frame->image_width, H = frame->image_height;
     const BinLayout B = bin_layout(D, W, H);
     const ImgLayout I = img_layout(W, H);
     if (binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, B.total);
-    if (image_bytes < I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, I.total);
+    if (!fwd_only && image_bytes < I.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "image buffer %zu < %zu", image_bytes, I.total);
+    if (fwd_only && frame->blend_counters) return fail(SR_ERR_UNSUPPORTED, "SR_FLAG_FORWARD_ONLY and blend_counters exclude each other");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const FrameDev f = make_frame(frame, g);
     if (frame->blend_counters && !(f.tile_w == 16 && f.tile_h == 16 && (f.colors == 3 || f.colors == 6)))
@@ -517,7 +519,8 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
         const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0) | (rows ? 4 : 0) | (quads ? 8 : 0);
         const GeomLayout GL = geom_layout(g->P);   // (D and the visible count, left in the geometry state by the emission scan)
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
-                                     out_allmap, at<float>(image, I.final_T), at<uint32_t>(image, I.n_contrib), at<uint16_t>(binning, B.hit_mask), flags,
+                                     out_allmap, fwd_only ? nullptr : at<float>(image, I.final_T), fwd_only ? nullptr : at<uint32_t>(image, I.n_contrib),
+                                     fwd_only ? nullptr : at<uint16_t>(binning, B.hit_mask), flags,
                                      reinterpret_cast<unsigned long long*>(frame->blend_counters), at<uint32_t>(geom, GL.block_base) + GL.n_scan_blocks, s));
     }
     return debug_sync(frame, s, "render_forward");

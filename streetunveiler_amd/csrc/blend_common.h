@@ -226,14 +226,16 @@ __device__ __forceinline__ bool intersect(float xl, float yl, const float4 e0, c
     h.alpha = fminf(kAlphaCap, e3.z * h.G);
     // (the reference also skips on `power > 0`: never true -- rho3d and rho2d are sums of squares, fminf drops a NaN operand, and a NaN
     // power fails that test as well -- so the comparison is not evaluated here)
-    // The reference's `if (p.z == 0) continue` is not evaluated per pair either (splats whose p.z vanishes identically -- a zero scale --
-    // are dropped at staging: stage_entry).  For a healthy splat p.z = 0 means the pixel's ray is parallel to the splat's plane:
-    // a set of measure zero in exact arithmetic, and in float32 a coin toss among the pairs whose p.z is pure rounding noise -- which of
-    // them land on exactly 0 depends on the operation order, so the staged cross products here and the reference's cross(k, l) skip
-    // DIFFERENT pairs.  (Found by the fuzz sweep: a pixel 2 000 contributors deep lost a contribution of alpha 0.044 that float64 and the
-    // float32 oracle both blend.)  With ppz = 0, rcp gives inf, rho3d is inf or NaN, the comparison above takes the screen-space
-    // path and fminf drops rho3d: the pair is blended through its 2-D filter footprint, exactly what exact arithmetic does with the
-    // astronomically large rho3d of a nearly parallel ray.  sx, sy, pz_inv are only read on the ray-splat path.
+    // The reference's `if (p.z == 0) continue` (Appendix A.4; SR_REFERENCE_PZ_SKIP = 1, the shipped value) is evaluated on the staged cross
+    // product p.z = x A.z + y B.z + C.z.  For a healthy splat p.z == 0 means the pixel's ray is parallel to the splat's plane: a set of
+    // measure zero in exact arithmetic, and in float32 a coin toss among the pairs whose p.z is pure rounding noise -- which of them land on
+    // exactly 0 depends on the operation order, so this expression and the reference's cross(k, l).z can skip DIFFERENT pairs of that
+    // noise set (the oracle's margin walk classifies them; profiles/r05_parity_c3.json counts them).  A splat whose p.z vanishes
+    // identically (a zero scale) has three exact-zero coefficients and is skipped everywhere, here as there.
+    // SR_REFERENCE_PZ_SKIP = 0 (variant pz_zero_through_filter) is the exact-arithmetic rule instead: with ppz = 0, rcp gives inf, rho3d is
+    // inf or NaN, the comparison above takes the screen-space path and fminf drops rho3d -- the pair is blended through its 2-D filter
+    // footprint, what exact arithmetic does with the astronomically large rho3d of a nearly parallel ray (identically-zero splats are
+    // dropped at staging: stage_entry).  sx, sy, pz_inv are only read on the ray-splat path.
 #if SR_REFERENCE_PZ_SKIP
     return !(h.depth < kNear) & !(h.alpha < kAlphaFloor) & !(ppz == 0.f);   // upstream's per-pair `if (p.z == 0) continue`, on THIS cross product
 #else

@@ -440,9 +440,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
                     } else {
                         float J[9];
                         sh_to_rgb(f.sh_degree, shs + (size_t)i * f.sh_coeffs * 3, dx, dy, dz, rgb, out_clamped);
-                        sh_dir_jacobian(f.sh_degree, shs + (size_t)i * f.sh_coeffs * 3, dx, dy, dz, len, J);
+                        if (f.sh_jac) {   // (NULL with SR_FLAG_FORWARD_ONLY: K8 is the only reader)
+                            sh_dir_jacobian(f.sh_degree, shs + (size_t)i * f.sh_coeffs * 3, dx, dy, dz, len, J);
 #pragma unroll
-                        for (int k = 0; k < 9; ++k) f.sh_jac[9 * (size_t)i + k] = J[k];
+                            for (int k = 0; k < 9; ++k) f.sh_jac[9 * (size_t)i + k] = J[k];
+                        }
                     }
                 }
                 out_radius = (int32_t)radius;
@@ -460,9 +462,10 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     if (kLdsSH) {
         const float* row = s_sh + tid * kShHalfStride;
         float res[3] = {0.f, 0.f, 0.f}, dd[9];
+        const bool want_jac = f.sh_jac != nullptr;   // (NULL with SR_FLAG_FORWARD_ONLY: K8 is the only reader of the 36-B rows)
         if (need_sh) {
             sh_to_rgb_lo(f.sh_degree, row, sdx, sdy, sdz, res);
-            sh_dir_jacobian_lo(f.sh_degree, row, sdx, sdy, sdz, dd);
+            if (want_jac) sh_dir_jacobian_lo(f.sh_degree, row, sdx, sdy, sdz, dd);
         }
         __syncthreads();   // every thread is done with the first halves
         sh_half_store(s_sh, tid, half_b);
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
         if (need_sh) {
             float rgb[3];
             sh_to_rgb_hi(f.sh_degree, row, sdx, sdy, sdz, res, rgb, out_clamped);
-            sh_dir_jacobian_hi(f.sh_degree, row, sdx, sdy, sdz, slen, dd, J);
+            if (want_jac) sh_dir_jacobian_hi(f.sh_degree, row, sdx, sdy, sdz, slen, dd, J);
             q3.w = rgb[0];
             q4 = make_float4(rgb[1], rgb[2], q4.z, sradius);
         }
@@ -483,18 +486,22 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
         float* s_jac = s_sh + kPreBlock * kRecFloats;
         s_rec[tid * kRecQuads + 0] = q0; s_rec[tid * kRecQuads + 1] = q1; s_rec[tid * kRecQuads + 2] = q2; s_rec[tid * kRecQuads + 3] = q3;
         s_rec[tid * kRecQuads + 4] = q4;
+        if (want_jac) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) s_jac[tid * 9 + k] = J[k];   // (stride 9 words: conflict-free)
+            for (int k = 0; k < 9; ++k) s_jac[tid * 9 + k] = J[k];   // (stride 9 words: conflict-free)
+        }
         __syncthreads();
         {
             const int nrows = min(kPreBlock, P - base);
             float4* dst = recs + (size_t)base * kRecQuads;
             for (int fq = tid; fq < nrows * kRecQuads; fq += kPreBlock) dst[fq] = s_rec[fq];
             // 9 floats per row: rows * 9 floats are 16-B aligned per block of 128 rows (128 * 36 B) -- whole float4 chunks, plus a scalar tail
-            float* jd = f.sh_jac + (size_t)base * 9;
-            const int nf = nrows * 9, nq = nf / 4;
-            for (int fq = tid; fq < nq; fq += kPreBlock) reinterpret_cast<float4*>(jd)[fq] = reinterpret_cast<const float4*>(s_jac)[fq];
-            for (int fk = nq * 4 + tid; fk < nf; fk += kPreBlock) jd[fk] = s_jac[fk];
+            if (want_jac) {
+                float* jd = f.sh_jac + (size_t)base * 9;
+                const int nf = nrows * 9, nq = nf / 4;
+                for (int fq = tid; fq < nq; fq += kPreBlock) reinterpret_cast<float4*>(jd)[fq] = reinterpret_cast<const float4*>(s_jac)[fq];
+                for (int fk = nq * 4 + tid; fk < nf; fk += kPreBlock) jd[fk] = s_jac[fk];
+            }
         }
         if (!in_range) return;
         radii[i] = out_radius; tiles_touched[i] = out_tiles; rect[i] = out_rect; depth_keys[i] = out_key; clamped[i] = out_clamped;

@@ -205,7 +205,7 @@ __device__ __forceinline__ void render_forward_body(float4 (*s_e)[kWave], const 
             if (lane == 0) { atomicAdd(&g_stats[12], kept); atomicAdd(&g_stats[13], steps); }
         }
         // exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel here
-        if ((uint32_t)lane < n) {
+        if (hit_mask && (uint32_t)lane < n) {   // (NULL with SR_FLAG_FORWARD_ONLY: no backward will read it)
             uint32_t hm = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
@@ -226,8 +226,10 @@ __device__ __forceinline__ void render_forward_body(float4 (*s_e)[kWave], const 
         if (px < f.W && py < f.H) {
             const size_t pix = (size_t)py * f.W + px;
             const float Tq = fabsf(T[q]);
-            final_T[pix] = Tq; final_T[HW + pix] = M1[q]; final_T[2 * HW + pix] = M2[q];
-            n_contrib[pix] = lastc[q]; n_contrib[HW + pix] = medc[q];
+            if (final_T) {   // the backward's per-pixel state (NULL with SR_FLAG_FORWARD_ONLY)
+                final_T[pix] = Tq; final_T[HW + pix] = M1[q]; final_T[2 * HW + pix] = M2[q];
+                n_contrib[pix] = lastc[q]; n_contrib[HW + pix] = medc[q];
+            }
             out_color[pix] = C0[q] + Tq * bg0;
             out_color[HW + pix] = C1[q] + Tq * bg1;
             out_color[2 * HW + pix] = C2[q] + Tq * bg2;
@@ -365,7 +367,7 @@ __device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], u
                 if (ballot64(T[q] > 0.f) == 0ull) { alive &= ~(1u << q); break; }
             }
         }
-        if ((uint32_t)lane < n) {
+        if (hit_mask && (uint32_t)lane < n) {
             uint32_t hm = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) hm |= (uint32_t)s_hit[q][lane] << q;
@@ -385,8 +387,10 @@ __device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], u
         if (px < f.W && py < f.H) {
             const size_t pix = (size_t)py * f.W + px;
             const float Tq = fabsf(T[q]);
-            final_T[pix] = Tq; final_T[HW + pix] = M1[q]; final_T[2 * HW + pix] = M2[q];
-            n_contrib[pix] = lastc[q]; n_contrib[HW + pix] = medc[q];
+            if (final_T) {   // the backward's per-pixel state (NULL with SR_FLAG_FORWARD_ONLY)
+                final_T[pix] = Tq; final_T[HW + pix] = M1[q]; final_T[2 * HW + pix] = M2[q];
+                n_contrib[pix] = lastc[q]; n_contrib[HW + pix] = medc[q];
+            }
             out_color[pix] = C0[q] + Tq * bg0;
             out_color[HW + pix] = C1[q] + Tq * bg1;
             out_color[2 * HW + pix] = C2[q] + Tq * bg2;

@@ -20,12 +20,15 @@ from __future__ import annotations
 import contextlib
 import contextvars
 import os
+import weakref
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 _BUCKET_INPLACE_BYTES = 32 << 20  # tensors at least this large are all-reduced in place
+# replicated camera lists (the tensor OBJECTS, weakly held, with the version they were checked at) already compared with the cameras actually rendered
+_CAMERA_LISTS_CHECKED = weakref.WeakKeyDictionary()
 
 
 def _exchange_wanted(group=None) -> bool:
@@ -97,19 +100,55 @@ def allreduce_gradients(grads: Sequence[torch.Tensor], group=None, average: bool
     handles = []
     for g in sorted(large, key=lambda t: -t.numel()):  # largest first so the long transfer starts immediately
         handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
-    if small:
-        flat = torch.cat([g.reshape(-1) for g in small])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for g in small:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
-    for h in handles:
-        h.wait()
+    with STALLS.waiting(bool(grads) and grads[0].is_cuda):
+        if small:
+            flat = torch.cat([g.reshape(-1) for g in small])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            off = 0
+            for g in small:
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                off += n
+        for h in handles:
+            h.wait()
     if average:
         for g in grads:
             g.div_(world)
+
+
+class StallClock:
+    """Event pairs on the CURRENT (compute) stream around the points where it waits for a collective.  With RCCL `work.wait()` only makes the
+    compute stream depend on the communication stream (the host returns at once), so host wall clocks see nothing; the distance between
+    an event recorded just before the wait and one recorded just after it is the time the compute stream stood still for communication --
+    the EXPOSED part of the exchange (with gloo, where wait() blocks the host, the same pair spans the idle gap).  bench.py reads
+    `drain_ms()` after a synchronize; two event records cost ~10 us of stream time per wait point.  Off unless `enabled` is set."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False   # a diagnostic: whoever switches it on (bench.py) must drain it, or the pairs pile up over a training run
+
+    @contextlib.contextmanager
+    def waiting(self, enabled: bool = True):
+        if not (self.enabled and enabled and torch.cuda.is_available()):
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        try:
+            yield
+        finally:
+            b.record()
+            self.pairs.append((a, b))
+
+    def drain_ms(self) -> float:
+        """Sum of the recorded stalls (ms) and forget them; call after torch.cuda.synchronize()."""
+        total = sum(a.elapsed_time(b) for a, b in self.pairs)
+        self.pairs = []
+        return float(total)
+
+
+# process-wide clock of the compute-stream stalls caused by this module's collectives (bench.py: exposed exchange time per step)
+STALLS = StallClock()
 
 
 class ShExchange:
@@ -163,11 +202,16 @@ class ShExchange:
         if self.all_campos is not None:      # every rank knows the camera list: [world, 3] or [world, frames_per_rank, 3]
             cams = self.all_campos.to(device=device, dtype=torch.float32).reshape(world, K, 3)
             # the replicated list must agree with the cameras the frames were rendered with (row j = the j-th FORWARD of the step)
-            rank = dist.get_rank(self.group)
-            mine = torch.stack([f[2] for f in frames]).to(device=device, dtype=torch.float32)
-            if not torch.allclose(cams[rank], mine, rtol=1e-5, atol=1e-6):
-                raise RuntimeError("factored_sh_exchange: all_campos[rank] does not list this rank's cameras in the order of its forward "
-                                   "calls (row j must be the camera of the j-th rasterizer call inside the block)")
+            # (checked the first time a given camera list is used, and with SURFEL_EXCHANGE_DEBUG=1 on every step: the comparison reads
+            # device memory back -- a host sync inside the backward, on the path where K8 is meant to overlap the all-gather)
+            version = getattr(self.all_campos, "_version", 0)
+            if _CAMERA_LISTS_CHECKED.get(self.all_campos) != version or os.environ.get("SURFEL_EXCHANGE_DEBUG") == "1":
+                rank = dist.get_rank(self.group)
+                mine = torch.stack([f[2] for f in frames]).detach().to(device="cpu", dtype=torch.float32)
+                if not torch.allclose(cams[rank].detach().cpu(), mine, rtol=1e-5, atol=1e-6):
+                    raise RuntimeError("factored_sh_exchange: all_campos[rank] does not list this rank's cameras in the order of its forward "
+                                       "calls (row j must be the camera of the j-th rasterizer call inside the block)")
+                _CAMERA_LISTS_CHECKED[self.all_campos] = version
             return cams.transpose(0, 1).reshape(K * world, 3).contiguous()
         mine = torch.stack([f[2] for f in frames]).to(device=device, dtype=torch.float32).reshape(K * 3).contiguous()
         cams = torch.empty(world * K * 3, dtype=torch.float32, device=device)
@@ -210,8 +254,9 @@ class ShExchange:
             pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.bytes_sent += t.numel() * t.element_size()
         t0 = time.perf_counter()
-        for _, hh, _ in frames:
-            hh.wait()
+        with STALLS.waiting(gc.is_cuda):
+            for _, hh, _ in frames:
+                hh.wait()
         self.exchange_ms += (time.perf_counter() - t0) * 1e3
         self.calls += 1
         gathered = (frames[0][0] if len(frames) == 1 else torch.cat([f[0] for f in frames])).view((len(frames) * world,) + tuple(gc.shape))
@@ -221,8 +266,9 @@ class ShExchange:
             expand = _C.sh_gradient_expand
         out = expand(means3D.detach(), cams, gathered, sh_coeffs, degree)
         t0 = time.perf_counter()
-        for w in pending:
-            w.wait()
+        with STALLS.waiting(gc.is_cuda and bool(pending)):
+            for w in pending:
+                w.wait()
         self.exchange_ms += (time.perf_counter() - t0) * 1e3
         return out
 

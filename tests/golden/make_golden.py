@@ -8,6 +8,7 @@ repo.  G3/G4 freeze the CPU oracle's per-stage outputs on small seeded scenes
 (regression pins for the oracle itself; gradients there are cross-checked
 against float64 autograd when the fixture is made).
 """
+import math
 import os
 import sys
 
@@ -75,7 +76,7 @@ def g3_g4_from_oracle():
     fwd = so.rasterize_forward(g["means3D"].numpy(), g["opacities"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
                                shs=g["shs"].numpy(), viewmatrix=cam.world_view_transform.numpy(),
                                projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(), bg=bg,
-                               image_width=W, image_height=H, sh_degree=3)
+                               image_width=W, image_height=H, sh_degree=3, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     dc, da = synthetic_upstream_grads(W, H)
     grads = so.rasterize_backward(fwd, dc.numpy(), da.numpy())
     _, g64 = forward_backward64(fwd, dc.numpy(), da.numpy())
@@ -102,7 +103,7 @@ def g3_g4_from_oracle():
     fwd = so.rasterize_forward(g["means3D"].numpy(), g["opacities"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
                                shs=g["shs"].numpy(), viewmatrix=cam.world_view_transform.numpy(),
                                projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
-                               bg=np.zeros(3, np.float32), image_width=W, image_height=H, sh_degree=0)
+                               bg=np.zeros(3, np.float32), image_width=W, image_height=H, sh_degree=0, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     np.savez_compressed(
         os.path.join(HERE, "c1_checksums.npz"),
         num_rendered=np.array(fwd["num_rendered"]), radii_sum=np.array(fwd["radii"].astype(np.int64).sum()),

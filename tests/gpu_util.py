@@ -20,7 +20,7 @@ def settings_for(cam, bg, deg, debug=False, dev=DEV):
 def run_oracle(g, cam, bg, deg, dc=None, da=None, mode="sh", colors=None, Tpre=None, tile=(16, 16)):
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
               campos=cam.camera_center.numpy(), bg=np.asarray(bg, np.float32), image_width=cam.image_width,
-              image_height=cam.image_height, sh_degree=deg, tile=tile)
+              image_height=cam.image_height, sh_degree=deg, tile=tile, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     n = lambda k: g[k].numpy()
     if Tpre is not None:
         fwd = so.rasterize_forward(n("means3D"), n("opacities"), shs=n("shs") if colors is None else None,
@@ -139,7 +139,7 @@ def forced_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=No
     forced = dict(valid=raw["decisions"]["valid"], use3d=raw["decisions"]["use3d"], n_contrib=raw["img"]["n_contrib"].view(np.uint32))
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
               bg=np.asarray(bg, np.float32), image_width=cam.image_width, image_height=cam.image_height, sh_degree=deg, tile=tile or (16, 16),
-              forced=forced, f64=bool(f64), reuse=base)
+              forced=forced, f64=bool(f64), reuse=base, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     n = lambda k: g[k].numpy()
     if colors is not None:
         fwd = so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), colors_precomp=colors, **kw)
@@ -167,7 +167,9 @@ def k8_term_magnitudes(g, cam, dT):
     on the float64 transMat gradient dT [P,9] (rows Tu | Tv | Tw).  dL_dscales = R^T (B^T dT) has up to 800x cancellation between
     those terms on the benchmark scenes (profiles/r03_parity_c3.json), so a float32 rounding of the INPUT sums -- either
     implementation's -- shows up in these two tensors amplified by that factor; K8's own float32 arithmetic does not (float32 K8 on
-    exact sums: p99.9 2e-6).  Rows of these two tensors are therefore measured against this magnitude.  -> (scales[P], rotations[P])."""
+    exact sums: p99.9 2e-6).  Rows of these two tensors are therefore measured against this magnitude; so are the rows of dL_dmeans3D, whose
+    three components are sums of the same kind (no cancellation to speak of under the unrotated benchmark camera, some under a rotated one:
+    the worst of 2.5 M rows of C4's camera 7 sits at 1.1e-2 of its own magnitude).  -> (scales[P], rotations[P], means3D[P])."""
     W, H = cam.image_width, cam.image_height
     proj = cam.full_proj_transform.numpy().astype(np.float64).reshape(16)
     B = np.zeros((3, 4))
@@ -184,7 +186,10 @@ def k8_term_magnitudes(g, cam, dT):
     s = g["scales"].numpy().astype(np.float64)
     dscale = np.maximum((dL0 * Ra[:, :, 0]).sum(1), (dL1 * Ra[:, :, 1]).sum(1))
     drot = 2.0 * np.abs(q).max(1) * (dL0 * s[:, :1] + dL1 * s[:, 1:2]).sum(1)   # (the normal column of dL/dR is not a cancellation source)
-    return dscale, drot
+    # dL_dmeans3D[k] = sum_r B[r][k] dT[r][2] (+ the SH direction term): three products per component under the unrotated benchmark camera
+    # (B is then sparse), nine cancelling ones once the view matrix carries a rotation (BASELINE config 4's yawed cameras)
+    dmean = np.einsum("rk,pr->pk", Ba, dTa[:, :, 2]).max(1)
+    return dscale, drot, dmean
 
 
 def gradient_row_errors(hip, bwd64, vis, scene=None):
@@ -194,8 +199,8 @@ def gradient_row_errors(hip, bwd64, vis, scene=None):
     out = {}
     mags = None
     if scene is not None and "dL_dtransMat64" in bwd64 and "scales" in scene[0]:
-        ms, mr = k8_term_magnitudes(scene[0], scene[1], bwd64["dL_dtransMat64"])
-        mags = {"dL_dscales": ms, "dL_drotations": mr}
+        ms, mr, mm = k8_term_magnitudes(scene[0], scene[1], bwd64["dL_dtransMat64"])
+        mags = {"dL_dscales": ms, "dL_drotations": mr, "dL_dmeans3D": mm}
     for key in STRICT_ROW_BARS:
         ref = bwd64.get(key + "64", bwd64.get(key))
         if key not in hip or hip[key] is None or ref is None:
@@ -279,7 +284,7 @@ def free_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None
     pairs whose contribute / path decision in the kernels differs from the checker's own (assert_free_parity demands 0 at robust pixels)."""
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
               bg=np.asarray(bg, np.float32), image_width=cam.image_width, image_height=cam.image_height, sh_degree=deg, tile=tile or (16, 16),
-              f64=True, reuse=base)
+              f64=True, reuse=base, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     n = lambda k: g[k].numpy()
     if colors is not None:
         fwd = so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), colors_precomp=colors, **kw)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 W, H = 1920, 1080
 
 
-def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, report=None):
+def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, report=None, camera_index=None):
     """One BASELINE configuration in full against the CPU oracle [REF gaussian_renderer/__init__.py:129-165: the operator call and the
     meaning of its outputs]:
       1. integers bit-exact: D, radii, the sorted duplicate list, the tile ranges (the float32 oracle's 64-bit stable sort);
@@ -26,7 +26,7 @@ def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, repo
          Gaussian, the non-robust remainder counted against its measured fraction (tests/gpu_util.py assert_free_parity)."""
     from tests.gpu_util import (assert_close_frac, assert_free_parity, assert_grads_close, assert_strict_parity, check_allmap,
                                 forced_f64_reference, free_f64_reference, run_hip, run_hip_raw, run_oracle)
-    cam = synthetic_camera(W, H)
+    cam = synthetic_camera(W, H, index=camera_index)   # (None: the unrotated camera; k: camera k of the 8-camera batch, yawed (k - 3.5) * 5 degrees)
     g = synthetic_gaussians(P, W, H, seed=0) if scene is None else scene(P, W, H)
     bg = np.zeros(3, np.float32)
     dc, da = synthetic_upstream_grads(W, H, seed=1, aux=aux)
@@ -93,6 +93,23 @@ def test_c3_3m_against_oracle():
     """BASELINE config 3 -- the configuration the metric is quoted on: 3 M Gaussians, 1920x1080, all seven aux-map gradients live.
     The oracle needs ~12 s per free-running pass on the GPU box's host (128 threads) and ~3 s per forced pass."""
     _against_oracle(3_000_000, True, "C3", pixel_budget=8e-3, gaussian_budget=0.25)
+
+
+@pytest.mark.parametrize("k", [0, 7])
+def test_c4_3m_yawed_cameras_against_oracle(k):
+    """BASELINE config 4's per-GPU workload at full size: the C3 scene (3 M Gaussians, 1920x1080, all aux gradients) through camera k of
+    the 8-camera batch -- the two outermost ones, yawed -17.5 and +17.5 degrees (rank k renders camera k: streetunveiler_amd/parallel.py).
+    A rotated view matrix exercises what the unrotated C3 camera cannot: every term of the world->view rotation in K1 / K8, splats
+    leaving the frustum on one side only, tile lists that thin out across the frame.  The same four-way check as C3: bit-exact lists,
+    the float32 oracle, the strict float64 bar on the kernels' own decisions, the free-running float64 reference.  (The exchange of
+    the 8 per-camera gradients is covered by the gloo / one-rank RCCL tests; the rendering of each frame is what this pins.)"""
+    import json, os
+    rep = {}
+    try:
+        _against_oracle(3_000_000, True, f"C4 camera {k}", pixel_budget=8e-3, gaussian_budget=0.25, camera_index=k, report=rep)
+    finally:
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(rep, open(f"gpurun_out/c4_camera{k}_parity.json", "w"), indent=1, default=float)
 
 
 def test_clustered_street_scene_against_oracle():

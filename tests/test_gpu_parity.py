@@ -2,6 +2,7 @@
 
 Bars (BASELINE.json north_star): integer / index outputs bit-exact (radii, tiles_touched, depth keys, sorted
 (tile, depth, id) lists, tile ranges, contributor counts up to threshold flips); float outputs within 1e-4."""
+import math
 import os
 
 import numpy as np
@@ -352,7 +353,8 @@ def test_sh_layout_fallbacks_and_scale_modifier():
         shs_cpu = g["shs"][:, :M].contiguous()
         fwd = so.rasterize_forward(g["means3D"].numpy(), g["opacities"].numpy(), g["scales"].numpy(), g["rotations"].numpy(), shs=shs_cpu.numpy(),
                                    viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
-                                   campos=cam.camera_center.numpy(), bg=bg, image_width=W, image_height=H, sh_degree=deg, scale_modifier=modifier)
+                                   campos=cam.camera_center.numpy(), bg=bg, image_width=W, image_height=H, sh_degree=deg, scale_modifier=modifier,
+                                   tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
         bwd = so.rasterize_backward(fwd, dc.numpy(), da.numpy())
         if misalign:   # a view that starts 4 bytes into its storage: contiguous but not 16-byte aligned
             buf = torch.zeros(P * M * 3 + 1, device=DEV)
@@ -763,3 +765,51 @@ def test_wide_frame_with_few_gaussians_and_counter_variant_errors():
     assert counters[0] > 0 and counters[7] <= counters[1] and counters[9] <= counters[8] <= counters[10]
     with pytest.raises(_lib.SurfelRasterError, match="blend_counters"):
         GaussianRasterizer(s, tile=(32, 16), blend_counters=counters)(**kw)
+
+
+def test_forward_only_mode_is_bit_identical_and_writes_no_backward_state():
+    """SR_FLAG_FORWARD_ONLY: the reference's inference callers run the operator under torch.no_grad() [REF /root/reference/render.py:68;
+    /root/reference/utils/mesh_utils.py:82-100] -- the shim then tells the library that no backward follows.  color / allmap / radii are
+    bit-identical to the training forward (3 channels with SHs and with precomputed colours, 6 / 9 channels, both forward mappings, a second
+    tile shape); the image state comes back empty; a call with grad enabled is NOT forward-only and still backpropagates."""
+    from diff_surfel_rasterization import GaussianRasterizer, _C
+    from tests.gpu_util import DEV, settings_for
+    W, H, P = 330, 200, 30_000
+    cam, g = _scene(P, W, H, 21, 1e-3, 2e-2, cam_index=2)
+    d = {k: v.to(DEV) for k, v in g.items()}
+    e = torch.empty(0, device=DEV)
+    s = settings_for(cam, [0.1, 0.3, 0.2], 3)
+    cols6 = torch.rand(P, 6, generator=torch.Generator().manual_seed(3)).to(DEV)
+    bg6 = torch.rand(6, generator=torch.Generator().manual_seed(4)).to(DEV)
+    cases = [dict(sh=d["shs"], col=e, bg=s.bg, kw={}), dict(sh=e, col=cols6[:, :3].contiguous(), bg=s.bg, kw={}),
+             dict(sh=e, col=cols6, bg=bg6, kw={}), dict(sh=d["shs"], col=cols6, bg=torch.cat([s.bg, bg6]), kw={}),
+             dict(sh=d["shs"], col=e, bg=s.bg, kw=dict(row_mapped=True)), dict(sh=d["shs"], col=e, bg=s.bg, kw=dict(row_mapped=False)),
+             dict(sh=d["shs"], col=e, bg=s.bg, kw=dict(tile=(32, 16))), dict(sh=d["shs"], col=e, bg=s.bg, kw=dict(tile=(8, 8)))]
+    for c in cases:
+        run = lambda fo: _C.rasterize_gaussians(c["bg"], d["means3D"], c["col"], d["opacities"], d["scales"], d["rotations"], 1.0, e, s.viewmatrix, s.projmatrix,
+                                                s.tanfovx, s.tanfovy, H, W, c["sh"], 3, s.campos, False, False, forward_only=fo, **c["kw"])
+        D0, color0, allmap0, radii0, _, _, img0 = run(False)
+        D1, color1, allmap1, radii1, _, _, img1 = run(True)
+        assert D0 == D1 and D0 > 50_000
+        assert torch.equal(color0, color1) and torch.equal(allmap0, allmap1) and torch.equal(radii0, radii1), c["kw"]
+        assert img1.numel() == 0 and img0.numel() > 0
+    # through the operator: no_grad -> forward-only; grad mode with a leaf that requires grad -> the training forward
+    seen = []
+    real = _C.rasterize_gaussians
+    spy = lambda *a, **k: (seen.append(bool(k.get("forward_only"))), real(*a, **k))[1]
+    _C.rasterize_gaussians = spy
+    try:
+        t = {k: v.clone().requires_grad_() for k, v in d.items()}
+        m2d = torch.zeros(P, 3, device=DEV, requires_grad=True)
+        call = lambda: GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+        with torch.no_grad():
+            c_ng, _, a_ng = call()
+        c_g, _, a_g = call()
+        c_det, _, _ = GaussianRasterizer(s)(means3D=d["means3D"], means2D=torch.zeros(P, 3, device=DEV), shs=d["shs"], opacities=d["opacities"],
+                                            scales=d["scales"], rotations=d["rotations"])   # grad mode on, but nothing requires grad
+    finally:
+        _C.rasterize_gaussians = real
+    assert seen == [True, False, True]
+    assert torch.equal(c_ng, c_g.detach()) and torch.equal(a_ng, a_g.detach()) and torch.equal(c_det, c_ng)
+    (c_g.sum() + a_g.sum()).backward()
+    assert t["means3D"].grad is not None and torch.isfinite(t["means3D"].grad).all() and t["shs"].grad.abs().sum() > 0

@@ -1,5 +1,6 @@
 """GPU (-m gpu): the reference's operator surface (render / render_with_mask / render_semantic[_with_mask],
 SURVEY 8a rows A1-A4) on top of the HIP rasterizer, end to end against the CPU oracle."""
+import math
 import os
 
 import numpy as np
@@ -30,7 +31,7 @@ def _oracle(g, cam, bg, deg, idx=None, colors=None):
     sel = (lambda a: a) if idx is None else (lambda a: a[idx])
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
               campos=cam.camera_center.numpy(), bg=np.asarray(bg, np.float32), image_width=cam.image_width,
-              image_height=cam.image_height, sh_degree=deg)
+              image_height=cam.image_height, sh_degree=deg, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     n = lambda k: sel(g[k].numpy())
     if colors is None:
         return so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), shs=n("shs"), **kw)

@@ -1,7 +1,8 @@
-"""The named compile-time switches of include/surfel_switches.h (SURVEY.md Appendix A's (!) items): every non-default value is BUILT
-(kernels and oracle with the same -D: streetunveiler_amd/build.py VARIANTS) and checked -- kernels against oracle under that value
-(tests/switch_worker.py, one process per build: SURFEL_RASTER_LIB / SURFEL_ORACLE_LIB), and against the shipped build to show that the
-switch does what its name says."""
+"""The named compile-time switches of include/surfel_switches.h (SURVEY.md Appendix A's (!) items).  The shipped build has every switch
+at upstream's value (sr_build_switches() == 0); every non-default value is BUILT on demand (kernels: streetunveiler_amd.build
+build_variant -> lib/variants/<name>/; oracle with the same -D: oracle.surfel_oracle.build_variant -> oracle/variants/<name>/) and
+checked -- kernels against oracle under that value (tests/switch_worker.py, one process per build: SURFEL_RASTER_LIB /
+SURFEL_ORACLE_LIB), and against the shipped build to show that the switch does what its name says."""
 import os
 import subprocess
 import sys
@@ -14,7 +15,7 @@ sys.path.insert(0, ROOT)
 from streetunveiler_amd import build as sb  # noqa: E402
 
 BITS = {"default": 0, "tightbbox": 1, "detach_weight": 2, "no_radius_floor": 4, "median_plain_index": 8, "proxy_view_depth": 16,
-        "backward_wh_from_focal": 32, "reference_pz_skip": 64}
+        "backward_wh_from_size": 32, "pz_zero_through_filter": 64}
 
 
 def test_switch_list_is_shared_by_kernels_and_oracle():
@@ -35,10 +36,12 @@ def _run(name, tmp_path):
     env = dict(os.environ)
     env.pop("SURFEL_RASTER_LIB", None); env.pop("SURFEL_ORACLE_LIB", None)
     if name != "default":
-        d = sb.variant_dir(name)
-        lib, oracle = os.path.join(d, "libsurfel_raster.so"), os.path.join(d, "libsurfel_oracle.so")
-        if not (os.path.exists(lib) and os.path.exists(oracle)):   # (built by __graft_entry__.build(); hipcc is on the GPU box too)
-            lib, oracle = sb.build_variant(name)
+        from oracle import surfel_oracle as so
+        lib, oracle = os.path.join(sb.variant_dir(name), "libsurfel_raster.so"), so.variant_path(name)
+        if not os.path.exists(lib):      # (pre-built here by `python -m streetunveiler_amd.build --variant all`; hipcc is on the GPU box too)
+            lib = sb.build_variant(name)
+        if not os.path.exists(oracle):
+            oracle = so.build_variant(name)
         env.update(SURFEL_RASTER_LIB=lib, SURFEL_ORACLE_LIB=oracle)
     out = os.path.join(str(tmp_path), name + ".npz")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_worker.py"), str(BITS[name]), out], cwd=ROOT, env=env,
@@ -77,14 +80,15 @@ def test_switch_variant_against_its_oracle_and_against_the_shipped_build(name, s
         big = np.abs(d["B_dL_dmeans2D"]) > 1e-3 * np.abs(d["B_dL_dmeans2D"]).max()
         np.testing.assert_allclose(d["B_dL_dmeans2D"][big], 2.0 * v["B_dL_dmeans2D"][big], rtol=1e-4)
         np.testing.assert_allclose(v["A_dL_dmeans2D"], d["A_dL_dmeans2D"], rtol=1e-4, atol=1e-6 * np.abs(d["A_dL_dmeans2D"]).max())   # reference projection: Tw.z == view z up to rounding
-    elif name == "backward_wh_from_focal":
+    elif name == "backward_wh_from_size":   # scene C: an image size upstream's int(focal * tanfov * 2) truncates to W - 1 (the SHIPPED build does that)
         assert v["C_found"] and d["C_found"], "no image size in the searched range truncates: widen the search in switch_worker.py"
         Wc = int(v["C_size"][0])
-        big = np.abs(d["C_dL_dmeans2D"][:, 0]) > 1e-3 * np.abs(d["C_dL_dmeans2D"][:, 0]).max()
-        np.testing.assert_allclose(v["C_dL_dmeans2D"][big, 0] / d["C_dL_dmeans2D"][big, 0], (Wc - 1) / Wc, rtol=1e-5)   # the proxy's W / 2 factor
+        big = np.abs(v["C_dL_dmeans2D"][:, 0]) > 1e-3 * np.abs(v["C_dL_dmeans2D"][:, 0]).max()
+        np.testing.assert_allclose(d["C_dL_dmeans2D"][big, 0] / v["C_dL_dmeans2D"][big, 0], (Wc - 1) / Wc, rtol=1e-5)   # the proxy's W / 2 factor
         assert _differs(v["C_dL_dmeans3D"], d["C_dL_dmeans3D"], rel=1e-5) and same_forward()
-    elif name == "reference_pz_skip":  # scene D: at pixel column 16 the big splat's p.z is exactly 0 -- upstream skips the pair there
+    elif name == "pz_zero_through_filter":  # scene D: at pixel column 16 the big splat's p.z is exactly 0 -- the SHIPPED build skips the pair there, like upstream
         col_d, col_v = d["D_color"][:, :, 16], v["D_color"][:, :, 16]
+        # (the shipped build leaves that column to the background and the small splats; the variant blends the big splat through its 2-D footprint)
         assert _differs(col_v, col_d, rel=1e-2), "the p.z == 0 column renders the same with and without the per-pair skip"
         others = [x for x in range(33) if x != 16]
         assert np.array_equal(v["D_color"][:, :, others], d["D_color"][:, :, others]) and same_forward()

@@ -6,9 +6,11 @@ polynomial and the matrix conventions.  G3/G4 are regression pins of the
 oracle (the rasterizer itself is "parity unpinned": its native source is an
 un-vendored submodule of the reference).
 """
+import math
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import surfel_oracle as so
@@ -64,7 +66,9 @@ def test_camera_matches_reference_recipe(golden_dir):
 def test_oracle_small_scene_regression(golden_dir):
     z = np.load(os.path.join(golden_dir, "oracle_small.npz"))
     g = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
-    fwd = _fwd(g, dict(view=g["view"], proj=g["proj"], campos=g["campos"]), 32, 32, 3, g["bg"])
+    cam = synthetic_camera(32, 32, index=2)   # (the fixture's camera: tests/golden/make_golden.py g3_g4_from_oracle)
+    fwd = _fwd(g, dict(view=g["view"], proj=g["proj"], campos=g["campos"]), 32, 32, 3, g["bg"],
+               tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     for k in ["radii", "tiles_touched", "rect", "keys", "point_list", "ranges", "n_contrib", "clamped"]:
         np.testing.assert_array_equal(fwd[k], z[f"fwd_{k}"], err_msg=k)   # integer outputs: bit-exact
     assert fwd["num_rendered"] == int(z["fwd_num_rendered"])
@@ -109,7 +113,7 @@ def test_analytic_backward_matches_float64_autograd_variants():
         g = {k: v.numpy() for k, v in synthetic_gaussians(P, W, H, seed=P, scale_lo=lo, scale_hi=hi).items()}
         kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
                   campos=cam.camera_center.numpy(), bg=np.array([0.2, 0.5, 0.9], np.float32), image_width=W,
-                  image_height=H, sh_degree=deg)
+                  image_height=H, sh_degree=deg, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
         if mode == "sh":
             fwd = so.rasterize_forward(g["means3D"], g["opacities"], g["scales"], g["rotations"], shs=g["shs"], **kw)
         elif mode == "color":
@@ -195,3 +199,51 @@ def test_quaternion_and_scaling_rotation_match_reference(golden_dir):
     # inverse_sigmoid [REF utils/general_utils.py:21-22] is the inverse of the opacity activation the operator fuses (SR_ACT_SIGMOID_OPACITY)
     x = torch.tensor(z["g7_inverse_sigmoid_out"])
     np.testing.assert_allclose(torch.sigmoid(x).numpy(), z["g7_inverse_sigmoid_in"], rtol=1e-6, atol=1e-7)
+
+
+_ASAN_SCRIPT = r"""
+import math, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import surfel_oracle as so, knn_oracle
+from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
+assert so._LIB_PATH.endswith("_asan/libsurfel_oracle.so"), so._LIB_PATH
+for (P, W, H, deg, tile) in [(300, 50, 37, 3, (16, 16)), (200, 33, 20, 1, (8, 8)), (0, 16, 16, 0, (16, 16)), (40, 70, 18, 2, (32, 16))]:
+    cam = synthetic_camera(W, H, index=5)
+    g = {k: v.numpy() for k, v in synthetic_gaussians(max(P, 1), W, H, seed=P, scale_lo=0.01, scale_hi=0.2).items()}
+    g = {k: v[:P] for k, v in g.items()}
+    kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
+              bg=np.array([0.2, 0.5, 0.9], np.float32), image_width=W, image_height=H, sh_degree=deg, tile=tile,
+              tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
+    fwd = so.rasterize_forward(g["means3D"], g["opacities"], g["scales"], g["rotations"], shs=g["shs"], **kw)
+    dc, da = synthetic_upstream_grads(W, H, seed=3)
+    so.rasterize_backward(fwd, dc.numpy(), da.numpy())
+    x = so.rasterize_forward(g["means3D"], g["opacities"], g["scales"], g["rotations"], shs=g["shs"], f64=True, reuse=fwd, **kw)
+    so.rasterize_backward(x, dc.numpy(), da.numpy())
+    so.render_margins(fwd); so.render_margins(x, f64=True); so.pz_zero_census(fwd)
+    if P:
+        pre = so.rasterize_forward(g["means3D"], g["opacities"], colors_precomp=np.ones((P, 3), np.float32), transMat_precomp=fwd["transMat"], **kw)
+        so.rasterize_backward(pre, dc.numpy(), da.numpy())
+        so.mark_visible(g["means3D"], kw["viewmatrix"])
+pts = np.random.default_rng(0).standard_normal((257, 3)).astype(np.float32)
+knn_oracle.knn_mean_dist2(pts); knn_oracle.knn_mean_dist2(pts[:40], K=3, reference=pts, take_sqrt=True)
+print("asan walk OK")
+"""
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """SURVEY.md 5 (race / memory checking of the checker itself): the C oracle compiled with -fsanitize=address,undefined (make -C oracle
+    asan; single-threaded) walks every entry point -- K1, binning, K6/K7/K8 in float32 and float64, margins, the p.z census, precomputed
+    transMat, ragged images, an empty scene, three tile shapes, the kNN oracle -- in a fresh interpreter with libasan preloaded; any
+    out-of-bounds access or undefined operation aborts that process."""
+    import shutil, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not shutil.which("gcc") or not os.path.isabs(libasan):
+        pytest.skip("no gcc / libasan on this machine")
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1",
+               SURFEL_ORACLE_LIB=os.path.join(root, "oracle", "_asan", "libsurfel_oracle.so"), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-c", _ASAN_SCRIPT % dict(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan walk OK" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]

@@ -19,7 +19,10 @@ try:    # which build the counters describe (run this script in the build contai
         HEAD += "+uncommitted kernel changes"
 except Exception:
     HEAD = os.environ.get("SR_HEAD")
-META = {"round": tag.split("_")[0], "head": HEAD}
+sys.path.insert(0, ROOT_)
+from streetunveiler_amd.build import source_digest
+# source_digest: content hash of csrc/ + include/ + build.py AS PROFILED -- bench.py refuses to quote these counters once it differs
+META = {"round": tag.split("_")[0], "head": HEAD, "source_digest": source_digest()}
 dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
 

@@ -14,6 +14,7 @@ conditioning of the chain with respect to its float32 inputs (rows measured agai
 
     python tools/parity_report.py [--gaussians 500000 --width 1920 --height 1080] [--out FILE]      (GPU box)
 """
+import math
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -36,6 +37,56 @@ def row_err(got, ref):
     return np.abs(a - r).max(1) / (np.abs(r).max(1) + 1e-3 * np.abs(r).max())
 
 
+def truncating_sizes():
+    """Upstream's backward takes the image size as int(focal * tanfov * 2), focal = size / (2 tanfov), in float32 (SR_BACKWARD_WH_FROM_FOCAL,
+    shipped = 1): for which sizes that is size - 1.  tanfov arrives as the reference computes it, math.tan(fov / 2) with
+    fov = 2 atan(size / (2 focal)) [REF /root/reference/utils/graphics_utils.py:81-85, gaussian_renderer/__init__.py:35-36]."""
+    def truncates(size, focal):
+        t = np.float32(math.tan(0.5 * (2.0 * math.atan(size / (2.0 * focal)))))
+        f = np.float32(size) / (np.float32(2.0) * t)
+        return int(np.float32(np.float32(f * t) * np.float32(2.0))) == size - 1
+    named = {"C1 256x256 fx=0.8W": [(256, 204.8), (256, 204.8)], "C2/C3/C4 1920x1080 fx=0.8W": [(1920, 1536.0), (1080, 1536.0)],
+             "C5 3840x2160 fx=0.8W": [(3840, 3072.0), (2160, 3072.0)],
+             "Waymo front camera 1920x1280 f~2060": [(1920, 2060.0), (1280, 2060.0)], "the same at -r 4 (480x320)": [(480, 515.0), (320, 515.0)]}
+    out = {"named": {k: {"width_truncates": bool(truncates(*v[0])), "height_truncates": bool(truncates(*v[1]))} for k, v in named.items()}}
+    sizes = list(range(64, 4097)); factors = [0.5 + 0.01 * i for i in range(151)]   # focal = factor * size
+    hits = sum(truncates(sz, f * sz) for sz in sizes for f in factors)
+    out["grid"] = dict(sizes="64..4096", focal_over_size="0.50..2.00 step 0.01", pairs=len(sizes) * len(factors), truncating=int(hits),
+                       fraction=hits / (len(sizes) * len(factors)))
+    out["effect"] = "where it truncates, K8's viewport uses W - 1 (H - 1): dL_dmeans2D (the densification proxy) scales by (W - 1) / W, the dL/dT chain shifts by half a pixel"
+    return out
+
+
+def upstream_semantics(P, W, H, fwd, raw, hip_color):
+    """What the two upstream rules the shipped build follows (include/surfel_switches.h: SR_REFERENCE_PZ_SKIP = 1, SR_BACKWARD_WH_FROM_FOCAL = 1)
+    change on this scene: the (pixel, splat) pairs the per-pair `if (p.z == 0) continue` removes -- in the oracle's (k x l).z and in the
+    kernels' staged cross product (counted against the pz_zero_through_filter build of the kernels, run in a subprocess) -- and the image sizes
+    upstream's int(focal * tanfov * 2) truncates."""
+    import subprocess, tempfile
+    from oracle import surfel_oracle as so
+    from streetunveiler_amd import build as sb
+    out = {"oracle_pz_census": so.pz_zero_census(fwd), "oracle_pz_census_up_to_the_kernels_last_contributor": so.pz_zero_census(fwd, raw["img"]["n_contrib"].view(np.uint32))}
+    lib = os.path.join(sb.variant_dir("pz_zero_through_filter"), "libsurfel_raster.so")
+    if not os.path.exists(lib):
+        lib = sb.build_variant("pz_zero_through_filter")
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "v.npz")
+        env = dict(os.environ, SURFEL_RASTER_LIB=lib)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dump_decisions.py"), str(P), str(W), str(H), f], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        v = np.load(f)
+        assert int(v["switches"]) == 64
+        only_variant = v["valid"] & ~raw["decisions"]["valid"]; only_shipped = raw["decisions"]["valid"] & ~v["valid"]
+        pop = lambda a: int(np.unpackbits(a.view(np.uint8)).sum())
+        dcol = np.abs(v["color"].astype(np.float64) - hip_color)
+        out["kernels"] = dict(pairs_the_pz_skip_removes=pop(only_variant), pairs_valid_only_with_the_skip=pop(only_shipped),
+                              pixels_whose_colour_differs=int((dcol.max(0) > 0).sum()), max_colour_difference=float(dcol.max()),
+                              pixels_with_other_last_contributor=int((v["n_contrib"][0] != raw["img"]["n_contrib"].view(np.uint32)[0]).sum()),
+                              note="pairs counted over the WHOLE lists (the decision dump does not stop at the pixel's last contributor)")
+    out["backward_image_size"] = truncating_sizes()
+    return out
+
+
 def report(P, W, H, seed=0, deg=3, aux=True, scale_lo=5e-4, scale_hi=5e-3, eps=None):
     from oracle import surfel_oracle as so
     from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
@@ -46,7 +97,7 @@ def report(P, W, H, seed=0, deg=3, aux=True, scale_lo=5e-4, scale_hi=5e-3, eps=N
     bg = np.zeros(3, np.float32)
     n = lambda k: g[k].numpy()
     kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(), bg=bg,
-              image_width=W, image_height=H, sh_degree=deg)
+              image_width=W, image_height=H, sh_degree=deg, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     orc = lambda **k: so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), shs=n("shs"), **kw, **k)
     sec = {}
     t = time.time(); hip = run_hip(g, cam, bg, deg, dc, da); raw = run_hip_raw(g, cam, bg, deg, decisions=True); sec["hip"] = round(time.time() - t, 2)
@@ -65,6 +116,10 @@ def report(P, W, H, seed=0, deg=3, aux=True, scale_lo=5e-4, scale_hi=5e-3, eps=N
                                      and np.array_equal(raw["bin"]["ranges"].view(np.uint32), fwd["ranges"])),
            "definition": "image error = |a - b| / (1 + |b|) per element; gradient error = max_j |a - b|[row, j] / (max_j |b|[row, j] + 1e-3 * tensor max) "
                          "per visible Gaussian row; '64' references run K8 in float64 as well as the blend"}
+    out["build_switches"] = dict(kernels=int(__import__("streetunveiler_amd._lib", fromlist=["load"]).load().sr_build_switches()), oracle=int(so.build_switches()),
+                                 meaning="0 = every named switch at upstream's value (include/surfel_switches.h)")
+    if seed == 0 and scale_lo == 5e-4 and scale_hi == 5e-3 and deg == 3:   # (the subprocess renders the benchmark scene)
+        out["upstream_semantics"] = upstream_semantics(P, W, H, fwd, raw, hip["color"])
     # every per-pair decision of the kernels (contribute or not, which path), pixel by pixel up to where the float64 walk stops, against the
     # float64 checker's own: at robust pixels the "forced decisions" of section 1 are the arbiter's own decisions
     dis = m64["disagree"]
@@ -80,7 +135,7 @@ def report(P, W, H, seed=0, deg=3, aux=True, scale_lo=5e-4, scale_hi=5e-3, eps=N
         fz["gradients"][key] = dict(tensor_max=float(np.abs(ref).max()), hip_rows=quantiles(row_err(hip[key], ref)[vis]), oracle_f32_rows=quantiles(row_err(fbwd[key], ref)[vis]),
                                     f32_k8_on_exact_sums_rows=quantiles(row_err(dbwd[key], ref)[vis]))
     # what sets the level of scales / rotations: rows against the magnitude of the terms K8 sums
-    ms, mr = k8_term_magnitudes(g, cam, dbwd["dL_dtransMat64"])
+    ms, mr, _mm = k8_term_magnitudes(g, cam, dbwd["dL_dtransMat64"])
     for key, mag in (("dL_dscales", ms), ("dL_drotations", mr)):
         ref = dbwd[key + "64"].reshape(P, -1)
         res = np.abs(ref).max(1) + 1e-3 * np.abs(ref).max()
@@ -122,12 +177,13 @@ def report(P, W, H, seed=0, deg=3, aux=True, scale_lo=5e-4, scale_hi=5e-3, eps=N
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--gaussians", type=int, default=500_000); ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--no-aux", action="store_true"); ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_parity.json"))
+    ap.add_argument("--no-aux", action="store_true"); ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_parity.json"))
     a = ap.parse_args()
     r = report(a.gaussians, a.width, a.height, aux=not a.no_aux)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(r, open(a.out, "w"), indent=1)
-    print(json.dumps({k: r[k] for k in ("config", "radii_equal", "binning_bit_exact", "seconds")}))
+    print(json.dumps({k: r[k] for k in ("config", "radii_equal", "binning_bit_exact", "seconds", "build_switches")}))
+    print("UPSTREAM SEMANTICS", json.dumps(r.get("upstream_semantics")))
     for k, v in r["forced_vs_f64"]["images"].items():
         print("FORCED vs F64", k, "hip max/p999", v["hip"]["max"], v["hip"]["p999"], ">1e-4:", v["hip_over_1e4"], "| oracle_f32", v["oracle_f32"]["max"], ">1e-4:", v["oracle_f32_over_1e4"])
     for k, v in r["forced_vs_f64"]["gradients"].items():

@@ -62,7 +62,7 @@ try:   # the checker: the CPU oracle on the last n Gaussians alone
     f = so.rasterize_forward(means3D[-n:].detach().cpu().numpy(), opacities[-n:].detach().cpu().numpy(), scales[-n:].detach().cpu().numpy(),
                              rotations[-n:].detach().cpu().numpy(), shs=shs[-n:].detach().cpu().numpy(), viewmatrix=cam.world_view_transform.numpy(),
                              projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(), bg=np.zeros(3, np.float32),
-                             image_width=W, image_height=H, sh_degree=3)
+                             image_width=W, image_height=H, sh_degree=3, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
     out["tail_radii_equal_oracle"] = bool(np.array_equal(f["radii"], r1[-n:].cpu().numpy()))
 except Exception as e:   # noqa
     out["tail_radii_equal_oracle"] = f"oracle unavailable: {e}"
