@@ -249,12 +249,14 @@ def _cpu_model():
     return None
 
 
-def train_step_section(args, params, cam, dev):
+def train_step_section(args, params, cam, dev, D, V):
     """Untimed extra (like stage_ms): one late training iteration's rasterizer calls on this scene, the reference's way -- render +
     render_semantic (two passes) + five class-filtered renders = 8 operator calls [REF train.py:84-109] -- and as this build's two
-    rasterizations (render_and_semantic + render_class_distortions); ms per fwd+bwd and how far the resulting maps are apart."""
+    rasterizations (render_and_semantic + render_class_distortions); ms per fwd+bwd and how far the resulting maps are apart.  Then the
+    fused pattern again with the library's stage timers on: per-stage ms of one iteration and a `roofline` block for its dominant kernel."""
+    from streetunveiler_amd import _lib
     from streetunveiler_amd.gaussian_renderer import SurfelModel
-    from streetunveiler_amd.train_pattern import compare_and_time
+    from streetunveiler_amd.train_pattern import compare_and_time, fused_pattern, make_weights
     sem = torch.randint(0, 6, (args.gaussians,), generator=torch.Generator().manual_seed(0)).to(dev)
     sem[sem == 4] = 2   # the reference prunes the sky Gaussians before training
     for t in params.values():
@@ -262,11 +264,147 @@ def train_step_section(args, params, cam, dev):
     pc = SurfelModel(params["means3D"], params["scales"], params["rotations"], params["opacities"], params["shs"], sem, args.sh_degree, 3)
     try:
         res = compare_and_time(cam.to(dev), pc, torch.zeros(3, device=dev), list(params.values()))
+        lib = _lib.load()
+        weights = make_weights(args.height, args.width, dev); bg = torch.zeros(3, device=dev); camd = cam.to(dev)
+        iters = 3
+        torch.cuda.synchronize(); lib.sr_set_stage_timing(1)
+        for _ in range(iters):
+            for t in params.values():
+                t.grad = None
+            fused_pattern(camd, pc, bg, weights)["loss"].backward()
+        torch.cuda.synchronize()
+        st = _lib.stage_stats()
+        lib.sr_set_stage_timing(0)
+        res["fused_stage_ms_per_iteration"] = {k: round(ms / iters, 4) for k, (ms, n) in st.items() if n}
+        res["roofline"] = train_step_roofline(args, res["fused_stage_ms_per_iteration"], D, V, n_classes=5)
     finally:
         for t in params.values():
             t.grad = None
         torch.cuda.empty_cache()
     return res
+
+
+def train_step_roofline(args, stage_ms, D, V, n_classes):
+    """The `roofline` block of the training-step pattern: its dominant kernel against HBM, as for the headline kernel -- algorithmic
+    bytes (the per-class pass reads 56 B per list entry -- index + the 52 B of the record it stages -- and its backward leaves
+    one 15-float gradient record per entry, counted as K7's are: read-modify-write = 120 B; 20 B per pixel and class of state each way)
+    over the launch time measured in this run, the committed counter traffic of the same pattern (profiles/rNN_train_step_*), and the
+    vector-issue figures that actually bound it."""
+    npx = args.width * args.height
+    ab = {"class_fwd": D * 56 + n_classes * npx * 20, "class_bwd": D * 56 + D * 120 + n_classes * npx * 24,
+          "blend_fwd": D * (76 + 24) + npx * (60 + 24), "blend_bwd": D * (76 + 24) + D * (72 + 24) * 2 + npx * (60 + 40 + 24)}   # (9-channel pass: six more colour floats per entry, pixel and record)
+    kernels = {"class_fwd": "class_forward_kernel", "class_bwd": "class_backward_kernel", "blend_fwd": "render_forward_kernel", "blend_bwd": "render_backward_kernel"}
+    cand = {k: stage_ms.get(k) for k in ab if stage_ms.get(k)}
+    if not cand:
+        return None
+    dom = max(cand, key=cand.get)
+    prof = argparse.Namespace(tag="train_step", sh_degree=3) if (args.tag == "c3" and args.sh_degree == 3) else argparse.Namespace(tag="custom", sh_degree=args.sh_degree)
+    out = {"bound": "hbm", "kernel": kernels[dom], "avg_launch_ms": cand[dom], "algorithmic_bytes_per_launch": ab[dom], "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    out["achieved"] = round(ab[dom] / (cand[dom] * 1e-3) / 1e9, 2); out["frac"] = round(out["achieved"] / HBM_PEAK_GBS, 5)
+    out["traffic"], out["traffic_source"] = pmc_traffic(kernels[dom], prof)
+    out["per_kernel"] = {}
+    for k, ms in cand.items():
+        t, _ = pmc_traffic(kernels[k], prof)
+        out["per_kernel"][kernels[k]] = {"ms": ms, "algorithmic_bytes": ab[k], "hbm_frac": round(ab[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": t,
+                                         "traffic_over_algorithmic": None if not t else round(t / ab[k], 3), "issue_roof": valu_issue_roof(kernels[k], ms, prof)}
+    out["note"] = ("the per-class kernels are vector-issue-bound like K6 / K7 (per_kernel.*.issue_roof.datasheet_issue_frac), the HBM fraction is reported for "
+                   "comparability with the headline block; duplicates D and visible V as in config")
+    return out
+
+
+XGMI_LINK_GBS = 153.0   # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links per GPU, ~153 GB/s each)
+
+
+def rccl_topology(log_path, backend, world):
+    """What the communicator says it built: channel count and ring / tree lines of RCCL's own INIT / GRAPH log (NCCL_DEBUG_FILE, this rank)."""
+    import re
+    out = {"backend": backend, "channels": None, "log": log_path}
+    if backend != "nccl" or not log_path or not os.path.exists(log_path):
+        return out
+    try:
+        txt = open(log_path, errors="replace").read()
+    except OSError:
+        return out
+    ch = [int(b) for _, b in re.findall(r"Channel (\d+)/(\d+)", txt)]
+    if ch:
+        out["channels"] = max(ch)
+    m = re.findall(r"(\d+) coll channels", txt)
+    if m:
+        out["coll_channels"] = int(m[-1]); out["channels"] = out["channels"] or int(m[-1])
+    m = re.search(r"nranks (\d+)", txt)
+    if m:
+        out["nranks_in_log"] = int(m.group(1))
+    out["rings_logged"] = len(re.findall(r"Ring \d+", txt)); out["trees_logged"] = len(re.findall(r"Trees? \[", txt))
+    ver = re.search(r"(RCCL version [^\n]+|NCCL version [^\n]+)", txt)
+    if ver:
+        out["version"] = ver.group(1).strip()[:80]
+    return out
+
+
+def isolated_collectives(P, world, dev, exchange):
+    """The step's collectives alone, nothing else on the GPU (after the timed region): the all-gather of the 12-B colour gradients and the
+    all-reduce of the other 40 B/Gaussian (factored exchange), or the all-reduce of all 232 B/Gaussian -- ms, bytes and bandwidth each.
+    busbw as nccl-tests define it: all-reduce 2 (N - 1) / N x bytes / t, all-gather (N - 1) / N x total bytes / t."""
+    out = {}
+
+    def timed(fn, iters=5):
+        fn(); torch.cuda.synchronize(); dist.barrier()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+    n = max(world, 1)
+    if exchange == "factored":
+        gc = torch.zeros(P * 3, device=dev); gathered = torch.empty(P * 3 * world, device=dev)
+        ms = timed(lambda: dist.all_gather_into_tensor(gathered, gc))
+        total = gathered.numel() * 4
+        out["all_gather_colour_gradients"] = {"bytes_per_rank": P * 12, "bytes_gathered": total, "ms": round(ms, 4),
+                                              "algbw_GBs": round(total / ms / 1e6, 2), "busbw_GBs": round(total * (n - 1) / n / ms / 1e6, 2)}
+        rest = torch.zeros(P * 10, device=dev)
+        del gc, gathered
+    else:
+        rest = torch.zeros(P * 58, device=dev)
+    ms = timed(lambda: dist.all_reduce(rest))
+    nbytes = rest.numel() * 4
+    out["all_reduce_rest"] = {"bytes": nbytes, "ms": round(ms, 4), "algbw_GBs": round(nbytes / ms / 1e6, 2),
+                              "busbw_GBs": round(nbytes * 2 * (n - 1) / n / ms / 1e6, 2)}
+    return out
+
+
+def predicted_xgmi(P, world, exchange):
+    """Wire time of the step's collectives from the link figures alone (no latency, perfect pipelining): a ring moves its payload over ONE
+    link per hop (busbw = one link), a direct exchange on the fully connected 8-GPU xGMI mesh uses the N - 1 links of a GPU at once."""
+    n = max(world, 1)
+    if n == 1:
+        return {"all_gather_ms": 0.0, "all_reduce_ms": 0.0, "note": "one rank: nothing crosses a link"}
+    ag_bytes = P * 12 * n if exchange == "factored" else 0
+    ar_bytes = P * (40 if exchange == "factored" else 232)
+    ring = lambda moved: moved / (XGMI_LINK_GBS * 1e9) * 1e3
+    return {"link_GBs": XGMI_LINK_GBS,
+            "ring": {"all_gather_ms": round(ring(ag_bytes * (n - 1) / n), 3), "all_reduce_ms": round(ring(ar_bytes * 2 * (n - 1) / n), 3)},
+            "direct_all_links": {"all_gather_ms": round(ring(ag_bytes * (n - 1) / n) / (n - 1), 3), "all_reduce_ms": round(ring(ar_bytes * 2 * (n - 1) / n) / (n - 1), 3)},
+            "note": "ring = per-link bound (what a single RCCL ring reaches); direct = every peer link busy at once (the mesh's ceiling); RCCL with several "
+                    "channels lands between the two"}
+
+
+def exchange_report(detail, P, world, K, ms_per_step, exchange):
+    """The first N > 1 run has to explain itself: per-rank step times, how much of the exchange the compute stream actually waited for,
+    what the same collectives cost alone, and what the links would allow."""
+    if detail is None:
+        return None
+    iso = detail.get("isolated_collectives", {})
+    # per step: one all-gather per frame of the rank (K of them with gradient accumulation), one all-reduce
+    alone = sum(v["ms"] * (K if name == "all_gather_colour_gradients" else 1) for name, v in iso.items())
+    exposed = max(detail["exposed_ms_per_step_per_rank"]) if detail["exposed_ms_per_step_per_rank"] else 0.0
+    out = dict(detail)
+    out["collectives_alone_ms_per_step"] = round(alone, 4)
+    out["exposed_ms_per_step_max_over_ranks"] = round(exposed, 4)
+    out["hidden_fraction_of_the_collectives"] = None if alone <= 0 else round(max(0.0, 1.0 - exposed / alone), 4)
+    out["exposed_fraction_of_the_step"] = round(exposed / ms_per_step, 4) if ms_per_step else None
+    out["predicted_xgmi"] = predicted_xgmi(P, world, exchange)
+    return out
 
 
 def self_launch(args):
@@ -288,7 +426,14 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    from streetunveiler_amd import parallel as par
     from streetunveiler_amd.parallel import allreduce_gradients, factored_sh_exchange, init_distributed
+    rccl_log = None
+    if args.gpus > 1 or os.environ.get("SURFEL_EXCHANGE_SINGLE_RANK") == "1":
+        # the communicator's own account of what it built (rings / channels), one file per rank: read back after the warm-up collectives
+        rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"sr_rccl_{os.getpid()}.log")
+        os.environ.setdefault("NCCL_DEBUG", "INFO"); os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH"); os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        rccl_log = os.environ["NCCL_DEBUG_FILE"].replace("%p", str(os.getpid())).replace("%h", os.uname().nodename)
     rank, world, local_rank = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: start {args.gpus} ranks "
@@ -393,6 +538,7 @@ def main():
     exchange_check = None
 
     worlds_seen = None
+    rccl_info = None
     if multi:   # bring the communicator up before anything is timed, whatever --warmup says
         w = torch.zeros(1024, device=dev); wg = torch.empty(1024 * world, device=dev)
         dist.all_reduce(w); dist.all_gather_into_tensor(wg, w)
@@ -401,6 +547,13 @@ def main():
         mine = torch.tensor([float(dist.get_world_size())], device=dev); seen = torch.empty(world, device=dev)
         dist.all_gather_into_tensor(seen, mine)
         worlds_seen = [int(x) for x in seen.tolist()]
+        if any(w != args.gpus for w in worlds_seen) and os.environ.get("SURFEL_EXCHANGE_SINGLE_RANK") != "1":
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the ranks report communicator sizes {worlds_seen}: the job is not ONE {args.gpus}-rank group")
+        rccl_info = rccl_topology(rccl_log, dist.get_backend(), world)
+        if rccl_info.get("channels") is not None and world > 1 and rccl_info["channels"] <= 1:
+            raise SystemExit(f"bench.py: RCCL built a single-channel ring for {world} ranks ({rccl_info}): one xGMI link would carry the whole exchange -- "
+                             f"check NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS / the topology file")
+        par.STALLS.enabled = True   # compute-stream stalls at the collectives' wait points = the exposed part of the exchange
         if args.exchange == "factored":
             # one untimed trial step of the factored exchange.  Only a failure of the COLLECTIVE LAYER (a backend that lacks
             # all_gather_into_tensor, a communicator error: torch.distributed raises DistBackendError / NotImplementedError, on every
@@ -426,6 +579,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    par.STALLS.drain_ms()
     exchange_log.update(ms=0.0, bytes=0, calls=0, early_starts=0)
     # Timed region: HIP events (recorded by the library on the launch stream) around the DOMINANT kernel only -- the blend backward,
     # the kernel of `roofline` -- because every event record costs ~5 us of stream time (tools/step_timeline.py: bracketing both blend
@@ -441,6 +595,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     timed_exchange = dict(exchange_log)
+    exposed_ms = par.STALLS.drain_ms() / args.steps if multi else 0.0   # (after sync(): every event pair has completed)
+    par.STALLS.enabled = False
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4)
     stats = _lib.stage_stats()
@@ -451,7 +607,16 @@ def main():
     stats_all = _lib.stage_stats()
     lib.sr_set_stage_timing(0)
     stats = {k: (stats[k] if stats[k][1] else stats_all[k]) for k in stats_all}
+    exchange_detail = None
     if multi:
+        mine = torch.tensor([elapsed / args.steps * 1e3, exposed_ms], device=dev, dtype=torch.float64)
+        allr = torch.empty(2 * world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, 2).tolist()
+        exchange_detail = {"per_rank_ms_per_step": [round(a, 4) for a, _ in allr],
+                           "exposed_ms_per_step_per_rank": [round(b, 4) for _, b in allr],
+                           "exposed_definition": "time rank r's compute stream stood still at the collectives' wait points (event pairs around work.wait()), per step"}
+        exchange_detail["isolated_collectives"] = isolated_collectives(P, world, dev, args.exchange)
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -537,7 +702,8 @@ def main():
                            "exchange_bytes_sent_per_step_rank0": int(timed_exchange["bytes"] / args.steps),
                            "exchange_early_starts_per_step": timed_exchange["early_starts"] / args.steps,
                            "exchange_selfcheck": exchange_check, "backend": dist.get_backend(),
-                           "world_size_seen_by_each_rank": worlds_seen} if multi else {})},
+                           "world_size_seen_by_each_rank": worlds_seen, "rccl": rccl_info,
+                           "exchange": exchange_report(exchange_detail, P, world, K, ms_per_step, args.exchange)} if multi else {})},
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": None if ach is None else round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 5),
@@ -559,7 +725,7 @@ def main():
         }
         if world == 1 and not multi and not args.no_train_step:
             try:
-                out["train_step"] = train_step_section(args, params, cam, dev)
+                out["train_step"] = train_step_section(args, params, cam, dev, D, V)
             except Exception as e:   # an untimed extra must never cost the line
                 out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:

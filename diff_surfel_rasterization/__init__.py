@@ -67,7 +67,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             fused["mask"] = mask
         if probe:              # tests / profiling: {"quadrant_cull": bool, "blend_counters": int64[16] device tensor, "ballot_ranking": bool}
             fused.update(probe)
-        if forward_only:       # SR_FLAG_FORWARD_ONLY: no backward will follow -- images bit-identical, backward state not written
+        if forward_only and not (probe and "blend_counters" in probe):   # SR_FLAG_FORWARD_ONLY: no backward will follow -- images bit-identical, backward state not written (the counting variant keeps the full forward)
             fused["forward_only"] = True
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
                 s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered,
@@ -201,10 +201,7 @@ class GaussianRasterizer(nn.Module):
         """Extension: the distortion maps of the class-filtered renders of ONE view in one pass.
         `classes` [P] integer class per Gaussian (negative / >= n_classes: in no class).  Returns (dist[n_classes,H,W], radii[P]);
         dist[k] == allmap[6] of this operator called on the Gaussians of class k only, differentiable w.r.t. means3D, means2D
-        (densification proxy), opacities, scales, rotations.  Tiles of up to four 8x8 quadrants (not 32x16), n_classes <= 6."""
-        if self.tile is not None and tuple(int(t) for t in self.tile) == (32, 16):
-            raise ValueError(f"tile={tuple(self.tile)} and class_distortions (render_class_distortions) are mutually exclusive: the per-class "
-                             "pass exists for 8x8, 16x8, 16x16 and 32x8 tiles -- pick one of them")
+        (densification proxy), opacities, scales, rotations.  Every tile shape of the sweep; n_classes <= 6."""
         return _ClassDistortions.apply(means3D, means2D, opacities, scales, rotations, classes, int(n_classes), self.raster_settings,
                                        self.activations, mask, tuple(int(t) for t in self.tile) if self.tile else None)
 
@@ -225,12 +222,6 @@ class GaussianRasterizer(nn.Module):
             if shs is None or colors_precomp is not None or extra_colors.ndim != 2 or extra_colors.shape[1] != 6:
                 raise Exception("extra_colors needs SHs as the colour source and must have dimensions (num_points, 6)")
             colors_precomp = extra_colors
-        # the shared-geometry extensions (6 / 9 colour channels) are instantiated for tiles of up to four 8x8 quadrants (8x8, 16x8, 16x16,
-        # 32x8): refuse 32x16 here, by name, instead of letting the C call answer SR_ERR_UNSUPPORTED (INTEGRATION.md "Tile shapes")
-        if self.tile is not None and tuple(int(t) for t in self.tile) == (32, 16) and colors_precomp is not None and colors_precomp.ndim == 2 \
-                and colors_precomp.shape[1] == 6:
-            raise ValueError(f"tile={tuple(self.tile)} and the multi-colour passes (colors_precomp[P,6] / extra_colors: render_semantic, "
-                             "render_and_semantic) are mutually exclusive: those passes exist for 8x8, 16x8, 16x16 and 32x8 tiles -- pick one of them")
         empty = torch.Tensor([]).to(means3D.device)
         shs = empty if shs is None else shs
         colors_precomp = empty if colors_precomp is None else colors_precomp

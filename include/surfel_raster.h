@@ -77,8 +77,8 @@ typedef struct SrFrame {
     const float* projmatrix;  /* device [16] = full_proj_transform ((P*W2C)^T), row-major */
     const float* campos;      /* device [3] */
     int32_t tile_width;       /* 0 = 16 (the reference's BLOCK_X); BASELINE config 5 sweeps 8x8, 16x8, 16x16, 32x8, 32x16.  The 6- and
-                               * 9-channel passes (SrGaussians.color_channels) and the per-class pass exist for every shape but 32x16, the
-                               * counter variant (blend_counters) for 16x16 only */
+                               * 9-channel passes (SrGaussians.color_channels) and the per-class pass exist for every shape, the counter
+                               * variant (blend_counters) for 16x16 only */
     int32_t tile_height;      /* 0 = 16 (BLOCK_Y).  Same shape in every call that shares the state buffers */
     uint32_t flags;           /* SR_FLAG_* bits; per call, nothing about a call is process-wide state */
     uint64_t* blend_counters; /* NULL, or device [16] u64 owned by the caller: selects the COUNTING variant of the forward blend (same
@@ -246,7 +246,7 @@ int sr_backward_geometry(const SrFrame* frame, const SrGaussians* g, const int32
  *     in no class, contributes nowhere); shs must be NULL.  sr_forward_plan is called first, exactly as for a render.
  *   - class_image: sr_class_image_bytes(W, H, n_classes) bytes of caller-owned state between forward and backward.
  *   - out_dist / dL_ddist: [n_classes, H, W].  grads: as sr_backward (dL_dcolors / dL_dsh are not produced: pass NULL).
- *   - tiles of up to four 8x8 quadrants (16x16, 8x8, 16x8, 32x8; not 32x16); 1 <= n_classes <= 6. */
+ *   - every tile shape of the sweep; 1 <= n_classes <= 6. */
 size_t sr_class_image_bytes(int32_t image_width, int32_t image_height, int32_t n_classes);
 int sr_class_forward_render(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, void* geom, size_t geom_bytes, void* binning,
                             size_t binning_bytes, void* class_image, size_t class_image_bytes, uint32_t num_rendered, float* out_dist,
@@ -327,7 +327,9 @@ int sr_debug_lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t 
  * summed duration (ms) and the number of launches of one stage since timing was (re-)enabled. */
 typedef enum SrStage {
     SR_STAGE_PREPROCESS = 0, SR_STAGE_DEPTH_SORT = 1, SR_STAGE_SCAN = 2, SR_STAGE_EXPAND_X = 3, SR_STAGE_EXPAND_Y = 4,
-    SR_STAGE_RANGES = 5, SR_STAGE_BLEND_FWD = 6, SR_STAGE_BLEND_BWD = 7, SR_STAGE_PREPROCESS_BWD = 8, SR_STAGE_COUNT = 9
+    SR_STAGE_RANGES = 5, SR_STAGE_BLEND_FWD = 6, SR_STAGE_BLEND_BWD = 7, SR_STAGE_PREPROCESS_BWD = 8,
+    /* the per-class distortion pass's own kernels (its K1..K5 and K8 are the stages above) */
+    SR_STAGE_CLASS_PARTITION = 9, SR_STAGE_CLASS_FWD = 10, SR_STAGE_CLASS_BWD = 11, SR_STAGE_COUNT = 12
 } SrStage;
 void sr_set_stage_timing(int enable);
 int sr_stage_stats(int stage, float* total_ms, int* launches);

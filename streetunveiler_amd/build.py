@@ -87,6 +87,11 @@ def build_variant(name: str, force: bool = False, verbose: bool = False) -> str:
 
 def build(force: bool = False, verbose: bool = False, libdir: str = LIBDIR, defines=()) -> str:
     os.makedirs(libdir, exist_ok=True)
+    lib = os.path.join(libdir, "libsurfel_raster.so")
+    # a library newer than every source, header and this script is current even where its object files did not travel (the variants' .o
+    # files are not shipped to the GPU box)
+    if not force and not _stale(lib, [os.path.join(CSRC, src) for src, _ in SOURCES] + HEADERS + [__file__]):
+        return lib
     objs, jobs = [], []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
@@ -105,7 +110,6 @@ def build(force: bool = False, verbose: bool = False, libdir: str = LIBDIR, defi
 
     with ThreadPoolExecutor(max_workers=max(4, (os.cpu_count() or 4))) as ex:
         list(ex.map(run, jobs))
-    lib = os.path.join(libdir, "libsurfel_raster.so")
     if force or jobs or _stale(lib, objs):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs)
     return lib

@@ -42,10 +42,12 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
                                   const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s);
 hipError_t launch_pair_decisions(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                  unsigned long long* valid_bits, unsigned long long* use3d_bits, hipStream_t s);
-hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list,
+hipError_t launch_class_partition(int P, int n_tiles, int n_classes, const float* class_cols, const uint2* ranges, const uint32_t* point_list, uint8_t* ids,
+                                  uint32_t* cls_list, uint2* cls_ranges, hipStream_t s);
+hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* cls_ranges, const uint32_t* tile_order, const uint32_t* cls_list,
                                 const float4* recs, float* out_dist, float* cls_state, uint32_t* cls_last, uint32_t* tile_total, uint16_t* hit_mask,
                                 int cull, hipStream_t s);
-hipError_t launch_class_backward(const FrameDev& f, int n_classes, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list,
+hipError_t launch_class_backward(const FrameDev& f, int n_classes, const uint2* cls_ranges, const uint32_t* tile_order, const uint32_t* cls_list,
                                  const float4* recs, const float* cls_state, const uint32_t* cls_last, const uint32_t* tile_total,
                                  const float* dL_ddist, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s);
 hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii, const uint8_t* clamped, const float4* recs, const float4* inst_grads,
@@ -270,8 +272,6 @@ int check_common(const SrFrame* frame, const SrGaussians* g) {
         const int tw = frame->tile_width > 0 ? frame->tile_width : kTile, th = frame->tile_height > 0 ? frame->tile_height : kTile;
         const bool known = (tw == 16 && th == 16) || (tw == 8 && th == 8) || (tw == 16 && th == 8) || (tw == 32 && th == 8) || (tw == 32 && th == 16);
         if (!known) return fail(SR_ERR_UNSUPPORTED, "tile shape %dx%d not in {8x8, 16x8, 16x16, 32x8, 32x16}", tw, th);
-        if (tw == 32 && th == 16 && (g->color_channels == 6 || g->color_channels == 9))
-            return fail(SR_ERR_UNSUPPORTED, "6 / 9 colour channels are built for tiles of up to four 8x8 quadrants (8x8, 16x8, 16x16, 32x8), not 32x16");
     }
     if (!frame->bg || !frame->viewmatrix || !frame->projmatrix || !frame->campos) return fail(SR_ERR_INVALID_ARGUMENT, "bg / viewmatrix / projmatrix / campos must be non-NULL device pointers");
     if (g->P > 0) {
@@ -468,7 +468,10 @@ int bin_duplicates(const SrFrame* frame, const SrGaussians* g, const FrameDev& f
     return debug_sync(frame, s, "tile_ranges");
 }
 
-struct ClassLayout { size_t state, last, tile_total, total; };
+// per-class state between the forward and the backward of the class pass.  (The class-ordered copy of the tile lists lives in the binning
+// buffer's `columns` region -- the column items of the expanding partition are dead once pass Y has run -- and the class id bytes in the
+// geometry buffer's `sh_jac` region: the class pass has no SH colour.)
+struct ClassLayout { size_t state, last, tile_total, ranges, total; };
 ClassLayout class_layout(int W, int H, int n_classes) {
     ClassLayout L{};
     const size_t hw = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1), n = (size_t)(n_classes > 0 ? n_classes : 1);
@@ -476,7 +479,8 @@ ClassLayout class_layout(int W, int H, int n_classes) {
     L.state = 0;
     L.last = align_up(n * 3 * hw * 4, 256);
     L.tile_total = L.last + align_up(n * hw * 4, 256);
-    L.total = L.tile_total + align_up((tiles > 0 ? tiles : 1) * n * 4, 256);
+    L.ranges = L.tile_total + align_up((tiles > 0 ? tiles : 1) * n * 4, 256);
+    L.total = L.ranges + align_up((tiles > 0 ? tiles : 1) * n * 8, 256);
     return L;
 }
 
@@ -484,8 +488,7 @@ int check_class_pass(const SrFrame* frame, const SrGaussians* g, int n_classes) 
     if (int rc = check_common(frame, g)) return rc;
     if (n_classes < 1 || n_classes > 6) return fail(SR_ERR_UNSUPPORTED, "n_classes %d not in 1..6", n_classes);
     const int tw = frame->tile_width > 0 ? frame->tile_width : kTile, th = frame->tile_height > 0 ? frame->tile_height : kTile;
-    if (!((tw == 16 && th == 16) || (th == 8 && (tw == 8 || tw == 16 || tw == 32))))
-        return fail(SR_ERR_UNSUPPORTED, "the per-class distortion pass is built for the 16x16, 8x8, 16x8 and 32x8 tiles (not %dx%d)", tw, th);
+    (void)tw; (void)th;   // (every tile shape check_common accepts: 8x8, 16x8, 16x16, 32x8, 32x16)
     if (g->P > 0 && (g->shs || !g->colors_precomp || (g->color_channels != 0 && g->color_channels != 3)))
         return fail(SR_ERR_INVALID_ARGUMENT, "the per-class distortion pass takes the class ids in colors_precomp[P,3] (column 0), no SHs");
     return SR_OK;
@@ -542,8 +545,16 @@ int sr_class_forward_render(const SrFrame* frame, const SrGaussians* g, int32_t 
     float4* recs = nullptr;
     if (int rc = bin_duplicates(frame, g, f, geom, geom_bytes, binning, B, D, s, &recs)) return rc;
     {
-        StageTimer t(SR_STAGE_BLEND_FWD, s);
-        SR_HIP(launch_class_forward(f, n_classes, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), recs, out_dist,
+        // every tile list, stably partitioned by class: [class 0 by depth | class 1 by depth | ...] + a (begin, end) pair per (tile, class)
+        StageTimer t(SR_STAGE_CLASS_PARTITION, s);
+        const GeomLayout GL = geom_layout(g->P);
+        SR_HIP(launch_class_partition(g->P, f.tiles_x * f.tiles_y, n_classes, g->colors_precomp, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list),
+                                      g->P > 0 && geom ? at<uint8_t>(geom, GL.sh_jac) : nullptr, at<uint32_t>(binning, B.columns), at<uint2>(class_image, C.ranges), s));
+    }
+    if (int rc = debug_sync(frame, s, "class_partition")) return rc;
+    {
+        StageTimer t(SR_STAGE_CLASS_FWD, s);
+        SR_HIP(launch_class_forward(f, n_classes, at<uint2>(class_image, C.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.columns), recs, out_dist,
                                     at<float>(class_image, C.state), at<uint32_t>(class_image, C.last), at<uint32_t>(class_image, C.tile_total),
                                     at<uint16_t>(binning, B.hit_mask), (frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1, s));
     }
@@ -570,10 +581,10 @@ int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_clas
     float4* inst_grads = static_cast<float4*>(workspace);
     uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(3), 256);
     {
-        StageTimer t(SR_STAGE_BLEND_BWD, s);
+        StageTimer t(SR_STAGE_CLASS_BWD, s);
         if (D > 0) SR_HIP(hipMemsetAsync(written, 0, D, s));
         if (D > 0)
-            SR_HIP(launch_class_backward(f, n_classes, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), at<float4>(geom, L.recs),
+            SR_HIP(launch_class_backward(f, n_classes, at<uint2>(class_image, C.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.columns), at<float4>(geom, L.recs),
                                          at<float>(class_image, C.state), at<uint32_t>(class_image, C.last), at<uint32_t>(class_image, C.tile_total), dL_ddist,
                                          at<uint16_t>(binning, B.hit_mask), inst_grads, written, s));
     }

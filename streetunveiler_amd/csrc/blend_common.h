@@ -162,7 +162,7 @@ __device__ __forceinline__ uint32_t cell_mask16(const float Tu[3], const float T
 // SH colour AND six precomputed channels (render + render_semantic as one pass).  Channels 3.. come straight from the caller's
 // [P,6] array at staging time: columns 3..5 for NC = 6 (columns 0..2 went through K1 into the record), all six for NC = 9.
 // ---------------------------------------------------------------------------------------------
-template <int NC> constexpr int entry_quads() { return NC == 9 ? 7 : 6; }
+template <int NC> constexpr int entry_quads() { return NC == 9 ? 7 : (NC == 0 ? 4 : 6); }   // NC = 0: geometry only (e0..e3: the per-class distortion pass)
 
 __device__ __forceinline__ float4 load_extra(const float* __restrict__ colors6, uint32_t gid, int first) {
     const float* c = colors6 + 6 * (size_t)gid + first;
@@ -187,8 +187,10 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 (&q)[kRecQuads], co
     // with opacity 0 and never passes the alpha test.  (An isolated p.z == 0 of a healthy splat is rounding noise: see intersect().)
     const bool plane_degenerate = A[2] == 0.f && B[2] == 0.f && C[2] == 0.f;
     s_e[3][slot] = make_float4(mx, my, plane_degenerate ? 0.f : opacity, ex.z);
-    s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[3].w);   // n.xyz, c0  (component-wise: a whole-quad copy of an array element keeps the array in scratch)
-    s_e[5][slot] = make_float4(q[4].x, q[4].y, ex.x, ex.y);   // c1, c2 | c3, c4
+    if (NC != 0) {
+        s_e[4][slot] = make_float4(q[3].x, q[3].y, q[3].z, q[3].w);   // n.xyz, c0  (component-wise: a whole-quad copy of an array element keeps the array in scratch)
+        s_e[5][slot] = make_float4(q[4].x, q[4].y, ex.x, ex.y);   // c1, c2 | c3, c4
+    }
     if (NC == 9) s_e[6][slot] = make_float4(ey.x, ey.y, ey.z, 0.f);
     if (cells16) *cells16 = cell_mask16(Tu, Tv, Tw, mx, my, opacity);   // (counter variant: what a 4x4-cell culling would keep)
     if (cells_rows) {   // (row-mapped forward: per-cell bits; a quadrant is visited if one of its cells is)
@@ -422,6 +424,51 @@ __device__ __forceinline__ float wave_reduce24(float (&v)[24], int lane) {
     a += dpp_mov<0x4E>(a); b += dpp_mov<0x4E>(b);    // quad_perm:[2,3,0,1] = lane ^ 2
     a += dpp_mov<0xB1>(a); b += dpp_mov<0xB1>(b);    // quad_perm:[1,0,3,2] = lane ^ 1: every lane of a quad holds the totals
     return (lane & 2) ? b : a;
+}
+
+// The same reduction for 16 values (the per-class distortion backward: 15 live accumulators): 16 -> 8 -> 4 registers in-row (24 bank-masked
+// DPP adds), two half folds and one row-pair fold on 4 registers (3 swaps), two quad levels on one.  26 DPP + 3 swaps against the 40 + 5
+// of wave_reduce24.  Afterwards EVERY lane holds the 64-lane total of value reduce16_index(lane); the lanes with bits 0 and 1 clear
+// (16 of them) cover all sixteen.  Same preconditions as dpp_fold_rows (all 64 lanes active; >= 7 instructions between a write and
+// its DPP read inside the block: 8 here).
+__device__ __forceinline__ int reduce16_index(int l) { return ((l >> 4) & 1) + 2 * ((l >> 5) & 1) + 4 * ((l >> 2) & 1) + 8 * ((l >> 3) & 1); }
+__device__ __forceinline__ bool reduce16_holds_total(int l) { return (l & 3) == 0; }
+__device__ __forceinline__ float wave_reduce16(float (&v)[16]) {
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %2, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %0, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %1, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %2, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %3, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+        "s_nop 1\n"
+        : "+&v"(v[0]), "+&v"(v[1]), "+&v"(v[2]), "+&v"(v[3]), "+&v"(v[4]), "+&v"(v[5]), "+&v"(v[6]), "+&v"(v[7])
+        : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    fold32(v[0], v[2]); fold32(v[1], v[3]);   // lanes < 32: values 0 / 1 (+ 4 bit2 + 8 bit3), lanes >= 32: values 2 / 3
+    fold16(v[0], v[1]);                       // bit4 clear: value 0 or 2, bit4 set: value 1 or 3; summed over all four rows
+    float a = v[0];
+    a += dpp_mov<0x4E>(a);                    // quad_perm:[2,3,0,1] = lane ^ 2
+    a += dpp_mov<0xB1>(a);                    // quad_perm:[1,0,3,2] = lane ^ 1
+    return a;
 }
 
 // 64-lane totals of three more values (the 9-channel variant): afterwards every lane of 16-lane row r holds the total of value r

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kWave) void pair_decisions_kernel(FrameDev f, const
 
 // launchers ---------------------------------------------------------------------------------------
 // Tile shapes (BASELINE config 5's sweep): the reference's 16x16 plus 8x8, 16x8, 32x8, 32x16 = QX x QY quadrants of 8x8
-// pixels, i.e. 1 / 2 / 4 / 8 pixels per lane.  Only the reference shape carries the 6- / 9-channel and counter variants.
+// pixels, i.e. 1 / 2 / 4 / 8 pixels per lane.  Every shape carries the 6- / 9-channel passes; only the reference shape the counter variant.
 #define SR_FOR_TILE_SHAPE(F)                                                    \
     if (f.tile_w == 16 && f.tile_h == 16) { F(2, 2); }                          \
     else if (f.tile_w == 8 && f.tile_h == 8) { F(1, 1); }                       \
@@ -508,9 +508,11 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
                                 hipLaunchKernelGGL(render_forward_auto_kernel, dim3((n_tiles + kXcds - 1) / kXcds * kXcds * 2), block, 0, s, f, ranges,
                                                    tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask, frame_counts);
         else                    SR_LAUNCH_FWD(false, 3, 2, 1, 2);
+    } else if (f.colors != 3 && f.tile_w == 32 && f.tile_h == 16) {
+        // 32x16 with 6 / 9 channels: two 32x8 band waves per tile, like the 3-channel pass (K7 walks the list once per band there: render_bwd.hip)
+        if (f.colors == 9) { SR_LAUNCH_FWD(false, 9, 4, 1, 2); } else { SR_LAUNCH_FWD(false, 6, 4, 1, 2); }
     } else if (f.colors != 3) {
-        // the shared-geometry passes on the other shapes with up to four pixels per lane: 8x8, 16x8, 32x8.  (32x16 keeps eight
-        // pixels per lane in K7 -- 234 VGPRs with three channels already -- and stays 3-channel: api.hip refuses it by name.)
+        // the shared-geometry passes on the other shapes with up to four pixels per lane: 8x8, 16x8, 32x8
         if (f.tile_h != 8) return hipErrorInvalidValue;
 #define SR_FWD_NC(QX)                                                                                        \
         { if (f.colors == 9) { SR_LAUNCH_FWD(false, 9, QX, 1, 1); } else { SR_LAUNCH_FWD(false, 6, QX, 1, 1); } }

@@ -14,7 +14,10 @@ namespace sr {
 // `written[]` at the same index (zeroed per call).  Gradient record slots: see common.h.
 // Register budget: three waves per SIMD (<= 168 VGPRs) wherever the per-pixel state allows it -- the loop is latency-bound
 // at two -- i.e. up to four pixels per lane with three colour channels.
-template <int NC, int QX, int QY>
+// BANDS = 2 (32x16 tile with 6 / 9 colour channels: eight pixels per lane do not fit the register file there): the wave walks the list
+// TWICE, once per 32x8 band (QY = 1 quadrant row each, four pixels per lane), and the second walk ADDS its sums to the records the first
+// one wrote -- same wave, program order, a fence in between -- so a record still holds the whole tile's contribution and K8 is unchanged.
+template <int NC, int QX, int QY, int BANDS = 1>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(QX * QY <= 4 && NC == 3 ? 3 : 1, QX * QY <= 4 && NC == 3 ? 3 : 8)))
 void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
                                                                  const uint32_t* __restrict__ point_list,
@@ -32,16 +35,20 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
     const int lane = threadIdx.x;
     const int tile = (int)tile_order[blockIdx.x];   // longest lists first
     constexpr int NQ = QX * QY;   // 8x8 quadrants per tile = pixels per lane
-    const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8);
-    const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
+    static_assert(BANDS == 1 || QY == 1, "a banded walk handles one quadrant row per band");
+    const int tx0 = (tile % f.tiles_x) * (QX * 8), tile_y0 = (tile / f.tiles_x) * (QY * 8 * BANDS);
+    const float Xc = (float)(tx0 + QX * 4), Yc = (float)(tile_y0 + QY * 4 * BANDS);   // the TILE's centre: the local origin of staging and moments
     const int lx = lane & 7, ly = lane >> 3;
     const uint2 range = ranges[tile];
     const uint32_t count = range.y - range.x;
     const size_t HW = (size_t)f.H * f.W;
     const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
+  for (int band = 0; band < BANDS; ++band) {
+    const int ty0 = tile_y0 + band * (QY * 8);
+    if (BANDS > 1 && band > 0) __threadfence();   // the first walk's records and `written` flags, visible to this wave's loads
 
     // per-pixel constants (upstream gradients folded with the forward's final accumulators) and state
-    const float xl0 = (float)(lx - QX * 4), yl0 = (float)(ly - QY * 4);   // tile-local pixel of quadrant 0; quadrant q adds 8*(q%QX, q/QX)
+    const float xl0 = (float)(lx - QX * 4), yl0 = (float)(ly - QY * 4 * BANDS + band * (QY * 8));   // tile-local pixel of quadrant 0; quadrant q adds 8*(q%QX, q/QX)
     float gr[NQ], gg[NQ], gb[NQ], gn0[NQ], gn1[NQ], gn2[NQ], g_depth[NQ], g_median[NQ], a0[NQ], a1[NQ], a2[NQ];
     float gc3[NQ], gc4[NQ], gc5[NQ], gc6[NQ], gc7[NQ], gc8[NQ];   // only live in the 6- / 9-channel variants
     uint32_t lastc[NQ], medc[NQ], quad_last[NQ];
@@ -88,7 +95,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
         load_record(recs, gid, nr); nr[4].z = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
         if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
-        nhit = decode_hits<QX, QY>(hit_mask[pos]);
+        nhit = (decode_hits<QX, QY * BANDS>(hit_mask[pos]) >> (band * QX * QY)) & ((1u << (QX * QY)) - 1u);
     }
     for (int rd = rounds - 1; rd >= 0; --rd) {
         const uint32_t rbase = (uint32_t)rd * kWave;
@@ -114,7 +121,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             load_record(recs, gid, nr); nr[4].z = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
             if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
-            nhit = decode_hits<QX, QY>(hit_mask[pos]);
+            nhit = (decode_hits<QX, QY * BANDS>(hit_mask[pos]) >> (band * QX * QY)) & ((1u << (QX * QY)) - 1u);
         }
         unsigned long long bits = ballot64(m != 0);
         // entries of this round that get a record: those with an (entry, quadrant) pair that reached a pixel in the forward.  (Such a
@@ -215,11 +222,16 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             acc[0].w = fmaf(ox, acc[0].x, acc[0].w); acc[1].x = fmaf(ox, acc[0].y, acc[1].x); acc[1].y = fmaf(ox, acc[0].z, acc[1].y);
             acc[1].z = fmaf(oy, acc[0].x, acc[1].z); acc[1].w = fmaf(oy, acc[0].y, acc[1].w); acc[2].x = fmaf(oy, acc[0].z, acc[2].x);
             float4* o = inst_grads + (size_t)slot * kGQ;
+            if (BANDS > 1 && band > 0 && written[slot]) {   // the upper band left a record for this duplicate: add to it
+#pragma unroll
+                for (int k = 0; k < kGQ; ++k) { const float4 p = o[k]; acc[k].x += p.x; acc[k].y += p.y; acc[k].z += p.z; acc[k].w += p.w; }
+            }
 #pragma unroll
             for (int k = 0; k < kGQ; ++k) o[k] = acc[k];
             written[slot] = 1;   // K8 reads this 1-B flag (zeroed per call) before it touches the record
         }
     }
+  }   // band
 }
 
 #define SR_FOR_TILE_SHAPE(F)                                                    \
@@ -241,6 +253,11 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
                        n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written)
     if (f.tile_w == 16 && f.tile_h == 16) {
         if (f.colors == 9) SR_LAUNCH_BWD(9, 2, 2); else if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
+    } else if (f.colors != 3 && f.tile_w == 32 && f.tile_h == 16) {   // eight pixels per lane: two banded walks of four (BANDS = 2)
+#define SR_LAUNCH_BWD_BANDED(NCH) hipLaunchKernelGGL((render_backward_kernel<NCH, 4, 1, 2>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, extra, \
+                                                     final_T, n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written)
+        if (f.colors == 9) SR_LAUNCH_BWD_BANDED(9); else SR_LAUNCH_BWD_BANDED(6);
+#undef SR_LAUNCH_BWD_BANDED
     } else if (f.colors != 3) {   // 6 / 9 channels on the shapes with up to four pixels per lane (render.hip launch_render_forward)
         if (f.tile_h != 8) return hipErrorInvalidValue;
 #define SR_BWD_NC(QX) { if (f.colors == 9) SR_LAUNCH_BWD(9, QX, 1); else SR_LAUNCH_BWD(6, QX, 1); }

@@ -1,81 +1,160 @@
 // render_class.hip -- the per-class distortion pass (second half): the reference's training iteration renders
 // the same view once per semantic class with `render(..., semantic_filter_bit = 1 << k, reverse_semantic = True)` and uses only
 // `rend_dist` of each [REF /root/reference/train.py:94-103] -- five full rasterizations (boolean-indexed inputs, K1..K8 each) for
-// five distortion maps.  Here K1..K5 run ONCE on all Gaussians; the forward blend walks every tile list once and keeps one
-// transmittance / distortion chain PER CLASS (a list entry belongs to exactly one class, which is wave-uniform, so the chain is
-// picked by a uniform branch); the backward runs one wave per (tile, class) that skips the other classes' entries and stops at
-// the class's deepest contributor; every (tile, Gaussian) duplicate gets at most one gradient record, so K8 is unchanged.
-// Per class the arithmetic is exactly the class-filtered render's: same list order, same alpha / transmittance thresholds, same
-// early termination -- a Gaussian of another class is to a class chain what it is to the reference's subset render: absent.
-// The class id of a Gaussian travels in the first colour slot of its splat record (colors_precomp[:, 0]; there is no colour here).
+// five distortion maps.  Here K1..K5 run ONCE on all Gaussians; then every tile list is stably partitioned by class
+// (class_partition_kernel: the list of tile t becomes [class 0 by depth | class 1 by depth | ...], with a (begin, end) pair per
+// (tile, class)), and both blend kernels run one wave per (tile, class) on that class's SUB-LIST alone -- a Gaussian of another class
+// is to a class chain what it is to the reference's subset render: absent.  Per class the arithmetic is exactly the class-filtered
+// render's: same list order, same alpha / transmittance thresholds, same early termination; contributor numbers count positions
+// in the class's own list, as in the subset render.  Every (tile, Gaussian) duplicate gets at most one gradient record, so K8 is
+// unchanged.  The class id of a Gaussian arrives in the first colour slot (colors_precomp[:, 0]; there is no colour here).
+// (Round 4 walked the whole tile list in every (tile, class) wave of the backward and kept all class chains in one forward wave:
+// 67 M staged entries for 8.6 M useful ones, 9.3 GiB fetched per backward launch, a third of the forward's issue slots scalar --
+// profiles/r05_train_step_*)
 #include "blend_common.h"
 
 namespace sr {
 
 constexpr int kClassMax = 8;
+constexpr uint8_t kNoClass = 255;
 
-// QX x 1 quadrants per wave; SPLIT = 2: the reference's 16x16 tile as two 16x8 band waves (two pixels per lane), SPLIT = 1: the 8x8 /
-// 16x8 / 32x8 tiles of BASELINE config 5's sweep, one wave per tile.
-template <int NCLS, int QX, int SPLIT>
-__global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
-                                                              const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
-                                                              float* __restrict__ out_dist,       // [NCLS, H, W]
-                                                              float* __restrict__ cls_state,      // [NCLS, 3, H, W]: T_final, M1, M2
-                                                              uint32_t* __restrict__ cls_last,    // [NCLS, H, W]: last contributor
-                                                              uint32_t* __restrict__ tile_total,  // [tiles, NCLS]: deepest contributor of the class in the tile (zeroed by the caller)
+// class id bytes: [P] u8 from colors_precomp[:, 0] (negative / >= n_classes / NaN: in no class)
+__global__ __launch_bounds__(256) void class_ids_kernel(int P, int n_classes, const float* __restrict__ cols, uint8_t* __restrict__ ids) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float c = cols[3 * (size_t)i];
+    const int ci = (int)c;
+    ids[i] = (c >= 0.f && ci < n_classes) ? (uint8_t)ci : kNoClass;
+}
+
+// One wave per tile: stable partition of the tile's list by class.  Two sweeps over the list (count, scatter) with wave ballots, four
+// chunks of 64 entries in flight per step (the id -> class gather is a dependent load: one chunk at a time the kernel is a chain of
+// memory latencies, 0.15 ms at C3); the class bytes of the first kClsCache entries wait in LDS for the second sweep.  Entries of no class
+// are dropped.  cls_list shares the tile's span of positions: class c of tile t occupies [cls_ranges[t * n + c].x, .y) inside
+// [ranges[t].x, ranges[t].y).
+constexpr int kClsCache = 8192, kClsUnroll = 4;
+__global__ __launch_bounds__(kWave) void class_partition_kernel(int n_classes, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                                                                 const uint8_t* __restrict__ ids, uint32_t* __restrict__ cls_list, uint2* __restrict__ cls_ranges) {
+    __shared__ uint8_t s_cls[kClsCache];
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const uint2 range = ranges[tile];
+    const uint32_t n = range.y - range.x;
+    uint32_t cnt[kClassMax];
+#pragma unroll
+    for (int k = 0; k < kClassMax; ++k) cnt[k] = 0;
+    for (uint32_t base = 0; base < n; base += kWave * kClsUnroll) {
+        // (clamped addresses instead of predicated loads: a predicate makes every load a branch of its own with a wait inside, and the
+        // four dependent pairs run one after the other)
+        uint32_t c[kClsUnroll], g4[kClsUnroll];
+#pragma unroll
+        for (int u = 0; u < kClsUnroll; ++u) g4[u] = point_list[range.x + min(base + u * kWave + lane, n - 1u)];
+#pragma unroll
+        for (int u = 0; u < kClsUnroll; ++u) c[u] = ids[g4[u]];
+#pragma unroll
+        for (int u = 0; u < kClsUnroll; ++u) c[u] = (base + u * kWave + lane < n) ? c[u] : (uint32_t)kNoClass;
+#pragma unroll
+        for (int u = 0; u < kClsUnroll; ++u) {
+            const uint32_t j = base + u * kWave + lane;
+            if (j < (uint32_t)kClsCache) s_cls[j] = (uint8_t)c[u];   // (kNoClass beyond the end of the list: never read as an entry)
+#pragma unroll
+            for (int k = 0; k < kClassMax; ++k)
+                if (k < n_classes) cnt[k] += (uint32_t)__popcll(ballot64(c[u] == (uint32_t)k));
+        }
+    }
+    uint32_t begin[kClassMax], at = range.x;
+#pragma unroll
+    for (int k = 0; k < kClassMax; ++k) {
+        begin[k] = at;
+        if (k < n_classes) {
+            if (lane == 0) cls_ranges[(size_t)tile * n_classes + k] = make_uint2(at, at + cnt[k]);
+            at += cnt[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // (one wave: its own LDS writes are visible to it in program order)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t base = 0; base < n; base += kWave * kClsUnroll) {
+        uint32_t gid[kClsUnroll], c[kClsUnroll];
+#pragma unroll
+        for (int u = 0; u < kClsUnroll; ++u) gid[u] = point_list[range.x + min(base + u * kWave + lane, n - 1u)];
+        if (base + kWave * kClsUnroll <= (uint32_t)kClsCache) {   // wave-uniform: the whole step is in the LDS cache
+#pragma unroll
+            for (int u = 0; u < kClsUnroll; ++u) c[u] = (uint32_t)s_cls[min(base + u * kWave + lane, n - 1u)];
+        } else {
+#pragma unroll
+            for (int u = 0; u < kClsUnroll; ++u) c[u] = (uint32_t)ids[gid[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kClsUnroll; ++u) c[u] = (base + u * kWave + lane < n) ? c[u] : (uint32_t)kNoClass;
+#pragma unroll
+        for (int u = 0; u < kClsUnroll; ++u) {
+#pragma unroll
+            for (int k = 0; k < kClassMax; ++k) {
+                if (k >= n_classes) continue;
+                const unsigned long long b = ballot64(c[u] == (uint32_t)k);
+                if (c[u] == (uint32_t)k) cls_list[begin[k] + (uint32_t)__popcll(b & below)] = gid[u];
+                begin[k] += (uint32_t)__popcll(b);
+            }
+        }
+    }
+}
+
+// the three record quads the class pass stages (transform rows, centre, opacity); the others stay zero
+__device__ __forceinline__ void load_record_geometry(const float4* __restrict__ recs, uint32_t gid, float4 (&q)[kRecQuads]) {
+    const float4* r = recs + (size_t)gid * kRecQuads;
+    q[0] = r[0]; q[1] = r[1]; q[2] = r[2];
+}
+
+// One wave per (tile band, class): QX x 1 quadrants per wave; SPLIT = 2: the reference's 16x16 tile as two 16x8 band waves (two pixels per
+// lane), SPLIT = 1: the 8x8 / 16x8 / 32x8 tiles of BASELINE config 5's sweep.  A single transmittance / distortion chain.
+template <int QX, int SPLIT>
+__global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_classes, const uint2* __restrict__ cls_ranges, const uint32_t* __restrict__ tile_order,
+                                                              const uint32_t* __restrict__ cls_list, const float4* __restrict__ recs,
+                                                              float* __restrict__ out_dist,       // [n_classes, H, W]
+                                                              float* __restrict__ cls_state,      // [n_classes, 3, H, W]: T_final, M1, M2
+                                                              uint32_t* __restrict__ cls_last,    // [n_classes, H, W]: last contributor (position in the class's list, 1-based)
+                                                              uint32_t* __restrict__ tile_total,  // [tiles, n_classes]: deepest contributor of the class in the tile (zeroed by the caller)
                                                               uint16_t* __restrict__ hit_mask, int cull) {
     constexpr int QY = 1, NQ = QX;
     constexpr uint32_t kQuadMask = (1u << NQ) - 1u;
-    __shared__ float4 s_e[entry_quads<3>()][kWave];
+    __shared__ float4 s_e[entry_quads<0>()][kWave];
     const int lane = threadIdx.x;
-    int tile = blockIdx.x, part = 0;
-    if (SPLIT > 1) {   // the bands of a tile on one XCD (render.hip)
-        const int xcd = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
-        tile = (k / SPLIT) * kXcds + xcd; part = k % SPLIT;
-        if (tile >= f.tiles_x * f.tiles_y) return;
-    }
+    // the waves of one tile -- its classes, and the SPLIT bands of each (they walk the same sub-list) -- on one XCD
+    const int xcd = blockIdx.x % kXcds;
+    int k = blockIdx.x / kXcds;
+    const int part = k % SPLIT; k /= SPLIT;
+    const int cls = k % n_classes;
+    int tile = (k / n_classes) * kXcds + xcd;
+    if (tile >= f.tiles_x * f.tiles_y) return;
     tile = (int)tile_order[tile];
     const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8 * SPLIT) + part * (QY * 8);
     const float Xc = (float)(tx0 + QX * 4), Yc = (float)((tile / f.tiles_x) * (QY * 8 * SPLIT) + QY * SPLIT * 4);
     const float yshift = (float)(part * (QY * 8) - QY * (SPLIT - 1) * 4);
     const int lx = lane & 7, ly = lane >> 3;
-    const uint2 range = ranges[tile];
+    const uint2 range = cls_ranges[(size_t)tile * n_classes + cls];
     const uint32_t n_total = range.y - range.x;
     const float yl = (float)(ly - QY * 4) + yshift;
-    float xl[NQ];
-    float T[NCLS][NQ], M1[NCLS][NQ], M2[NCLS][NQ], dist[NCLS][NQ];
-    uint32_t lastc[NCLS][NQ];
-    uint32_t done = 0, alive = 0;   // bit c * NQ + q: pixel (lane, q) finished for class c / some pixel of quadrant q still open for class c
+    float xl[NQ], T[NQ], M1[NQ], M2[NQ], dist[NQ];
+    uint32_t lastc[NQ];
+    uint32_t done = 0, alive = 0;   // bit q: pixel (lane, q) finished / some pixel of quadrant q still open
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int px = tx0 + q * 8 + lx, py = ty0 + ly;
         xl[q] = (float)(q * 8 + lx - QX * 4);
         const bool outside = !(px < f.W && py < f.H);
-#pragma unroll
-        for (int c = 0; c < NCLS; ++c) {
-            T[c][q] = 1.f; M1[c][q] = M2[c][q] = dist[c][q] = 0.f; lastc[c][q] = 0;
-            if (outside) done |= 1u << (c * NQ + q);
-        }
-        if (ballot64(!outside) != 0) {
-#pragma unroll
-            for (int c = 0; c < NCLS; ++c) alive |= 1u << (c * NQ + q);
-        }
+        T[q] = 1.f; M1[q] = M2[q] = dist[q] = 0.f; lastc[q] = 0;
+        if (outside) done |= 1u << q;
+        if (ballot64(!outside) != 0) alive |= 1u << q;
     }
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 nr[kRecQuads];
-    if ((uint32_t)lane < n_total) load_record(recs, point_list[range.x + lane], nr);
+#pragma unroll
+    for (int i = 0; i < kRecQuads; ++i) nr[i] = zero4;
+    if ((uint32_t)lane < n_total) load_record_geometry(recs, cls_list[range.x + lane], nr);
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         uint32_t m = 0;
-        bool has_class = false;
-        if ((uint32_t)lane < n) {
-            const float cls_f = nr[3].w;            // class id (colors_precomp[:, 0])
-            const int ci = (int)cls_f;
-            has_class = cls_f >= 0.f && ci < NCLS;
-            m = stage_entry<QX, QY, 3>(nr, make_float4(0.f, 0.f, has_class ? (float)ci : -1.f, 0.f), zero4, Xc, Yc, cull & 1, s_e, lane, yshift);
-            m = has_class ? (m & (alive >> (ci * NQ)) & kQuadMask) : 0u;
-        }
-        if (base + kWave + lane < n_total) load_record(recs, point_list[range.x + base + kWave + lane], nr);
+        if ((uint32_t)lane < n) m = stage_entry<QX, QY, 0>(nr, zero4, zero4, Xc, Yc, cull & 1, s_e, lane, yshift) & alive & kQuadMask;
+        if (base + kWave + lane < n_total) load_record_geometry(recs, cls_list[range.x + base + kWave + lane], nr);
         unsigned long long bits = ballot64(m != 0);
         unsigned long long hit[NQ];
 #pragma unroll
@@ -83,44 +162,37 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
         while (bits) {
             const int j = __ffsll((long long)bits) - 1;
             bits &= bits - 1;
-            const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
-            const int cj = __builtin_amdgcn_readfirstlane((int)e3.w);
-            const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & (alive >> (cj * NQ)) & kQuadMask;
+            const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & alive;
             if (!mj) continue;
+            const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
             const uint32_t contributor = base + (uint32_t)j + 1u;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
-                const bool ok = intersect(xl[q], yl, e0, e1, e2, e3, h);
-#pragma unroll
-                for (int c = 0; c < NCLS; ++c) {
-                    if (cj != c) continue;        // wave-uniform: the entry's class picks the chain
-                    const uint32_t bit = 1u << (c * NQ + q);
-                    const bool valid = ok & !(done & bit);
-                    if (ballot64(valid) == 0) continue;
-                    hit[q] |= 1ull << j;
-                    if (valid) {
-                        const float test_T = T[c][q] * (1.f - h.alpha);
-                        if (test_T < kTStop) {
-                            done |= bit;  // this entry is NOT blended
-                        } else {
-                            const float w = h.alpha * T[c][q];
-                            const float A = 1.f - T[c][q];
-                            const float mm = kFN * (1.f - kNear * fast_rcp(h.depth));
-                            dist[c][q] += (mm * mm * A + M2[c][q] - 2.f * mm * M1[c][q]) * w;
-                            M1[c][q] += mm * w;
-                            M2[c][q] += mm * mm * w;
-                            T[c][q] = test_T;
-                            lastc[c][q] = contributor;
-                        }
+                const bool valid = intersect(xl[q], yl, e0, e1, e2, e3, h) & !(done & (1u << q));
+                if (ballot64(valid) == 0) continue;
+                hit[q] |= 1ull << j;
+                if (valid) {
+                    const float test_T = T[q] * (1.f - h.alpha);
+                    if (test_T < kTStop) {
+                        done |= 1u << q;  // this entry is NOT blended
+                    } else {
+                        const float w = h.alpha * T[q];
+                        const float A = 1.f - T[q];
+                        const float mm = kFN * (1.f - kNear * fast_rcp(h.depth));
+                        dist[q] += (mm * mm * A + M2[q] - 2.f * mm * M1[q]) * w;
+                        M1[q] += mm * w;
+                        M2[q] += mm * mm * w;
+                        T[q] = test_T;
+                        lastc[q] = contributor;
                     }
-                    if (ballot64(!(done & bit)) == 0) alive &= ~bit;
                 }
+                if (ballot64(!(done & (1u << q))) == 0) alive &= ~(1u << q);
             }
         }
-        // (entry, quadrant) hit mask for the backward: one byte per band; only entries that carry a class are looked at there
-        if ((uint32_t)lane < n && has_class) {
+        // (entry, quadrant) hit mask for the backward: one byte per band
+        if ((uint32_t)lane < n) {
             uint32_t hm = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
@@ -128,47 +200,53 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, const 
             else hit_mask[range.x + base + lane] = (uint16_t)hm;
         }
     }
-    // entries behind the point where every chain of the band had closed keep whatever hit byte they had: the backward never gets
-    // there (it stops at the class's deepest contributor)
+    // entries behind the point where this band's chain had closed keep whatever hit byte they had: the backward walks to the deepest
+    // contributor of EITHER band, but masks every quadrant with its own deepest contributor (`need`), so those bytes are never acted on
     const size_t HW = (size_t)f.H * f.W;
+    uint32_t deepest = 0;
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) {
-        uint32_t deepest = 0;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int px = tx0 + q * 8 + lx, py = ty0 + ly;
-            if (px < f.W && py < f.H) {
-                const size_t pix = (size_t)py * f.W + px;
-                out_dist[c * HW + pix] = dist[c][q];
-                cls_state[(c * 3 + 0) * HW + pix] = T[c][q]; cls_state[(c * 3 + 1) * HW + pix] = M1[c][q]; cls_state[(c * 3 + 2) * HW + pix] = M2[c][q];
-                cls_last[c * HW + pix] = lastc[c][q];
-            }
-            deepest = max(deepest, lastc[c][q]);
+    for (int q = 0; q < NQ; ++q) {
+        const int px = tx0 + q * 8 + lx, py = ty0 + ly;
+        if (px < f.W && py < f.H) {
+            const size_t pix = (size_t)py * f.W + px;
+            out_dist[cls * HW + pix] = dist[q];
+            cls_state[(cls * 3 + 0) * HW + pix] = T[q]; cls_state[(cls * 3 + 1) * HW + pix] = M1[q]; cls_state[(cls * 3 + 2) * HW + pix] = M2[q];
+            cls_last[cls * HW + pix] = lastc[q];
         }
-        deepest = wave_max_u32(deepest);
-        if (lane == 0 && deepest) atomicMax(&tile_total[(size_t)tile * NCLS + c], deepest);
+        deepest = max(deepest, lastc[q]);
     }
+    deepest = wave_max_u32(deepest);
+    if (lane == 0 && deepest) atomicMax(&tile_total[(size_t)tile * n_classes + cls], deepest);
 }
 
 // One wave per (tile, class): the blend backward of the class-filtered render with the distortion gradient as the only upstream
-// gradient (no colour, depth, normal, alpha, median terms): psi = dLw, Z = sum_{k>i} w_k dLw_k  (render.hip, K7).
-template <int NCLS, int QX, int QY>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list,
+// gradient (no colour, depth, normal, alpha, median terms): psi = dLw, Z = sum_{k>i} w_k dLw_k  (render_bwd.hip, K7).  Walks the
+// class's sub-list back to front from the deepest contributor any pixel of the tile has.
+template <int QX, int QY>
+#ifndef SR_CLASS_BWD_WAVES
+#define SR_CLASS_BWD_WAVES 4
+#endif
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(QX * QY <= 4 ? SR_CLASS_BWD_WAVES : 2, QX * QY <= 4 ? SR_CLASS_BWD_WAVES : 2)))
+void class_backward_kernel(FrameDev f, int n_classes, const uint2* __restrict__ cls_ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ cls_list,
                            const float4* __restrict__ recs, const float* __restrict__ cls_state, const uint32_t* __restrict__ cls_last,
                            const uint32_t* __restrict__ tile_total, const float* __restrict__ dL_ddist, const uint16_t* __restrict__ hit_mask,
                            float4* __restrict__ inst_grads, uint8_t* __restrict__ written) {
     constexpr int NQ = QX * QY, kGQ = kGradQuads;
-    __shared__ float4 s_e[entry_quads<3>()][kWave];
+    __shared__ float4 s_e[entry_quads<0>()][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGQ * 4];
     const int lane = threadIdx.x;
-    const int tile = (int)tile_order[blockIdx.x / NCLS], cls = blockIdx.x % NCLS;
-    const uint32_t total = tile_total[(size_t)tile * NCLS + cls];   // deepest list position any pixel of the tile needs for this class
+    // the classes of one tile on one XCD (their pixels' state and the records of their Gaussians' neighbours share that L2)
+    const int xcd = blockIdx.x % kXcds, kk = blockIdx.x / kXcds;
+    const int cls = kk % n_classes;
+    int tile = (kk / n_classes) * kXcds + xcd;
+    if (tile >= f.tiles_x * f.tiles_y) return;
+    tile = (int)tile_order[tile];
+    const uint32_t total = tile_total[(size_t)tile * n_classes + cls];   // deepest position of the class's list any pixel of the tile needs
     if (total == 0) return;
     const int tx0 = (tile % f.tiles_x) * (QX * 8), ty0 = (tile / f.tiles_x) * (QY * 8);
     const float Xc = (float)(tx0 + QX * 4), Yc = (float)(ty0 + QY * 4);
     const int lx = lane & 7, ly = lane >> 3;
-    const uint2 range = ranges[tile];
+    const uint32_t first_pos = cls_ranges[(size_t)tile * n_classes + cls].x;
     const size_t HW = (size_t)f.H * f.W;
     const float xl0 = (float)(lx - QX * 4), yl0 = (float)(ly - QY * 4);
     float a0[NQ], a1[NQ], a2[NQ], T[NQ], Z[NQ];
@@ -189,29 +267,35 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
     const int rounds = (int)((total + kWave - 1) / kWave);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 nr[kRecQuads];
+#pragma unroll
+    for (int i = 0; i < kRecQuads; ++i) nr[i] = zero4;
     uint32_t nhit = 0;
-    auto fetch = [&](uint32_t pos) { const uint32_t gid = point_list[pos]; load_record(recs, gid, nr); nr[4].z = __uint_as_float(first_index(f, gid)); nhit = decode_hits<QX, QY>(hit_mask[pos]); };
-    if ((uint32_t)((rounds - 1) * kWave + lane) < total) fetch(range.x + (rounds - 1) * kWave + lane);
+    auto fetch = [&](uint32_t pos) {
+        const uint32_t gid = cls_list[pos];
+        load_record_geometry(recs, gid, nr);
+        nr[4].w = reinterpret_cast<const float*>(recs + (size_t)gid * kRecQuads + 4)[3];   // the radius (emission_index)
+        nr[4].z = __uint_as_float(first_index(f, gid));
+        nhit = decode_hits<QX, QY>(hit_mask[pos]);
+    };
+    if ((uint32_t)((rounds - 1) * kWave + lane) < total) fetch(first_pos + (rounds - 1) * kWave + lane);
     for (int rd = rounds - 1; rd >= 0; --rd) {
         const uint32_t rbase = (uint32_t)rd * kWave;
         const uint32_t n = min((uint32_t)kWave, total - rbase);
         uint32_t m = 0, slot = 0;
         if ((uint32_t)lane < n) {
-            (void)stage_entry<QX, QY, 3>(nr, zero4, zero4, Xc, Yc, 0, s_e, lane);
-            if (nr[3].w == (float)cls) {            // the other classes' entries are not there for this chain
-                slot = emission_index(nr, __float_as_uint(nr[4].z), tile % f.tiles_x, tile / f.tiles_x, f);
-                uint32_t need = 0;
+            (void)stage_entry<QX, QY, 0>(nr, zero4, zero4, Xc, Yc, 0, s_e, lane);
+            slot = emission_index(nr, __float_as_uint(nr[4].z), tile % f.tiles_x, tile / f.tiles_x, f);
+            uint32_t need = 0;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
-                m = nhit & need;
-            }
+            for (int q = 0; q < NQ; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
+            m = nhit & need;
         }
         {
             float4* z = reinterpret_cast<float4*>(&s_out[lane][0]);
 #pragma unroll
             for (int k = 0; k < kGQ; ++k) z[k] = zero4;
         }
-        if (rd > 0) fetch(range.x + rbase - kWave + lane);
+        if (rd > 0) fetch(first_pos + rbase - kWave + lane);
         unsigned long long bits = ballot64(m != 0);
         const unsigned long long wrote = bits;   // every entry with a forward hit gets a record (see K7)
         while (bits) {
@@ -220,11 +304,11 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
             const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
             const uint32_t cidx = rbase + (uint32_t)j;
-            float v[24];
+            float v[16];
 #pragma unroll
-            for (int k = 0; k < 24; ++k) {
+            for (int k = 0; k < 16; ++k) {
                 v[k] = 0.f;
-                if (k < 15) asm volatile("" : "+v"(v[k]));   // opaque zero for the live accumulators (see K7); 15..23 stay constant zero
+                if (k < 15) asm volatile("" : "+v"(v[k]));   // opaque zero for the live accumulators (see K7); v[15] stays constant zero
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -267,8 +351,8 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
                 }
             }
             {
-                const float tot = wave_reduce24(v, lane);
-                if (reduce24_holds_total(lane)) s_out[j][reduce24_index(lane)] = tot;
+                const float tot = wave_reduce16(v);   // record floats 15..23 (colour, normal) stay the zeros s_out was reset to
+                if (reduce16_holds_total(lane)) s_out[j][reduce16_index(lane)] = tot;
             }
         }
         if ((wrote >> lane) & 1ull) {
@@ -289,37 +373,47 @@ void class_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
     }
 }
 
-hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list,
+hipError_t launch_class_partition(int P, int n_tiles, int n_classes, const float* class_cols, const uint2* ranges, const uint32_t* point_list, uint8_t* ids,
+                                  uint32_t* cls_list, uint2* cls_ranges, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    if (n_classes < 1 || n_classes > kClassMax) return hipErrorInvalidValue;
+    if (P > 0) hipLaunchKernelGGL(class_ids_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, n_classes, class_cols, ids);
+    // (P == 0: every list is empty, the kernel only writes the empty (begin, end) pairs)
+    hipLaunchKernelGGL(class_partition_kernel, dim3(n_tiles), dim3(kWave), 0, s, n_classes, ranges, point_list, ids, cls_list, cls_ranges);
+    return hipGetLastError();
+}
+
+hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* cls_ranges, const uint32_t* tile_order, const uint32_t* cls_list,
                                 const float4* recs, float* out_dist, float* cls_state, uint32_t* cls_last, uint32_t* tile_total, uint16_t* hit_mask,
                                 int cull, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    const bool ref_tile = f.tile_w == 16 && f.tile_h == 16;
-    if (!ref_tile && !(f.tile_h == 8 && (f.tile_w == 8 || f.tile_w == 16 || f.tile_w == 32))) return hipErrorInvalidValue;   // (32x16: eight pixels per lane)
+    if (n_classes < 1 || n_classes > kClassMax) return hipErrorInvalidValue;
+    const bool two_bands = f.tile_h == 16 && (f.tile_w == 16 || f.tile_w == 32);   // 16x16 and 32x16: two band waves per (tile, class)
+    if (!two_bands && !(f.tile_h == 8 && (f.tile_w == 8 || f.tile_w == 16 || f.tile_w == 32))) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(tile_total, 0, sizeof(uint32_t) * (size_t)n_tiles * n_classes, s);
     if (e != hipSuccess) return e;
-    const dim3 grid(ref_tile ? (n_tiles + kXcds - 1) / kXcds * kXcds * 2 : n_tiles);
-#define SR_CF_SHAPE(N, QX, SPLIT) hipLaunchKernelGGL((class_forward_kernel<N, QX, SPLIT>), grid, dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, out_dist, cls_state, cls_last, tile_total, hit_mask, cull)
-#define SR_CF(N) { if (ref_tile) SR_CF_SHAPE(N, 2, 2); else if (f.tile_w == 8) SR_CF_SHAPE(N, 1, 1); else if (f.tile_w == 16) SR_CF_SHAPE(N, 2, 1); else SR_CF_SHAPE(N, 4, 1); }
-    switch (n_classes) { case 1: SR_CF(1); break; case 2: SR_CF(2); break; case 3: SR_CF(3); break; case 4: SR_CF(4); break;
-                         case 5: SR_CF(5); break; case 6: SR_CF(6); break; default: return hipErrorInvalidValue; }
-#undef SR_CF
+    const int split = two_bands ? 2 : 1;
+    const dim3 grid((unsigned)((n_tiles + kXcds - 1) / kXcds * kXcds) * (unsigned)(split * n_classes));
+#define SR_CF_SHAPE(QX, SPLIT) hipLaunchKernelGGL((class_forward_kernel<QX, SPLIT>), grid, dim3(kWave), 0, s, f, n_classes, cls_ranges, tile_order, cls_list, recs, out_dist, cls_state, cls_last, tile_total, hit_mask, cull)
+    if (two_bands) { if (f.tile_w == 16) SR_CF_SHAPE(2, 2); else SR_CF_SHAPE(4, 2); }
+    else if (f.tile_w == 8) SR_CF_SHAPE(1, 1); else if (f.tile_w == 16) SR_CF_SHAPE(2, 1); else SR_CF_SHAPE(4, 1);
 #undef SR_CF_SHAPE
     return hipGetLastError();
 }
 
-hipError_t launch_class_backward(const FrameDev& f, int n_classes, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list,
+hipError_t launch_class_backward(const FrameDev& f, int n_classes, const uint2* cls_ranges, const uint32_t* tile_order, const uint32_t* cls_list,
                                  const float4* recs, const float* cls_state, const uint32_t* cls_last, const uint32_t* tile_total,
                                  const float* dL_ddist, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    const bool ref_tile = f.tile_w == 16 && f.tile_h == 16;
-    if (!ref_tile && !(f.tile_h == 8 && (f.tile_w == 8 || f.tile_w == 16 || f.tile_w == 32))) return hipErrorInvalidValue;
-#define SR_CB_SHAPE(N, QX, QY) hipLaunchKernelGGL((class_backward_kernel<N, QX, QY>), dim3(n_tiles * N), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, cls_state, cls_last, tile_total, dL_ddist, hit_mask, inst_grads, written)
-#define SR_CB(N) { if (ref_tile) SR_CB_SHAPE(N, 2, 2); else if (f.tile_w == 8) SR_CB_SHAPE(N, 1, 1); else if (f.tile_w == 16) SR_CB_SHAPE(N, 2, 1); else SR_CB_SHAPE(N, 4, 1); }
-    switch (n_classes) { case 1: SR_CB(1); break; case 2: SR_CB(2); break; case 3: SR_CB(3); break; case 4: SR_CB(4); break;
-                         case 5: SR_CB(5); break; case 6: SR_CB(6); break; default: return hipErrorInvalidValue; }
-#undef SR_CB
+    if (n_classes < 1 || n_classes > kClassMax) return hipErrorInvalidValue;
+    const bool two_rows = f.tile_h == 16 && (f.tile_w == 16 || f.tile_w == 32);
+    if (!two_rows && !(f.tile_h == 8 && (f.tile_w == 8 || f.tile_w == 16 || f.tile_w == 32))) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((n_tiles + kXcds - 1) / kXcds * kXcds) * (unsigned)n_classes);
+#define SR_CB_SHAPE(QX, QY) hipLaunchKernelGGL((class_backward_kernel<QX, QY>), grid, dim3(kWave), 0, s, f, n_classes, cls_ranges, tile_order, cls_list, recs, cls_state, cls_last, tile_total, dL_ddist, hit_mask, inst_grads, written)
+    if (two_rows) { if (f.tile_w == 16) SR_CB_SHAPE(2, 2); else SR_CB_SHAPE(4, 2); }   // (32x16: eight pixels per lane, two waves per SIMD)
+    else if (f.tile_w == 8) SR_CB_SHAPE(1, 1); else if (f.tile_w == 16) SR_CB_SHAPE(2, 1); else SR_CB_SHAPE(4, 1);
 #undef SR_CB_SHAPE
     return hipGetLastError();
 }

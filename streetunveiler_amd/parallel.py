@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 _BUCKET_INPLACE_BYTES = 32 << 20  # tensors at least this large are all-reduced in place
 # replicated camera lists (the tensor OBJECTS, weakly held, with the version they were checked at) already compared with the cameras actually rendered
-_CAMERA_LISTS_CHECKED = weakref.WeakKeyDictionary()
+_CAMERA_LISTS_CHECKED = {}   # id(tensor) -> (weak reference to it, version)
 
 
 def _exchange_wanted(group=None) -> bool:
@@ -205,13 +205,16 @@ class ShExchange:
             # (checked the first time a given camera list is used, and with SURFEL_EXCHANGE_DEBUG=1 on every step: the comparison reads
             # device memory back -- a host sync inside the backward, on the path where K8 is meant to overlap the all-gather)
             version = getattr(self.all_campos, "_version", 0)
-            if _CAMERA_LISTS_CHECKED.get(self.all_campos) != version or os.environ.get("SURFEL_EXCHANGE_DEBUG") == "1":
+            seen = _CAMERA_LISTS_CHECKED.get(id(self.all_campos))   # (keyed by identity: tensors compare elementwise)
+            if not (seen and seen[0]() is self.all_campos and seen[1] == version) or os.environ.get("SURFEL_EXCHANGE_DEBUG") == "1":
                 rank = dist.get_rank(self.group)
                 mine = torch.stack([f[2] for f in frames]).detach().to(device="cpu", dtype=torch.float32)
                 if not torch.allclose(cams[rank].detach().cpu(), mine, rtol=1e-5, atol=1e-6):
                     raise RuntimeError("factored_sh_exchange: all_campos[rank] does not list this rank's cameras in the order of its forward "
                                        "calls (row j must be the camera of the j-th rasterizer call inside the block)")
-                _CAMERA_LISTS_CHECKED[self.all_campos] = version
+                if len(_CAMERA_LISTS_CHECKED) > 256:
+                    _CAMERA_LISTS_CHECKED.clear()
+                _CAMERA_LISTS_CHECKED[id(self.all_campos)] = (weakref.ref(self.all_campos), version)
             return cams.transpose(0, 1).reshape(K * world, 3).contiguous()
         mine = torch.stack([f[2] for f in frames]).to(device=device, dtype=torch.float32).reshape(K * 3).contiguous()
         cams = torch.empty(world * K * 3, dtype=torch.float32, device=device)

@@ -37,11 +37,9 @@ def _run(name, tmp_path):
     env.pop("SURFEL_RASTER_LIB", None); env.pop("SURFEL_ORACLE_LIB", None)
     if name != "default":
         from oracle import surfel_oracle as so
-        lib, oracle = os.path.join(sb.variant_dir(name), "libsurfel_raster.so"), so.variant_path(name)
-        if not os.path.exists(lib):      # (pre-built here by `python -m streetunveiler_amd.build --variant all`; hipcc is on the GPU box too)
-            lib = sb.build_variant(name)
-        if not os.path.exists(oracle):
-            oracle = so.build_variant(name)
+        # both idempotent: nothing is compiled when the variant is newer than every source (pre-built in the container by
+        # `python -m streetunveiler_amd.build --variant all`, the .so travels); hipcc and gcc are on the GPU box too
+        lib, oracle = sb.build_variant(name), so.build_variant(name)
         env.update(SURFEL_RASTER_LIB=lib, SURFEL_ORACLE_LIB=oracle)
     out = os.path.join(str(tmp_path), name + ".npz")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_worker.py"), str(BITS[name]), out], cwd=ROOT, env=env,
