@@ -312,7 +312,7 @@ def train_step_roofline(args, stage_ms, D, V, n_classes):
     return out
 
 
-XGMI_LINK_GBS = 153.0   # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links per GPU, ~153 GB/s each)
+XGMI_LINK_GBS = 76.8    # one xGMI link, ONE direction: 7 links per GPU at ~153.6 GB/s bidirectional each (the figure SURVEY.md 8e quotes per link)
 
 
 def rccl_topology(log_path, backend, world):

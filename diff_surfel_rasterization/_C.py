@@ -26,6 +26,47 @@ import torch
 from streetunveiler_amd import _lib as L
 
 
+# Tracing: with SURFEL_ROCTX=1 every operator entry point is bracketed by a roctx range (libroctx64: rocprofv3 --marker-trace
+# shows "surfel:forward" / "surfel:backward" / "surfel:class_forward" / ... around the kernels of one call).  Off by default: no library is
+# loaded and the context manager is a no-op.
+_roctx = None
+
+
+def _roctx_lib():
+    global _roctx
+    if _roctx is None:
+        _roctx = False
+        import os
+        if os.environ.get("SURFEL_ROCTX") == "1":
+            for name in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
+                try:
+                    lib = C.CDLL(name)
+                    lib.roctxRangePushA.argtypes = [C.c_char_p]; lib.roctxRangePushA.restype = C.c_int
+                    lib.roctxRangePop.restype = C.c_int
+                    _roctx = lib
+                    break
+                except OSError:
+                    continue
+    return _roctx
+
+
+class _range:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        lib = _roctx_lib()
+        self.on = bool(lib)
+        if self.on:
+            lib.roctxRangePushA(("surfel:" + self.name).encode())
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _roctx.roctxRangePop()
+        return False
+
+
 def _ptr(t: torch.Tensor):
     return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
 
@@ -115,7 +156,7 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
     sh = _f32c(sh, "sh")
     dev = means3D.device
     P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _range("forward"):
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile,
                           quadrant_cull, blend_counters, ballot_ranking, row_mapped, forward_only)
         mask = _mask(mask, P, dev)
@@ -161,7 +202,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
     P = int(means3D.shape[0])
     H, W = int(dL_dcolor.shape[1]), int(dL_dcolor.shape[2])
     M = int(sh.shape[1]) if sh is not None and sh.numel() else 0
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _range("backward"):
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, False, debug, tile)
         # the backward never dereferences opacities (it reads the packed record); pass means3D as a non-NULL stand-in
         g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp, activations)
@@ -225,7 +266,7 @@ def class_distortions(bg, means3D, classes, opacities, scales, rotations, scale_
         raise L.SurfelRasterError("classes must have one entry per Gaussian")
     cols = torch.zeros((P, 3), dtype=torch.float32, device=dev)     # class id in the first colour slot of the splat record
     cols[:, 0] = classes.to(device=dev, dtype=torch.float32).reshape(P)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _range("class_forward"):
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, 0, campos, False, debug, tile)
         mask = _mask(mask, P, dev)
         g = _gaussians(means3D, opacities, scales, rotations, None, cols, None, activations, mask)
@@ -253,7 +294,7 @@ def class_distortions_backward(bg, means3D, radii, cols, scales, rotations, scal
     dev = means3D.device
     P = int(means3D.shape[0])
     H, W = int(dL_ddist.shape[1]), int(dL_ddist.shape[2])
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _range("class_backward"):
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, 0, campos, False, debug, tile)
         g = _gaussians(means3D, means3D, scales, rotations, None, cols, None, activations)
         flat = torch.empty(P * 10, dtype=torch.float32, device=dev)     # means3D | opacity | scales | rotations: one buffer, one all-reduce

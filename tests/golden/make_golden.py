@@ -63,6 +63,18 @@ def g1_g2_from_reference():
     np.savez_compressed(os.path.join(HERE, "camera_golden.npz"), **cams)
 
 
+def g1b_degree4_from_reference():
+    """G1b: the reference's eval_sh at degree 4 (25 coefficients) -- only its python fallback goes that far."""
+    sys.path.insert(0, "/root/reference")
+    from utils.sh_utils import eval_sh                     # noqa: E402
+    sys.path.pop(0)
+    g = torch.Generator().manual_seed(4)
+    sh = torch.randn(32, 3, 25, generator=g)
+    dirs = torch.randn(32, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    np.savez_compressed(os.path.join(HERE, "sh4_golden.npz"), sh=sh.numpy(), dirs=dirs.numpy(), rgb_deg4=eval_sh(4, sh, dirs).numpy())
+
+
 def g3_g4_from_oracle():
     from oracle import surfel_oracle as so
     from oracle.torch64 import forward_backward64
@@ -401,9 +413,11 @@ def g7_g8_rotation_and_checkpoint():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g12", "g34", "g56", "g78"]
+    which = sys.argv[1:] or ["g12", "g1b", "g34", "g56", "g78"]
     if "g12" in which:
         g1_g2_from_reference()
+    if "g1b" in which:
+        g1b_degree4_from_reference()
     if "g34" in which:
         g3_g4_from_oracle()
     if "g56" in which:

@@ -1,6 +1,7 @@
 """CPU: the C-ABI shared library loads and exports every symbol include/surfel_raster.h declares."""
 import ctypes
 import os
+import sys
 import re
 
 import pytest
@@ -111,3 +112,25 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
             assert scratch == 0 and spills == 0, f"{name}: {scratch} B scratch, {spills} spilled VGPRs"
             kernels += 1
     assert kernels >= 40
+
+
+def test_roctx_ranges_are_opt_in_and_balanced():
+    """SURFEL_ROCTX=1 brackets every operator entry point with a roctx range (rocprofv3 --marker-trace); without it
+    no tracing library is loaded.  Here: the shim loads libroctx64 only when asked, and a push is always matched by its pop."""
+    import subprocess
+    code = ("from diff_surfel_rasterization import _C\n"
+            "lib = _C._roctx_lib()\n"
+            "import os\n"
+            "want = os.environ.get('SURFEL_ROCTX') == '1'\n"
+            "assert bool(lib) == want, (lib, want)\n"
+            "with _C._range('outer'):\n"
+            "    with _C._range('inner'):\n"
+            "        pass\n"
+            "if want:\n"
+            "    assert lib.roctxRangePop() < 0   # nothing left on the stack: every push above was popped\n"
+            "print('roctx', want)\n")
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SURFEL_ROCTX=flag), capture_output=True, text=True, timeout=300)
+        if flag == "1" and "OSError" in r.stderr:
+            pytest.skip("libroctx64 not present on this machine")
+        assert r.returncode == 0 and f"roctx {flag == '1'}" in r.stdout, r.stdout + r.stderr[-2000:]

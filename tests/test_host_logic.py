@@ -18,6 +18,8 @@ def test_python_sh_fallback_matches_reference(golden_dir):
     sh, dirs = torch.tensor(z["sh"]), torch.tensor(z["dirs"])
     for deg in range(4):
         np.testing.assert_allclose(eval_sh(deg, sh, dirs).numpy(), z[f"rgb_deg{deg}"], atol=1e-6)
+    z4 = np.load(os.path.join(golden_dir, "sh4_golden.npz"))   # degree 4: 25 coefficients, reached by the reference's python function only
+    np.testing.assert_allclose(eval_sh(4, torch.tensor(z4["sh"]), torch.tensor(z4["dirs"])).numpy(), z4["rgb_deg4"], atol=2e-6)
     rgb = torch.tensor(z["rgb2sh_in"])
     np.testing.assert_allclose(RGB2SH(rgb).numpy(), z["rgb2sh_out"], atol=1e-6)
     np.testing.assert_allclose(SH2RGB(RGB2SH(rgb)).numpy(), z["sh2rgb_out"], atol=1e-6)
