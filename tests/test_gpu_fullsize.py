@@ -106,7 +106,7 @@ def test_c4_3m_yawed_cameras_against_oracle(k):
     import json, os
     rep = {}
     try:
-        # (outlier_frac: one row in a million may sit between the 1e-2 row cap and twice that -- tests/gpu_util.py rows_within says which row did)
+        # (outlier_frac: one row in a million may sit between the 1e-2 row cap and five times that -- tests/gpu_util.py rows_within says which row did)
         _against_oracle(3_000_000, True, f"C4 camera {k}", pixel_budget=8e-3, gaussian_budget=0.25, camera_index=k, report=rep, outlier_frac=1e-6)
     finally:
         os.makedirs("gpurun_out", exist_ok=True)

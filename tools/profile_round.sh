@@ -19,3 +19,5 @@ rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --o
 python bench.py --config $CFG 2>$D/bench.err | tail -1 > $D/bench.json
 python tools/collect_profiles.py $D ${TAG}_${CFG} $D/out
 ls $D/out
+# the raw CSVs stay on the box (gpurun merges at most 64 MiB back): the condensed files in out/ and the logs are what is kept
+find $D -maxdepth 1 -name "*.csv" -delete

@@ -18,3 +18,5 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D -o grbm
 python tools/train_step_bench.py --steps 10 --warmup 3 2>$D/bench.err | tail -1 > $D/bench.json
 python tools/collect_profiles.py $D ${TAG}_train_step $D/out
 ls $D/out
+# the raw CSVs stay on the box (gpurun merges at most 64 MiB back): the condensed files in out/ and the logs are what is kept
+find $D -maxdepth 1 -name "*.csv" -delete
