@@ -252,11 +252,12 @@ def _cpu_model():
 def train_step_section(args, params, cam, dev, D, V):
     """Untimed extra (like stage_ms): one late training iteration's rasterizer calls on this scene, the reference's way -- render +
     render_semantic (two passes) + five class-filtered renders = 8 operator calls [REF train.py:84-109] -- and as this build's two
-    rasterizations (render_and_semantic + render_class_distortions); ms per fwd+bwd and how far the resulting maps are apart.  Then the
-    fused pattern again with the library's stage timers on: per-stage ms of one iteration and a `roofline` block for its dominant kernel."""
+    rasterizations (render_and_semantic + render_class_distortions) and as ONE plan (render_train_view: one K1, one binning, one K8); ms per
+    fwd+bwd and how far the resulting maps are apart.  Then the one-plan pattern again with the library's stage timers on: per-stage ms of
+    one iteration and a `roofline` block for its dominant kernel."""
     from streetunveiler_amd import _lib
     from streetunveiler_amd.gaussian_renderer import SurfelModel
-    from streetunveiler_amd.train_pattern import compare_and_time, fused_pattern, make_weights
+    from streetunveiler_amd.train_pattern import compare_and_time, make_weights, one_plan_pattern
     sem = torch.randint(0, 6, (args.gaussians,), generator=torch.Generator().manual_seed(0)).to(dev)
     sem[sem == 4] = 2   # the reference prunes the sky Gaussians before training
     for t in params.values():
@@ -271,12 +272,12 @@ def train_step_section(args, params, cam, dev, D, V):
         for _ in range(iters):
             for t in params.values():
                 t.grad = None
-            fused_pattern(camd, pc, bg, weights)["loss"].backward()
+            one_plan_pattern(camd, pc, bg, weights)["loss"].backward()
         torch.cuda.synchronize()
         st = _lib.stage_stats()
         lib.sr_set_stage_timing(0)
-        res["fused_stage_ms_per_iteration"] = {k: round(ms / iters, 4) for k, (ms, n) in st.items() if n}
-        res["roofline"] = train_step_roofline(args, res["fused_stage_ms_per_iteration"], D, V, n_classes=5)
+        res["one_plan_stage_ms_per_iteration"] = {k: round(ms / iters, 4) for k, (ms, n) in st.items() if n}
+        res["roofline"] = train_step_roofline(args, res["one_plan_stage_ms_per_iteration"], D, V, n_classes=5)
     finally:
         for t in params.values():
             t.grad = None

@@ -136,8 +136,11 @@ def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transM
 def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, activations=0, tile=None, mask=None, quadrant_cull=True, blend_counters=None,
-                        ballot_ranking=False, row_mapped=None, forward_only=False):
-    """`forward_only=True` (SR_FLAG_FORWARD_ONLY): no backward will follow -- what the reference's inference callers do under
+                        ballot_ranking=False, row_mapped=None, forward_only=False, classes=None, n_classes=0):
+    """`classes` [P] integer tensor + `n_classes` (extension, SURVEY 8f N1 in full): the per-class distortion pass runs on the plan AND the
+    binning of this very render (sr_class_forward_shared); the return tuple then ends with (dist[n_classes,H,W], class_state) and
+    rasterize_gaussians_backward takes `class_state` / `dL_ddist` to return the gradients of colour, allmap and distortion maps from ONE K8.
+    `forward_only=True` (SR_FLAG_FORWARD_ONLY): no backward will follow -- what the reference's inference callers do under
     torch.no_grad() [REF /root/reference/render.py:68; utils/mesh_utils.py:82-100].  color / allmap / radii are bit-identical; the state
     only a backward reads is not written (imgBuffer comes back empty, the SH direction Jacobian and the hit masks stay unwritten), so the
     returned buffers must not be handed to rasterize_gaussians_backward.
@@ -177,6 +180,19 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
         L.check(lib.sr_forward_render(C.byref(fr), C.byref(g), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                       _ptr(img), img.numel(), num_rendered, _ptr(color), _ptr(allmap), stream),
                 "sr_forward_render")
+        if classes is not None and int(n_classes) > 0:
+            if classes.numel() != P:
+                raise L.SurfelRasterError("classes must have one entry per Gaussian")
+            if forward_only:
+                raise L.SurfelRasterError("the shared-plan class pass is a training pass: not with forward_only")
+            cls = classes.to(device=dev, dtype=torch.int32).contiguous()
+            dist = torch.empty((int(n_classes), H, W), dtype=torch.float32, device=dev)
+            cstate = torch.empty((lib.sr_class_shared_bytes(P, W, H, int(n_classes), num_rendered),), dtype=torch.uint8, device=dev)
+            with _range("class_forward"):
+                L.check(lib.sr_class_forward_shared(C.byref(fr), C.byref(g), int(n_classes), _ptr(cls), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
+                                                    _ptr(cstate), cstate.numel(), num_rendered, _ptr(dist), stream), "sr_class_forward_shared")
+            del keep
+            return num_rendered, color, allmap, radii, geom, binning, img, dist, cstate
     del keep
     return num_rendered, color, allmap, radii, geom, binning, img
 
@@ -184,7 +200,7 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
 def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap, sh, degree, campos,
                                  geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None, defer_sh=False,
-                                 activations=0, tile=None, after_blend=None):
+                                 activations=0, tile=None, after_blend=None, class_state=None, dL_ddist=None, n_classes=0):
     """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry.
 
     `defer_sh=True` (frame-parallel ranks, streetunveiler_amd.parallel): with SHs as the colour source, dL_dsh is NOT
@@ -232,7 +248,19 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered), NC),), dtype=torch.uint8, device=dev)
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),
                               _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations))
-        if after_blend is not None and defer_sh and NC == 3:
+        if class_state is not None:   # the shared-plan class pass: K7 -> class backward into the same records -> ONE K8
+            dL_ddist = _f32c(dL_ddist, "dL_ddist")
+            L.check(lib.sr_backward_blend(C.byref(fr), C.byref(g), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
+                                          binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(), int(num_rendered), _ptr(dL_dcolor),
+                                          _ptr(dL_dallmap), _ptr(ws), ws.numel(), _stream(dev)), "sr_backward_blend")
+            with _range("class_backward"):
+                L.check(lib.sr_class_backward_shared(C.byref(fr), C.byref(g), int(n_classes), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
+                                                     binningBuffer.numel(), _ptr(class_state), class_state.numel(), int(num_rendered), _ptr(dL_ddist),
+                                                     _ptr(ws), ws.numel(), _stream(dev)), "sr_class_backward_shared")
+            L.check(lib.sr_backward_geometry(C.byref(fr), C.byref(g), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
+                                             binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(), int(num_rendered), _ptr(ws),
+                                             ws.numel(), C.byref(grads), _stream(dev)), "sr_backward_geometry")
+        elif after_blend is not None and defer_sh and NC == 3:
             L.check(lib.sr_backward_blend(C.byref(fr), C.byref(g), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
                                           binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(), int(num_rendered), _ptr(dL_dcolor),
                                           _ptr(dL_dallmap), _ptr(ws), ws.numel(), _stream(dev)), "sr_backward_blend")

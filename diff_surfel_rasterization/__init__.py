@@ -142,6 +142,51 @@ class _RasterizeGaussians(torch.autograd.Function):
                 none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None, None, None, None)
 
 
+class _RasterizeWithClassDistortions(torch.autograd.Function):
+    """The operator AND the per-class distortion pass of the same view on ONE plan / binning / K8 (sr_class_forward_shared,
+    sr_class_backward_shared): outputs (color, radii, allmap, dist[n_classes,H,W])."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, classes, n_classes, raster_settings, activations, tile, mask):
+        s = raster_settings
+        ctx.activations, ctx.n_classes = int(activations), int(n_classes)
+        ctx.tile = tuple(int(t) for t in tile) if tile else None
+        fused = {"activations": ctx.activations} if ctx.activations else {}
+        if ctx.tile:
+            fused["tile"] = ctx.tile
+        if mask is not None:
+            fused["mask"] = mask
+        empty = torch.empty(0, device=means3D.device)
+        num_rendered, color, allmap, radii, geom, binning, img, dist, cstate = _C.rasterize_gaussians(
+            s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, empty, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
+            s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered, s.debug, classes=classes, n_classes=ctx.n_classes, **fused)
+        ctx.raster_settings, ctx.num_rendered = s, num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, radii, sh, geom, binning, img, cstate)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        return color, radii, allmap, dist
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_allmap, grad_dist):
+        s = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, radii, sh, geom, binning, img, cstate = ctx.saved_tensors
+        dev = means3D.device
+        z = lambda c: torch.zeros((c, s.image_height, s.image_width), dtype=torch.float32, device=dev)
+        grad_color = z(int(s.bg.numel())) if grad_color is None else grad_color
+        grad_allmap = z(7) if grad_allmap is None else grad_allmap
+        grad_dist = z(ctx.n_classes) if grad_dist is None else grad_dist
+        empty = torch.empty(0, device=dev)
+        kwargs = {"activations": ctx.activations} if ctx.activations else {}
+        if ctx.tile:
+            kwargs["tile"] = ctx.tile
+        g2d, gcol, gop, g3d, _, gsh, gsc, grot = _C.rasterize_gaussians_backward(
+            s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, empty, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
+            grad_color, grad_allmap, sh, s.sh_degree, s.campos, geom, ctx.num_rendered, binning, img, s.debug,
+            class_state=cstate, dL_ddist=grad_dist, n_classes=ctx.n_classes, **kwargs)
+        none_if_empty = lambda g, ref: g if ref.numel() else None
+        return (g3d, g2d, none_if_empty(gsh, sh), none_if_empty(gcol, colors_precomp), gop, gsc, grot, None, None, None, None, None, None)
+
+
 class _ClassDistortions(torch.autograd.Function):
     """The per-class distortion pass (include/surfel_raster.h, sr_class_forward_render / sr_class_backward)."""
 
@@ -204,6 +249,23 @@ class GaussianRasterizer(nn.Module):
         (densification proxy), opacities, scales, rotations.  Every tile shape of the sweep; n_classes <= 6."""
         return _ClassDistortions.apply(means3D, means2D, opacities, scales, rotations, classes, int(n_classes), self.raster_settings,
                                        self.activations, mask, tuple(int(t) for t in self.tile) if self.tile else None)
+
+    def forward_with_class_distortions(self, means3D, means2D, opacities, scales, rotations, classes, n_classes, shs=None, colors_precomp=None,
+                                       extra_colors=None, mask=None):
+        """Extension (SURVEY 8f N1 in full): this operator's (color, radii, allmap) AND the per-class distortion maps of the same view --
+        `class_distortions` -- from ONE preprocess, ONE binning and ONE per-Gaussian backward.  Same colour options as `forward` (shs |
+        colors_precomp [P,3] / [P,6] | shs + extra_colors [P,6]); returns (color, radii, allmap, dist[n_classes,H,W]).  The maps are
+        bit-identical to the two separate calls; the gradients agree to float summation order."""
+        if (shs is None) == (colors_precomp is None) and extra_colors is None:
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if extra_colors is not None:
+            if shs is None or colors_precomp is not None or extra_colors.ndim != 2 or extra_colors.shape[1] != 6:
+                raise Exception("extra_colors needs SHs as the colour source and must have dimensions (num_points, 6)")
+            colors_precomp = extra_colors
+        empty = torch.Tensor([]).to(means3D.device)
+        return _RasterizeWithClassDistortions.apply(means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp,
+                                                    opacities, scales, rotations, classes, int(n_classes), self.raster_settings, self.activations,
+                                                    tuple(int(t) for t in self.tile) if self.tile else None, mask)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, mask=None, extra_colors=None):

@@ -255,6 +255,24 @@ int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_clas
                       void* binning, size_t binning_bytes, void* class_image, size_t class_image_bytes, uint32_t num_rendered,
                       const float* dL_ddist, void* workspace, size_t workspace_bytes, const SrGradients* grads, void* stream);
 
+/* The same per-class pass on the plan AND the binning of a colour pass of the same frame (SURVEY.md 8f N1 in full: K1..K5 once for the
+ * colour render, the semantic channels and the per-class distortion maps; one K8 for all of their gradients):
+ *   forward:  sr_forward_plan -> sr_forward_render (any colour configuration) -> sr_class_forward_shared
+ *   backward: sr_backward_blend -> sr_class_backward_shared -> sr_backward_geometry
+ * `classes` [P] int32 (negative or >= n_classes: in no class).  class_state: sr_class_shared_bytes(P, W, H, n_classes, num_rendered) bytes of
+ * caller-owned state between forward and backward (per-class image state, class bytes, this pass's own hit masks; the class-ordered list
+ * goes into a region of `binning` the colour pass no longer needs).  sr_class_backward_shared ADDS its gradient sums to the records
+ * sr_backward_blend left in `workspace` (and starts records for duplicates only the class chains reached), so the one
+ * sr_backward_geometry that follows returns the gradients of colour, allmap AND distortion maps together.  `g` / `frame` as given to
+ * the colour pass (scales + rotations, no precomputed transMat). */
+size_t sr_class_shared_bytes(int32_t P, int32_t image_width, int32_t image_height, int32_t n_classes, uint32_t num_rendered);
+int sr_class_forward_shared(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, const int32_t* classes, void* geom, size_t geom_bytes,
+                            void* binning, size_t binning_bytes, void* class_state, size_t class_state_bytes, uint32_t num_rendered,
+                            float* out_dist, void* stream);
+int sr_class_backward_shared(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, void* geom, size_t geom_bytes, void* binning,
+                             size_t binning_bytes, void* class_state, size_t class_state_bytes, uint32_t num_rendered, const float* dL_ddist,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* Frame-parallel SH gradient (no reference counterpart -- the reference is single-GPU).  The SH adjoint is
  * linear in the clamp-masked colour gradient and its only other per-view input is the camera position, so ranks that
  * rendered n_views frames of the SAME Gaussians all-gather dL_dcolors (12 B/Gaussian) instead of all-reducing dL_dsh

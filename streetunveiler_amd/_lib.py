@@ -59,7 +59,7 @@ class SrImageView(C.Structure):
 # every symbol include/surfel_raster.h declares (checked by tests/test_abi.py)
 EXPORTS = ["sr_abi_version", "sr_build_switches", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
            "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan", "sr_sh_gradient_expand", "sr_knn_workspace_bytes", "sr_knn_mean_dist2",
-           "sr_forward_render", "sr_backward", "sr_backward_blend", "sr_backward_colors", "sr_backward_geometry", "sr_debug_pair_decisions", "sr_class_image_bytes", "sr_class_forward_render", "sr_class_backward", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_debug_radix_sort", "sr_debug_radix_sort_temp_bytes", "sr_debug_lds_atomic_ranks", "sr_rank_mode", "sr_postprocess_forward",
+           "sr_forward_render", "sr_backward", "sr_backward_blend", "sr_backward_colors", "sr_backward_geometry", "sr_debug_pair_decisions", "sr_class_image_bytes", "sr_class_forward_render", "sr_class_backward", "sr_class_shared_bytes", "sr_class_forward_shared", "sr_class_backward_shared", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_debug_radix_sort", "sr_debug_radix_sort_temp_bytes", "sr_debug_lds_atomic_ranks", "sr_rank_mode", "sr_postprocess_forward",
            "sr_postprocess_backward"]
 
 _lib = None
@@ -106,6 +106,12 @@ def load():
                                          C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(SrGradients), C.c_void_p]
     lib.sr_debug_pair_decisions.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                             C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sr_class_shared_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32]
+    lib.sr_class_shared_bytes.restype = C.c_size_t
+    lib.sr_class_forward_shared.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.sr_class_backward_shared.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sr_class_image_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.sr_class_image_bytes.restype = C.c_size_t
     lib.sr_class_forward_render.argtypes = [C.POINTER(SrFrame), C.POINTER(SrGaussians), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,

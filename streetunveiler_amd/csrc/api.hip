@@ -42,14 +42,14 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
                                   const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s);
 hipError_t launch_pair_decisions(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                  unsigned long long* valid_bits, unsigned long long* use3d_bits, hipStream_t s);
-hipError_t launch_class_partition(int P, int n_tiles, int n_classes, const float* class_cols, const uint2* ranges, const uint32_t* point_list, uint8_t* ids,
-                                  uint32_t* cls_list, uint2* cls_ranges, hipStream_t s);
+hipError_t launch_class_partition(int P, int n_tiles, int n_classes, const float* class_cols, const int32_t* class_i32, const uint2* ranges,
+                                  const uint32_t* point_list, uint8_t* ids, uint32_t* cls_list, uint2* cls_ranges, hipStream_t s);
 hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* cls_ranges, const uint32_t* tile_order, const uint32_t* cls_list,
                                 const float4* recs, float* out_dist, float* cls_state, uint32_t* cls_last, uint32_t* tile_total, uint16_t* hit_mask,
                                 int cull, hipStream_t s);
 hipError_t launch_class_backward(const FrameDev& f, int n_classes, const uint2* cls_ranges, const uint32_t* tile_order, const uint32_t* cls_list,
                                  const float4* recs, const float* cls_state, const uint32_t* cls_last, const uint32_t* tile_total,
-                                 const float* dL_ddist, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s);
+                                 const float* dL_ddist, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, int shared_rec_quads, hipStream_t s);
 hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii, const uint8_t* clamped, const float4* recs, const float4* inst_grads,
                                   const uint8_t* written, const uint32_t* tiles_touched, bool mask_clamped, float* dL_dcolors, hipStream_t s);
 // radix_sort.hip
@@ -548,7 +548,7 @@ int sr_class_forward_render(const SrFrame* frame, const SrGaussians* g, int32_t 
         // every tile list, stably partitioned by class: [class 0 by depth | class 1 by depth | ...] + a (begin, end) pair per (tile, class)
         StageTimer t(SR_STAGE_CLASS_PARTITION, s);
         const GeomLayout GL = geom_layout(g->P);
-        SR_HIP(launch_class_partition(g->P, f.tiles_x * f.tiles_y, n_classes, g->colors_precomp, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list),
+        SR_HIP(launch_class_partition(g->P, f.tiles_x * f.tiles_y, n_classes, g->colors_precomp, nullptr, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list),
                                       g->P > 0 && geom ? at<uint8_t>(geom, GL.sh_jac) : nullptr, at<uint32_t>(binning, B.columns), at<uint2>(class_image, C.ranges), s));
     }
     if (int rc = debug_sync(frame, s, "class_partition")) return rc;
@@ -586,7 +586,7 @@ int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_clas
         if (D > 0)
             SR_HIP(launch_class_backward(f, n_classes, at<uint2>(class_image, C.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.columns), at<float4>(geom, L.recs),
                                          at<float>(class_image, C.state), at<uint32_t>(class_image, C.last), at<uint32_t>(class_image, C.tile_total), dL_ddist,
-                                         at<uint16_t>(binning, B.hit_mask), inst_grads, written, s));
+                                         at<uint16_t>(binning, B.hit_mask), inst_grads, written, 0, s));
     }
     if (int rc = debug_sync(frame, s, "class_backward")) return rc;
     {
@@ -595,6 +595,85 @@ int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_clas
                                           at<uint32_t>(geom, L.tiles_touched), *grads, s));
     }
     return debug_sync(frame, s, "preprocess_backward");
+}
+
+// ---- the per-class pass on the binning of a colour pass (one plan, one binning, one K8 for both: SURVEY.md 8f N1 in full) -------------
+namespace {
+struct ClassSharedLayout { ClassLayout C; size_t ids, hit, total; };
+ClassSharedLayout class_shared_layout(int P, int W, int H, int n_classes, uint32_t D) {
+    ClassSharedLayout L{};
+    L.C = class_layout(W, H, n_classes);
+    L.ids = L.C.total;                                                   // class byte per Gaussian (the colour pass owns the sh_jac region here)
+    L.hit = L.ids + align_up((size_t)(P > 0 ? P : 1), 256);              // this pass's own (entry, quadrant) hit masks: the colour pass keeps the binning buffer's
+    L.total = L.hit + align_up((size_t)(D > 0 ? D : 1) * 2, 256);
+    return L;
+}
+}  // namespace
+
+size_t sr_class_shared_bytes(int32_t P, int32_t W, int32_t H, int32_t n_classes, uint32_t D) { return class_shared_layout(P, W, H, n_classes, D).total; }
+
+int sr_class_forward_shared(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, const int32_t* classes, void* geom, size_t geom_bytes,
+                            void* binning, size_t binning_bytes, void* class_state, size_t class_state_bytes, uint32_t D, float* out_dist, void* stream) {
+    if (int rc = check_common(frame, g)) return rc;
+    if (n_classes < 1 || n_classes > 6) return fail(SR_ERR_UNSUPPORTED, "n_classes %d not in 1..6", n_classes);
+    if (!binning || !class_state || !out_dist || (g->P > 0 && !classes)) return fail(SR_ERR_INVALID_ARGUMENT, "binning / class_state / out_dist / classes is NULL");
+    if (g->transMat_precomp) return fail(SR_ERR_UNSUPPORTED, "the per-class pass takes scales and rotations, not a precomputed transMat");
+    const int W = frame->image_width, H = frame->image_height, P = g->P;
+    const BinLayout B = bin_layout(D, W, H);
+    const ClassSharedLayout S = class_shared_layout(P, W, H, n_classes, D);
+    if (binning_bytes < B.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "binning buffer %zu < %zu", binning_bytes, B.total);
+    if (class_state_bytes < S.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "class state buffer %zu < %zu", class_state_bytes, S.total);
+    float4* recs = nullptr;
+    if (P > 0 && D > 0) {
+        if (!geom) return fail(SR_ERR_INVALID_ARGUMENT, "geom is NULL");
+        const GeomLayout L = geom_layout(P);
+        if (geom_bytes < L.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom buffer %zu < %zu", geom_bytes, L.total);
+        recs = at<float4>(geom, L.recs);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame(frame, g);
+    {
+        StageTimer t(SR_STAGE_CLASS_PARTITION, s);
+        SR_HIP(launch_class_partition(P, f.tiles_x * f.tiles_y, n_classes, nullptr, classes, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.point_list),
+                                      at<uint8_t>(class_state, S.ids), at<uint32_t>(binning, B.columns), at<uint2>(class_state, S.C.ranges), s));
+    }
+    if (int rc = debug_sync(frame, s, "class_partition")) return rc;
+    {
+        StageTimer t(SR_STAGE_CLASS_FWD, s);
+        SR_HIP(launch_class_forward(f, n_classes, at<uint2>(class_state, S.C.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.columns), recs, out_dist,
+                                    at<float>(class_state, S.C.state), at<uint32_t>(class_state, S.C.last), at<uint32_t>(class_state, S.C.tile_total),
+                                    at<uint16_t>(class_state, S.hit), (frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1, s));
+    }
+    return debug_sync(frame, s, "class_forward");
+}
+
+int sr_class_backward_shared(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, void* geom, size_t geom_bytes, void* binning,
+                             size_t binning_bytes, void* class_state, size_t class_state_bytes, uint32_t D, const float* dL_ddist, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (int rc = check_common(frame, g)) return rc;
+    if (n_classes < 1 || n_classes > 6) return fail(SR_ERR_UNSUPPORTED, "n_classes %d not in 1..6", n_classes);
+    const int P = g->P;
+    if (P == 0 || D == 0) return SR_OK;
+    if (!geom || !binning || !class_state || !dL_ddist || !workspace) return fail(SR_ERR_INVALID_ARGUMENT, "NULL buffer argument");
+    const int W = frame->image_width, H = frame->image_height;
+    const GeomLayout L = geom_layout(P);
+    const BinLayout B = bin_layout(D, W, H);
+    const ClassSharedLayout S = class_shared_layout(P, W, H, n_classes, D);
+    if (geom_bytes < L.total || binning_bytes < B.total || class_state_bytes < S.total) return fail(SR_ERR_BUFFER_TOO_SMALL, "state buffer too small");
+    if (workspace_bytes < sr_backward_workspace_bytes(P, D, g->color_channels)) return fail(SR_ERR_BUFFER_TOO_SMALL, "workspace %zu < %zu", workspace_bytes, sr_backward_workspace_bytes(P, D, g->color_channels));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FrameDev f = make_frame(frame, g);
+    f.first = at<uint32_t>(geom, L.first); f.first_base = at<uint32_t>(geom, L.block_base);
+    // the records and flags sr_backward_blend of the SAME frame left in the workspace: this pass adds to them
+    float4* inst_grads = static_cast<float4*>(workspace);
+    uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)D * record_bytes(g->color_channels), 256);
+    {
+        StageTimer t(SR_STAGE_CLASS_BWD, s);
+        SR_HIP(launch_class_backward(f, n_classes, at<uint2>(class_state, S.C.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.columns), at<float4>(geom, L.recs),
+                                     at<float>(class_state, S.C.state), at<uint32_t>(class_state, S.C.last), at<uint32_t>(class_state, S.C.tile_total), dL_ddist,
+                                     at<uint16_t>(class_state, S.hit), inst_grads, written, (int)(record_bytes(g->color_channels) / 16), s));
+    }
+    return debug_sync(frame, s, "class_backward_shared");
 }
 
 namespace {

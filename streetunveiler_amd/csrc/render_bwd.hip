@@ -3,6 +3,10 @@
 // chains of a quadrant block better (K7 1.688 -> 1.670 ms) but costs the forward kernel a spill at its 80-register budget.
 #include "blend_common.h"
 
+#ifndef SR_K7_NINE_BANDED
+#define SR_K7_NINE_BANDED 0
+#endif
+
 namespace sr {
 
 // ---------------------------------------------------------------------------------------------
@@ -252,6 +256,10 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
     hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, extra, final_T, \
                        n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written)
     if (f.tile_w == 16 && f.tile_h == 16) {
+#if SR_K7_NINE_BANDED   // A/B (tools/notes_round5_measured.md): the 9-channel K7 as two banded walks of two pixels per lane (158 VGPRs, three waves per SIMD)
+        if (f.colors == 9) hipLaunchKernelGGL((render_backward_kernel<9, 2, 1, 2>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, extra,
+                                              final_T, n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written); else
+#endif
         if (f.colors == 9) SR_LAUNCH_BWD(9, 2, 2); else if (f.colors == 6) SR_LAUNCH_BWD(6, 2, 2); else SR_LAUNCH_BWD(3, 2, 2);
     } else if (f.colors != 3 && f.tile_w == 32 && f.tile_h == 16) {   // eight pixels per lane: two banded walks of four (BANDS = 2)
 #define SR_LAUNCH_BWD_BANDED(NCH) hipLaunchKernelGGL((render_backward_kernel<NCH, 4, 1, 2>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, extra, \

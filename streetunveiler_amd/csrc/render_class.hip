@@ -27,6 +27,14 @@ __global__ __launch_bounds__(256) void class_ids_kernel(int P, int n_classes, co
     ids[i] = (c >= 0.f && ci < n_classes) ? (uint8_t)ci : kNoClass;
 }
 
+// ... or from an int32 array (the shared-plan entry points: the colour slot carries real colours there)
+__global__ __launch_bounds__(256) void class_ids_i32_kernel(int P, int n_classes, const int32_t* __restrict__ classes, uint8_t* __restrict__ ids) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int ci = classes[i];
+    ids[i] = (ci >= 0 && ci < n_classes) ? (uint8_t)ci : kNoClass;
+}
+
 // One wave per tile: stable partition of the tile's list by class.  Two sweeps over the list (count, scatter) with wave ballots, four
 // chunks of 64 entries in flight per step (the id -> class gather is a dependent load: one chunk at a time the kernel is a chain of
 // memory latencies, 0.15 ms at C3); the class bytes of the first kClsCache entries wait in LDS for the second sweep.  Entries of no class
@@ -222,7 +230,9 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_
 // One wave per (tile, class): the blend backward of the class-filtered render with the distortion gradient as the only upstream
 // gradient (no colour, depth, normal, alpha, median terms): psi = dLw, Z = sum_{k>i} w_k dLw_k  (render_bwd.hip, K7).  Walks the
 // class's sub-list back to front from the deepest contributor any pixel of the tile has.
-template <int QX, int QY>
+// kShared: the records already hold what K7 of a colour pass over the SAME binning left there (sr_class_backward_shared): this pass ADDS its
+// 15 sums to a written record (rec_quads float4 per record: 6, or 7 after a 9-channel K7) and starts a new one -- zero-filled -- elsewhere.
+template <int QX, int QY, bool kShared>
 #ifndef SR_CLASS_BWD_WAVES
 #define SR_CLASS_BWD_WAVES 4
 #endif
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(QX * QY <
 void class_backward_kernel(FrameDev f, int n_classes, const uint2* __restrict__ cls_ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ cls_list,
                            const float4* __restrict__ recs, const float* __restrict__ cls_state, const uint32_t* __restrict__ cls_last,
                            const uint32_t* __restrict__ tile_total, const float* __restrict__ dL_ddist, const uint16_t* __restrict__ hit_mask,
-                           float4* __restrict__ inst_grads, uint8_t* __restrict__ written) {
+                           float4* __restrict__ inst_grads, uint8_t* __restrict__ written, int rec_quads) {
     constexpr int NQ = QX * QY, kGQ = kGradQuads;
     __shared__ float4 s_e[entry_quads<0>()][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGQ * 4];
@@ -365,19 +375,33 @@ void class_backward_kernel(FrameDev f, int n_classes, const uint2* __restrict__ 
             const float ox = -fminf(fmaxf(centre.x, -Xc), (float)(f.W - 1) - Xc), oy = -fminf(fmaxf(centre.y, -Yc), (float)(f.H - 1) - Yc);
             acc[0].w = fmaf(ox, acc[0].x, acc[0].w); acc[1].x = fmaf(ox, acc[0].y, acc[1].x); acc[1].y = fmaf(ox, acc[0].z, acc[1].y);
             acc[1].z = fmaf(oy, acc[0].x, acc[1].z); acc[1].w = fmaf(oy, acc[0].y, acc[1].w); acc[2].x = fmaf(oy, acc[0].z, acc[2].x);
-            float4* o = inst_grads + (size_t)slot * kGQ;
+            if (kShared) {
+                float4* o = inst_grads + (size_t)slot * rec_quads;
+                if (written[slot]) {   // the colour pass left a record here: add the fifteen geometry sums (floats 0..14 = quads 0..3)
 #pragma unroll
-            for (int k = 0; k < kGQ; ++k) o[k] = acc[k];
-            written[slot] = 1;
+                    for (int k = 0; k < 4; ++k) { const float4 p = o[k]; o[k] = make_float4(p.x + acc[k].x, p.y + acc[k].y, p.z + acc[k].z, p.w + acc[k].w); }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kGQ; ++k) o[k] = acc[k];
+                    for (int k = kGQ; k < rec_quads; ++k) o[k] = zero4;
+                    written[slot] = 1;
+                }
+            } else {
+                float4* o = inst_grads + (size_t)slot * kGQ;
+#pragma unroll
+                for (int k = 0; k < kGQ; ++k) o[k] = acc[k];
+                written[slot] = 1;
+            }
         }
     }
 }
 
-hipError_t launch_class_partition(int P, int n_tiles, int n_classes, const float* class_cols, const uint2* ranges, const uint32_t* point_list, uint8_t* ids,
-                                  uint32_t* cls_list, uint2* cls_ranges, hipStream_t s) {
+hipError_t launch_class_partition(int P, int n_tiles, int n_classes, const float* class_cols, const int32_t* class_i32, const uint2* ranges,
+                                  const uint32_t* point_list, uint8_t* ids, uint32_t* cls_list, uint2* cls_ranges, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
     if (n_classes < 1 || n_classes > kClassMax) return hipErrorInvalidValue;
-    if (P > 0) hipLaunchKernelGGL(class_ids_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, n_classes, class_cols, ids);
+    if (P > 0 && class_i32) hipLaunchKernelGGL(class_ids_i32_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, n_classes, class_i32, ids);
+    else if (P > 0) hipLaunchKernelGGL(class_ids_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, n_classes, class_cols, ids);
     // (P == 0: every list is empty, the kernel only writes the empty (begin, end) pairs)
     hipLaunchKernelGGL(class_partition_kernel, dim3(n_tiles), dim3(kWave), 0, s, n_classes, ranges, point_list, ids, cls_list, cls_ranges);
     return hipGetLastError();
@@ -404,16 +428,18 @@ hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* c
 
 hipError_t launch_class_backward(const FrameDev& f, int n_classes, const uint2* cls_ranges, const uint32_t* tile_order, const uint32_t* cls_list,
                                  const float4* recs, const float* cls_state, const uint32_t* cls_last, const uint32_t* tile_total,
-                                 const float* dL_ddist, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s) {
+                                 const float* dL_ddist, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, int shared_rec_quads, hipStream_t s) {
+    // shared_rec_quads = 0: this pass owns the records (6 quads each); 6 / 7: it adds to those of a colour pass (kShared)
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     if (n_classes < 1 || n_classes > kClassMax) return hipErrorInvalidValue;
     const bool two_rows = f.tile_h == 16 && (f.tile_w == 16 || f.tile_w == 32);
     if (!two_rows && !(f.tile_h == 8 && (f.tile_w == 8 || f.tile_w == 16 || f.tile_w == 32))) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n_tiles + kXcds - 1) / kXcds * kXcds) * (unsigned)n_classes);
-#define SR_CB_SHAPE(QX, QY) hipLaunchKernelGGL((class_backward_kernel<QX, QY>), grid, dim3(kWave), 0, s, f, n_classes, cls_ranges, tile_order, cls_list, recs, cls_state, cls_last, tile_total, dL_ddist, hit_mask, inst_grads, written)
-    if (two_rows) { if (f.tile_w == 16) SR_CB_SHAPE(2, 2); else SR_CB_SHAPE(4, 2); }   // (32x16: eight pixels per lane, two waves per SIMD)
-    else if (f.tile_w == 8) SR_CB_SHAPE(1, 1); else if (f.tile_w == 16) SR_CB_SHAPE(2, 1); else SR_CB_SHAPE(4, 1);
+#define SR_CB_SHAPE(QX, QY) { if (shared_rec_quads) hipLaunchKernelGGL((class_backward_kernel<QX, QY, true>), grid, dim3(kWave), 0, s, f, n_classes, cls_ranges, tile_order, cls_list, recs, cls_state, cls_last, tile_total, dL_ddist, hit_mask, inst_grads, written, shared_rec_quads); \
+                             else hipLaunchKernelGGL((class_backward_kernel<QX, QY, false>), grid, dim3(kWave), 0, s, f, n_classes, cls_ranges, tile_order, cls_list, recs, cls_state, cls_last, tile_total, dL_ddist, hit_mask, inst_grads, written, (int)kGradQuads); }
+    if (two_rows) { if (f.tile_w == 16) SR_CB_SHAPE(2, 2) else SR_CB_SHAPE(4, 2) }   // (32x16: eight pixels per lane, two waves per SIMD)
+    else if (f.tile_w == 8) SR_CB_SHAPE(1, 1) else if (f.tile_w == 16) SR_CB_SHAPE(2, 1) else SR_CB_SHAPE(4, 1)
 #undef SR_CB_SHAPE
     return hipGetLastError();
 }

@@ -299,14 +299,51 @@ def render_class_distortions(viewpoint_camera, pc, pipe, bg_color: torch.Tensor,
                                     fused_activations=_fused_activations(pc, pipe))
     means3D, means2D, opacity, scales, rotations, cov3D_precomp = _geometry_inputs(pc, pipe, screenspace_points, None, scaling_modifier)
     assert cov3D_precomp is None
-    # class of a Gaussian -> its chain (position in class_ids), -1 = not rendered
-    lut = torch.full((max(max(class_ids) + 1, len(concerned_classes_list)),), -1, dtype=torch.int32, device=dev)
-    lut[torch.tensor(class_ids, device=dev)] = torch.arange(len(class_ids), dtype=torch.int32, device=dev)
-    sem = pc.get_semantics.to(torch.int64).clamp(0, lut.numel() - 1)
-    chain = torch.where((pc.get_semantics >= 0) & (pc.get_semantics < lut.numel()), lut[sem], torch.full_like(lut[sem], -1))
+    chain = _class_chain_ids(pc, class_ids, dev)
     dist, radii = rasterizer.class_distortions(means3D=means3D, means2D=means2D, opacities=opacity, scales=scales, rotations=rotations,
                                                classes=chain, n_classes=len(class_ids))
     return {"rend_dist": dist.unsqueeze(1), "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
+
+
+def _class_chain_ids(pc, class_ids, dev):
+    """class of a Gaussian -> its chain (position in class_ids), -1 = not rendered"""
+    lut = torch.full((max(max(class_ids) + 1, len(concerned_classes_list)),), -1, dtype=torch.int32, device=dev)
+    lut[torch.tensor(class_ids, device=dev)] = torch.arange(len(class_ids), dtype=torch.int32, device=dev)
+    sem = pc.get_semantics.to(torch.int64).clamp(0, lut.numel() - 1)
+    return torch.where((pc.get_semantics >= 0) & (pc.get_semantics < lut.numel()), lut[sem], torch.full_like(lut[sem], -1))
+
+
+def render_train_view(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, class_ids=None, scaling_modifier=1.0):
+    """Everything a late training iteration of the reference rasterizes for one view [REF train.py:84-109] -- `render()`,
+    `render_semantic()` and the per-class `rend_dist` maps -- from ONE preprocess, ONE binning and ONE per-Gaussian backward
+    (extension, SURVEY 8f N1 in full: `render_and_semantic` + `render_class_distortions` on a shared plan).  Returns the union of their
+    dicts, with the per-class maps as `class_rend_dist` [len(class_ids), 1, H, W].  Maps bit-identical to the separate calls."""
+    assert not pipe.convert_SHs_python, "the 9-channel pass takes the SHs themselves"
+    if class_ids is None:
+        class_ids = [i for i, n in enumerate(concerned_classes_list) if n != "sky"]
+    class_ids = [int(c) for c in class_ids]
+    dev = pc.get_xyz.device
+    screenspace_points = _screenspace_points(pc)
+    n_cls = len(concerned_classes_list)
+    assert n_cls == 6
+    bg_prob = [0.0] * n_cls
+    bg_prob[concerned_classes_ind_map["sky"]] = 1.0
+    bg9 = torch.cat([bg_color.to(dev).float().reshape(3), torch.tensor(bg_prob, dtype=torch.float32, device=dev)])
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg9, scaling_modifier),
+                                    fused_activations=_fused_activations(pc, pipe))
+    means3D, means2D, opacity, scales, rotations, cov3D_precomp = _geometry_inputs(pc, pipe, screenspace_points, None, scaling_modifier)
+    assert cov3D_precomp is None
+    semantic_6 = (pc.get_semantics.view(-1, 1) == torch.arange(n_cls, device=dev).view(1, -1)).float()
+    color9, radii, allmap, dist = rasterizer.forward_with_class_distortions(
+        means3D=means3D, means2D=means2D, opacities=opacity, scales=scales, rotations=rotations, classes=_class_chain_ids(pc, class_ids, dev),
+        n_classes=len(class_ids), shs=pc.get_features, extra_colors=semantic_6)
+    rets = {"render": color9[:3], "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
+    rets.update(postprocess_allmap(viewpoint_camera, pipe, allmap))
+    output_semantic = color9[3:]
+    uncertainty, best = _top2_margin(output_semantic)
+    rets.update({"render_semantics": output_semantic, "semantic_uncertainty": uncertainty,
+                 "semantic_rgb": _SEMANTIC_COLOR.to(dev)[best].permute(2, 0, 1) / 255.0, "class_rend_dist": dist.unsqueeze(1)})
+    return rets
 
 
 def render_semantic(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,

@@ -17,7 +17,7 @@ import torch
 from diff_surfel_rasterization import GaussianRasterizer
 
 from .gaussian_renderer import (PipelineParams, _geometry_inputs, _screenspace_points, _settings, concerned_classes_ind_map,
-                                concerned_classes_list, render, render_and_semantic, render_class_distortions)
+                                concerned_classes_list, render, render_and_semantic, render_class_distortions, render_train_view)
 
 LAMBDA_DIST = 100.0   # opt.lambda_dist's order of magnitude; any fixed weight serves the comparison
 
@@ -69,6 +69,17 @@ def fused_pattern(cam, pc, bg, weights) -> Dict[str, torch.Tensor]:
     return maps
 
 
+def one_plan_pattern(cam, pc, bg, weights) -> Dict[str, torch.Tensor]:
+    """The same maps from ONE plan: preprocess, binning and the per-Gaussian backward run once for the 9-channel render AND the per-class
+    distortion pass (`render_train_view`)."""
+    out = render_train_view(cam, pc, PipelineParams(), bg)
+    dist = out["class_rend_dist"]
+    maps = dict(render=out["render"], render_semantics=out["render_semantics"], rend_dist=out["rend_dist"], rend_normal=out["rend_normal"],
+                class_dist=[dist[j] for j in range(dist.shape[0])])
+    maps["loss"] = _loss(maps, weights)
+    return maps
+
+
 def make_weights(H: int, W: int, device, seed: int = 5) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     return {"render": torch.randn(3, H, W, generator=g).to(device), "semantics": torch.randn(6, H, W, generator=g).to(device),
@@ -80,7 +91,7 @@ def compare_and_time(cam, pc, bg, leaves, iters: int = 3, warmup: int = 1) -> Di
     dev = pc.get_xyz.device
     weights = make_weights(int(cam.image_height), int(cam.image_width), dev)
     out, grads, keep = {}, {}, {}
-    for name, fn in (("reference_8_calls", reference_pattern), ("fused_2_calls", fused_pattern)):
+    for name, fn in (("reference_8_calls", reference_pattern), ("fused_2_calls", fused_pattern), ("one_plan", one_plan_pattern)):
         def step():
             for t in leaves:
                 t.grad = None
@@ -104,8 +115,15 @@ def compare_and_time(cam, pc, bg, leaves, iters: int = 3, warmup: int = 1) -> Di
     diff["class_dist"] = max(float((x - y).abs().max()) for x, y in zip(a["class_dist"], b["class_dist"]))
     out["max_abs_difference_of_maps"] = diff
     out["max_gradient_difference_of_tensor_scale"] = max(float((x - y).abs().max() / (x.abs().max() + 1e-30)) for x, y in zip(grads["reference_8_calls"], grads["fused_2_calls"]))
+    c = keep["one_plan"]
+    d1 = {k: float((a[k] - c[k]).abs().max()) for k in ("render", "render_semantics", "rend_dist", "rend_normal")}
+    d1["class_dist"] = max(float((x - y).abs().max()) for x, y in zip(a["class_dist"], c["class_dist"]))
+    out["one_plan_max_abs_difference_of_maps"] = d1
+    out["one_plan_max_gradient_difference_of_tensor_scale"] = max(float((x - y).abs().max() / (x.abs().max() + 1e-30)) for x, y in zip(grads["reference_8_calls"], grads["one_plan"]))
     out["speedup"] = round(out["reference_8_calls_ms"] / out["fused_2_calls_ms"], 2)
+    out["one_plan_speedup"] = round(out["reference_8_calls_ms"] / out["one_plan_ms"], 2)
     out["pattern"] = ("one late training iteration of the reference (train.py:84-109): render + render_semantic (2 passes) + 5 class-filtered renders = "
-                      "8 operator calls with boolean-indexed inputs, against render_and_semantic + render_class_distortions = 2 rasterizations; "
+                      "8 operator calls with boolean-indexed inputs, against render_and_semantic + render_class_distortions = 2 rasterizations, against render_train_view = "
+                      "both on ONE preprocess / binning / per-Gaussian backward; "
                       "fwd+bwd incl. the allmap post-processing and the loss kernels, untimed extra section")
     return out

@@ -538,3 +538,73 @@ def test_training_iteration_eight_calls_equal_two_rasterizations():
     assert d["class_dist"] <= 2e-6, d
     assert r["max_gradient_difference_of_tensor_scale"] <= 5e-5, r
     assert r["reference_8_calls_ms"] > 0 and r["fused_2_calls_ms"] > 0
+    # ... and as ONE plan (render_train_view: one K1, one binning, one K8 -- the class backward adds into the colour pass's records)
+    d1 = r["one_plan_max_abs_difference_of_maps"]
+    assert d1["render"] == 0.0 and d1["render_semantics"] == 0.0 and d1["rend_dist"] == 0.0 and d1["rend_normal"] == 0.0, d1
+    assert d1["class_dist"] <= 2e-6, d1
+    assert r["one_plan_max_gradient_difference_of_tensor_scale"] <= 5e-5, r
+    assert r["one_plan_ms"] > 0
+
+
+def test_shared_plan_class_pass_equals_the_two_calls_on_every_tile_shape():
+    """`forward_with_class_distortions` (sr_class_forward_shared / sr_class_backward_shared) against the operator + `class_distortions` called
+    separately: colour, allmap, radii and the class maps bit-identical, every gradient to float summation order -- with SH colours, with
+    precomputed colours, with the 9-channel pass, on four tile shapes; a Gaussian only a class chain reaches (occluded in the full render)
+    still gets its gradient."""
+    from diff_surfel_rasterization import GaussianRasterizer
+    from tests.gpu_util import assert_grads_close, settings_for
+    P, W, H = 5000, 216, 130
+    cam = synthetic_camera(W, H, index=1)
+    g = synthetic_gaussians(P, W, H, seed=33, scale_lo=3e-3, scale_hi=8e-2)
+    g["opacities"] = (g["opacities"] * 0.5 + 0.5).contiguous()   # opaque enough that the full render saturates where single classes do not
+    n_cls = 4
+    cls = torch.randint(-1, n_cls, (P,), generator=torch.Generator().manual_seed(5))
+    gen = torch.Generator().manual_seed(6)
+    six = torch.rand(P, 6, generator=gen)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+    for tile, mode in [(None, "sh"), ((8, 8), "nine"), ((32, 16), "nine"), ((16, 8), "col3"), ((32, 8), "sh")]:
+        nc = 9 if mode == "nine" else 3
+        bg = torch.linspace(0.05, 0.6, nc)
+        s = settings_for(cam, bg.numpy(), 3 if mode != "col3" else 0)
+        w_c = torch.randn(nc, H, W, generator=gen).to(DEV); w_a = torch.randn(7, H, W, generator=gen).to(DEV); w_d = (torch.rand(n_cls, H, W, generator=gen) + 0.5).to(DEV)
+
+        def leaves():
+            t = {k: g[k].to(DEV).clone().requires_grad_() for k in names}
+            t["m2d"] = torch.zeros(P, 3, device=DEV, requires_grad=True)
+            t["six"] = six.to(DEV).clone().requires_grad_()
+            return t
+
+        def colour_kw(t):
+            if mode == "sh":
+                return dict(shs=t["shs"])
+            if mode == "nine":
+                return dict(shs=t["shs"], extra_colors=t["six"])
+            return dict(colors_precomp=t["six"][:, :3].contiguous())
+
+        a = leaves()
+        r = GaussianRasterizer(s, tile=tile)
+        c1, rad1, al1, d1 = r.forward_with_class_distortions(means3D=a["means3D"], means2D=a["m2d"], opacities=a["opacities"], scales=a["scales"], rotations=a["rotations"],
+                                                             classes=cls.to(DEV), n_classes=n_cls, **colour_kw(a))
+        ((c1 * w_c).sum() + (al1 * w_a).sum() + 50.0 * (d1 * w_d).sum()).backward()
+        b = leaves()
+        c2, rad2, al2 = r(means3D=b["means3D"], means2D=b["m2d"], opacities=b["opacities"], scales=b["scales"], rotations=b["rotations"], **colour_kw(b))
+        d2, rad3 = r.class_distortions(b["means3D"], b["m2d"], b["opacities"], b["scales"], b["rotations"], cls.to(DEV), n_cls)
+        ((c2 * w_c).sum() + (al2 * w_a).sum() + 50.0 * (d2 * w_d).sum()).backward()
+        assert torch.equal(c1, c2) and torch.equal(al1, al2) and torch.equal(rad1, rad2) and torch.equal(d1, d2) and torch.equal(rad1, rad3), (tile, mode)
+        for k in a:
+            if a[k].grad is None:
+                assert b[k].grad is None or not b[k].grad.any(), (tile, mode, k)
+                continue
+            assert float(b[k].grad.abs().max()) > 0, (tile, mode, k)
+            assert_grads_close(a[k].grad.cpu().numpy(), b[k].grad.cpu().numpy(), 2e-5, f"one plan {tile} {mode} d{k}", max_bad_frac=1e-4, hard=1e-3)
+        # the class chains reach duplicates the saturated full render never blended: gradients only the class pass produces
+        only_dist = GaussianRasterizer(s, tile=tile)
+        e = leaves()
+        dd, _ = only_dist.class_distortions(e["means3D"], e["m2d"], e["opacities"], e["scales"], e["rotations"], cls.to(DEV), n_cls)
+        (dd * w_d).sum().backward()
+        f = leaves()
+        cc, _, aa = only_dist(means3D=f["means3D"], means2D=f["m2d"], opacities=f["opacities"], scales=f["scales"], rotations=f["rotations"], **colour_kw(f))
+        ((cc * w_c).sum() + (aa * w_a).sum()).backward()
+        class_only = (e["means3D"].grad.abs().sum(1) > 0) & (f["means3D"].grad.abs().sum(1) == 0)
+        assert class_only.any(), "the scene has no Gaussian that only a class chain reaches"
+        assert (a["means3D"].grad[class_only].abs().sum(1) > 0).all()

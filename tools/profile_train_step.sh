@@ -1,4 +1,4 @@
-# rocprofv3 evidence for the fused training-step pattern (tools/train_step_bench.py) at the C3 size: kernel stats, HBM traffic, SQ counters.
+# rocprofv3 evidence for the training-step pattern (tools/train_step_bench.py: render_train_view, one plan) at the C3 size: kernel stats, HBM traffic, SQ counters.
 # usage (GPU box): bash tools/profile_train_step.sh <round tag, e.g. r05>      -> gpurun_out/<tag>_train_step/out/<tag>_train_step_*.{csv,json}
 # Counters in their own passes with --kernel-trace only (never together with sys / hip / hsa traces).
 set -e
