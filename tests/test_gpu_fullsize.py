@@ -250,3 +250,55 @@ def test_more_than_65536_tiles_against_oracle():
     ln = (fwd["ranges"][:, 1].astype(np.int64) - fwd["ranges"][:, 0])[order]
     cls = np.where(ln > 0, np.minimum(15, np.maximum(0, 20 - np.floor(np.log2(np.maximum(ln, 1))).astype(np.int64))), 15)
     assert (np.diff(cls) >= 0).all() and all((np.diff(order[cls == c]) > 0).all() for c in np.unique(cls))
+
+
+def test_class_pass_on_lists_longer_than_its_lds_cache():
+    """The per-class pass where a tile list is longer than the partition kernel's LDS class cache (8 192 entries: beyond it the second sweep
+    gathers the class bytes again) and where class sub-lists run to thousands of entries: the clustered street-like scene (list length
+    p99 ~27 k, max ~41 k at 3 M Gaussians).  Every class map equals `allmap[6]` of the operator on the class subset, the gradients the sum of
+    the subset calls' -- the reference's call pattern [REF train.py:94-103] -- and the one-plan form agrees with both."""
+    from diff_surfel_rasterization import GaussianRasterizer, _C
+    from streetunveiler_amd.synthetic import clustered_gaussians
+    from tests.gpu_util import DEV, assert_grads_close, settings_for
+    P = 1_500_000
+    cam = synthetic_camera(W, H)
+    g = clustered_gaussians(P, W, H, 0.5)
+    n_cls = 3
+    cls = torch.randint(0, n_cls, (P,), generator=torch.Generator().manual_seed(8))
+    s = settings_for(cam, np.zeros(3, np.float32), 0)
+    names = ("means3D", "opacities", "scales", "rotations")
+    g_dist = (torch.rand(n_cls, H, W, generator=torch.Generator().manual_seed(9)) + 0.5).to(DEV)
+    t = {k: g[k].to(DEV).requires_grad_() for k in names}
+    m2d = torch.zeros(P, 3, device=DEV, requires_grad=True)
+    e = torch.empty(0, device=DEV)
+    D, _, _, _, _, binning, _ = _C.rasterize_gaussians(s.bg, t["means3D"].detach(), torch.zeros(P, 3, device=DEV), t["opacities"].detach(), t["scales"].detach(),
+                                                       t["rotations"].detach(), 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, H, W, e, 0, s.campos, False, False)
+    ranges = _C.binning_view(binning, P, D, W, H)["ranges"].long()
+    longest = int((ranges[:, 1] - ranges[:, 0]).max())
+    assert longest > 8192, f"longest tile list {longest}: the scene does not reach beyond the class cache"
+    del binning
+    dist, radii = GaussianRasterizer(s).class_distortions(t["means3D"], m2d, t["opacities"], t["scales"], t["rotations"], cls.to(DEV), n_cls)
+    (dist * g_dist).sum().backward()
+    one = {k: t[k].grad.clone() for k in names}
+    sums = {k: torch.zeros_like(one[k]) for k in names}
+    for k in range(n_cls):
+        idx = (cls == k).to(DEV)
+        u = {n: g[n].to(DEV)[idx].clone().requires_grad_() for n in names}
+        m = torch.zeros(int(idx.sum()), 3, device=DEV, requires_grad=True)
+        _, r, allmap = GaussianRasterizer(s)(means3D=u["means3D"], means2D=m, opacities=u["opacities"], colors_precomp=torch.zeros(int(idx.sum()), 3, device=DEV),
+                                             scales=u["scales"], rotations=u["rotations"])
+        d = allmap[6]
+        assert float((d.detach() - dist[k].detach()).abs().max()) <= 1e-6 * max(1.0, float(d.detach().abs().max())), k
+        assert torch.equal(r, radii[idx])
+        (d * g_dist[k]).sum().backward()
+        for n in names:
+            sums[n][idx] += u[n].grad
+    for n in names:
+        assert float(sums[n].abs().max()) > 0
+        assert_grads_close(one[n].cpu().numpy(), sums[n].cpu().numpy(), 2e-5, f"class pass, long lists, d{n}", max_bad_frac=0.0, hard=2e-5)
+    # the one-plan form on the same scene: the class maps are the same bits
+    v = {k: g[k].to(DEV) for k in names}
+    _, _, _, dist1 = GaussianRasterizer(s).forward_with_class_distortions(means3D=v["means3D"], means2D=torch.zeros(P, 3, device=DEV), opacities=v["opacities"], scales=v["scales"],
+                                                                           rotations=v["rotations"], classes=cls.to(DEV), n_classes=n_cls,
+                                                                           colors_precomp=torch.zeros(P, 3, device=DEV))
+    assert torch.equal(dist1, dist.detach())

@@ -66,9 +66,7 @@ def upstream_semantics(P, W, H, fwd, raw, hip_color):
     from oracle import surfel_oracle as so
     from streetunveiler_amd import build as sb
     out = {"oracle_pz_census": so.pz_zero_census(fwd), "oracle_pz_census_up_to_the_kernels_last_contributor": so.pz_zero_census(fwd, raw["img"]["n_contrib"].view(np.uint32))}
-    lib = os.path.join(sb.variant_dir("pz_zero_through_filter"), "libsurfel_raster.so")
-    if not os.path.exists(lib):
-        lib = sb.build_variant("pz_zero_through_filter")
+    lib = sb.build_variant("pz_zero_through_filter")   # (idempotent: compiles only if the variant is older than a source)
     with tempfile.TemporaryDirectory() as d:
         f = os.path.join(d, "v.npz")
         env = dict(os.environ, SURFEL_RASTER_LIB=lib)
