@@ -5,6 +5,8 @@ sweeps hold against the oracle:
   * 9 channels (SH colour + six precomputed) == the 3-channel SH call + the 6-channel call: colour / allmap / radii bit for bit,
     gradients = the sum of the two calls' gradients;
   * per-class distortion pass == `allmap[6]` of the operator on each class subset, gradients = the sum over the subsets;
+  * one plan (forward_with_class_distortions, 9 channels + class maps on one K1 / binning / K8) == those two calls: maps bit for bit, gradients
+    = their sum;
   * mask= == boolean-indexing every input first: images bit for bit, gradients scattered back;
   * fused activations == torch's sigmoid / exp / normalize in front of the operator (images bit for bit? no: K1 evaluates them itself --
     to 1e-5), gradients w.r.t. the raw parameters.
@@ -63,7 +65,7 @@ def f64_class_gradients(g, cam, tile, cls, n_cls, gd):
 def one(seed):
     sc = make_scene(seed)
     g, cam, deg, P = sc["g"], sc["cam"], sc["deg"], sc["P"]
-    tile = sc["tile"] if sc["tile"] != (32, 16) else (32, 8)      # the extensions exist for up to four pixels per lane
+    tile = sc["tile"]      # (every shape of the sweep, 32x16 included since round 5)
     tl = None if tile == (16, 16) else tile
     W, H = cam.image_width, cam.image_height
     rng = np.random.default_rng(seed + 1)
@@ -119,6 +121,19 @@ def one(seed):
                 ref = f64_class_gradients(g, cam, tile, cls, n_cls, gd)[n]
                 e_class = float((gcl[n].double().cpu() - ref).abs().max()); e_sub = float((sums[n].double().cpu() - ref).abs().max())
                 assert e_class <= 2.0 * e_sub + 1e-12, f"class d{n}: {err:.2e} of max(scale, 1e-3) from the subset renders; {e_class:.2e} vs their {e_sub:.2e} from float64"
+    # ---- one plan: the 9-channel render AND the class pass on one K1 / binning / K8 (sr_class_*_shared) ----
+    tp = leaves(g, extra=("shs",)); cp = cols.clone().requires_grad_()
+    op = GaussianRasterizer(settings_for(cam, bg9, deg), tile=tl).forward_with_class_distortions(
+        means3D=tp["means3D"], means2D=tp["means2D"], opacities=tp["opacities"], scales=tp["scales"], rotations=tp["rotations"], classes=cls, n_classes=n_cls,
+        shs=tp["shs"], extra_colors=cp)
+    torch.autograd.backward([op[0], op[2], op[3]], [gc, ga, gd])
+    assert torch.equal(op[0], o9[0]) and torch.equal(op[2], o9[2]) and torch.equal(op[1], o9[1]) and torch.equal(op[3], dist.detach()), "one-plan forward"
+    gp = grads(tp)
+    for k in NAMES + ("means2D",):
+        want = g9[k] + gcl[k]
+        err = float((gp[k] - want).abs().max()) / max(float(want.abs().max()), 1e-3)
+        assert err <= 1e-4, f"one plan d{k}: {err:.2e} of max(scale, 1e-3) from the two calls' sum"
+    close(gp["shs"], g9["shs"], 3e-5, "one plan dshs"); close(cp.grad, c9.grad, 3e-5, "one plan dextra")
     # ---- mask ----
     m = (torch.rand(P, generator=gen) < 0.6).to(DEV)
     tm = leaves(g, extra=("shs",))
