@@ -551,9 +551,9 @@ def main():
         if any(w != args.gpus for w in worlds_seen) and os.environ.get("SURFEL_EXCHANGE_SINGLE_RANK") != "1":
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the ranks report communicator sizes {worlds_seen}: the job is not ONE {args.gpus}-rank group")
         rccl_info = rccl_topology(rccl_log, dist.get_backend(), world)
-        if rccl_info.get("channels") is not None and world > 1 and rccl_info["channels"] <= 1:
+        if rccl_info.get("channels") is not None and world > 1 and rccl_info["channels"] <= 1 and os.environ.get("SURFEL_ALLOW_SINGLE_CHANNEL") != "1":
             raise SystemExit(f"bench.py: RCCL built a single-channel ring for {world} ranks ({rccl_info}): one xGMI link would carry the whole exchange -- "
-                             f"check NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS / the topology file")
+                             f"check NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS / the topology file (SURFEL_ALLOW_SINGLE_CHANNEL=1 runs anyway)")
         par.STALLS.enabled = True   # compute-stream stalls at the collectives' wait points = the exposed part of the exchange
         if args.exchange == "factored":
             # one untimed trial step of the factored exchange.  Only a failure of the COLLECTIVE LAYER (a backend that lacks

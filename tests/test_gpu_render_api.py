@@ -608,3 +608,32 @@ def test_shared_plan_class_pass_equals_the_two_calls_on_every_tile_shape():
         class_only = (e["means3D"].grad.abs().sum(1) > 0) & (f["means3D"].grad.abs().sum(1) == 0)
         assert class_only.any(), "the scene has no Gaussian that only a class chain reaches"
         assert (a["means3D"].grad[class_only].abs().sum(1) > 0).all()
+
+
+def test_class_passes_on_empty_and_fully_culled_scenes():
+    """Edge cases of the per-class pass and of its one-plan form: no Gaussians at all, and Gaussians that are all behind the camera
+    (P > 0, D = 0) -- zero distortion maps, the background colour, zero gradients, no kernel faults."""
+    from diff_surfel_rasterization import GaussianRasterizer
+    from tests.gpu_util import settings_for
+    W, H = 70, 45
+    cam = synthetic_camera(W, H)
+    bg = np.array([0.2, 0.4, 0.6], np.float32)
+    s = settings_for(cam, bg, 3)
+    for P, behind in ((0, False), (300, True)):
+        g = synthetic_gaussians(max(P, 1), W, H, seed=2)
+        g = {k: v[:P].clone() for k, v in g.items()}
+        if behind:
+            g["means3D"][:, 2] *= -1
+        t = {k: v.to(DEV).requires_grad_() for k, v in g.items()}
+        cls = torch.zeros(P, dtype=torch.int32, device=DEV)
+        m2d = torch.zeros(P, 3, device=DEV, requires_grad=True)
+        r = GaussianRasterizer(s)
+        dist, radii = r.class_distortions(t["means3D"], m2d, t["opacities"], t["scales"], t["rotations"], cls, 3)
+        assert dist.shape == (3, H, W) and not dist.any() and not radii.any()
+        c, rad, a, d1 = r.forward_with_class_distortions(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
+                                                          classes=cls, n_classes=3, shs=t["shs"])
+        assert not d1.any() and not a.any() and not rad.any()
+        assert torch.allclose(c, torch.as_tensor(bg).to(DEV)[:, None, None].expand(3, H, W))
+        (c.sum() + a.sum() + d1.sum() + dist.sum()).backward()
+        for k, v in t.items():
+            assert v.grad is None or not v.grad.any(), k
