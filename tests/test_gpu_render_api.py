@@ -610,6 +610,45 @@ def test_shared_plan_class_pass_equals_the_two_calls_on_every_tile_shape():
         assert (a["means3D"].grad[class_only].abs().sum(1) > 0).all()
 
 
+def test_shared_plan_class_pass_with_fused_activations_and_mask():
+    """The one-plan form under the other opt-in extensions: raw parameters with the activations fused into K1 / K8 (SR_ACT_*) and a
+    Gaussian mask read by K1 -- against the same two separate calls of this build."""
+    from diff_surfel_rasterization import GaussianRasterizer
+    from tests.gpu_util import assert_grads_close, settings_for
+    P, W, H = 4000, 200, 120
+    cam = synthetic_camera(W, H, index=6)
+    g = synthetic_gaussians(P, W, H, seed=44, scale_lo=3e-3, scale_hi=6e-2)
+    raw = dict(means3D=g["means3D"], shs=g["shs"], opacities=torch.logit(g["opacities"].clamp(1e-4, 1 - 1e-4)), scales=torch.log(g["scales"]),
+               rotations=g["rotations"] * 1.7)
+    n_cls = 5
+    cls = torch.randint(0, n_cls, (P,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    mask = (torch.rand(P, generator=torch.Generator().manual_seed(3)) < 0.7).to(DEV)
+    s = settings_for(cam, np.array([0.3, 0.2, 0.1], np.float32), 3)
+    gen = torch.Generator().manual_seed(4)
+    w_c = torch.randn(3, H, W, generator=gen).to(DEV); w_a = torch.randn(7, H, W, generator=gen).to(DEV); w_d = (torch.rand(n_cls, H, W, generator=gen) + 0.5).to(DEV)
+
+    def leaves():
+        t = {k: v.to(DEV).clone().requires_grad_() for k, v in raw.items()}
+        t["m2d"] = torch.zeros(P, 3, device=DEV, requires_grad=True)
+        return t
+
+    r = GaussianRasterizer(s, fused_activations=True)
+    a = leaves()
+    c1, rad1, al1, d1 = r.forward_with_class_distortions(means3D=a["means3D"], means2D=a["m2d"], opacities=a["opacities"], scales=a["scales"], rotations=a["rotations"],
+                                                         classes=cls, n_classes=n_cls, shs=a["shs"], mask=mask)
+    ((c1 * w_c).sum() + (al1 * w_a).sum() + 20.0 * (d1 * w_d).sum()).backward()
+    b = leaves()
+    c2, rad2, al2 = r(means3D=b["means3D"], means2D=b["m2d"], opacities=b["opacities"], scales=b["scales"], rotations=b["rotations"], shs=b["shs"], mask=mask)
+    d2, _ = r.class_distortions(b["means3D"], b["m2d"], b["opacities"], b["scales"], b["rotations"], cls, n_cls, mask=mask)
+    ((c2 * w_c).sum() + (al2 * w_a).sum() + 20.0 * (d2 * w_d).sum()).backward()
+    assert torch.equal(c1, c2) and torch.equal(al1, al2) and torch.equal(rad1, rad2) and torch.equal(d1, d2)
+    assert not rad1[~mask].any() and (rad1[mask] > 0).any()
+    for k in a:
+        assert float(b[k].grad.abs().max()) > 0, k
+        assert not a[k].grad[~mask].any(), k
+        assert_grads_close(a[k].grad.cpu().numpy(), b[k].grad.cpu().numpy(), 2e-5, f"one plan, fused activations + mask, d{k}", max_bad_frac=1e-4, hard=1e-3)
+
+
 def test_class_passes_on_empty_and_fully_culled_scenes():
     """Edge cases of the per-class pass and of its one-plan form: no Gaussians at all, and Gaussians that are all behind the camera
     (P > 0, D = 0) -- zero distortion maps, the background colour, zero gradients, no kernel faults."""
