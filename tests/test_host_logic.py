@@ -399,3 +399,53 @@ def test_densification_statistics_match_reference_gaussian_model(golden_dir):
         np.testing.assert_array_equal(denom.numpy(), z[f"g9_after{v}_denom"])
         np.testing.assert_array_equal(maxr.numpy(), z[f"g9_after{v}_max_radii2D"])
     assert denom.max() == 2 and (denom == 0).any()
+
+
+def test_bench_measurement_helpers(tmp_path, monkeypatch):
+    """The parts of bench.py a first real multi-GPU run leans on, exercised without a GPU: RCCL's INIT log -> channel count (a single-channel
+    ring must be recognisable), the predicted xGMI wire times, the exchange report, and the rule that a counter profile of OTHER kernel
+    sources is not quoted."""
+    import argparse, importlib, json, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    # --- RCCL log parsing (lines as RCCL 2.26 writes them with NCCL_DEBUG=INFO, NCCL_DEBUG_SUBSYS=INIT,GRAPH) ---
+    log = tmp_path / "rccl.log"
+    log.write_text("host:1:2 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6\n"
+                   "host:1:2 [0] NCCL INFO comm 0x1 rank 0 nranks 8 cudaDev 0 busId 1000 - Init START\n"
+                   + "".join(f"host:1:2 [0] NCCL INFO Channel {c:02d}/32 : 0 1 2 3 4 5 6 7\n" for c in range(32))
+                   + "host:1:2 [0] NCCL INFO Ring 00 : 7 -> 0 -> 1\nhost:1:2 [0] NCCL INFO 32 coll channels, 32 collnet channels\n")
+    info = bench.rccl_topology(str(log), "nccl", 8)
+    assert info["channels"] == 32 and info["coll_channels"] == 32 and info["nranks_in_log"] == 8 and info["version"].startswith("RCCL version")
+    log.write_text("host:1:2 [0] NCCL INFO Channel 00/01 : 0 1\n")
+    assert bench.rccl_topology(str(log), "nccl", 2)["channels"] == 1            # what bench.py refuses to time
+    assert bench.rccl_topology(str(log), "gloo", 2)["channels"] is None          # nothing to read for another backend
+    assert bench.rccl_topology(str(tmp_path / "missing.log"), "nccl", 2)["channels"] is None
+    # --- predicted wire time: C3, 8 ranks, factored exchange ---
+    P = 3_000_000
+    px = bench.predicted_xgmi(P, 8, "factored")
+    ag, ar = P * 12 * 8 * 7 / 8, P * 40 * 2 * 7 / 8
+    assert abs(px["ring"]["all_gather_ms"] - ag / 76.8e9 * 1e3) < 2e-3 and abs(px["ring"]["all_reduce_ms"] - ar / 76.8e9 * 1e3) < 2e-3
+    assert abs(px["direct_all_links"]["all_gather_ms"] * 7 - px["ring"]["all_gather_ms"]) < 1e-2
+    assert bench.predicted_xgmi(P, 1, "factored")["all_gather_ms"] == 0.0
+    assert bench.predicted_xgmi(P, 2, "allreduce")["ring"]["all_gather_ms"] == 0.0
+    # --- exchange report: exposed vs alone ---
+    detail = {"per_rank_ms_per_step": [4.0, 4.2], "exposed_ms_per_step_per_rank": [0.5, 0.7],
+              "isolated_collectives": {"all_gather_colour_gradients": {"ms": 0.4}, "all_reduce_rest": {"ms": 1.0}}}
+    rep = bench.exchange_report(detail, P, 2, 2, 4.2, "factored")
+    assert rep["collectives_alone_ms_per_step"] == pytest.approx(0.4 * 2 + 1.0) and rep["exposed_ms_per_step_max_over_ranks"] == 0.7
+    assert rep["hidden_fraction_of_the_collectives"] == pytest.approx(1 - 0.7 / 1.8, abs=1e-4) and rep["exposed_fraction_of_the_step"] == pytest.approx(0.7 / 4.2, abs=1e-4)
+    assert bench.exchange_report(None, P, 2, 1, 4.0, "factored") is None
+    # --- a profile is quoted only while its source digest is the current one ---
+    from streetunveiler_amd.build import source_digest
+    prof = tmp_path / "profiles"; prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    args = argparse.Namespace(tag="c3", sh_degree=3)
+    kernels = {"sr::render_backward_kernel": {"traffic_bytes_per_launch": 123}}
+    json.dump({"round": "r99", "head": "abc", "source_digest": source_digest(), "kernels": kernels}, open(prof / "r99_c3_hbm_traffic.json", "w"))
+    t, src = bench.pmc_traffic("render_backward_kernel", args)
+    assert t == 123 and src["round"] == "r99" and "stale" not in src
+    json.dump({"round": "r99", "head": "abc", "source_digest": "0" * 16, "kernels": kernels}, open(prof / "r99_c3_hbm_traffic.json", "w"))
+    t, src = bench.pmc_traffic("render_backward_kernel", args)
+    assert t is None and "stale" in src and "re-run tools/profile_round.sh" in src["stale"]
+    assert bench.pmc_traffic("render_backward_kernel", argparse.Namespace(tag="custom", sh_degree=3)) == (None, None)
