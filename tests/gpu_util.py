@@ -302,7 +302,7 @@ def free_f64_reference(g, cam, bg, deg, dc=None, da=None, tile=None, colors=None
     return fwd, bwd, so.render_margins(fwd, f64=True, kernel_decisions=kernel_decisions)
 
 
-def _assert_everything_but_the_differing_pixels(hip, nc, fwd64, bwd64, margins, tag, rep, scene, value_slack, lenient, outlier_frac=0.0):
+def _assert_everything_but_the_differing_pixels(hip, nc, fwd64, bwd64, margins, tag, rep, scene, value_slack, lenient, outlier_frac=0.0, differing_cap=1e-4):
     """The robust / non-robust split PREDICTS where two correct float32 implementations may decide differently; this is the check on what
     actually happened.  A pixel DIFFERS if one of its pair decisions, its stopping entry or its median entry in the kernels is not the
     free-running float64 checker's.  Every other pixel -- robust or not -- saw the same contributor set on both sides and must meet the value
@@ -325,7 +325,7 @@ def _assert_everything_but_the_differing_pixels(hip, nc, fwd64, bwd64, margins, 
     if rep is not None:
         rep[f"{tag}differing_pixels"] = dict(pixels=int(differs.sum()), fraction=frac, gaussians_in_their_lists=int((affected & vis).sum()),
                                              fraction_of_visible=float((affected & vis).sum() / max(1, vis.sum())))
-    assert frac <= 1e-4 or differs.sum() <= 3, f"{tag}: {int(differs.sum())} pixels ({frac:.2e}) hold a decision that differs from the float64 checker's"
+    assert frac <= differing_cap or differs.sum() <= 3, f"{tag}: {int(differs.sum())} pixels ({frac:.2e}) hold a decision that differs from the float64 checker's"
     if lenient:   # (fuzz sweep on ill-conditioned random scenes: its value bars are relative to the float32 oracle -- the robust-element checks carry them)
         return
     keep = ~differs
@@ -349,7 +349,7 @@ def _assert_everything_but_the_differing_pixels(hip, nc, fwd64, bwd64, margins, 
 
 def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report=None, scene=None, pixel_budget=NONROBUST_PIXEL_BUDGET,
                        gaussian_budget=NONROBUST_GAUSSIAN_BUDGET, value_slack=1.0, nonrobust_pixel_cap=2e-2, nonrobust_row_cap=5e-2,
-                       oracle32=None, oracle32_fwd=None, outlier_frac=0.0):
+                       oracle32=None, oracle32_fwd=None, outlier_frac=0.0, differing_cap=1e-4):
     """HIP against the free-running float64 reference.
       * every ROBUST pixel: same last contributor, colour and the six summed aux maps within 1e-4 * (1 + |value|) -- no exempt
         fraction; where the median selection is robust too: same median contributor and median depth within the same bar;
@@ -361,6 +361,9 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
     camera-plane regime, where the ray-splat intersection itself is ill-conditioned in float32.
     `nonrobust_*_cap`: the loose bars of the non-robust remainder (None = only finite: a flipped decision can move a few-pixel splat's whole
     gradient -- the random scenes of the fuzz sweep check those elements with forced decisions instead).
+    `differing_cap`: the largest fraction of the frame that may hold a decision differing from the checker's (all of them non-robust pixels --
+    a robust one fails earlier): 1e-4 everywhere in the suite (C3: 1.5e-5); the FUZZ_BIG=4 sweep of tools/fuzz_parity.py, whose translucent
+    regime puts tens of millions of duplicates on small frames (pixels thousands of contributors deep), passes 5e-4 (measured 1.3e-4 .. 2.3e-4).
     `oracle32` = the float32 oracle's backward on the same scene: a robust-row bar then reads "within the bar, OR at least twice as accurate
     as the float32 restatement of the reference on the same rows" (ill-conditioned random scenes -- translucent deep lists of large
     splats -- where float32 itself is 1e-2 off the float64 reference: tools/fuzz_diagnose.py); `oracle32_fwd` = its forward: the same
@@ -383,7 +386,7 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
         assert not dis[rob_px].any(), f"{tag}: {int((dis[rob_px] > 0).sum())} robust pixels hold a pair the kernels decided differently from the float64 checker"
         if hip_n_contrib is not None and bwd64 is not None:
             _assert_everything_but_the_differing_pixels(hip, nc, fwd64, bwd64, margins, tag, rep if report is not None else None, scene, value_slack,
-                                                        oracle32 is not None or oracle32_fwd is not None, outlier_frac)
+                                                        oracle32 is not None or oracle32_fwd is not None, outlier_frac, differing_cap)
     for name, a, b, mask in [("color", hip["color"], fwd64["color"], rob_px)] + \
                             [(f"allmap[{c}]", hip["allmap"][c], fwd64["allmap"][c], rob_med if c == 5 else rob_px) for c in range(7)]:
         err = np.abs(np.asarray(a, np.float64) - b) / (1.0 + np.abs(b))
