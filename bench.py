@@ -408,6 +408,25 @@ def exchange_report(detail, P, world, K, ms_per_step, exchange):
     return out
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def _discard_further_stdout():
+    try:
+        sys.stdout.flush()
+        null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null, 1)
+        os.close(null)
+    except OSError:
+        pass
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a torchrun environment: start the N workers ourselves -- one process per GPU under
     torch.distributed.run on the loopback address, same flags -- and hand their output through.  (The driver wraps its N > 1 runs in
@@ -731,7 +750,15 @@ def main():
                 out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g_cpu, cam, dc_cpu, da_cpu)
+    # The JSON line is the LAST thing on stdout.  With NCCL_DEBUG set RCCL printf()s a version banner into libc's stdout buffer at init, which
+    # a pipe only sees when the process exits -- i.e. after the line, and once per rank.  So: every rank flushes libc's buffers now, the ranks
+    # meet, rank 0 prints, and everybody points fd 1 at /dev/null for whatever else gets flushed at exit.
+    _flush_c_stdio()
+    if multi:
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(out), flush=True)
+    _discard_further_stdout()
     if multi:
         dist.barrier()
         dist.destroy_process_group()
