@@ -570,7 +570,11 @@ def main():
         if any(w != args.gpus for w in worlds_seen) and os.environ.get("SURFEL_EXCHANGE_SINGLE_RANK") != "1":
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the ranks report communicator sizes {worlds_seen}: the job is not ONE {args.gpus}-rank group")
         rccl_info = rccl_topology(rccl_log, dist.get_backend(), world)
-        if rccl_info.get("channels") is not None and world > 1 and rccl_info["channels"] <= 1 and os.environ.get("SURFEL_ALLOW_SINGLE_CHANNEL") != "1":
+        # (decided by ALL ranks together: a rank that left on its own would leave the others waiting in the next collective)
+        mine = torch.tensor([float(rccl_info["channels"] if rccl_info.get("channels") is not None else -1)], device=dev); seen = torch.empty(world, device=dev)
+        dist.all_gather_into_tensor(seen, mine)
+        rccl_info["channels_seen_by_each_rank"] = [int(x) for x in seen.tolist()]
+        if world > 1 and any(0 <= c <= 1 for c in rccl_info["channels_seen_by_each_rank"]) and os.environ.get("SURFEL_ALLOW_SINGLE_CHANNEL") != "1":
             raise SystemExit(f"bench.py: RCCL built a single-channel ring for {world} ranks ({rccl_info}): one xGMI link would carry the whole exchange -- "
                              f"check NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS / the topology file (SURFEL_ALLOW_SINGLE_CHANNEL=1 runs anyway)")
         par.STALLS.enabled = True   # compute-stream stalls at the collectives' wait points = the exposed part of the exchange
