@@ -86,7 +86,7 @@ def _stream(device):
 
 
 def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile=None,
-           quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=None, forward_only=False):
+           quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=None, forward_only=False, no_precomp_color_grad=False):
     keep = [_f32c(bg, "bg"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos"), blend_counters]
     if blend_counters is not None and (blend_counters.dtype != torch.int64 or blend_counters.numel() < 16 or not blend_counters.is_cuda):
         raise L.SurfelRasterError("blend_counters must be a CUDA (ROCm) int64 tensor with 16 entries")
@@ -94,7 +94,7 @@ def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W,
                    int(bool(prefiltered)), int(bool(debug)), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
                    int(tile[0]) if tile else 0, int(tile[1]) if tile else 0, (0 if quadrant_cull else L.SR_FLAG_NO_QUADRANT_CULL) | (L.SR_FLAG_BALLOT_RANKING if ballot_ranking else 0) |
                    (0 if row_mapped is None else (L.SR_FLAG_ROW_MAPPED_FORWARD if row_mapped else L.SR_FLAG_QUADRANT_MAPPED_FORWARD)) |
-                   (L.SR_FLAG_FORWARD_ONLY if forward_only else 0),
+                   (L.SR_FLAG_FORWARD_ONLY if forward_only else 0) | (L.SR_FLAG_NO_PRECOMP_COLOR_GRAD if no_precomp_color_grad else 0),
                    _ptr(blend_counters))
     return fr, keep
 
@@ -200,9 +200,11 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
 def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap, sh, degree, campos,
                                  geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None, defer_sh=False,
-                                 activations=0, tile=None, after_blend=None, class_state=None, dL_ddist=None, n_classes=0):
+                                 activations=0, tile=None, after_blend=None, class_state=None, dL_ddist=None, n_classes=0, want_precomp_color_grad=True):
     """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry.
 
+    `want_precomp_color_grad=False` (6 / 9 colour channels): dL/dcolors_precomp is not wanted (SR_FLAG_NO_PRECOMP_COLOR_GRAD; an empty
+    tensor comes back for it) -- what the autograd shim passes when colors_precomp / extra_colors does not require grad.
     `defer_sh=True` (frame-parallel ranks, streetunveiler_amd.parallel): with SHs as the colour source, dL_dsh is NOT
     expanded (empty tensor returned) and dL_dcolors carries the clamp-masked dL/drgb [P,3] to be all-gathered and expanded
     with `sh_gradient_expand`.  `after_blend(dL_dcolors)`: with `defer_sh`, called between the two halves of the backward
@@ -219,7 +221,9 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
     H, W = int(dL_dcolor.shape[1]), int(dL_dcolor.shape[2])
     M = int(sh.shape[1]) if sh is not None and sh.numel() else 0
     with torch.cuda.device(dev), _range("backward"):
-        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, False, debug, tile)
+        skip_cg = (not want_precomp_color_grad) and _channels(colors_precomp) == 6   # ([P,6] precomputed channels: the 6- and the 9-channel pass)
+        fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, False, debug, tile,
+                          no_precomp_color_grad=skip_cg)
         # the backward never dereferences opacities (it reads the packed record); pass means3D as a non-NULL stand-in
         g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp, activations)
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -243,7 +247,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         NC = g.color_channels
         if int(dL_dcolor.shape[0]) != NC or keep[0].numel() != NC:
             raise L.SurfelRasterError(f"dL_dcolor / bg must have {NC} channels")
-        dL_dcolors = e(P, 6 if NC == 9 else NC) if has(colors_precomp) or defer_sh else e(0, 3)
+        dL_dcolors = e(P, 6 if NC == 9 else NC) if (has(colors_precomp) and not skip_cg) or defer_sh else e(0, 3)
         dL_dtransMat = e(P, 9) if has(transMat_precomp) else e(0, 9)
         ws = torch.empty((lib.sr_backward_workspace_bytes(P, int(num_rendered), NC),), dtype=torch.uint8, device=dev)
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),

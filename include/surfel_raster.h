@@ -116,6 +116,10 @@ typedef struct SrFrame {
                                       * and radii are bit-identical to the training forward (a test requires it); calling a backward on the
                                       * state of such a forward is undefined */
 
+#define SR_FLAG_NO_PRECOMP_COLOR_GRAD 32u /* backward (sr_backward / sr_backward_blend), 6 / 9 colour channels: the caller does not want dL/dcolors_precomp
+                                      * (SrGradients.dL_dcolors NULL) -- the one-hot class channels of render_semantic are constants -- so K7 does not
+                                      * form those sums (the channels still feed dL/dalpha); every other gradient is unchanged */
+
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
  * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp
  * and exactly one of (scales, rotations) / transMat_precomp must be non-NULL. */

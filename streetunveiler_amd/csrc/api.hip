@@ -39,7 +39,7 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
                                  unsigned long long* counters, const uint32_t* frame_counts, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s);
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, bool precomp_color_grads, hipStream_t s);
 hipError_t launch_pair_decisions(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                  unsigned long long* valid_bits, unsigned long long* use3d_bits, hipStream_t s);
 hipError_t launch_class_partition(int P, int n_tiles, int n_classes, const float* class_cols, const int32_t* class_i32, const uint2* ranges,
@@ -717,7 +717,8 @@ int sr_backward_blend(const SrFrame* frame, const SrGaussians* g, void* geom, si
         if (D > 0) SR_HIP(hipMemsetAsync(c.written, 0, D, c.s));
         if (D > 0)
             SR_HIP(launch_render_backward(c.f, at<uint2>(binning, c.B.ranges), at<uint32_t>(binning, c.B.order), at<uint32_t>(binning, c.B.point_list), at<float4>(geom, c.L.recs), g->colors_precomp,
-                                          at<float>(image, c.I.final_T), at<uint32_t>(image, c.I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, c.B.hit_mask), c.inst_grads, c.written, c.s));
+                                          at<float>(image, c.I.final_T), at<uint32_t>(image, c.I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, c.B.hit_mask), c.inst_grads, c.written,
+                                          !(frame->flags & SR_FLAG_NO_PRECOMP_COLOR_GRAD), c.s));
     }
     return debug_sync(frame, c.s, "render_backward");
 }

@@ -21,7 +21,10 @@ namespace sr {
 // BANDS = 2 (32x16 tile with 6 / 9 colour channels: eight pixels per lane do not fit the register file there): the wave walks the list
 // TWICE, once per 32x8 band (QY = 1 quadrant row each, four pixels per lane), and the second walk ADDS its sums to the records the first
 // one wrote -- same wave, program order, a fence in between -- so a record still holds the whole tile's contribution and K8 is unchanged.
-template <int NC, int QX, int QY, int BANDS = 1>
+// kXG = false (6 / 9 channels, SR_FLAG_NO_PRECOMP_COLOR_GRAD): nobody wants dL/dcolors_precomp -- the one-hot class channels of
+// render_semantic / render_and_semantic are constants -- so their six per-entry sums (and, with 9 channels, the second wave reduction
+// they need) are not formed; the channels still feed dL/dalpha.  The record keeps its size, the slots stay zero.
+template <int NC, int QX, int QY, int BANDS = 1, bool kXG = true>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(QX * QY <= 4 && NC == 3 ? 3 : 1, QX * QY <= 4 && NC == 3 ? 3 : 8)))
 void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
                                                                  const uint32_t* __restrict__ point_list,
@@ -138,7 +141,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
             const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
-            constexpr int NV = NC == 3 ? 21 : 24;   // slots 21..23 carry colour channels 3..5 only
+            constexpr int NV = (NC == 3 || !kXG) ? 21 : 24;   // slots 21..23 carry colour channels 3..5 only
             float v[24];
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
@@ -179,9 +182,9 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     const float med_add = (cidx == medc[q] - (SR_MEDIAN_CONTRIBUTOR_MINUS_ONE ? 1u : 0u)) ? g_median[q] : 0.f;
                     const float dL_dz = fmaf(w, fmaf(t1 * (inv_depth * inv_depth), 2.f * kFN * kNear, g_depth[q]), med_add);
                     const float dL_dG = e3.z * dL_dalpha;
-                    v[18] += w * gr[q]; v[19] += w * gg[q]; v[20] += w * gb[q];
-                    if (NC >= 6) { v[21] += w * gc3[q]; v[22] += w * gc4[q]; v[23] += w * gc5[q]; }
-                    if (NC == 9) { w6 += w * gc6[q]; w7 += w * gc7[q]; w8 += w * gc8[q]; }
+                    if (NC != 6 || kXG) { v[18] += w * gr[q]; v[19] += w * gg[q]; v[20] += w * gb[q]; }   // (6 channels: all of them precomputed)
+                    if (NC >= 6 && kXG) { v[21] += w * gc3[q]; v[22] += w * gc4[q]; v[23] += w * gc5[q]; }
+                    if (NC == 9 && kXG) { w6 += w * gc6[q]; w7 += w * gc7[q]; w8 += w * gc8[q]; }
                     v[15] += w * gn0[q]; v[16] += w * gn1[q]; v[17] += w * gn2[q];
                     v[14] += h.G * dL_dalpha;
                     v[11] += dL_dz;   // (both paths)
@@ -205,7 +208,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             {
                 const float tot = wave_reduce24<NV>(v, lane);
                 if (reduce24_holds_total(lane)) s_out[j][reduce24_index(lane)] = tot;
-                if (NC == 9) {
+                if (NC == 9 && kXG) {
                     const float t3 = wave_reduce3(w6, w7, w8);   // row 0: channel 6, row 1: channel 8, row 2: channel 7
                     if ((lane & 15) == 0 && lane < 48) s_out[j][24 + (lane == 0 ? 0 : (lane == 16 ? 2 : 1))] = t3;
                 }
@@ -249,9 +252,16 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
 // flags: bit 0 = quadrant culling on (SR_FLAG_NO_QUADRANT_CULL clear), bit 1 = counter variant (counters != NULL), bit 2 = row-mapped kernel
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, hipStream_t s) {
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, bool precomp_color_grads, hipStream_t s) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
+    if (!precomp_color_grads && f.tile_w == 16 && f.tile_h == 16 && f.colors != 3) {   // (the reference tile only: elsewhere the sums are formed and nobody reads them)
+#define SR_LAUNCH_BWD_NOXG(NCH) hipLaunchKernelGGL((render_backward_kernel<NCH, 2, 2, 1, false>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, extra, \
+                                                   final_T, n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written)
+        if (f.colors == 9) SR_LAUNCH_BWD_NOXG(9); else SR_LAUNCH_BWD_NOXG(6);
+#undef SR_LAUNCH_BWD_NOXG
+        return hipGetLastError();
+    }
 #define SR_LAUNCH_BWD(NCH, QX, QY)                                                                                                          \
     hipLaunchKernelGGL((render_backward_kernel<NCH, QX, QY>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, extra, final_T, \
                        n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written)

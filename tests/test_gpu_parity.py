@@ -869,3 +869,40 @@ def test_forward_only_mode_is_bit_identical_and_writes_no_backward_state():
     assert torch.equal(c_ng, c_g.detach()) and torch.equal(a_ng, a_g.detach()) and torch.equal(c_det, c_ng)
     (c_g.sum() + a_g.sum()).backward()
     assert t["means3D"].grad is not None and torch.isfinite(t["means3D"].grad).all() and t["shs"].grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("tile", [None, (8, 8)])
+def test_constant_extra_colours_skip_their_gradient_sums(tile):
+    """SR_FLAG_NO_PRECOMP_COLOR_GRAD: when colors_precomp[P,6] / extra_colors does not require grad (render_semantic's one-hot class channels
+    are constants) the shim tells K7 not to form dL/dcolors_precomp.  Every other gradient is bit-identical to the run that does form it
+    (the sums of the other slots go through the same reduction tree), for the 6- and the 9-channel pass; on the reference tile that is the
+    kXG = false instantiation, on another shape the flag changes nothing."""
+    from diff_surfel_rasterization import GaussianRasterizer
+    from tests.gpu_util import DEV, settings_for
+    P, W, H = 6000, 240, 136
+    cam, g = _scene(P, W, H, 61, 3e-3, 5e-2, 3)
+    six = torch.rand(P, 6, generator=torch.Generator().manual_seed(1)).to(DEV)
+    gen = torch.Generator().manual_seed(2)
+    for nc in (6, 9):
+        bg = np.linspace(0.1, 0.7, nc).astype(np.float32)
+        s = settings_for(cam, bg, 3 if nc == 9 else 0)
+        w_c = torch.randn(nc, H, W, generator=gen).to(DEV); w_a = torch.randn(7, H, W, generator=gen).to(DEV)
+
+        def run(extra_needs_grad):
+            t = {k: v.to(DEV).clone().requires_grad_() for k, v in g.items()}
+            m2d = torch.zeros(P, 3, device=DEV, requires_grad=True)
+            ex = six.clone().requires_grad_(extra_needs_grad)
+            kw = dict(shs=t["shs"], extra_colors=ex) if nc == 9 else dict(colors_precomp=ex)
+            c, _, a = GaussianRasterizer(s, tile=tile)(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], **kw)
+            ((c * w_c).sum() + (a * w_a).sum()).backward()
+            grads = {k: t[k].grad for k in ("means3D", "opacities", "scales", "rotations")}
+            grads["m2d"] = m2d.grad
+            if nc == 9:
+                grads["shs"] = t["shs"].grad
+            return grads, ex.grad
+
+        with_g, gx = run(True)
+        without, none = run(False)
+        assert gx is not None and float(gx.abs().max()) > 0 and none is None
+        for k in with_g:
+            assert torch.equal(with_g[k], without[k]), (nc, tile, k)
