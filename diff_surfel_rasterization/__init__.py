@@ -138,7 +138,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             rest = [grad_means3D, grad_opacities, grad_scales, grad_rotations] if exchange.reduce_all else []
             extra = {"frame": ctx.sh_frame} if ctx.sh_frame is not None else {}
             grad_sh = exchange.run(grad_colors_precomp, means3D, s.campos, int(sh.shape[1]), s.sh_degree, also_reduce=rest, **extra)
-        none_if_empty = lambda g, ref: g if ref.numel() and g.numel() else None
+        none_if_empty = lambda g, ref: g if (g is not None and ref.numel() and g.numel()) else None
         return (grad_means3D, grad_means2D, none_if_empty(grad_sh, sh), none_if_empty(grad_colors_precomp, colors_precomp),
                 grad_opacities, none_if_empty(grad_scales, scales), none_if_empty(grad_rotations, rotations),
                 none_if_empty(grad_cov3Ds_precomp, cov3Ds_precomp), None, None, None, None, None, None)
@@ -187,7 +187,7 @@ class _RasterizeWithClassDistortions(torch.autograd.Function):
             s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, empty, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
             grad_color, grad_allmap, sh, s.sh_degree, s.campos, geom, ctx.num_rendered, binning, img, s.debug,
             class_state=cstate, dL_ddist=grad_dist, n_classes=ctx.n_classes, **kwargs)
-        none_if_empty = lambda g, ref: g if ref.numel() and g.numel() else None
+        none_if_empty = lambda g, ref: g if (g is not None and ref.numel() and g.numel()) else None
         return (g3d, g2d, none_if_empty(gsh, sh), none_if_empty(gcol, colors_precomp), gop, gsc, grot, None, None, None, None, None, None)
 
 
