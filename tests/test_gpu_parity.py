@@ -761,7 +761,7 @@ def test_extensions_short_sweep():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_extensions.py"), "12", "5000"], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "12/12 scenes consistent" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-    for seed in ("3427", "3574"):   # distortion-only gradients that are float32 cancellation noise: held against the float64 backward instead
+    for seed in ("3427", "3574", "30703"):   # distortion-only gradients that are float32 cancellation noise: held against the float64 backward instead
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_extensions.py"), "1", seed], cwd=root, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "1/1 scenes consistent" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
