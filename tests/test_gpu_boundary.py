@@ -1,0 +1,139 @@
+"""-m gpu: the drop-in boundary's contract on streams, threads, layouts and repeated backwards ("kernels on the current
+torch stream", "per-call state only", inputs borrowed and never mutated).  The backward is atomic-free, so "same result" below always
+means bit for bit."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
+from tests.gpu_util import DEV, settings_for
+from diff_surfel_rasterization import GaussianRasterizer
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("means3D", "opacities", "scales", "rotations", "shs")
+
+
+def _scene(P, W, H, seed):
+    cam = synthetic_camera(W, H)
+    g = synthetic_gaussians(P, W, H, seed=seed)
+    dc, da = synthetic_upstream_grads(W, H, seed=seed + 1)
+    return cam, g, dc, da
+
+
+def _step(cam, g, dc, da, deg=3, leaves=None, retain=False):
+    """One forward + backward through the operator on whatever stream is current; everything returned stays on the device."""
+    t = leaves or {k: g[k].to(DEV).requires_grad_() for k in NAMES}
+    m2 = torch.zeros(t["means3D"].shape[0], 3, device=DEV, requires_grad=True)
+    color, radii, allmap = GaussianRasterizer(settings_for(cam, [0.1, 0.2, 0.3], deg))(
+        means3D=t["means3D"], means2D=m2, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], shs=t["shs"])
+    loss = (color * dc).sum() + (allmap * da).sum()
+    grads = torch.autograd.grad(loss, [t[k] for k in NAMES] + [m2], retain_graph=retain)
+    return dict(color=color.detach(), radii=radii, allmap=allmap.detach(), **{"d" + k: v for k, v in zip(NAMES + ("means2D",), grads)}), loss
+
+
+def _same(a, b, tag):
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{tag}: {k} differs (max |d| = {(a[k].double() - b[k].double()).abs().max().item():.3e})"
+
+
+def test_side_stream_gives_the_default_streams_bits():
+    """The operator queues everything on torch's CURRENT stream (forward read-back included): under `torch.cuda.stream(side)` with the
+    default stream kept busy by unrelated work, the outputs and gradients are the default-stream run's, bit for bit."""
+    cam, g, dc, da = _scene(40_000, 640, 360, 11)
+    dc, da = dc.to(DEV), da.to(DEV)
+    base, _ = _step(cam, g, dc, da)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    busy = torch.randn(4096, 4096, device=DEV)
+    for _ in range(3):
+        busy = busy @ busy * 1e-3                      # default stream: long-running, unrelated
+        side.wait_stream(torch.cuda.current_stream())  # (the inputs were produced on the default stream)
+        with torch.cuda.stream(side):
+            got, _ = _step(cam, g, dc, da)
+        side.synchronize()
+        _same(base, got, "side stream")
+    torch.cuda.synchronize()
+
+
+def test_two_threads_on_two_streams():
+    """Per-call state only: two python threads, each with its own stream and its own scene, interleave forward and backward calls (the
+    forward's read-back blocks only its own thread); every iteration of either thread reproduces that scene's single-threaded bits."""
+    scenes = [_scene(30_000, 512, 288, 21), _scene(50_000, 640, 360, 31)]
+    scenes = [(cam, g, dc.to(DEV), da.to(DEV)) for cam, g, dc, da in scenes]
+    base = [_step(*s)[0] for s in scenes]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for it in range(6):
+                    got, _ = _step(*scenes[i])
+                    stream.synchronize()
+                    _same(base[i], got, f"thread {i} iteration {it}")
+        except Exception as e:                          # noqa: BLE001 -- reported by the main thread
+            errors.append(f"thread {i}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a worker thread hung"
+    assert not errors, "\n".join(errors)
+
+
+def test_strided_and_double_inputs_are_borrowed_not_required_contiguous():
+    """The reference's callers hand over whatever the model's getters return; the shim makes float32 contiguous copies when (and only
+    when) it has to, never writes to an input, and the gradients come back in the INPUT's layout and dtype."""
+    cam, g, dc, da = _scene(20_000, 480, 272, 41)
+    dc, da = dc.to(DEV), da.to(DEV)
+    base, _ = _step(cam, g, dc, da)
+    P = g["means3D"].shape[0]
+    # transposed storage for the [P, 3] / [P, 4] / [P, 2] tensors, a strided slice of a wider buffer for the SH rows, float64 opacities
+    leaves = {}
+    for k in ("means3D", "scales", "rotations"):
+        leaves[k] = g[k].t().contiguous().to(DEV).t().requires_grad_()
+        assert not leaves[k].is_contiguous()
+    wide = torch.zeros(P, 20, 3, device=DEV); wide[:, 2:18] = g["shs"].to(DEV)
+    leaves["shs"] = wide[:, 2:18].detach().requires_grad_()
+    assert not leaves["shs"].is_contiguous()
+    leaves["opacities"] = g["opacities"].double().to(DEV).requires_grad_()
+    before = {k: v.detach().clone() for k, v in leaves.items()}
+    got, _ = _step(cam, g, dc, da, leaves=leaves)
+    for k, v in leaves.items():
+        assert torch.equal(v.detach(), before[k]), f"input {k} was written to"
+    assert got["dopacities"].dtype == torch.float64 and got["dmeans3D"].shape == (P, 3) and got["dshs"].shape == (P, 16, 3)
+    got["dopacities"] = got["dopacities"].float()
+    _same(base, got, "strided / float64 inputs")
+
+
+def test_backward_twice_with_retain_graph_and_once_without():
+    """The saved state buffers are read-only for the backward (its records live in a per-call workspace): with `retain_graph=True` a
+    second backward returns the first one's bits; without it torch's own "backward through the graph a second time" error is raised,
+    as for any autograd.Function."""
+    cam, g, dc, da = _scene(20_000, 480, 272, 51)
+    dc, da = dc.to(DEV), da.to(DEV)
+    t = {k: g[k].to(DEV).requires_grad_() for k in NAMES}
+    m2 = torch.zeros(t["means3D"].shape[0], 3, device=DEV, requires_grad=True)
+    color, radii, allmap = GaussianRasterizer(settings_for(cam, [0., 0., 0.], 3))(
+        means3D=t["means3D"], means2D=m2, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], shs=t["shs"])
+    loss = (color * dc).sum() + (allmap * da).sum()
+    leaves = [t[k] for k in NAMES] + [m2]
+    first = torch.autograd.grad(loss, leaves, retain_graph=True)
+    second = torch.autograd.grad(loss, leaves, retain_graph=False)
+    for k, a, b in zip(NAMES + ("means2D",), first, second):
+        assert torch.equal(a, b), f"second backward: d{k} differs"
+    with pytest.raises(RuntimeError, match="second time|already been freed"):
+        torch.autograd.grad(loss, leaves)
+    # ... and .backward() ACCUMULATES into .grad as for any other op: two frames' gradients add up
+    cam2, g2, dc2, da2 = _scene(20_000, 480, 272, 51)
+    for _ in range(2):
+        c, _, a = GaussianRasterizer(settings_for(cam, [0., 0., 0.], 3))(
+            means3D=t["means3D"], means2D=m2, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], shs=t["shs"])
+        ((c * dc).sum() + (a * da).sum()).backward()
+    for k, a in zip(NAMES + ("means2D",), first):
+        leaf = m2 if k == "means2D" else t[k]
+        assert torch.equal(leaf.grad, a + a), f"accumulated d{k} is not twice one frame's"
