@@ -3,7 +3,6 @@ torch stream", "per-call state only", inputs borrowed and never mutated).  The b
 means bit for bit."""
 import threading
 
-import numpy as np
 import pytest
 import torch
 
@@ -129,7 +128,6 @@ def test_backward_twice_with_retain_graph_and_once_without():
     with pytest.raises(RuntimeError, match="second time|already been freed"):
         torch.autograd.grad(loss, leaves)
     # ... and .backward() ACCUMULATES into .grad as for any other op: two frames' gradients add up
-    cam2, g2, dc2, da2 = _scene(20_000, 480, 272, 51)
     for _ in range(2):
         c, _, a = GaussianRasterizer(settings_for(cam, [0., 0., 0.], 3))(
             means3D=t["means3D"], means2D=m2, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], shs=t["shs"])
@@ -137,3 +135,36 @@ def test_backward_twice_with_retain_graph_and_once_without():
     for k, a in zip(NAMES + ("means2D",), first):
         leaf = m2 if k == "means2D" else t[k]
         assert torch.equal(leaf.grad, a + a), f"accumulated d{k} is not twice one frame's"
+
+
+def test_backward_captures_into_a_hip_graph():
+    """The backward has no host synchronisation, no allocation by the library and no process-wide state: `sr_backward` (memset of the
+    written flags, K7, K8) is captured into a HIP graph and every replay returns the eager call's bits.  (The forward cannot be: its
+    `num_rendered` read-back is the reference's own host sync.  Captured through `_C` directly: `torch.autograd.grad` inside
+    `torch.cuda.graph` dumps core on this torch / ROCm pair for pure-torch graphs too.)"""
+    from diff_surfel_rasterization import _C
+    cam, g, dc, da = _scene(10_000, 256, 256, 61)
+    g = {k: v.to(DEV) for k, v in g.items()}
+    dc, da = dc.to(DEV), da.to(DEV)
+    s = settings_for(cam, [0., 0., 0.], 3)
+    e = torch.empty(0, device=DEV)
+    fwd = lambda: _C.rasterize_gaussians(s.bg, g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, s.viewmatrix, s.projmatrix,
+                                         s.tanfovx, s.tanfovy, 256, 256, g["shs"], 3, s.campos, False, False)
+    D, color, allmap, radii, geom, binning, img = fwd()[:7]
+    bwd = lambda: _C.rasterize_gaussians_backward(s.bg, g["means3D"], radii, e, g["scales"], g["rotations"], 1.0, e, s.viewmatrix, s.projmatrix,
+                                                  s.tanfovx, s.tanfovy, dc, da, g["shs"], 3, s.campos, geom, D, binning, img, False)
+    ref = bwd()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        bwd()                                         # warm-up on a side stream, as torch's capture rules ask
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = bwd()
+    for _ in range(3):
+        for o in out: o.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(zip(ref, out)):
+            assert torch.equal(a, b), f"graph replay: gradient {k} differs from the eager call"
