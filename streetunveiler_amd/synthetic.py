@@ -47,6 +47,42 @@ def synthetic_gaussians(P: int, width: int, height: int, seed: int = 0, sh_coeff
                 opacities=opacities.float(), shs=shs.float().contiguous())
 
 
+def posed_scene(P: int, width: int, height: int, seed: int = 0, scale_lo: float = 5e-4, scale_hi: float = 5e-3, spread: float = 10.0,
+                sh_coeffs: int = 16, near_third: bool = False):
+    """The benchmark scene seen by a camera in GENERAL position: a random rotation (any yaw / pitch / roll), a centre drawn from
+    U(-spread, spread)^3, fx in [0.55, 1.4] W and fy = fx * U(0.8, 1.25) (so FoVx and FoVy are unrelated), the Gaussians drawn in that
+    camera's frame exactly as `synthetic_gaussians` draws them and moved to world coordinates (float64, then rounded).  The benchmark
+    cameras of SURVEY 8d all sit at the origin and only yaw: with them `campos`, the translation row of the view matrix and two of
+    the three rotation axes are zeros / ones that a wrong term could hide behind.  -> (camera, gaussians)"""
+    import numpy as np
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(4, generator=g, dtype=torch.float64); q = (q / q.norm()).tolist()
+    r, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                  [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                  [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]], dtype=np.float64)     # camera -> world
+    c = ((torch.rand(3, generator=g, dtype=torch.float64) * 2 - 1) * spread).numpy()
+    fx = float(torch.rand(1, generator=g) * 0.85 + 0.55) * width
+    fy = fx * float(torch.rand(1, generator=g) * 0.45 + 0.8)
+    cam = make_camera(width, height, focal2fov(fx, width), focal2fov(fy, height), R=R, t=-R.T @ c)
+    tx, ty = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    zc = torch.rand(P, generator=g) * 49.0 + 1.0
+    xc = (torch.rand(P, generator=g) * 2.2 - 1.1) * zc * tx
+    yc = (torch.rand(P, generator=g) * 2.2 - 1.1) * zc * ty
+    if near_third:   # a third of the Gaussians around / behind the near plane (view depth -0.1 .. 0.4)
+        zc = zc.clone(); zc[: P // 3] = torch.rand(P // 3, generator=g) * 0.5 - 0.1
+    local = torch.stack([xc, yc, zc], dim=1).double()
+    means3D = (local @ torch.tensor(R).t() + torch.tensor(c)).float().contiguous()
+    lo, hi = math.log(scale_lo), math.log(scale_hi)
+    scales = (zc[:, None] * torch.exp(torch.rand(P, 2, generator=g) * (hi - lo) + lo)).contiguous()
+    qq = torch.randn(P, 4, generator=g)
+    rotations = (qq / qq.norm(dim=1, keepdim=True)).contiguous()
+    opacities = torch.sigmoid(torch.randn(P, 1, generator=g) * 1.5).contiguous()
+    shs = torch.randn(P, sh_coeffs, 3, generator=g)
+    shs[:, 1:] *= 0.1
+    return cam, dict(means3D=means3D, scales=scales.float(), rotations=rotations.float(), opacities=opacities.float(), shs=shs.float().contiguous())
+
+
 def clustered_gaussians(P: int, width: int, height: int, fraction: float = 0.5, seed: int = 0) -> Dict[str, torch.Tensor]:
     """A street-like, NON-uniform variant of the benchmark scene: `fraction` of the Gaussians is squeezed into four screen regions
     (dense facades / vegetation) and made translucent, so the tile lists are heavy-tailed (1920x1080, 3 M Gaussians: list length

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 W, H = 1920, 1080
 
 
-def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, report=None, camera_index=None, outlier_frac=0.0, size=(W, H)):
+def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, report=None, camera_index=None, outlier_frac=0.0, size=(W, H), posed=None, loose_hard=0.25):
     """One BASELINE configuration in full against the CPU oracle [REF gaussian_renderer/__init__.py:129-165: the operator call and the
     meaning of its outputs]:
       1. integers bit-exact: D, radii, the sorted duplicate list, the tile ranges (the float32 oracle's 64-bit stable sort);
@@ -29,6 +29,9 @@ def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, repo
     W, H = size
     cam = synthetic_camera(W, H, index=camera_index)   # (None: the unrotated camera; k: camera k of the 8-camera batch, yawed (k - 3.5) * 5 degrees)
     g = synthetic_gaussians(P, W, H, seed=0) if scene is None else scene(P, W, H)
+    if posed is not None:   # (seed, spread): the same scene statistics seen by a camera in general position
+        from streetunveiler_amd.synthetic import posed_scene
+        cam, g = posed_scene(P, W, H, seed=posed[0], spread=posed[1])
     bg = np.zeros(3, np.float32)
     dc, da = synthetic_upstream_grads(W, H, seed=1, aux=aux)
     fwd, bwd = run_oracle(g, cam, bg, 3, dc, da)
@@ -47,9 +50,11 @@ def _against_oracle(P, aux, tag, pixel_budget, gaussian_budget, scene=None, repo
         # (no per-element cap here: with 3 M rows the float32 oracle's own worst rows -- global-coordinate cancellation of grazing
         # splats, 0.3 of a row against the float64 arbiter in profiles/r03_parity_c3.json -- exceed any; steps 3 and 4 are the tight ones)
         # ... but a loose one stays: no element may be off by a quarter of its tensor's scale, whatever its row's conditioning
-        assert_grads_close(out[k], bwd[k], 2e-3, f"{tag} {k}", hard=0.25)
+        assert_grads_close(out[k], bwd[k], 2e-3, f"{tag} {k}", hard=loose_hard)
     _, fwd64, bwd64 = forced_f64_reference(g, cam, bg, 3, dc, da, base=fwd, raw=raw)
-    assert_strict_parity(out, fwd64, bwd64, tag=tag + " ", scene=(g, cam), outlier_frac=outlier_frac)
+    fwd32 = forced_f64_reference(g, cam, bg, 3, None, None, base=fwd, raw=raw, f64=False)[1] if posed is not None else None
+    assert_strict_parity(out, fwd64, bwd64, tag=tag + " ", scene=(g, cam), outlier_frac=outlier_frac, elementwise32=fwd32, report=report if posed is not None else None)
+    del fwd32
     del fwd64, bwd64
     # (with the kernels' per-pair decision dump: every one of them at a robust pixel must be the float64 checker's own)
     xfwd, xbwd, margins = free_f64_reference(g, cam, bg, 3, dc, da, base=fwd, kernel_decisions=raw["decisions"])
@@ -112,6 +117,24 @@ def test_c4_3m_yawed_cameras_against_oracle(k):
     finally:
         os.makedirs("gpurun_out", exist_ok=True)
         json.dump(rep, open(f"gpurun_out/c4_camera{k}_parity.json", "w"), indent=1, default=float)
+
+
+def test_c3_size_general_camera_pose_against_oracle():
+    """The C3 workload (3 M Gaussians, 1920x1080, all aux gradients) seen by a camera in GENERAL position: a random rotation about all
+    three axes, the camera centre ~25 units from the origin (world coordinates up to ~75), FoVx unrelated to FoVy
+    (streetunveiler_amd.synthetic.posed_scene).  The benchmark cameras sit at the origin and only yaw; a trained street scene does
+    neither.  The same four-way check as C3, bit-exact lists included."""
+    import json, os
+    rep = {}
+    try:
+        # (loose_hard: the float32 ORACLE's worst row here -- Gaussian 2072707, a radius-16 splat at depth 1.5 holding the largest rotation
+        # and proxy gradients of the frame -- is 0.35 of the tensor's scale off the float64 arbiter, under its own decisions and under the
+        # kernels' alike (upstream's global-pixel-coordinate k = x Tw - Tu cancels there); the kernels' row is within 2.6e-3.  Steps 3 and
+        # 4 hold the kernels to the float64 references as everywhere else.)
+        _against_oracle(3_000_000, True, "posed", pixel_budget=8e-3, gaussian_budget=0.25, report=rep, outlier_frac=1e-6, posed=(7, 25.0), loose_hard=0.5)
+    finally:
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(rep, open("gpurun_out/posed_parity.json", "w"), indent=1, default=float)
 
 
 def test_c5_scene_6m_at_4k_against_oracle():

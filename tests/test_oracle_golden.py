@@ -134,6 +134,30 @@ def test_analytic_backward_matches_float64_autograd_variants():
             assert np.abs(grads[k] - ref).max() <= 1e-3 * (np.abs(ref).max() + 1e-30), (mode, k)  # f32 analytic vs f64 autograd
 
 
+def test_analytic_backward_matches_float64_autograd_general_pose():
+    """K7 + K8 against float64 autograd with cameras in GENERAL position (streetunveiler_amd.synthetic.posed_scene: any rotation, a
+    centre away from the origin, FoVx unrelated to FoVy).  The benchmark cameras sit at the origin and only yaw: `campos`, the
+    translation row of the view matrix and most of its rotation block are then zeros and ones -- a term that uses the wrong one of
+    them would pass every other test."""
+    from streetunveiler_amd.synthetic import posed_scene
+    for seed, (P, W, H, deg, lo, hi) in enumerate([(90, 52, 35, 3, 0.01, 0.12), (70, 40, 40, 2, 0.02, 0.2), (60, 33, 47, 1, 0.01, 0.3)]):
+        cam, gt = posed_scene(P, W, H, seed=40 + seed, scale_lo=lo, scale_hi=hi, spread=8.0)
+        assert float(cam.camera_center.abs().max()) > 1.0 and abs(cam.FoVx - cam.FoVy) > 1e-3
+        g = {k: v.numpy() for k, v in gt.items()}
+        kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
+                  campos=cam.camera_center.numpy(), bg=np.array([0.3, 0.6, 0.1], np.float32), image_width=W,
+                  image_height=H, sh_degree=deg, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
+        fwd = so.rasterize_forward(g["means3D"], g["opacities"], g["scales"], g["rotations"], shs=g["shs"], **kw)
+        assert fwd["num_rendered"] > 50
+        dc, da = synthetic_upstream_grads(W, H, seed=P)
+        grads = so.rasterize_backward(fwd, dc.numpy(), da.numpy())
+        outs, g64 = forward_backward64(fwd, dc.numpy(), da.numpy())
+        np.testing.assert_allclose(fwd["color"], outs["color"], atol=2e-5)
+        np.testing.assert_allclose(fwd["allmap"], outs["allmap"], rtol=1e-4, atol=1e-3)
+        for k, ref in g64.items():
+            assert np.abs(grads[k] - ref).max() <= 1e-3 * (np.abs(ref).max() + 1e-30), (seed, k, np.abs(grads[k] - ref).max(), np.abs(ref).max())
+
+
 def test_mark_visible_and_empty_inputs():
     cam = synthetic_camera(32, 32)
     pts = np.array([[0, 0, 0.1], [0, 0, 0.2], [0, 0, 0.21], [0, 0, -3], [1, 1, 10]], np.float32)

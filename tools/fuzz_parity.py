@@ -2,7 +2,7 @@
 """Randomised parity sweep: HIP operator vs CPU oracle over many small random scenes (sizes, cameras, SH degree, tile shape,
 opacity / scale regimes, precomputed colours / transMat).  Exits non-zero if a scene misses the parity bars of
 tests/gpu_util.py.  python tools/fuzz_parity.py [n_scenes] [first_seed]   (FUZZ_SEEDS=a,b,c: exactly these scenes; tools/fuzz_diagnose.py
-prints one scene in detail, the float32 oracle beside the kernels)"""
+prints one scene in detail, the float32 oracle beside the kernels; seeds >= 100000: cameras in general position)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,6 +14,7 @@ from tests.test_gpu_parity import _check_binning
 
 big = int(os.environ.get("FUZZ_BIG", "1"))   # FUZZ_BIG=4: images up to 4x wider/higher, 16x the Gaussians
 shapes = [(16, 16)] * 4 + [(8, 8), (16, 8), (32, 8), (32, 16)]
+POSED_FROM = 100_000    # seeds from here up draw a camera in general position (the scenes of the seeds below stay what they were)
 
 
 def make_scene(seed):
@@ -24,15 +25,20 @@ def make_scene(seed):
     deg = int(rng.integers(0, 4))
     tile = shapes[int(rng.integers(0, len(shapes)))]
     cam = synthetic_camera(W, H, index=int(rng.integers(0, 8)))
-    g = synthetic_gaussians(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi)
     regime = int(rng.integers(0, 4))
+    posed = seed >= POSED_FROM
+    if posed:   # a camera in general position (any rotation, centre 0.5 .. 200 units out, FoVx unrelated to FoVy) instead of the origin / yaw-only ones
+        from streetunveiler_amd.synthetic import posed_scene
+        cam, g = posed_scene(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi, spread=float(10 ** rng.uniform(-0.3, 2.3)), near_third=regime == 3)
+    else:
+        g = synthetic_gaussians(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi)
     if regime == 1: g["opacities"] = g["opacities"] * 0.05                       # translucent: deep lists
     if regime == 2: g["opacities"] = (g["opacities"] * 0.2 + 0.8).clamp(max=1.0)  # opaque: early saturation
-    if regime == 3: g["means3D"][: P // 3, 2] = torch.rand(P // 3) * 0.5 - 0.1     # around / behind the near plane
+    if regime == 3 and not posed: g["means3D"][: P // 3, 2] = torch.rand(P // 3) * 0.5 - 0.1     # around / behind the near plane
     bg = rng.random(3).astype(np.float32)
     dc, da = synthetic_upstream_grads(W, H, seed=seed)
     colors = rng.random((P, 3)).astype(np.float32) if rng.random() < 0.25 else None
-    tag = f"(seed {seed}): P={P} {W}x{H} deg={deg} tile={tile} regime={regime} scales[{lo:.1e},{hi:.1e}] colors={'pre' if colors is not None else 'sh'}"
+    tag = f"(seed {seed}): P={P} {W}x{H} deg={deg} tile={tile} regime={regime}{' posed' if posed else ''} scales[{lo:.1e},{hi:.1e}] colors={'pre' if colors is not None else 'sh'}"
     return dict(g=g, cam=cam, bg=bg, deg=deg, dc=dc, da=da, colors=colors, tile=tile, regime=regime, P=P, tag=tag)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Which Gaussian holds the worst gradient row of a full-size parity run, and why: HIP, the float32 oracle and the float64 arbiter side by
-side under the kernels' own decisions.   python tools/worst_row.py [--camera 7] [--tensor dL_dmeans3D] [--gaussians 3000000]   (GPU box)"""
+side under the kernels' own decisions.   python tools/worst_row.py [--camera 7] [--tensor dL_dmeans3D] [--gaussians 3000000]   [--posed 7,25]   (GPU box)"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,9 +9,14 @@ from tests.gpu_util import forced_f64_reference, gradient_row_errors, run_hip, r
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--camera", type=int, default=7); ap.add_argument("--tensor", default="dL_dmeans3D"); ap.add_argument("--gaussians", type=int, default=3_000_000)
+ap.add_argument("--posed", default=None, help="seed,spread: a camera in general position (synthetic.posed_scene) instead of the benchmark camera")
 a = ap.parse_args()
 W, H, P = 1920, 1080, a.gaussians
 cam = synthetic_camera(W, H, index=a.camera); g = synthetic_gaussians(P, W, H, seed=0); bg = np.zeros(3, np.float32)
+if a.posed:
+    from streetunveiler_amd.synthetic import posed_scene
+    seed, spread = a.posed.split(",")
+    cam, g = posed_scene(P, W, H, seed=int(seed), spread=float(spread))
 dc, da = synthetic_upstream_grads(W, H, seed=1)
 fwd, _ = run_oracle(g, cam, bg, 3)
 raw = run_hip_raw(g, cam, bg, 3, decisions=True)
