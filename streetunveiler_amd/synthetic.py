@@ -83,6 +83,29 @@ def posed_scene(P: int, width: int, height: int, seed: int = 0, scale_lo: float 
     return cam, dict(means3D=means3D, scales=scales.float(), rotations=rotations.float(), opacities=opacities.float(), shs=shs.float().contiguous())
 
 
+def posed_rig(P: int, width: int, height: int, n_cams: int, seed: int = 0, scale_lo: float = 5e-4, scale_hi: float = 5e-3, spread: float = 10.0,
+              jitter: float = 2.0):
+    """`n_cams` cameras in general position looking at ONE set of Gaussians (a multi-camera step: streetunveiler_amd.parallel): camera 0
+    and the Gaussians are `posed_scene(seed)`; camera k > 0 is camera 0 moved by up to `jitter` units sideways / backwards and turned by
+    up to ~6 degrees about each axis -- every camera has its own centre (the yawed benchmark batch shares one: the origin), which is what
+    the per-view directions of the factored SH-gradient exchange depend on.  -> (cameras, gaussians)"""
+    import numpy as np
+    cam0, g = posed_scene(P, width, height, seed=seed, scale_lo=scale_lo, scale_hi=scale_hi, spread=spread)
+    W2C = cam0.world_view_transform.t().double().numpy()          # [R^T | t]
+    R0, c0 = W2C[:3, :3].T, cam0.camera_center.double().numpy()
+    gen = torch.Generator().manual_seed(seed + 7919)
+    cams = [cam0]
+    for _ in range(1, n_cams):
+        a = ((torch.rand(3, generator=gen, dtype=torch.float64) * 2 - 1) * 0.1).tolist()
+        cx, sx, cy, sy, cz, sz = math.cos(a[0]), math.sin(a[0]), math.cos(a[1]), math.sin(a[1]), math.cos(a[2]), math.sin(a[2])
+        Rs = (np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]))
+        off = ((torch.rand(3, generator=gen, dtype=torch.float64) * 2 - 1) * jitter).numpy()
+        off[2] = -abs(off[2])                                       # backwards, never into the scene
+        R, c = R0 @ Rs, c0 + R0 @ off
+        cams.append(make_camera(width, height, cam0.FoVx, cam0.FoVy, R=R, t=-R.T @ c))
+    return cams, g
+
+
 def clustered_gaussians(P: int, width: int, height: int, fraction: float = 0.5, seed: int = 0) -> Dict[str, torch.Tensor]:
     """A street-like, NON-uniform variant of the benchmark scene: `fraction` of the Gaussians is squeezed into four screen regions
     (dense facades / vegetation) and made translucent, so the tile lists are heavy-tailed (1920x1080, 3 M Gaussians: list length

@@ -143,6 +143,8 @@ def test_general_camera_poses_vs_oracle(seed, P, W, H, deg, lo, hi, spread):
     from streetunveiler_amd.synthetic import posed_scene
     cam, g = posed_scene(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi, spread=spread)
     assert float(cam.camera_center.abs().max()) > 0.5 and abs(cam.FoVx - cam.FoVy) > 1e-3
+    if seed == 2:   # quaternions "as given" (Appendix A.2): not unit length -- the operator does not normalise them, the model's getter does
+        g["rotations"] = (g["rotations"] * (torch.rand(P, 1, generator=torch.Generator().manual_seed(seed)) + 0.6)).contiguous()
     _full_check(cam, g, deg, np.array([0.2, 0.4, 0.1], np.float32), synthetic_upstream_grads(W, H, seed=seed), f"pose{seed}")
 
 
@@ -524,6 +526,26 @@ def test_sh_gradient_expand_matches_backward():
                 per_view.append((s.campos.clone(), lean[1].clone(), full[5].clone()))
     both = _C.sh_gradient_expand(d["means3D"], torch.stack([v[0] for v in per_view]), torch.stack([v[1] for v in per_view]), 16, 3)
     torch.testing.assert_close(both, per_view[0][2] + per_view[1][2], rtol=1e-5, atol=1e-6)
+    # ... and with cameras that do NOT share a centre (the yawed batch above does: the origin): three views of synthetic.posed_rig
+    from streetunveiler_amd.synthetic import posed_rig
+    rig, gp = posed_rig(P, W, H, 3, seed=13, scale_lo=5e-3, scale_hi=6e-2, spread=15.0)
+    dp = {k: v.to(DEV) for k, v in gp.items()}
+    views = []
+    for cam in rig:
+        s = settings_for(cam, np.zeros(3, np.float32), 3)
+        D, color, allmap, radii, geom, binning, img = _C.rasterize_gaussians(
+            s.bg, dp["means3D"], e, dp["opacities"], dp["scales"], dp["rotations"], 1.0, e, s.viewmatrix, s.projmatrix,
+            s.tanfovx, s.tanfovy, H, W, dp["shs"], 3, s.campos, False, False)
+        args = (s.bg, dp["means3D"], radii, e, dp["scales"], dp["rotations"], 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx,
+                s.tanfovy, dc.to(DEV), da.to(DEV), dp["shs"], 3, s.campos, geom, D, binning, img, False)
+        full = _C.rasterize_gaussians_backward(*args); lean = _C.rasterize_gaussians_backward(*args, defer_sh=True)
+        assert float(full[5].abs().max()) > 0 and torch.equal(_C.sh_gradient_expand(dp["means3D"], s.campos, lean[1], 16, 3), full[5])
+        views.append((s.campos.clone(), lean[1].clone(), full[5].clone()))
+    assert float((views[0][0] - views[1][0]).abs().max()) > 0.1
+    three = _C.sh_gradient_expand(dp["means3D"], torch.stack([v[0] for v in views]), torch.stack([v[1] for v in views]), 16, 3)
+    torch.testing.assert_close(three, views[0][2] + views[1][2] + views[2][2], rtol=1e-5, atol=1e-6 * float(three.abs().max()))
+    swapped = _C.sh_gradient_expand(dp["means3D"], torch.stack([views[1][0], views[0][0], views[2][0]]), torch.stack([v[1] for v in views]), 16, 3)
+    assert float((swapped - three).abs().max()) > 1e-3 * float(three.abs().max()), "the expansion does not depend on which camera a view's gradient is paired with"
     # general-layout path (M = 9 rows, degree 2)
     sh9 = d["shs"][:, :9].contiguous()
     nine = _C.sh_gradient_expand(d["means3D"], per_view[0][0], per_view[0][1], 9, 2)
@@ -531,15 +553,18 @@ def test_sh_gradient_expand_matches_backward():
     assert torch.equal(nine, ref[:, :9]) and sh9.shape[1] == 9
 
 
-def test_factored_sh_exchange_two_ranks_one_gpu():
+@pytest.mark.parametrize("rig", ["yawed", "posed"])
+def test_factored_sh_exchange_two_ranks_one_gpu(rig):
     """The N > 1 exchange end to end (autograd hook, all-gather, HIP expansion, all-reduce of the rest) with two ranks
-    sharing this box's one GPU over gloo; tools/check_factored_exchange.py compares against locally summed gradients."""
+    sharing this box's one GPU over gloo; tools/check_factored_exchange.py compares against locally summed gradients.
+    `posed`: three ranks whose cameras each have their own centre and orientation (the benchmark's yawed batch shares one centre, the
+    origin, so the per-view direction normalize(mean - campos_v) of the expansion is the same for every view there)."""
     import socket, subprocess, sys
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SURFEL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    env = dict(os.environ, SURFEL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", SURFEL_CHECK_RIG=rig)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2" if rig == "yawed" else "3", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tools", "check_factored_exchange.py")],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -770,6 +795,13 @@ def test_randomised_scenes_short_sweep():
     env = dict(os.environ, FUZZ_SEEDS="7021,7063,7082,9057,9061")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], cwd=root, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "5/5 scenes within the parity bars" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    # cameras in general position (seeds >= 100000: any rotation, the centre up to 200 units out, FoVx unrelated to FoVy) + the two scenes of a
+    # 600-scene sweep of them that needed the per-row / non-robust-count readings of the bars (tests/gpu_util.py rows_within, differing pixels)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "10", "100000"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "10/10 scenes within the parity bars" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], cwd=root, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, FUZZ_SEEDS="100525,100551"))
+    assert r.returncode == 0 and "2/2 scenes within the parity bars" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_extensions_short_sweep():

@@ -215,7 +215,16 @@ def test_render_semantic_with_mask_against_the_oracle_on_the_subset():
 def test_fused_postprocess_matches_torch_restatement():
     """csrc/postprocess.hip forward + backward against the plain-torch restatement (float64 on the CPU)."""
     W, H = 200, 120
-    cam = synthetic_camera(W, H, index=6)
+    _postprocess_against_torch(synthetic_camera(W, H, index=6), W, H)
+    # ... and a camera in general position: its own centre, rotation about all three axes, fx != fy (the back-projection's intrinsics and
+    # camera-to-world transform are then no longer diagonal / identity-like)
+    from streetunveiler_amd.synthetic import posed_scene
+    _postprocess_against_torch(posed_scene(1, W, H, seed=12, spread=20.0)[0], W, H)
+    with pytest.raises(Exception, match="no CPU path"):
+        postprocess_allmap(synthetic_camera(W, H), PipelineParams(), torch.zeros(7, H, W))
+
+
+def _postprocess_against_torch(cam, W, H):
     g = torch.Generator().manual_seed(4)
     allmap = torch.rand(7, H, W, generator=g)
     allmap[0] = allmap[0] * 20 + 1; allmap[5] = allmap[5] * 20 + 1
@@ -236,8 +245,6 @@ def test_fused_postprocess_matches_torch_restatement():
         assert np.isfinite(ggpu).all()
         scale = np.abs(gref).max()
         assert np.abs(ggpu - gref).max() <= 2e-4 * scale, np.abs(ggpu - gref).max() / scale
-    with pytest.raises(Exception, match="no CPU path"):
-        postprocess_allmap(cam, PipelineParams(), allmap)
 
 
 def test_fused_postprocess_matches_reference_fixture(golden_dir):

@@ -144,6 +144,8 @@ def test_analytic_backward_matches_float64_autograd_general_pose():
         cam, gt = posed_scene(P, W, H, seed=40 + seed, scale_lo=lo, scale_hi=hi, spread=8.0)
         assert float(cam.camera_center.abs().max()) > 1.0 and abs(cam.FoVx - cam.FoVy) > 1e-3
         g = {k: v.numpy() for k, v in gt.items()}
+        if seed == 1:   # quaternions "as given" (A.2 step 2): not unit length -- the operator does not normalise, the model's getter does
+            g["rotations"] = (g["rotations"] * np.random.default_rng(seed).uniform(0.6, 1.6, (P, 1))).astype(np.float32)
         kw = dict(viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
                   campos=cam.camera_center.numpy(), bg=np.array([0.3, 0.6, 0.1], np.float32), image_width=W,
                   image_height=H, sh_degree=deg, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Two (or more) frame-parallel ranks: gradients after `factored_sh_exchange` + `allreduce_gradients` must equal the sum of
 the gradients of all ranks' frames computed locally.  Launch with torchrun; SURFEL_DIST_BACKEND=gloo lets the ranks share
-one GPU (functional check), the default backend on a multi-GPU node is nccl (= RCCL)."""
+one GPU (functional check), the default backend on a multi-GPU node is nccl (= RCCL).
+SURFEL_CHECK_RIG=yawed (default; the benchmark's camera batch: every camera at the origin) | posed (synthetic.posed_rig: every camera
+with its own centre and orientation -- the per-view directions of the expansion then differ from rank to rank)."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,16 +14,22 @@ rank, world, local_rank = init_distributed()
 dev = torch.device("cuda", local_rank % torch.cuda.device_count())
 torch.cuda.set_device(dev)
 from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
+from streetunveiler_amd.synthetic import posed_rig, synthetic_camera, synthetic_gaussians, synthetic_upstream_grads
 
 P, W, H, deg = 20000, 320, 192, 3
-g = synthetic_gaussians(P, W, H, seed=3)
+if os.environ.get("SURFEL_CHECK_RIG", "yawed") == "posed":
+    rig, g = posed_rig(P, W, H, world, seed=3, scale_lo=2e-3, scale_hi=2e-2, spread=12.0)
+    assert len({tuple(c.camera_center.tolist()) for c in rig}) == world
+    camera = lambda index: rig[index]
+else:
+    g = synthetic_gaussians(P, W, H, seed=3)
+    camera = lambda index: synthetic_camera(W, H, index=index, n_cams=world)
 dc, da = [t.to(dev) for t in synthetic_upstream_grads(W, H, seed=4)]
 names = ["means3D", "shs", "opacities", "scales", "rotations"]
 
 
 def frame(index, exchange, reduce_all=False):
-    cam = synthetic_camera(W, H, index=index, n_cams=world)
+    cam = camera(index)
     s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3, device=dev), 1.0,
                                       cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), deg, cam.camera_center.to(dev), False, False)
     t = {k: g[k].to(dev).requires_grad_() for k in names}
@@ -59,7 +67,7 @@ for reduce_all in (False, True):
         assert scale > 0 and err <= 2e-5 * scale, f"rank {rank} reduce_all={reduce_all} {n}: max err {err:.3e} vs scale {scale:.3e}"
 # the densification statistics of the ranks' views (one packed exchange) against the per-view values computed locally
 def view_stats(index):
-    cam = synthetic_camera(W, H, index=index, n_cams=world)
+    cam = camera(index)
     s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3, device=dev), 1.0,
                                       cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), deg, cam.camera_center.to(dev), False, False)
     m2d = torch.zeros(P, 3, device=dev, requires_grad=True)

@@ -43,6 +43,11 @@ for seed in [int(a) for a in sys.argv[1:]]:
     for key in eh:
         q = lambda x: (float(np.quantile(x, 0.999)) if x.size else 0.0, float(x.max(initial=0)))
         print(f"  forced {key:14s} rows p99.9/max: hip {q(eh[key])[0]:.2e}/{q(eh[key])[1]:.2e} oracle32 {q(eo[key])[0]:.2e}/{q(eo[key])[1]:.2e}")
+        if eh[key].size and key in eo and eh[key].max() > 5e-3:   # which Gaussian, and is it the float32 oracle's bad row too?
+            ids = np.flatnonzero(vis); ih, io = int(np.argmax(eh[key])), int(np.argmax(eo[key])); i = int(ids[ih])
+            R = lambda d, k: np.asarray(d.get(k + "64", d.get(k)), np.float64).reshape(vis.size, -1)
+            print(f"      worst hip row: Gaussian {i} (oracle32 there {eo[key][ih]:.2e}; oracle32's worst row: Gaussian {int(ids[io])}, hip there {eh[key][io]:.2e}); radius {int(fwd['radii'][i])} tiles {int(fwd['tiles_touched'][i])}"
+                  f" depth {float(fwd['depths'][i]):.3f} centre {fwd['means2D'][i].tolist()} scales {g['scales'][i].tolist()}\n      hip {R(out, key)[i].tolist()}\n      o32 {R(sb32, key)[i].tolist()}\n      f64 {R(sb64, key)[i].tolist()}")
     bad = np.argwhere((nc[0] != xfwd["n_contrib"][0]) & rob_px)
     ft = lambda d: np.asarray(d["final_T"]).reshape(-1, *rob_px.shape)[0] if "final_T" in d else np.full(rob_px.shape, np.nan)
     for (y, x) in bad[:5]:
