@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _model(P, W, H, seed, dev, requires_grad=False):
-    g = synthetic_gaussians(P, W, H, seed=seed, scale_lo=3e-3, scale_hi=5e-2)
+def _model(P, W, H, seed, dev, requires_grad=False, gaussians=None):
+    g = synthetic_gaussians(P, W, H, seed=seed, scale_lo=3e-3, scale_hi=5e-2) if gaussians is None else gaussians
     sem = torch.randint(0, 6, (P,), generator=torch.Generator().manual_seed(seed))
     t = {k: v.to(dev) for k, v in g.items()}
     if requires_grad:
@@ -38,12 +38,16 @@ def _oracle(g, cam, bg, deg, idx=None, colors=None):
     return so.rasterize_forward(n("means3D"), n("opacities"), n("scales"), n("rotations"), colors_precomp=colors, **kw)
 
 
-def test_render_dict_and_backward_through_regularisers(monkeypatch):
+@pytest.mark.parametrize("posed", [False, True])
+def test_render_dict_and_backward_through_regularisers(monkeypatch, posed):
     from tests.gpu_util import assert_close_frac, assert_free_parity, free_f64_reference
     import streetunveiler_amd.gaussian_renderer as gr
     P, W, H = 6000, 208, 120
-    cam = synthetic_camera(W, H, index=2)
-    g, sem, pc, t = _model(P, W, H, 21, DEV, requires_grad=True)
+    cam, gp = synthetic_camera(W, H, index=2), None
+    if posed:   # a camera in general position (own centre, full rotation, FoVx != FoVy): the maps' back-projection uses all of it
+        from streetunveiler_amd.synthetic import posed_scene
+        cam, gp = posed_scene(P, W, H, seed=21, scale_lo=3e-3, scale_hi=5e-2, spread=12.0)
+    g, sem, pc, t = _model(P, W, H, 21, DEV, requires_grad=True, gaussians=gp)
     bg = torch.tensor([0.2, 0.3, 0.1])
     pipe = PipelineParams(depth_ratio=0.0)
     seen = {}
