@@ -104,7 +104,7 @@ def test_forward_backward_vs_oracle(P, W, H, deg, lo, hi, cam_index):
     _full_check(cam, g, deg, np.array([0.3, 0.1, 0.7], np.float32), synthetic_upstream_grads(W, H, seed=P), f"P{P}")
 
 
-def _full_check(cam, g, deg, bg, upstream, tag):
+def _full_check(cam, g, deg, bg, upstream, tag, **budgets):
     """Every stage against the float32 oracle, then the free-running float64 reference."""
     from tests.gpu_util import run_hip, run_hip_raw, run_oracle
     P = g["means3D"].shape[0]
@@ -128,7 +128,7 @@ def _full_check(cam, g, deg, bg, upstream, tag):
     # robust pixel, strict rows on every robust Gaussian, the non-robust remainder counted (tests/gpu_util.py)
     from tests.gpu_util import assert_free_parity, free_f64_reference
     xfwd, xbwd, margins = free_f64_reference(g, cam, bg, deg, dc, da, base=fwd, kernel_decisions=raw["decisions"])
-    assert_free_parity(out, nc, xfwd, xbwd, margins, tag=tag + " ", scene=(g, cam))
+    assert_free_parity(out, nc, xfwd, xbwd, margins, tag=tag + " ", scene=(g, cam), **budgets)
 
 
 @pytest.mark.parametrize("seed,P,W,H,deg,lo,hi,spread", [
@@ -146,6 +146,31 @@ def test_general_camera_poses_vs_oracle(seed, P, W, H, deg, lo, hi, spread):
     if seed == 2:   # quaternions "as given" (Appendix A.2): not unit length -- the operator does not normalise them, the model's getter does
         g["rotations"] = (g["rotations"] * (torch.rand(P, 1, generator=torch.Generator().manual_seed(seed)) + 0.6)).contiguous()
     _full_check(cam, g, deg, np.array([0.2, 0.4, 0.1], np.float32), synthetic_upstream_grads(W, H, seed=seed), f"pose{seed}")
+
+
+def test_cloned_gaussians_and_depth_ties():
+    """Densification clones Gaussians in place [REF scene/gaussian_model.py densify_and_clone]: identical means, hence identical depth keys,
+    in every tile they touch -- the list order among them is the stable sort's (ascending index), and the blend is order-dependent.  Here
+    every position is shared by 8 Gaussians with their own scales / rotations / colours, and a third of the scene sits on four depth
+    planes (thousands of equal keys per tile): lists bit-exact against the oracle's 64-bit stable sort, images and gradients as usual."""
+    P, W, H = 24000, 320, 200
+    cam, g = _scene(P, W, H, 77, 3e-3, 4e-2, 4)
+    base = g["means3D"][: P // 8].clone()
+    g["means3D"] = base.repeat(8, 1).contiguous()                       # Gaussian i and i + k P/8 share a position
+    third = P // 3
+    planes = torch.tensor([2.0, 5.0, 11.0, 23.0])[torch.arange(third) % 4]
+    world_z_axis = cam.world_view_transform[:3, 2]                      # view depth = p . column 2 (camera at the origin)
+    p = g["means3D"][:third]
+    depth = p @ world_z_axis
+    g["means3D"][:third] = p * (planes / depth)[:, None]                 # along the ray: same pixel, new depth ...
+    g["scales"][:third] = g["scales"][:third] * (planes / depth)[:, None]   # ... and the same footprint
+    from tests.gpu_util import run_oracle
+    fwd, _ = run_oracle(g, cam, np.zeros(3, np.float32), 3)
+    keys = fwd["depths"][fwd["radii"] > 0].view(np.uint32)
+    assert np.unique(keys).size < 0.5 * keys.size, "the scene was meant to be full of equal depth keys"
+    # (eight co-located Gaussians per position make every pixel's list eight times as dense in near-threshold decisions: 2.8 % of the
+    # pixels are non-robust here against ~1 % on the plain small scenes -- a classification, not an error; the robust ones hold the usual bars)
+    _full_check(cam, g, 3, np.array([0.1, 0.5, 0.2], np.float32), synthetic_upstream_grads(W, H, seed=77), "ties", pixel_budget=5e-2, gaussian_budget=0.6)
 
 
 def test_colors_precomp_and_transmat_precomp():
