@@ -48,7 +48,7 @@ def synthetic_gaussians(P: int, width: int, height: int, seed: int = 0, sh_coeff
 
 
 def posed_scene(P: int, width: int, height: int, seed: int = 0, scale_lo: float = 5e-4, scale_hi: float = 5e-3, spread: float = 10.0,
-                sh_coeffs: int = 16, near_third: bool = False):
+                sh_coeffs: int = 16, near_third: bool = False, behind_fraction: float = 0.0):
     """The benchmark scene seen by a camera in GENERAL position: a random rotation (any yaw / pitch / roll), a centre drawn from
     U(-spread, spread)^3, fx in [0.55, 1.4] W and fy = fx * U(0.8, 1.25) (so FoVx and FoVy are unrelated), the Gaussians drawn in that
     camera's frame exactly as `synthetic_gaussians` draws them and moved to world coordinates (float64, then rounded).  The benchmark
@@ -71,6 +71,9 @@ def posed_scene(P: int, width: int, height: int, seed: int = 0, scale_lo: float 
     yc = (torch.rand(P, generator=g) * 2.2 - 1.1) * zc * ty
     if near_third:   # a third of the Gaussians around / behind the near plane (view depth -0.1 .. 0.4)
         zc = zc.clone(); zc[: P // 3] = torch.rand(P // 3, generator=g) * 0.5 - 0.1
+    if behind_fraction > 0:   # the camera INSIDE the cloud, as on a street: the last `behind_fraction` of the Gaussians mirrored behind it
+        nb = int(P * behind_fraction)
+        if nb: zc = zc.clone(); zc[P - nb:] = -zc[P - nb:]
     local = torch.stack([xc, yc, zc], dim=1).double()
     means3D = (local @ torch.tensor(R).t() + torch.tensor(c)).float().contiguous()
     lo, hi = math.log(scale_lo), math.log(scale_hi)

@@ -208,7 +208,9 @@ def gradient_row_errors(hip, bwd64, vis, scene=None):
         if mags is not None and key in mags:
             P = ref.shape[0]
             r = np.asarray(ref, np.float64).reshape(P, -1); a = np.asarray(hip[key], np.float64).reshape(P, -1)
-            out[key] = (np.abs(a - r).max(1) / (np.maximum(mags[key], np.abs(r).max(1)) + 1e-3 * np.abs(r).max()))[vis]
+            num, den = np.abs(a - r).max(1), np.maximum(mags[key], np.abs(r).max(1)) + 1e-3 * np.abs(r).max()
+            # (a frame whose visible Gaussians reach no pixel has all-zero gradients on both sides: 0 / 0 is "no error", anything / 0 is inf)
+            out[key] = np.divide(num, den, out=np.where(num == 0, 0.0, np.inf), where=den > 0)[vis]
         else:
             out[key] = row_errors(hip[key], ref, vis)
     return out

@@ -226,6 +226,15 @@ def test_mark_visible_and_debug_mode():
     vis = GaussianRasterizer(settings_for(cam, [0, 0, 0], 0)).markVisible(g["means3D"].to(DEV))
     assert vis.dtype == torch.bool
     np.testing.assert_array_equal(vis.cpu().numpy(), so.mark_visible(g["means3D"].numpy(), cam.world_view_transform.numpy()))
+    # ... through a camera with its own centre and a full rotation, standing inside the cloud (60 % of the Gaussians behind it); and the
+    # independent statement of the rule: view depth > 0.2 with the depth computed in float64
+    from streetunveiler_amd.synthetic import posed_scene
+    camp, gp = posed_scene(5000, W, H, seed=9, spread=30.0, behind_fraction=0.6)
+    visp = GaussianRasterizer(settings_for(camp, [0, 0, 0], 0)).markVisible(gp["means3D"].to(DEV)).cpu().numpy()
+    np.testing.assert_array_equal(visp, so.mark_visible(gp["means3D"].numpy(), camp.world_view_transform.numpy()))
+    z64 = gp["means3D"].double().numpy() @ camp.world_view_transform.double().numpy()[:3, 2] + camp.world_view_transform.double().numpy()[3, 2]
+    sure = np.abs(z64 - 0.2) > 1e-4
+    assert 0.3 < visp.mean() < 0.5 and np.array_equal(visp[sure], (z64 > 0.2)[sure])
     # debug=True: sync-and-check after every kernel, same numbers
     a = run_hip(g, cam, [0, 0, 0], 2, debug=False)
     b = run_hip(g, cam, [0, 0, 0], 2, debug=True)

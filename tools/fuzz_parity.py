@@ -14,6 +14,7 @@ from tests.test_gpu_parity import _check_binning
 
 big = int(os.environ.get("FUZZ_BIG", "1"))   # FUZZ_BIG=4: images up to 4x wider/higher, 16x the Gaussians
 shapes = [(16, 16)] * 4 + [(8, 8), (16, 8), (32, 8), (32, 16)]
+SURROUND_FROM = 200_000  # ... and from here up the camera is INSIDE the cloud: 30-80 % of the Gaussians behind it
 POSED_FROM = 100_000    # seeds from here up draw a camera in general position (the scenes of the seeds below stay what they were)
 
 
@@ -29,7 +30,8 @@ def make_scene(seed):
     posed = seed >= POSED_FROM
     if posed:   # a camera in general position (any rotation, centre 0.5 .. 200 units out, FoVx unrelated to FoVy) instead of the origin / yaw-only ones
         from streetunveiler_amd.synthetic import posed_scene
-        cam, g = posed_scene(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi, spread=float(10 ** rng.uniform(-0.3, 2.3)), near_third=regime == 3)
+        cam, g = posed_scene(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi, spread=float(10 ** rng.uniform(-0.3, 2.3)), near_third=regime == 3,
+                             behind_fraction=float(rng.uniform(0.3, 0.8)) if seed >= SURROUND_FROM else 0.0)
     else:
         g = synthetic_gaussians(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi)
     if regime == 1: g["opacities"] = g["opacities"] * 0.05                       # translucent: deep lists
@@ -38,7 +40,7 @@ def make_scene(seed):
     bg = rng.random(3).astype(np.float32)
     dc, da = synthetic_upstream_grads(W, H, seed=seed)
     colors = rng.random((P, 3)).astype(np.float32) if rng.random() < 0.25 else None
-    tag = f"(seed {seed}): P={P} {W}x{H} deg={deg} tile={tile} regime={regime}{' posed' if posed else ''} scales[{lo:.1e},{hi:.1e}] colors={'pre' if colors is not None else 'sh'}"
+    tag = f"(seed {seed}): P={P} {W}x{H} deg={deg} tile={tile} regime={regime}{' posed' if posed else ''}{' surrounded' if seed >= SURROUND_FROM else ''} scales[{lo:.1e},{hi:.1e}] colors={'pre' if colors is not None else 'sh'}"
     return dict(g=g, cam=cam, bg=bg, deg=deg, dc=dc, da=da, colors=colors, tile=tile, regime=regime, P=P, tag=tag)
 
 
