@@ -25,11 +25,13 @@ size_t tile_scan_temp_bytes(int P);
 size_t expand_x_hist_bytes(int P, int tiles_x);
 size_t expand_y_hist_bytes(uint32_t D, int tiles_y);
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, uint32_t* sorted_keys,
-                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, int rank_mode, int tiles_x, int tiles_y, hipStream_t s);
+                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, int rank_mode, int tiles_x, int tiles_y,
+                          const uint32_t* n_visible, hipStream_t s);
 hipError_t run_tile_count_scan(int P, const uint32_t* tiles_touched, uint32_t* first, void* block_base, size_t base_bytes, uint32_t* total_host,
                                hipStream_t s);
 hipError_t run_expand_columns(int P, int tiles_x, int n_tiles, const uint2* rect_sorted, const uint32_t* sorted_gid, uint2* columns,
-                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, int rank_mode, hipStream_t s);
+                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, int rank_mode, const uint32_t* n_visible,
+                              hipStream_t s);
 hipError_t run_expand_rows(uint32_t D, int tiles_x, int tiles_y, const uint2* columns, const uint32_t* n_columns, uint32_t* hist, uint32_t* row_total,
                            uint32_t* point_list, uint32_t* tile_counts, int rank_mode, hipStream_t s);
 hipError_t run_tile_ranges_order(int n_tiles, const uint32_t* tile_counts, uint2* ranges, uint32_t* order, hipStream_t s);
@@ -56,7 +58,7 @@ hipError_t launch_color_gradients(int P, const FrameDev& f, const int32_t* radii
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode,
-                            int rect_bx = 0, int rect_by = 0);
+                            int rect_bx = 0, int rect_by = 0, const uint32_t* n_live = nullptr);
 hipError_t launch_rank_selfcheck(uint32_t* result, hipStream_t s);
 hipError_t lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t n, int bins, hipStream_t s);
 // knn.hip
@@ -417,7 +419,7 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
         StageTimer t(SR_STAGE_DEPTH_SORT, s);
         SR_HIP(run_depth_sort(P, at<uint32_t>(geom, L.depth_keys), at<uint2>(geom, L.rect), at<uint32_t>(geom, L.sorted_keys),
                               at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, sort_mode,
-                              f.tiles_x, f.tiles_y, s));
+                              f.tiles_x, f.tiles_y, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks + 1, s));   // (+1: the scan's visible count)
     }
     if (int rc = debug_sync(frame, s, "depth_sort")) return rc;
     if (copied && pinned) SR_HIP(hipEventSynchronize(copied));
@@ -448,7 +450,7 @@ int bin_duplicates(const SrFrame* frame, const SrGaussians* g, const FrameDev& f
             StageTimer t(SR_STAGE_EXPAND_X, s);
             SR_HIP(run_expand_columns(P, f.tiles_x, n_tiles, at<uint2>(geom, L.rect_sorted), at<uint32_t>(geom, L.sorted_gid), at<uint2>(binning, B.columns),
                                       at<uint32_t>(binning, B.n_columns), at<uint32_t>(geom, L.temp), at<uint32_t>(binning, B.row_total),
-                                      at<uint32_t>(binning, B.tile_counts), sort_mode, s));
+                                      at<uint32_t>(binning, B.tile_counts), sort_mode, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks + 1, s));
         }
         if (int rc = debug_sync(frame, s, "expand_columns")) return rc;
         {

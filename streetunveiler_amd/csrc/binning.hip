@@ -20,7 +20,7 @@ namespace sr {
 size_t radix_sort_temp_bytes(uint32_t n);
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode,
-                            int rect_bx = 0, int rect_by = 0);
+                            int rect_bx = 0, int rect_by = 0, const uint32_t* n_live = nullptr);
 size_t tile_count_scan_temp_bytes(uint32_t n);
 hipError_t tile_count_scan(const uint32_t* counts, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes, uint32_t* total_host, hipStream_t s);
 
@@ -427,15 +427,18 @@ size_t expand_x_hist_bytes(int P, int tiles_x) { return (size_t)tiles_x * (((siz
 size_t expand_y_hist_bytes(uint32_t D, int tiles_y) { return (size_t)tiles_y * (((size_t)(D > 0 ? D : 1) + kXpInputsY - 1) / kXpInputsY) * 4; }
 
 // launchers ---------------------------------------------------------------------------------------
-// K2: stable sort of (depth key, gaussian id) -- ties keep ascending id, culled Gaussians (key 0xFFFFFFFF) end up last.
+// K2: stable sort of (depth key, gaussian id) -- ties keep ascending id, culled Gaussians (key 0xFFFFFFFF) are dropped.
+// `n_visible` (device word, the emission scan's count of Gaussians with a tile): the sort compacts -- only the first *n_visible entries of
+// the three outputs are written, the culled Gaussians are dropped by the first pass (radix_sort.hip).
 hipError_t run_depth_sort(int P, const uint32_t* depth_keys, const uint2* rect, uint32_t* sorted_keys,
-                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, int rank_mode, int tiles_x, int tiles_y, hipStream_t s) {
+                          uint32_t* sorted_gid, uint2* rect_sorted, void* temp, size_t temp_bytes, int rank_mode, int tiles_x, int tiles_y,
+                          const uint32_t* n_visible, hipStream_t s) {
     if (P == 0) return hipSuccess;
     // the sort also delivers the tile rectangles in depth order, so the scan and the partition read sequentially: packed into a word that
     // rides along with the Gaussian's id where its fields (0 .. tiles_x, 0 .. tiles_y) fit into 32 bits -- up to 255 x 255 tiles, or
     // e.g. 511 x 127 -- and gathered by the last pass for wider frames (radix_sort.hip)
     const int bx = 32 - __builtin_clz((unsigned)(tiles_x > 0 ? tiles_x : 1)), by = 32 - __builtin_clz((unsigned)(tiles_y > 0 ? tiles_y : 1));
-    return radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, rect, rect_sorted, rank_mode, bx, by);
+    return radix_sort_pairs(depth_keys, nullptr, sorted_keys, sorted_gid, (uint32_t)P, 32, temp, temp_bytes, s, rect, rect_sorted, rank_mode, bx, by, n_visible);
 }
 
 // K2: emission offsets = scan of tiles_touched in id order (block-local values in first, block bases + total D in block_base).
@@ -460,14 +463,16 @@ static void launch_expand_scatter(int rank_mode, int bins, int blocks, hipStream
 
 // K3: Gaussians in depth order -> column items ordered by (tile column, depth).  Also zeroes tile_counts.  n_columns (device word) receives the number of column items.
 hipError_t run_expand_columns(int P, int tiles_x, int n_tiles, const uint2* rect_sorted, const uint32_t* sorted_gid, uint2* columns,
-                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, int rank_mode, hipStream_t s) {
+                              uint32_t* n_columns, uint32_t* hist, uint32_t* row_total, uint32_t* tile_counts, int rank_mode, const uint32_t* n_visible,
+                              hipStream_t s) {
     if (P == 0) return hipSuccess;
     if (tiles_x > kXpMaxBins || (rank_mode != kRankAtomic && rank_mode != kRankBallot)) return hipErrorInvalidValue;
     const int nb = (P + kXpInputsX - 1) / kXpInputsX;
-    hipLaunchKernelGGL(expand_hist_kernel<0>, dim3(nb), dim3(kXpThreads), 0, s, rect_sorted, (uint32_t)P, (const uint32_t*)nullptr, tiles_x, hist, nb,
+    // (n_visible: the depth sort compacted -- only the first *n_visible sorted entries exist; the grid is sized for P, surplus blocks leave at once)
+    hipLaunchKernelGGL(expand_hist_kernel<0>, dim3(nb), dim3(kXpThreads), 0, s, rect_sorted, (uint32_t)P, n_visible, tiles_x, hist, nb,
                        tiles_x, tile_counts, n_tiles);
-    hipLaunchKernelGGL(expand_scan_rows_kernel, dim3(tiles_x), dim3(kXpThreads), 0, s, hist, nb, (uint32_t)P, (const uint32_t*)nullptr, kXpInputsX, row_total);
-    launch_expand_scatter<0>(rank_mode, tiles_x, nb, s, rect_sorted, (uint32_t)P, (const uint32_t*)nullptr, tiles_x, (const uint32_t*)hist, nb,
+    hipLaunchKernelGGL(expand_scan_rows_kernel, dim3(tiles_x), dim3(kXpThreads), 0, s, hist, nb, (uint32_t)P, n_visible, kXpInputsX, row_total);
+    launch_expand_scatter<0>(rank_mode, tiles_x, nb, s, rect_sorted, (uint32_t)P, n_visible, tiles_x, (const uint32_t*)hist, nb,
                              (const uint32_t*)row_total, sorted_gid, columns, n_columns, (uint32_t*)nullptr);
     return hipGetLastError();
 }

@@ -20,7 +20,7 @@ namespace sr {
 
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode,
-                            int rect_bx = 0, int rect_by = 0);
+                            int rect_bx = 0, int rect_by = 0, const uint32_t* n_live = nullptr);
 size_t radix_sort_temp_bytes(uint32_t n);
 
 constexpr int kWave = 64;

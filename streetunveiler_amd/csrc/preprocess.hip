@@ -133,13 +133,14 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const Row sh, float dx, float
 // the direction Jacobian) are accumulated across the two halves.  The colour keeps the exact operation order of sh_to_rgb(): the
 // cut falls between two terms of its left-to-right sum.
 constexpr int kShHalfFloats = 24, kShHalfStride = 28;   // 7 quads per row: an odd quad stride keeps per-thread ds_read_b128 conflict-free
-__device__ __forceinline__ void sh_half_load(const float* __restrict__ shs, int base, int P, int half, int tid, float4 (&r)[6]) {
+// `skip[row]` != 0: the row is not fetched (a Gaussian behind the near plane or masked out: its colour is never evaluated)
+__device__ __forceinline__ void sh_half_load(const float* __restrict__ shs, int base, int P, int half, int tid, const uint8_t* skip, float4 (&r)[6]) {
     const int nrows = min(kPreBlock, P - base);
     const float4* src = reinterpret_cast<const float4*>(shs + (size_t)base * kShRowFloats);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int f = tid + k * kPreBlock, row = f / 6, c4 = f - row * 6;
-        r[k] = row < nrows ? src[row * 12 + half * 6 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[k] = (row < nrows && !skip[row]) ? src[row * 12 + half * 6 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 __device__ __forceinline__ void sh_half_store(float* s_sh, int tid, const float4 (&r)[6]) {
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     // SH half rows (kShHalfStride floats per Gaussian) while the colour is evaluated, then the outgoing records + sh_jac rows (20 + 9)
     constexpr int kK1LdsFloats = kPreBlock * (kShHalfStride > kRecFloats + 9 ? kShHalfStride : kRecFloats + 9);
     __shared__ __attribute__((aligned(16))) float s_sh[kLdsSH ? kK1LdsFloats : 4];
+    __shared__ uint8_t s_skip[kLdsSH ? kPreBlock : 4];
     const int tid = threadIdx.x, base = blockIdx.x * kPreBlock;
     const int i = base + tid;
     // every per-Gaussian input is requested up front, in front of the SH staging and its barrier: one memory round trip instead of four
@@ -363,9 +365,15 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
     }
     float4 half_b[6];   // the second halves of the block's SH rows: in flight during the geometry
     if (kLdsSH) {
+        // The 192-B SH row is 5/6 of a Gaussian's input bytes, and a camera inside the scene has most Gaussians behind it: rows whose
+        // Gaussian fails the near-plane test (or the mask) are not fetched.  The test needs the centre alone, so the rows are requested
+        // one short dependent step after everything else.
+        const float* vw = f.view;
+        s_skip[tid] = !(i < P && kept && ((vw[2] * px + vw[6] * py) + vw[10] * pz) + vw[14] > kNear);
+        __syncthreads();
         float4 half_a[6];
-        sh_half_load(shs, base, P, 0, tid, half_a);
-        sh_half_load(shs, base, P, 1, tid, half_b);
+        sh_half_load(shs, base, P, 0, tid, s_skip, half_a);
+        sh_half_load(shs, base, P, 1, tid, s_skip, half_b);
         sh_half_store(s_sh, tid, half_a);
         __syncthreads();
     }

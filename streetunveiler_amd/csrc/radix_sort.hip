@@ -27,33 +27,43 @@ constexpr int kRsMaxBins = 256;
 // gather is the cheaper way: 500 k items 69 us gathered / 73 us riding; 3 M: 181 / 167; 6 M: 334 / 295)
 constexpr uint32_t kSortRideFrom = 1u << 20;
 
+// Compacting sorts (the depth sort: `n_dev` = the frame's visible count, emission scan): the FIRST pass reads all n_host items and drops
+// those whose key is kDropKey (culled Gaussians) -- they are neither counted nor written -- and every later pass works on the *n_dev
+// survivors only: its blocks beyond them leave at once and the row scan stops where they stop.  A frame seen from inside the cloud (a
+// street: 50-80 % of the Gaussians behind the camera) sorts a fraction of P, and the one digit all culled keys share is gone.
+constexpr uint32_t kDropKey = kCulledKey;   // common.h: K1's depth key of a Gaussian without a tile
 template <int kSortItems>
-__global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, int bits,
-                                                             uint32_t* __restrict__ hist, int nblocks) {
+__global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n_host, const uint32_t* __restrict__ n_dev, int drop,
+                                                             int shift, int bits, uint32_t* __restrict__ hist, int nblocks) {
     constexpr int kSortTile = kRsThreads * kSortItems;
     __shared__ uint32_t s_h[kRsThreads / 64][kRsMaxBins];   // one histogram per wave: a quarter of the LDS-atomic collisions (-3 us per sort)
     const int tid = threadIdx.x, bins = 1 << bits, w = tid >> 6;
     const uint32_t mask = (uint32_t)bins - 1u;
-    for (int k = tid; k < (kRsThreads / 64) * kRsMaxBins; k += kRsThreads) (&s_h[0][0])[k] = 0;
+    const uint32_t n = n_dev ? min(*n_dev, n_host) : n_host;
     const uint32_t base = blockIdx.x * (uint32_t)kSortTile;
+    if (base >= n) return;   // (the row scan does not read this block's column)
+    for (int k = tid; k < (kRsThreads / 64) * kRsMaxBins; k += kRsThreads) (&s_h[0][0])[k] = 0;
     uint32_t key[kSortItems];
 #pragma unroll
-    for (int i = 0; i < kSortItems; ++i) { const uint32_t idx = base + (uint32_t)(i * kRsThreads + tid); key[i] = idx < n ? keys[idx] : 0u; }
+    for (int i = 0; i < kSortItems; ++i) { const uint32_t idx = base + (uint32_t)(i * kRsThreads + tid); key[i] = idx < n ? keys[idx] : kDropKey; }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
         const uint32_t idx = base + (uint32_t)(i * kRsThreads + tid);
-        if (idx < n) atomicAdd(&s_h[w][(key[i] >> shift) & mask], 1u);
+        if (idx < n && !(drop && key[i] == kDropKey)) atomicAdd(&s_h[w][(key[i] >> shift) & mask], 1u);
     }
     __syncthreads();
     if (tid < bins) hist[(size_t)tid * nblocks + blockIdx.x] = (s_h[0][tid] + s_h[1][tid]) + (s_h[2][tid] + s_h[3][tid]);
 }
 
 // Exclusive scan of every row (one block per digit), row totals out.
-__global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __restrict__ hist, int nblocks, uint32_t* __restrict__ row_total) {
+__global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __restrict__ hist, int stride, const uint32_t* __restrict__ n_dev, uint32_t n_host,
+                                                                  int items_per_block, uint32_t* __restrict__ row_total) {
     __shared__ uint32_t s_w[kRsThreads / 64];
     __shared__ uint32_t s_carry;
-    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    const uint32_t n = n_dev ? min(*n_dev, n_host) : n_host;
+    const int nblocks = (int)((n + (uint32_t)items_per_block - 1) / (uint32_t)items_per_block);   // (<= stride: the blocks that hold items)
+    uint32_t* row = hist + (size_t)blockIdx.x * stride;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
@@ -91,7 +101,8 @@ __device__ __forceinline__ uint2 unpack_rect(uint32_t w, int bx, int by) {
 template <int kBits, bool kAtomicRank, int kSortItems, bool kWide>   // digit width (compile time; 0 = run-time width <= 8), ranking (common.h take_run_slot), items per thread
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                uint32_t n, int shift, int bits_rt, const uint32_t* __restrict__ hist,
+                                                                uint32_t n_host, const uint32_t* __restrict__ n_dev, int drop, int shift, int bits_rt,
+                                                                const uint32_t* __restrict__ hist,
                                                                 const uint32_t* __restrict__ row_total, int nblocks,
                                                                 const uint2* __restrict__ aux_src, uint2* __restrict__ aux_out,
                                                                 const uint32_t* __restrict__ ride_in, uint32_t* __restrict__ ride_out, int bx, int by) {
@@ -100,26 +111,30 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     __shared__ uint32_t s_lstart[kRsMaxBins];                  // block-local start of digit b
     __shared__ uint32_t s_gbase[kRsMaxBins];                   // global position of the block's first item of digit b
     __shared__ uint32_t s_wsum[kRsThreads / 64];
+    __shared__ uint32_t s_live;
+    static_assert(kRsThreads / 64 == 4, "s_live sums four wave totals");
     __shared__ uint32_t s_key[kSortTile], s_val[kSortTile];        // the tile, stably reordered by digit
     const int bits = kBits ? kBits : bits_rt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, bins = 1 << bits;
     const uint32_t mask = (uint32_t)bins - 1u;
+    const uint32_t n = n_dev ? min(*n_dev, n_host) : n_host;
+    const uint32_t tile_base = blockIdx.x * (uint32_t)kSortTile;
+    if (tile_base >= n) return;
     for (int b = tid; b < (kRsThreads / 64) * kRsMaxBins; b += kRsThreads) (&s_run[0][0])[b] = 0;
     __syncthreads();
     // wave w owns items [wbase, wbase + 512), 64 at a time in order -> stable
-    const uint32_t tile_base = blockIdx.x * (uint32_t)kSortTile;
     const uint32_t wbase = tile_base + (uint32_t)w * (64 * kSortItems);
     uint32_t key[kSortItems], val[kSortItems], ride[kWide ? kSortItems : 1], slot[kWide ? kSortItems : 1];
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
         const uint32_t idx = wbase + (uint32_t)(i * 64 + lane);
-        key[i] = 0; val[i] = 0;
+        key[i] = kDropKey; val[i] = 0;
         if constexpr (kWide) ride[i] = 0;
         if (idx < n) {
             key[i] = keys_in[idx];
             val[i] = vals_in ? vals_in[idx] : idx;   // first pass of an index sort: the value is the position itself
             if constexpr (kWide) ride[i] = ride_in ? ride_in[idx] : pack_rect(aux_src[idx], bx, by);
-            atomicAdd(&s_run[w][(key[i] >> shift) & mask], 1u);
+            if (!(drop && key[i] == kDropKey)) atomicAdd(&s_run[w][(key[i] >> shift) & mask], 1u);
         }
     }
     __syncthreads();
@@ -135,6 +150,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         __syncthreads();
         uint32_t off = incl - tot;
         for (int k = 0; k < w; ++k) off += s_wsum[k];
+        if (tid == 0) s_live = (s_wsum[0] + s_wsum[1]) + (s_wsum[2] + s_wsum[3]);   // the tile's items that take part (all of them unless `drop`)
         // first output position of every digit = exclusive scan of the row totals (<= 256 values, L2-hot: cheaper here, in every
         // block, than as a kernel of its own between the row scan and this one)
         const uint32_t rt = tid < bins ? row_total[tid] : 0u;
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
         const uint32_t idx = wbase + (uint32_t)(i * 64 + lane);
-        const bool live = idx < n;
+        const bool live = idx < n && !(drop && key[i] == kDropKey);
         const uint32_t d = (key[i] >> shift) & mask;
         // rank among the wave's items of the same digit, in item order, and the advance of the (wave, digit) run (common.h)
         const uint32_t pos = take_run_slot<kAtomicRank>(s_run[w], d, live, bits);
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     }
     __syncthreads();
     // coalesced write-out: consecutive local slots of one digit are consecutive in global memory
-    const uint32_t count = min((uint32_t)kSortTile, n - tile_base);
+    const uint32_t count = s_live;   // (= min(kSortTile, n - tile_base) unless items were dropped)
     uint32_t dest[kWide ? kSortItems : 1];
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < kSortItems; ++i)
-            if (wbase + (uint32_t)(i * 64 + lane) < n) s_val[slot[i]] = ride[i];
+            if (wbase + (uint32_t)(i * 64 + lane) < n && !(drop && key[i] == kDropKey)) s_val[slot[i]] = ride[i];
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < kSortItems; ++i) {
@@ -355,9 +371,11 @@ size_t radix_sort_temp_bytes(uint32_t n) {
 // vals_in == nullptr means "value = index".  keys_in / vals_in are not modified.  If aux_out != nullptr the sort also delivers
 // aux_out[i] = aux_src[vals_out[i]] (an 8-B payload in sorted order): packed into a word that rides along with the value when it is
 // a tile rectangle whose fields fit (value = index, fields < 2^rect_bx / 2^rect_by, 2 (bx + by) <= 32), gathered by the last pass otherwise.
+// `n_live` != nullptr (device word): a COMPACTING sort -- items whose key is 0xFFFFFFFF are dropped by the first pass, *n_live must be the
+// number of the others, and only keys_out / vals_out / aux_out[0 .. *n_live) are written.
 hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode,
-                            int rect_bx, int rect_by) {
+                            int rect_bx, int rect_by, const uint32_t* n_live) {
     if (n == 0) return hipSuccess;
     if (temp_bytes < radix_sort_temp_bytes(n) || (rank_mode != kRankAtomic && rank_mode != kRankBallot)) return hipErrorInvalidValue;
     int passes = (total_bits + 7) / 8;
@@ -386,10 +404,12 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         uint32_t* ro = last ? nullptr : ((p & 1) ? reinterpret_cast<uint32_t*>(aux_out) : tr);
         const bool big = bits == 8 && n >= kSortBigFrom;
         const int nb = big ? rs_blocks(n, kSortItemsBig) : nb8;
-        if (big) hipLaunchKernelGGL(rs_hist_kernel<kSortItemsBig>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
-        else hipLaunchKernelGGL(rs_hist_kernel<kRsItems>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, shift, bits, hist, nb);
-        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, row_total);
-#define SR_SCATTER_W(B, A, I, Wd) hipLaunchKernelGGL((rs_scatter_kernel<B, A, I, Wd>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, shift, bits, hist, \
+        const uint32_t* nd = (n_live && p > 0) ? n_live : nullptr;   // the first pass reads everything and drops; the later ones see the survivors
+        const int drop = (n_live && p == 0) ? 1 : 0;
+        if (big) hipLaunchKernelGGL(rs_hist_kernel<kSortItemsBig>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, nd, drop, shift, bits, hist, nb);
+        else hipLaunchKernelGGL(rs_hist_kernel<kRsItems>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, nd, drop, shift, bits, hist, nb);
+        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, nd, n, kRsThreads * (big ? kSortItemsBig : kRsItems), row_total);
+#define SR_SCATTER_W(B, A, I, Wd) hipLaunchKernelGGL((rs_scatter_kernel<B, A, I, Wd>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, nd, drop, shift, bits, hist, \
                                                  row_total, nb, (Wd ? p == 0 : last) ? aux_src : nullptr, last ? aux_out : nullptr, ri, ro, rect_bx, rect_by)
 #define SR_SCATTER_R(B, A, I) do { if (wide) SR_SCATTER_W(B, A, I, true); else SR_SCATTER_W(B, A, I, false); } while (0)
 #define SR_SCATTER(B, I) do { if (rank_mode == kRankAtomic) SR_SCATTER_R(B, true, I); else SR_SCATTER_R(B, false, I); } while (0)

@@ -385,7 +385,10 @@ def test_rank_self_check_and_forced_ballot_fallback():
             assert D == fwd["num_rendered"]
             np.testing.assert_array_equal(pl.view(np.uint32), fwd["point_list"])
             np.testing.assert_array_equal(ranges.view(np.uint32), fwd["ranges"])
-        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+        V = int((fwd["radii"] > 0).sum())   # (the depth sort compacts: only the first V entries of its outputs are written)
+        np.testing.assert_array_equal(outs[0][1][:V], outs[1][1][:V])
+        order = np.argsort(fwd["depths"].view(np.uint32)[fwd["radii"] > 0], kind="stable")
+        np.testing.assert_array_equal(outs[0][1][:V], np.flatnonzero(fwd["radii"] > 0)[order].astype(outs[0][1].dtype))
         np.testing.assert_array_equal(outs[0][4], outs[1][4])
 
 
