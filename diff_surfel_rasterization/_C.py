@@ -394,6 +394,8 @@ def _view(buf: torch.Tensor, ptr, nbytes: int, dtype: torch.dtype) -> torch.Tens
 
 
 def geom_view(geom: torch.Tensor, P: int):
+    """Typed views into the geometry state (tests / tools).  `sorted_gid`: only its first frame_counts[1] entries -- the visible Gaussians in
+    depth order -- are written (the depth sort drops the culled ones)."""
     v = L.SrGeomView()
     L.check(L.load().sr_geom_view(_ptr(geom), geom.numel(), P, C.byref(v)), "sr_geom_view")
     return dict(splats=_view(geom, v.splats, P * 80, torch.float32).view(P, 20),

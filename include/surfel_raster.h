@@ -162,7 +162,7 @@ typedef struct SrGeomView {
     const uint32_t* depth_keys;    /* [P] float bits of view-space depth; 0xFFFFFFFF when culled */
     const uint32_t* tiles_touched; /* [P] */
     const uint8_t* clamped;        /* [P] bit c set when SH colour channel c was clamped at 0 */
-    const uint32_t* sorted_gid;    /* [P] Gaussian ids in ascending (depth bits, id) order; culled last */
+    const uint32_t* sorted_gid;    /* the frame_counts[1] visible Gaussians' ids in ascending (depth bits, id) order (room for P; culled ones are dropped) */
     const uint32_t* frame_counts;  /* [2] D (= *num_rendered_host of sr_forward_plan) and the number of Gaussians with at least one tile: what
                                     * the forward blend picks its mapping by (SR_FLAG_ROW_MAPPED_FORWARD) */
 } SrGeomView;

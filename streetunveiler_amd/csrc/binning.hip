@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kXpThreads) void expand_scatter_kernel(
         for (int i = 0; i < kXpPerThread; ++i)
             if (it_first[i] - q0 < (uint32_t)kXpBatch) s_start[it_first[i] - q0] = 1;   // (an empty item's 0xFFFFFFFF never lands in a batch)
         __syncthreads();   // (also orders s_prefix / s_goff writes and the previous batch's write-out)
-        // slot -> item.  Empty items only ever follow the non-empty ones (culled Gaussians sort last; a column item has >= 1 row), so
+        // slot -> item.  There are no empty items (the depth sort drops the culled Gaussians; a column item has >= 1 row) -- and trailing ones would do no harm --, so
         // the item of a slot is the number of marks up to it, minus one: one binary search per wave and batch for the wave's first
         // slot, then a ballot of the marks and a popcount per row of 64 slots.
         const uint32_t s0 = q0 + (uint32_t)(w * (kXpBatch / kXpWaves));

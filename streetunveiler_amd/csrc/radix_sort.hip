@@ -1,9 +1,9 @@
 // radix_sort.hip -- hand-written stable LSD radix sort of (u32 key, u32 value) pairs for gfx950 (wave64).
 //
-// Used twice per frame: (1) order the P Gaussians by their 32-bit depth key (4 passes x 8 bits; the value of
-// the first pass is the implicit index), (2) stable-partition the D duplicates by tile id
-// (ceil(log2 tiles) bits in 2 passes).  Stability is what makes the final list equal to the reference's
-// 64-bit (tile | depth) sort (binning.hip).
+// Used once per frame: order the visible Gaussians by their 32-bit depth key (4 passes x 8 bits; the value of the first pass is the
+// implicit index, the culled Gaussians are dropped by it: `n_live` below), and by the kNN grid for its Morton codes (knn.hip).
+// Stability is what makes the final list equal to the reference's 64-bit (tile | depth) sort: the tile partition that follows
+// (binning.hip) keeps the depth order it is handed.
 //
 // One pass = histogram -> one row scan (a block per digit) -> scatter (every scatter block turns the <= 256 row totals into digit
 // bases itself: no third tiny kernel in the dependency chain).  A 256-thread block owns 2048 consecutive items; each
