@@ -839,6 +839,11 @@ def test_randomised_scenes_short_sweep():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], cwd=root, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, FUZZ_SEEDS="100525,100551"))
     assert r.returncode == 0 and "2/2 scenes within the parity bars" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    # needle-shaped surfels (seeds >= 400000: half of the Gaussians with an axis ratio of 10 .. 316; the kernels' staged cross products hold
+    # the bars up to there -- 250 / 250 -- and start to lose them around 1000 : 1, tools/notes_round5_measured.md)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "10", "400000"], cwd=root, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, FUZZ_NEEDLE_MAX_LOG10="2.5"))
+    assert r.returncode == 0 and "10/10 scenes within the parity bars" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_extensions_short_sweep():
