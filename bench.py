@@ -316,6 +316,38 @@ def train_step_roofline(args, stage_ms, D, V, n_classes):
 XGMI_LINK_GBS = 76.8    # one xGMI link, ONE direction: 7 links per GPU at ~153.6 GB/s bidirectional each (the figure SURVEY.md 8e quotes per link)
 
 
+def camera_inside_scene_section(P, W, H, deg, dc, da, dev, behind=0.8, steps=10):
+    """NOT the headline metric -- reported beside it: the same P Gaussians with the camera standing INSIDE the cloud (a posed camera with
+    `behind` of the Gaussians behind it: what a street scene looks like to the operator; the benchmark frame sees 86 % of its Gaussians).
+    One fwd+bwd step as in the timed region, after it, on its own scene (streetunveiler_amd.synthetic.posed_scene; tools/time_surrounded.py)."""
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from streetunveiler_amd.synthetic import posed_scene
+    cam, g = posed_scene(P, W, H, seed=7, spread=25.0, behind_fraction=behind)
+    s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3, device=dev), 1.0, cam.world_view_transform.to(dev),
+                                      cam.full_proj_transform.to(dev), deg, cam.camera_center.to(dev), False, False)
+    t = {k: v.to(dev).requires_grad_() for k, v in g.items()}
+    m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+
+    def step():
+        for v in list(t.values()) + [m2]:
+            v.grad = None
+        c, r, am = GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2, shs=t["shs"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+        torch.autograd.backward([c, am], [dc, da])
+        return r
+    for _ in range(3):
+        r = step()
+    V = int((r > 0).sum())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"what": f"{P} Gaussians, {W}x{H}, posed camera with {behind:.0%} of the Gaussians behind it (untimed extra, not the metric)",
+            "visible_frac": round(V / P, 3), "ms_per_step": round(ms, 4), "msplats_per_s": round(P / ms / 1e3, 1), "steps": steps}
+
+
 def rccl_topology(log_path, backend, world):
     """What the communicator says it built: channel count and ring / tree lines of RCCL's own INIT / GRAPH log (NCCL_DEBUG_FILE, this rank)."""
     import re
@@ -752,6 +784,11 @@ def main():
                 out["train_step"] = train_step_section(args, params, cam, dev, D, V)
             except Exception as e:   # an untimed extra must never cost the line
                 out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if world == 1 and not multi and not args.no_train_step and args.tag == "c3":
+            try:
+                out["camera_inside_scene"] = camera_inside_scene_section(P, W, H, deg, dc, da, dev)
+            except Exception as e:   # an untimed extra must never cost the line
+                out["camera_inside_scene"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g_cpu, cam, dc_cpu, da_cpu)
     # The JSON line is the LAST thing on stdout.  With NCCL_DEBUG set RCCL printf()s a version banner into libc's stdout buffer at init, which
