@@ -449,3 +449,39 @@ def test_bench_measurement_helpers(tmp_path, monkeypatch):
     t, src = bench.pmc_traffic("render_backward_kernel", args)
     assert t is None and "stale" in src and "re-run tools/profile_round.sh" in src["stale"]
     assert bench.pmc_traffic("render_backward_kernel", argparse.Namespace(tag="custom", sh_degree=3)) == (None, None)
+
+
+def test_posed_scene_and_rig_are_what_they_say():
+    """The general-position scenes the parity tests rely on (streetunveiler_amd.synthetic.posed_scene / posed_rig): the camera has its own
+    centre, a proper rotation and unrelated FoVs; the Gaussians sit in front of it in ITS frame with the benchmark scene's statistics;
+    `behind_fraction` / `near_third` put exactly those Gaussians behind it / around the near plane; a rig's cameras share the Gaussians,
+    not the centre."""
+    import math
+    from streetunveiler_amd.synthetic import posed_rig, posed_scene
+    P, W, H = 4000, 320, 200
+    cam, g = posed_scene(P, W, H, seed=11, spread=20.0)
+    V = cam.world_view_transform.double()                      # W2C^T
+    R = V[:3, :3]
+    assert torch.allclose(R @ R.t(), torch.eye(3, dtype=torch.float64), atol=1e-6) and abs(float(torch.det(R)) - 1.0) < 1e-6
+    assert float(cam.camera_center.abs().max()) > 1.0 and abs(cam.FoVx - cam.FoVy) > 1e-3
+    assert torch.allclose(torch.cat([cam.camera_center.double(), torch.ones(1, dtype=torch.float64)]) @ V, torch.tensor([0, 0, 0, 1.0], dtype=torch.float64), atol=1e-5)
+    local = torch.cat([g["means3D"].double(), torch.ones(P, 1, dtype=torch.float64)], 1) @ V
+    z = local[:, 2]
+    assert float(z.min()) > 0.99 and float(z.max()) < 50.01
+    tx, ty = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    assert float((local[:, 0].abs() / (z * tx)).max()) < 1.1001 and float((local[:, 1].abs() / (z * ty)).max()) < 1.1001
+    inside = ((local[:, 0].abs() < z * tx) & (local[:, 1].abs() < z * ty)).double().mean()
+    assert 0.78 < float(inside) < 0.88                         # ~17 % outside the frustum sides, as in the benchmark scene (SURVEY 8d)
+    _, gb = posed_scene(P, W, H, seed=11, spread=20.0, behind_fraction=0.75)
+    zb = (torch.cat([gb["means3D"].double(), torch.ones(P, 1, dtype=torch.float64)], 1) @ V)[:, 2]
+    assert int((zb < 0).sum()) == 3000 and bool((zb[:1000] > 0).all())
+    _, gn = posed_scene(P, W, H, seed=11, spread=20.0, near_third=True)
+    zn = (torch.cat([gn["means3D"].double(), torch.ones(P, 1, dtype=torch.float64)], 1) @ V)[:, 2]
+    assert float(zn[: P // 3].min()) > -0.1001 and float(zn[: P // 3].max()) < 0.4001 and float(zn[P // 3:].min()) > 0.99
+    rig, gr = posed_rig(P, W, H, 4, seed=11, spread=20.0)
+    assert torch.equal(rig[0].world_view_transform, cam.world_view_transform) and torch.equal(gr["means3D"], g["means3D"])
+    centres = torch.stack([c.camera_center for c in rig])
+    assert float(torch.pdist(centres).min()) > 0.05 and float((centres - centres[0]).norm(dim=1).max()) < 2.0 * math.sqrt(3) + 1e-3
+    for c in rig[1:]:
+        zc = (torch.cat([gr["means3D"].double(), torch.ones(P, 1, dtype=torch.float64)], 1) @ c.world_view_transform.double())[:, 2]
+        assert float((zc > 0.2).double().mean()) > 0.98          # moved sideways / backwards, never into the scene
