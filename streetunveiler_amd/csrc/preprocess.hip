@@ -492,6 +492,10 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
         __syncthreads();
         float4* s_rec = reinterpret_cast<float4*>(s_sh);
         float* s_jac = s_sh + kPreBlock * kRecFloats;
+        // Rows of culled Gaussians are never read (the lists hold visible Gaussians only, K8 skips the others).  A 128-B line of the block's
+        // output whose rows are ALL culled is not written: seen from inside a scene most rows are such rows.  Whole lines only -- leaving
+        // single 16-B chunks out costs more in partial sectors than it saves (K1 0.209 -> 0.245 ms at C3).
+        s_skip[tid] = out_tiles == 0u;   // (reused: the SH rows are long in registers)
         s_rec[tid * kRecQuads + 0] = q0; s_rec[tid * kRecQuads + 1] = q1; s_rec[tid * kRecQuads + 2] = q2; s_rec[tid * kRecQuads + 3] = q3;
         s_rec[tid * kRecQuads + 4] = q4;
         if (want_jac) {
@@ -502,12 +506,20 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_forward_kernel(
         {
             const int nrows = min(kPreBlock, P - base);
             float4* dst = recs + (size_t)base * kRecQuads;
-            for (int fq = tid; fq < nrows * kRecQuads; fq += kPreBlock) dst[fq] = s_rec[fq];
+            for (int fq = tid; fq < nrows * kRecQuads; fq += kPreBlock) {
+                const int c0 = fq & ~7, r0 = c0 / kRecQuads, r1 = min((c0 + 7) / kRecQuads, nrows - 1);   // the rows of this chunk's 128-B line (2 or 3)
+                if (!(s_skip[r0] & s_skip[min(r0 + 1, r1)] & s_skip[r1])) dst[fq] = s_rec[fq];
+            }
             // 9 floats per row: rows * 9 floats are 16-B aligned per block of 128 rows (128 * 36 B) -- whole float4 chunks, plus a scalar tail
             if (want_jac) {
                 float* jd = f.sh_jac + (size_t)base * 9;
                 const int nf = nrows * 9, nq = nf / 4;
-                for (int fq = tid; fq < nq; fq += kPreBlock) reinterpret_cast<float4*>(jd)[fq] = reinterpret_cast<const float4*>(s_jac)[fq];
+                for (int fq = tid; fq < nq; fq += kPreBlock) {
+                    const int f0 = (fq & ~7) * 4, r0 = f0 / 9, r1 = min((f0 + 31) / 9, nrows - 1);       // the rows of this chunk's 128-B line (4 or 5)
+                    bool dead = true;
+                    for (int r = r0; r <= r1; ++r) dead = dead && s_skip[r];
+                    if (!dead) reinterpret_cast<float4*>(jd)[fq] = reinterpret_cast<const float4*>(s_jac)[fq];
+                }
                 for (int fk = nq * 4 + tid; fk < nf; fk += kPreBlock) jd[fk] = s_jac[fk];
             }
         }
