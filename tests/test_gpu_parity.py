@@ -883,6 +883,35 @@ def test_degenerate_parameters():
     _check_grads(out, bwd, names, "degenerate")
 
 
+def test_non_finite_parameters_do_not_spread():
+    """A diverging training run hands the operator NaN / Inf parameters.  A Gaussian whose centre, scales or rotation are not finite is culled
+    (radius 0, no gradient); one whose opacity or SH coefficients are not finite still renders (`min(0.99, NaN)` is 0.99 here as in the
+    reference's CUDA) and may carry non-finite gradients in ITS OWN rows -- in every case the images stay finite and no other Gaussian's
+    gradient row is touched."""
+    from tests.gpu_util import run_hip
+    P, W, H = 6000, 240, 136
+    cam, g = _scene(P, W, H, 3, 3e-3, 5e-2, 2)
+    dc, da = synthetic_upstream_grads(W, H, seed=3)
+    idx = torch.arange(0, P, 50)
+    healthy = np.ones(P, bool); healthy[idx.numpy()] = False
+    names = ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D")
+    for field, val in [("means3D", float("nan")), ("means3D", float("inf")), ("scales", float("nan")), ("scales", float("inf")), ("rotations", float("nan")),
+                       ("opacities", float("nan")), ("opacities", float("inf")), ("shs", float("nan"))]:
+        gg = {k: v.clone() for k, v in g.items()}
+        if field == "means3D": gg[field][idx, 2] = val
+        elif field == "shs": gg[field][idx, 0, 0] = val
+        else: gg[field][idx, 0] = val
+        out = run_hip(gg, cam, [0.1, 0.2, 0.3], 3, dc, da)
+        tag = f"{field} = {val}"
+        assert np.isfinite(out["color"]).all() and np.isfinite(out["allmap"]).all(), tag
+        bad = {k: ~np.isfinite(np.asarray(out[k]).reshape(P, -1)).all(1) for k in names}
+        assert not any(b[healthy].any() for b in bad.values()), f"{tag}: a healthy Gaussian has a non-finite gradient row"
+        if field in ("means3D", "scales", "rotations"):
+            assert not out["radii"][idx.numpy()].any() and not any(b.any() for b in bad.values()), f"{tag}: the poisoned Gaussians must be culled"
+            for k in names:
+                assert not np.asarray(out[k]).reshape(P, -1)[idx.numpy()].any(), f"{tag}: {k} of a culled Gaussian is not zero"
+
+
 def test_wide_frame_with_few_gaussians_and_counter_variant_errors():
     """(a) One Gaussian in a frame 750 tile columns wide: pass X's [columns][blocks] histogram lives in the geometry scratch, which is
     sized for the widest frame the binning accepts (it used to be sized by P alone: BUFFER_TOO_SMALL for P = 1 beyond 640 columns).
