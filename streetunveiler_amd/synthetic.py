@@ -48,7 +48,7 @@ def synthetic_gaussians(P: int, width: int, height: int, seed: int = 0, sh_coeff
 
 
 def posed_scene(P: int, width: int, height: int, seed: int = 0, scale_lo: float = 5e-4, scale_hi: float = 5e-3, spread: float = 10.0,
-                sh_coeffs: int = 16, near_third: bool = False, behind_fraction: float = 0.0):
+                sh_coeffs: int = 16, near_third: bool = False, behind_fraction: float = 0.0, focal_range=(0.55, 1.4)):
     """The benchmark scene seen by a camera in GENERAL position: a random rotation (any yaw / pitch / roll), a centre drawn from
     U(-spread, spread)^3, fx in [0.55, 1.4] W and fy = fx * U(0.8, 1.25) (so FoVx and FoVy are unrelated), the Gaussians drawn in that
     camera's frame exactly as `synthetic_gaussians` draws them and moved to world coordinates (float64, then rounded).  The benchmark
@@ -62,7 +62,7 @@ def posed_scene(P: int, width: int, height: int, seed: int = 0, scale_lo: float 
                   [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
                   [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]], dtype=np.float64)     # camera -> world
     c = ((torch.rand(3, generator=g, dtype=torch.float64) * 2 - 1) * spread).numpy()
-    fx = float(torch.rand(1, generator=g) * 0.85 + 0.55) * width
+    fx = float(torch.rand(1, generator=g) * (focal_range[1] - focal_range[0]) + focal_range[0]) * width   # (0.55 .. 1.4 W: FoVx 85 .. 39 degrees)
     fy = fx * float(torch.rand(1, generator=g) * 0.45 + 0.8)
     cam = make_camera(width, height, focal2fov(fx, width), focal2fov(fy, height), R=R, t=-R.T @ c)
     tx, ty = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)

@@ -14,6 +14,7 @@ from tests.test_gpu_parity import _check_binning
 
 big = int(os.environ.get("FUZZ_BIG", "1"))   # FUZZ_BIG=4: images up to 4x wider/higher, 16x the Gaussians
 shapes = [(16, 16)] * 4 + [(8, 8), (16, 8), (32, 8), (32, 16)]
+WIDE_FOV_FROM = 500_000  # ... and from here up fx is drawn from 0.15 .. 6 W (FoVx 147 .. 10 degrees) instead of 0.55 .. 1.4 W
 NEEDLES_FROM = 400_000   # ... and from here up half of the surfels are needles (axis ratio 10 .. 1000)
 SURROUND_FROM = 200_000  # ... and from here up the camera is INSIDE the cloud: 30-80 % of the Gaussians behind it
 POSED_FROM = 100_000    # seeds from here up draw a camera in general position (the scenes of the seeds below stay what they were)
@@ -32,10 +33,11 @@ def make_scene(seed):
     if posed:   # a camera in general position (any rotation, centre 0.5 .. 200 units out, FoVx unrelated to FoVy) instead of the origin / yaw-only ones
         from streetunveiler_amd.synthetic import posed_scene
         cam, g = posed_scene(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi, spread=float(10 ** rng.uniform(-0.3, 2.3)), near_third=regime == 3,
-                             behind_fraction=float(rng.uniform(0.3, 0.8)) if seed >= SURROUND_FROM else 0.0)
+                             behind_fraction=float(rng.uniform(0.3, 0.8)) if seed >= SURROUND_FROM else 0.0,
+                             focal_range=(0.15, 6.0) if seed >= WIDE_FOV_FROM else (0.55, 1.4))
     else:
         g = synthetic_gaussians(P, W, H, seed=seed, scale_lo=lo, scale_hi=hi)
-    if seed >= NEEDLES_FROM:   # what trained surfels look like: half of them 10 .. 1000 times thinner along one axis than along the other
+    if NEEDLES_FROM <= seed < WIDE_FOV_FROM:   # what trained surfels look like: half of them 10 .. 1000 times thinner along one axis than along the other
         # (FUZZ_NEEDLE_MAX_LOG10: the largest axis ratio, default 3 -- 1000 : 1; the ratio is set outright, whatever the two scales drawn above)
         ratio = torch.tensor(10.0 ** rng.uniform(1.0, float(os.environ.get("FUZZ_NEEDLE_MAX_LOG10", "3")), P), dtype=torch.float32)
         axis = torch.tensor(rng.integers(0, 2, P)); half = torch.tensor(rng.random(P) < 0.5)
@@ -47,7 +49,7 @@ def make_scene(seed):
     bg = rng.random(3).astype(np.float32)
     dc, da = synthetic_upstream_grads(W, H, seed=seed)
     colors = rng.random((P, 3)).astype(np.float32) if rng.random() < 0.25 else None
-    tag = f"(seed {seed}): P={P} {W}x{H} deg={deg} tile={tile} regime={regime}{' posed' if posed else ''}{' surrounded' if seed >= SURROUND_FROM else ''}{' needles' if seed >= NEEDLES_FROM else ''} scales[{lo:.1e},{hi:.1e}] colors={'pre' if colors is not None else 'sh'}"
+    tag = f"(seed {seed}): P={P} {W}x{H} deg={deg} tile={tile} regime={regime}{' posed' if posed else ''}{' surrounded' if seed >= SURROUND_FROM else ''}{' needles' if NEEDLES_FROM <= seed < WIDE_FOV_FROM else ''}{' wide-fov-range' if seed >= WIDE_FOV_FROM else ''} scales[{lo:.1e},{hi:.1e}] colors={'pre' if colors is not None else 'sh'}"
     return dict(g=g, cam=cam, bg=bg, deg=deg, dc=dc, da=da, colors=colors, tile=tile, regime=regime, P=P, tag=tag)
 
 
