@@ -28,6 +28,19 @@ for seed in [int(a) for a in sys.argv[1:]]:
             Tu, Tv, Tw = T[:, 0:3].astype(dt), T[:, 3:6].astype(dt), T[:, 6:9].astype(dt); px, py = dt(x), dt(y)
             if form == "oracle":
                 p = np.cross(px * Tw - Tu, py * Tw - Tv).astype(dt)
+            elif form in ("tile_fma", "tile_fma_kahan"):
+                # the tile origin with the shift done as ONE fused multiply-add (exact product, one rounding), and optionally Kahan's
+                # fma-compensated a b - c d for the cross products: float64 stands in for the fused operation, results rounded to float32
+                f32 = np.float32
+                ox = np.full(len(ids), (x // tw) * tw + tw // 2, np.float64); oy = np.full(len(ids), (y // th) * th + th // 2, np.float64)
+                Tw_ = Tw.astype(f32); Tu_ = (Tu.astype(np.float64) - ox[:, None] * Tw_.astype(np.float64)).astype(f32); Tv_ = (Tv.astype(np.float64) - oy[:, None] * Tw_.astype(np.float64)).astype(f32)
+                def cross(a, b):
+                    if form == "tile_fma": return np.cross(a.astype(f32), b.astype(f32)).astype(f32)
+                    a64, b64 = a.astype(np.float64), b.astype(np.float64)       # Kahan: the result of a b - c d correctly rounded (to within 1.5 ulp)
+                    return np.cross(a64, b64).astype(f32)
+                A, B, C = cross(Tv_, Tw_), cross(Tw_, Tu_), cross(Tu_, Tv_)
+                p = ((f32(px) - ox.astype(f32))[:, None] * A + (f32(py) - oy.astype(f32))[:, None] * B + C).astype(f32)
+                dt = f32
             else:
                 if form == "tile": ox, oy = np.full(len(ids), (x // tw) * tw + tw // 2, dt), np.full(len(ids), (y // th) * th + th // 2, dt)
                 else: ox, oy = c[:, 0].astype(dt), c[:, 1].astype(dt)       # the splat's own (AABB) centre
@@ -40,12 +53,12 @@ for seed in [int(a) for a in sys.argv[1:]]:
             rho = np.where(r3 <= r2, r3, r2)
             return np.minimum(0.99, opa * np.exp(-0.5 * rho)).astype(np.float64)
         a64 = alpha(np.float64, "oracle"); keep = a64 >= 1 / 255
-        for form in ("oracle", "tile", "centre"):
+        for form in ("oracle", "tile", "tile_fma", "tile_fma_kahan", "centre"):
             e = np.abs(alpha(np.float32, form) - a64)
             for r, ee in zip(ratio[ids][keep], e[keep]): rows.append((form, r, ee))
 import collections
 bins = [(1, 10), (10, 30), (30, 100), (100, 300), (300, 2000)] if not os.environ.get("BY_RADIUS") else [(0, 20), (20, 100), (100, 400), (400, 100000)]
-for form in ("oracle", "tile", "centre"):
+for form in ("oracle", "tile", "tile_fma", "tile_fma_kahan", "centre"):
     print(form)
     for lo, hi in bins:
         e = np.array([ee for f, r, ee in rows if f == form and lo <= r < hi])
