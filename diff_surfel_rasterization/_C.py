@@ -253,6 +253,10 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
         grads = L.SrGradients(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dtransMat),
                               _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations))
         if class_state is not None:   # the shared-plan class pass: K7 -> class backward into the same records -> ONE K8
+            if defer_sh or after_blend is not None:
+                # (a frame-parallel caller would get a locally expanded dL_dsh and no exchange hook -- silently)
+                raise L.SurfelRasterError("the shared-plan class pass (class_state) does not combine with the factored SH exchange "
+                                          "(defer_sh / after_blend): exchange its gradients with the plain all-reduce")
             dL_ddist = _f32c(dL_ddist, "dL_ddist")
             L.check(lib.sr_backward_blend(C.byref(fr), C.byref(g), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
                                           binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(), int(num_rendered), _ptr(dL_dcolor),
@@ -395,7 +399,8 @@ def _view(buf: torch.Tensor, ptr, nbytes: int, dtype: torch.dtype) -> torch.Tens
 
 def geom_view(geom: torch.Tensor, P: int):
     """Typed views into the geometry state (tests / tools).  `sorted_gid`: only its first frame_counts[1] entries -- the visible Gaussians in
-    depth order -- are written (the depth sort drops the culled ones)."""
+    depth order -- are written (the depth sort drops the culled ones).  `splats`: rows with radii == 0 are UNDEFINED (K1 skips the 128-B
+    lines whose rows are all culled: whatever torch.empty left there, possibly NaN) -- index with radii > 0."""
     v = L.SrGeomView()
     L.check(L.load().sr_geom_view(_ptr(geom), geom.numel(), P, C.byref(v)), "sr_geom_view")
     return dict(splats=_view(geom, v.splats, P * 80, torch.float32).view(P, 20),

@@ -158,7 +158,9 @@ typedef struct SrGradients {
 
 /* Views into the caller-owned state buffers (for tests / debugging; all device pointers). */
 typedef struct SrGeomView {
-    const float* splats;           /* [P,20] packed record: Tu.xyz Tv.x | Tv.yz Tw.xy | Tw.z xy.x xy.y opacity | n.xyz r | g b view-depth radius (zeros where radii == 0) */
+    const float* splats;           /* [P,20] packed record: Tu.xyz Tv.x | Tv.yz Tw.xy | Tw.z xy.x xy.y opacity | n.xyz r | g b view-depth radius.  Rows with radii == 0 are UNDEFINED: K1 does not write the
+                                    * 128-B lines of the record array whose rows are all culled (round 5), so such rows hold whatever the caller's buffer held -- possibly
+                                    * NaN; read a row only where radii > 0 (every kernel reaches the records through the tile lists, which hold visible Gaussians only) */
     const uint32_t* depth_keys;    /* [P] float bits of view-space depth; 0xFFFFFFFF when culled */
     const uint32_t* tiles_touched; /* [P] */
     const uint8_t* clamped;        /* [P] bit c set when SH colour channel c was clamped at 0 */

@@ -295,12 +295,27 @@ int check_common(const SrFrame* frame, const SrGaussians* g) {
     return SR_OK;
 }
 
+// The backward entry points read SrFrame.tanfovx / tanfovy (upstream's backward derives the image size from them: SR_BACKWARD_WH_FROM_FOCAL, the
+// shipped default; the forward never did): a caller that left them 0 or NaN would get inf * 0 = NaN, (int)NaN -- undefined behaviour -- and
+// a silently wrong viewport chain in K8.
+int check_backward_frame(const SrFrame* frame) {
+#if SR_BACKWARD_WH_FROM_FOCAL
+    if (!(frame->tanfovx > 0.f) || !(frame->tanfovy > 0.f) || !std::isfinite(frame->tanfovx) || !std::isfinite(frame->tanfovy))
+        return fail(SR_ERR_INVALID_ARGUMENT, "tanfovx / tanfovy must be finite and > 0 for a backward call (got %g, %g)", (double)frame->tanfovx, (double)frame->tanfovy);
+#else
+    (void)frame;
+#endif
+    return SR_OK;
+}
+
 FrameDev make_frame(const SrFrame* frame, const SrGaussians* g) {
     FrameDev f{};
     f.W = frame->image_width; f.H = frame->image_height;
     f.bw_W = f.W; f.bw_H = f.H;
 #if SR_BACKWARD_WH_FROM_FOCAL
-    {   // upstream's backward: focal = size / (2 tanfov) (rasterizer_impl), then W = int(focal_x * tan_fovx * 2) in float32
+    if (frame->tanfovx > 0.f && frame->tanfovy > 0.f && std::isfinite(frame->tanfovx) && std::isfinite(frame->tanfovy)) {
+        // upstream's backward: focal = size / (2 tanfov) (rasterizer_impl), then W = int(focal_x * tan_fovx * 2) in float32
+        // (a forward call may leave the two fields unset -- it never reads bw_W / bw_H; the backward entry points insist: check_backward_frame)
         const float focal_x = (float)f.W / (2.0f * frame->tanfovx), focal_y = (float)f.H / (2.0f * frame->tanfovy);
         f.bw_W = (int)(focal_x * frame->tanfovx * 2); f.bw_H = (int)(focal_y * frame->tanfovy * 2);
     }
@@ -537,6 +552,7 @@ int sr_class_forward_render(const SrFrame* frame, const SrGaussians* g, int32_t 
                             size_t binning_bytes, void* class_image, size_t class_image_bytes, uint32_t D, float* out_dist, void* stream) {
     if (int rc = check_class_pass(frame, g, n_classes)) return rc;
     if (!binning || !class_image || !out_dist) return fail(SR_ERR_INVALID_ARGUMENT, "binning / class_image / out_dist is NULL");
+    if (g->P > 0 && !geom) return fail(SR_ERR_INVALID_ARGUMENT, "geom is NULL (the class ids of the P Gaussians are staged in it, even when no duplicate was emitted)");
     const int W = frame->image_width, H = frame->image_height;
     const BinLayout B = bin_layout(D, W, H);
     const ClassLayout C = class_layout(W, H, n_classes);
@@ -567,6 +583,7 @@ int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_clas
                       void* binning, size_t binning_bytes, void* class_image, size_t class_image_bytes, uint32_t D, const float* dL_ddist,
                       void* workspace, size_t workspace_bytes, const SrGradients* grads, void* stream) {
     if (int rc = check_class_pass(frame, g, n_classes)) return rc;
+    if (int rc = check_backward_frame(frame)) return rc;
     if (!grads) return fail(SR_ERR_INVALID_ARGUMENT, "grads is NULL");
     const int P = g->P;
     if (P == 0) return SR_OK;
@@ -653,6 +670,7 @@ int sr_class_backward_shared(const SrFrame* frame, const SrGaussians* g, int32_t
                              size_t binning_bytes, void* class_state, size_t class_state_bytes, uint32_t D, const float* dL_ddist, void* workspace,
                              size_t workspace_bytes, void* stream) {
     if (int rc = check_common(frame, g)) return rc;
+    if (int rc = check_backward_frame(frame)) return rc;
     if (n_classes < 1 || n_classes > 6) return fail(SR_ERR_UNSUPPORTED, "n_classes %d not in 1..6", n_classes);
     const int P = g->P;
     if (P == 0 || D == 0) return SR_OK;
@@ -686,6 +704,7 @@ struct BackwardCtx {
 int backward_ctx(const SrFrame* frame, const SrGaussians* g, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
                  void* image, size_t image_bytes, uint32_t D, void* workspace, size_t workspace_bytes, void* stream, BackwardCtx* c) {
     if (int rc = check_common(frame, g)) return rc;
+    if (int rc = check_backward_frame(frame)) return rc;
     c->P = g->P;
     if (c->P == 0) return SR_OK;
     if (!geom || !binning || !image || !workspace) return fail(SR_ERR_INVALID_ARGUMENT, "NULL buffer argument");
@@ -728,6 +747,7 @@ int sr_backward_blend(const SrFrame* frame, const SrGaussians* g, void* geom, si
 int sr_backward_colors(const SrFrame* frame, const SrGaussians* g, const int32_t* radii, void* geom, size_t geom_bytes, uint32_t D,
                        void* workspace, size_t workspace_bytes, float* dL_dcolors, void* stream) {
     if (int rc = check_common(frame, g)) return rc;
+    if (int rc = check_backward_frame(frame)) return rc;
     const int P = g->P;
     if (P == 0) return SR_OK;
     if (g->color_channels == 6 || g->color_channels == 9) return fail(SR_ERR_UNSUPPORTED, "sr_backward_colors serves the 3-channel pass");

@@ -13,6 +13,12 @@ constexpr float kFN = kFar / (kFar - kNear);
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima), placed by hand at the
+// top of a round of the list walks: everything in flight there was issued a round earlier, and a wait that sits on EVERY control-flow
+// path lets the compiler's own counter tracking start the round from zero -- a wait inside the (lane < n) staging branch leaves the
+// skip path "pending", and the next use of a prefetched register then waits again, behind whatever store was issued in between.
+__device__ __forceinline__ void wait_vector_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // counters of the K6 counter variant (SrFrame.blend_counters, caller-owned, 16 x u64): [0] entries staged, [1] entries with a
 // non-zero quadrant mask, [2] quadrant tests executed, [3] quadrant tests with >= 1 valid lane, [4] valid (pixel, entry) pairs,
 // [5] / [6] tests with a valid pixel in rows 0-3 / rows 4-7 of the quadrant, [7] entries with a valid pixel anywhere in the tile,

@@ -33,6 +33,15 @@
 
 namespace sr {
 
+// exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel in the forward.  16 bits per list entry;
+// two-band tiles: low byte = quadrants of the upper band, high byte = lower band (decode_hits, blend_common.h)
+template <int QX, int QY, int SPLIT>
+__device__ __forceinline__ void store_hit_mask(uint16_t* __restrict__ hit_mask, uint32_t pos, int part, uint32_t hm) {
+    if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)pos + part] = (uint8_t)hm;
+    else if (QY == 2) hit_mask[pos] = (uint16_t)((hm & ((1u << QX) - 1u)) | ((hm >> QX) << 8));
+    else hit_mask[pos] = (uint16_t)hm;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
@@ -82,26 +91,49 @@ __device__ __forceinline__ void render_forward_body(float4 (*s_e)[kWave], const 
         if (ballot64(T[q] > 0.f) != 0) alive |= 1u << q;
     }
 
+    // Memory pipeline of the walk (round 6): the list entry (gid) is requested TWO rounds ahead, the record it addresses one round ahead, and
+    // the hit masks of a round are stored behind the staging of the next one -- so the only wait of a round (for the records, at its top)
+    // is for operations issued a whole round earlier.  Before, `load_record(recs, point_list[..])` made every round wait for the list
+    // entry's round trip, and the wait for the records also waited for the hit-mask store issued right in front of it.
     float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f), ny = nx;
+    uint32_t gid_ahead = 0;
     if ((uint32_t)lane < n_total) {
         const uint32_t gid = point_list[range.x + lane];
-        load_record(recs, gid, nr);
+        load_record18(recs, gid, nr);   // (depth and radius, the record's last two floats, are not staged by the forward)
         if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
     }
+    if (kWave + (uint32_t)lane < n_total) gid_ahead = point_list[range.x + kWave + lane];
+    // the hit masks of the round that ended last, not stored yet: they wait as the round's scalar ballots (no vector register across the staging)
+    unsigned long long hit_prev[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) hit_prev[q] = 0ull;
+    uint32_t n_prev = 0, base_prev = 0;
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         uint32_t m = 0;
         int ys = yshift_px;
         asm volatile("" : "+s"(ys));   // converted again in every round: one v_cvt per 64 entries instead of a register held across the walk
         uint32_t cells16 = 0;
+        wait_vector_memory();   // every operation in flight was issued a round ago; on every path, so that nothing later in the round waits again
         if ((uint32_t)lane < n) m = stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, cull & 1, s_e, lane, (float)ys, kStats && QX == 2 && QY == 2 ? &cells16 : nullptr);
+        // (the record loads are the LAST memory operations of the round: nothing needs a temporary register while their 18 destinations
+        // are in flight -- at the 80-register budget the allocator otherwise moves half-arrived quads around, behind an s_waitcnt)
+        const uint32_t gid = gid_ahead;
+        if (hit_mask && (uint32_t)lane < n_prev) {
+            uint32_t hm = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit_prev[q] >> lane) & 1ull) << q;
+            store_hit_mask<QX, QY, SPLIT>(hit_mask, range.x + base_prev + lane, part, hm);
+        }
+        if (base + 2 * kWave + lane < n_total) gid_ahead = point_list[range.x + base + 2 * kWave + lane];
+        __builtin_amdgcn_sched_barrier(0);
         if (base + kWave + lane < n_total) {
-            const uint32_t gid = point_list[range.x + base + kWave + lane];
-            load_record(recs, gid, nr);
+            load_record18(recs, gid, nr);   // (depth and radius, the record's last two floats, are not staged by the forward)
             if (NC == 6) nx = load_extra(extra, gid, 3);
             if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
         }
+        __builtin_amdgcn_sched_barrier(0);
         const uint32_t alive_at_round_start = alive;
         unsigned long long bits = ballot64((m & alive) != 0);
         if (kStats && lane == 0) { atomicAdd(&g_stats[0], (unsigned long long)n); atomicAdd(&g_stats[1], (unsigned long long)__popcll(bits)); }
@@ -205,15 +237,17 @@ __device__ __forceinline__ void render_forward_body(float4 (*s_e)[kWave], const 
             if (lane == 0) { atomicAdd(&g_stats[12], kept); atomicAdd(&g_stats[13], steps); }
         }
         // exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel here
-        if (hit_mask && (uint32_t)lane < n) {   // (NULL with SR_FLAG_FORWARD_ONLY: no backward will read it)
-            uint32_t hm = 0;
+        if (hit_mask) {   // (NULL with SR_FLAG_FORWARD_ONLY: no backward will read it)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
-            // 16 bits per list entry; two-band tiles: low byte = quadrants of the upper band, high byte = lower band
-            if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base + lane) + part] = (uint8_t)hm;
-            else if (QY == 2) hit_mask[range.x + base + lane] = (uint16_t)((hm & ((1u << QX) - 1u)) | ((hm >> QX) << 8));
-            else hit_mask[range.x + base + lane] = (uint16_t)hm;
+            for (int q = 0; q < NQ; ++q) hit_prev[q] = hit[q];
+            n_prev = n; base_prev = base;   // stored behind the next round's staging, or behind the walk
         }
+    }
+    if (hit_mask && (uint32_t)lane < n_prev) {
+        uint32_t hm = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit_prev[q] >> lane) & 1ull) << q;
+        store_hit_mask<QX, QY, SPLIT>(hit_mask, range.x + base_prev + lane, part, hm);
     }
     const size_t HW = (size_t)f.H * f.W;
     const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
@@ -311,14 +345,24 @@ __device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], u
     // round ahead: 18 registers across the walk keep the kernel at 80 VGPRs = six waves per SIMD.  Round 3 prefetched four quads and fetched
     // the fifth at staging time, a round later: by then its line had left the L1 and often the L2 -- 13.7 M extra L1->L2 requests and
     // +0.33 GB of raw FETCH_SIZE per launch, tools/notes_round4_measured.md)
+    // (memory pipeline as in render_forward_body: list entries two rounds ahead, records one, hit masks stored behind the next staging)
+    uint32_t gid_ahead = 0;
     if ((uint32_t)lane < n_total) load_record18(recs, point_list[range.x + lane], nr);
+    if (kWave + (uint32_t)lane < n_total) gid_ahead = point_list[range.x + kWave + lane];
+    uint32_t hm_prev = 0, n_prev = 0, base_prev = 0;
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         int ys = yshift_px;
         asm volatile("" : "+s"(ys));
         uint32_t cm = 0;   // this lane's ENTRY: bit 4 q + c = its octagon reaches cell c of quadrant q
+        wait_vector_memory();
         if ((uint32_t)lane < n) (void)stage_entry<QX, QY, NC>(nr, nx, nx, Xc, Yc, 1, s_e, lane, (float)ys, nullptr, &cm);
-        if (base + kWave + lane < n_total) load_record18(recs, point_list[range.x + base + kWave + lane], nr);
+        const uint32_t gid = gid_ahead;
+        if (hit_mask && (uint32_t)lane < n_prev) store_hit_mask<QX, QY, SPLIT>(hit_mask, range.x + base_prev + lane, part, hm_prev);
+        if (base + 2 * kWave + lane < n_total) gid_ahead = point_list[range.x + base + 2 * kWave + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        if (base + kWave + lane < n_total) load_record18(recs, gid, nr);   // (last: see render_forward_body)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) s_hit[q][lane] = 0;
 #pragma unroll
@@ -367,15 +411,14 @@ __device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], u
                 if (ballot64(T[q] > 0.f) == 0ull) { alive &= ~(1u << q); break; }
             }
         }
-        if (hit_mask && (uint32_t)lane < n) {
+        if (hit_mask) {
             uint32_t hm = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) hm |= (uint32_t)s_hit[q][lane] << q;
-            if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base + lane) + part] = (uint8_t)hm;
-            else if (QY == 2) hit_mask[range.x + base + lane] = (uint16_t)((hm & ((1u << QX) - 1u)) | ((hm >> QX) << 8));
-            else hit_mask[range.x + base + lane] = (uint16_t)hm;
+            hm_prev = hm; n_prev = n; base_prev = base;
         }
     }
+    if (hit_mask && (uint32_t)lane < n_prev) store_hit_mask<QX, QY, SPLIT>(hit_mask, range.x + base_prev + lane, part, hm_prev);
     const size_t HW = (size_t)f.H * f.W;
     const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
     int lane_again = threadIdx.x;

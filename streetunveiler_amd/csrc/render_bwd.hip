@@ -9,6 +9,30 @@
 
 namespace sr {
 
+// Stores the gradient record a lane holds in its row of s_out (the round that just ended) at the duplicate's emission index `slot`.
+// kShiftInLds: the shift (ox, oy) of the moments waits in slots 22, 23 of the row (a 21-value record leaves them unused), else in registers.
+// add: a banded walk's second pass adds to the record the first pass left (same wave, program order, a fence in between).
+template <int kGQ, bool kShiftInLds>
+__device__ __forceinline__ void flush_record(const float* __restrict__ row, float4* __restrict__ inst_grads, uint8_t* __restrict__ written, uint32_t slot,
+                                             float ox, float oy, bool add) {
+    const float4* accl = reinterpret_cast<const float4*>(row);
+    float4 a0 = accl[0], a1 = accl[1], a2 = accl[2], a3 = accl[3], a4 = accl[4], a5 = accl[5], a6 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kGQ == 7) a6 = accl[6];
+    if (kShiftInLds) { ox = a5.z; oy = a5.w; a5.z = 0.f; a5.w = 0.f; }
+    a0.w = fmaf(ox, a0.x, a0.w); a1.x = fmaf(ox, a0.y, a1.x); a1.y = fmaf(ox, a0.z, a1.y);
+    a1.z = fmaf(oy, a0.x, a1.z); a1.w = fmaf(oy, a0.y, a1.w); a2.x = fmaf(oy, a0.z, a2.x);
+    float4* o = inst_grads + (size_t)slot * kGQ;
+    if (add && written[slot]) {   // the upper band left a record for this duplicate: add to it
+#define SR_ADD4(A, K) { const float4 p = o[K]; A.x += p.x; A.y += p.y; A.z += p.z; A.w += p.w; }
+        SR_ADD4(a0, 0) SR_ADD4(a1, 1) SR_ADD4(a2, 2) SR_ADD4(a3, 3) SR_ADD4(a4, 4) SR_ADD4(a5, 5)
+        if (kGQ == 7) SR_ADD4(a6, 6)
+#undef SR_ADD4
+    }
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5;
+    if (kGQ == 7) o[6] = a6;
+    written[slot] = 1;   // K8 reads this 1-B flag (zeroed per call) before it touches the record
+}
+
 // ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
@@ -93,42 +117,72 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
     }
 
     // entries behind the deepest contributor of the tile are never looked at: they get no record and keep a clear `written` flag
+    //
+    // Memory pipeline of the walk (round 6).  Nothing that comes back from memory is touched in the round that asks for it:
+    //   * the list entry (gid) of round r - 2 is requested during round r, the record of round r - 1 (address = that gid, which arrived a
+    //     round ago) too, RAW -- first[] and first_base[] stay two registers and the hit mask stays undecoded until round r - 1 stages them;
+    //   * the records of round r are STORED at the top of round r - 1, behind its staging: the wave's vector-memory counter retires in
+    //     issue order, so the wait for round r - 1's record loads -- issued before those stores -- never waits for a store.
+    // Before: `gid = point_list[pos]; load_record(recs, gid, ...)` and `first[gid] + first_base[..]` inside the prefetch made the wave wait
+    // for two dependent memory round trips (and for the stores of the previous flush in front of them) in EVERY round -- SQ_WAIT_INST_ANY was
+    // 26 % of the wave cycles (profiles/r05_c3_sq_counters.json).
     const int rounds = (int)((total + kWave - 1) / kWave);
     float4 nr[kRecQuads], nx = make_float4(0.f, 0.f, 0.f, 0.f), ny = nx;
-    uint32_t nhit = 0;
+    uint32_t nfirst = 0, nfbase = 0, nhraw = 0, gid_ahead = 0;
     if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
         const uint32_t pos = range.x + (rounds - 1) * kWave + lane;
         const uint32_t gid = point_list[pos];
-        load_record(recs, gid, nr); nr[4].z = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
+        load_record(recs, gid, nr); nfirst = f.first[gid]; nfbase = f.first_base[gid / kScanTile];
         if (NC == 6) nx = load_extra(extra, gid, 3);
-            if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
-        nhit = (decode_hits<QX, QY * BANDS>(hit_mask[pos]) >> (band * QX * QY)) & ((1u << (QX * QY)) - 1u);
+        if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
+        nhraw = hit_mask[pos];
     }
+    if (rounds > 1) gid_ahead = point_list[range.x + (rounds - 2) * kWave + lane];   // (every round but the last one is full)
+    // (with 21 values the lanes of value slots 21..23 hold copies of other totals: they must not reach s_out, whose slots 22, 23 are in use)
+    const bool holds_total = reduce24_holds_total(lane) && (NC != 3 || reduce24_index(lane) < 21);
+    bool pend = false;             // this lane holds a record of the previous round that is not stored yet
+    uint32_t pslot = 0;
+    // the shift of the moments to the Gaussian's own centre (see the staging below) waits for the flush in the lane's own row of s_out, in
+    // the two slots a 21-value record leaves unused (three channels: no registers across the entry loop); in registers otherwise
+    constexpr bool kShiftInLds = NC == 3;
+    float pox = 0.f, poy = 0.f;
     for (int rd = rounds - 1; rd >= 0; --rd) {
         const uint32_t rbase = (uint32_t)rd * kWave;
         const uint32_t n = min((uint32_t)kWave, total - rbase);
         uint32_t m = 0, slot = 0;
+        float ox = 0.f, oy = 0.f;
+        wait_vector_memory();   // (loads and stores of the previous round: see blend_common.h)
         if ((uint32_t)lane < n) {
             (void)stage_entry<QX, QY, NC>(nr, nx, ny, Xc, Yc, 0, s_e, lane);
-            m = nhit;   // (entry, quadrant) pairs that reached a pixel in the forward: exact, no culling test needed here
-            slot = emission_index(nr, __float_as_uint(nr[4].z), tile % f.tiles_x, tile / f.tiles_x, f);
+            // (entry, quadrant) pairs that reached a pixel in the forward: exact, no culling test needed here
+            m = (decode_hits<QX, QY * BANDS>((uint16_t)nhraw) >> (band * QX * QY)) & ((1u << (QX * QY)) - 1u);
+            slot = emission_index(nr, nfirst + nfbase, tile % f.tiles_x, tile / f.tiles_x, f);
             uint32_t need = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
             m &= need;
+            // Sx, Sy from tile-local coordinates to coordinates relative to the Gaussian's OWN centre (cx, cy): sum (xl - mx) dp = sum xl dp -
+            // mx S0 with mx = cx - Xc.  K8 sums these over the Gaussian's tiles and works with Tu - cx Tw, Tv - cy Tw: the same dL/dT as
+            // with moments about the image origin, without the cancellation of pixel coordinates ~1000 against extents of a few pixels
+            // (clamped into the image: the moments of a splat whose centre projects far off-screen are taken about the nearest image point)
+            const float mx = nr[2].y - Xc, my = nr[2].z - Yc;   // (the staged centre: same expression, same bits as stage_entry's)
+            ox = -fminf(fmaxf(mx, -Xc), (float)(f.W - 1) - Xc); oy = -fminf(fmaxf(my, -Yc), (float)(f.H - 1) - Yc);
         }
+        // (the prefetch comes BEFORE the stores of the flush: the wait for `gid_ahead` -- the last load of the previous round -- then has
+        // the same number of younger memory operations behind it on every path, none, instead of "seven stores or none")
+        if (rd > 0) {  // next round is always full
+            const uint32_t gid = gid_ahead;
+            load_record(recs, gid, nr); nfirst = f.first[gid]; nfbase = f.first_base[gid / kScanTile];
+            if (NC == 6) nx = load_extra(extra, gid, 3);
+            if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
+            nhraw = hit_mask[range.x + rbase - kWave + lane];
+            if (rd > 1) gid_ahead = point_list[range.x + rbase - 2 * kWave + lane];
+        }
+        if (pend) flush_record<kGQ, kShiftInLds>(&s_out[lane][0], inst_grads, written, pslot, pox, poy, BANDS > 1 && band > 0);   // one 96-B store per lane whose entry of the previous round got a contribution
         {
             float4* z = reinterpret_cast<float4*>(&s_out[lane][0]);
 #pragma unroll
-            for (int k = 0; k < kGQ; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (rd > 0) {  // next round is always full
-            const uint32_t pos = range.x + rbase - kWave + lane;
-            const uint32_t gid = point_list[pos];
-            load_record(recs, gid, nr); nr[4].z = __uint_as_float(first_index(f, gid));   // first emission index rides in the unused depth slot
-            if (NC == 6) nx = load_extra(extra, gid, 3);
-            if (NC == 9) { nx = load_extra(extra, gid, 0); ny = load_extra(extra, gid, 3); }
-            nhit = (decode_hits<QX, QY * BANDS>(hit_mask[pos]) >> (band * QX * QY)) & ((1u << (QX * QY)) - 1u);
+            for (int k = 0; k < kGQ; ++k) z[k] = (kShiftInLds && k == 5) ? make_float4(0.f, 0.f, ox, oy) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         unsigned long long bits = ballot64(m != 0);
         // entries of this round that get a record: those with an (entry, quadrant) pair that reached a pixel in the forward.  (Such a
@@ -207,37 +261,17 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             }
             {
                 const float tot = wave_reduce24<NV>(v, lane);
-                if (reduce24_holds_total(lane)) s_out[j][reduce24_index(lane)] = tot;
+                if (holds_total) s_out[j][reduce24_index(lane)] = tot;
                 if (NC == 9 && kXG) {
                     const float t3 = wave_reduce3(w6, w7, w8);   // row 0: channel 6, row 1: channel 8, row 2: channel 7
                     if ((lane & 15) == 0 && lane < 48) s_out[j][24 + (lane == 0 ? 0 : (lane == 16 ? 2 : 1))] = t3;
                 }
             }
         }
-        // flush this round's records: one 96-B store per lane whose entry got a contribution
-        if ((wrote >> lane) & 1ull) {
-            const float4* accl = reinterpret_cast<const float4*>(&s_out[lane][0]);
-            float4 acc[kGQ];
-#pragma unroll
-            for (int k = 0; k < kGQ; ++k) acc[k] = accl[k];
-            // Sx, Sy from tile-local coordinates to coordinates relative to the Gaussian's OWN centre (cx, cy): sum (xl - mx) dp = sum xl dp -
-            // mx S0 with mx = cx - Xc.  K8 sums these over the Gaussian's tiles and works with Tu - cx Tw, Tv - cy Tw: the same dL/dT as
-            // with moments about the image origin, without the cancellation of pixel coordinates ~1000 against extents of a few pixels
-            const float4 centre = s_e[3][lane];   // (mx, my, ..) = the Gaussian's centre relative to the tile centre
-            // (clamped into the image: the moments of a splat whose centre projects far off-screen are taken about the nearest image point)
-            const float ox = -fminf(fmaxf(centre.x, -Xc), (float)(f.W - 1) - Xc), oy = -fminf(fmaxf(centre.y, -Yc), (float)(f.H - 1) - Yc);
-            acc[0].w = fmaf(ox, acc[0].x, acc[0].w); acc[1].x = fmaf(ox, acc[0].y, acc[1].x); acc[1].y = fmaf(ox, acc[0].z, acc[1].y);
-            acc[1].z = fmaf(oy, acc[0].x, acc[1].z); acc[1].w = fmaf(oy, acc[0].y, acc[1].w); acc[2].x = fmaf(oy, acc[0].z, acc[2].x);
-            float4* o = inst_grads + (size_t)slot * kGQ;
-            if (BANDS > 1 && band > 0 && written[slot]) {   // the upper band left a record for this duplicate: add to it
-#pragma unroll
-                for (int k = 0; k < kGQ; ++k) { const float4 p = o[k]; acc[k].x += p.x; acc[k].y += p.y; acc[k].z += p.z; acc[k].w += p.w; }
-            }
-#pragma unroll
-            for (int k = 0; k < kGQ; ++k) o[k] = acc[k];
-            written[slot] = 1;   // K8 reads this 1-B flag (zeroed per call) before it touches the record
-        }
+        pend = ((wrote >> lane) & 1ull) != 0ull; pslot = slot;
+        if (!kShiftInLds) { pox = ox; poy = oy; }
     }
+    if (pend) flush_record<kGQ, kShiftInLds>(&s_out[lane][0], inst_grads, written, pslot, pox, poy, BANDS > 1 && band > 0);
   }   // band
 }
 

@@ -306,21 +306,27 @@ def render_class_distortions(viewpoint_camera, pc, pipe, bg_color: torch.Tensor,
 
 
 # Per-Gaussian class encodings derived from `pc.get_semantics` alone (the six one-hot channels, the class -> chain table look-up): a
-# training loop asks for them every iteration while the semantics only change at densification.  Cached per semantics TENSOR (identity +
-# in-place version, held weakly): a new or modified tensor misses.  ~0.1 ms per call at 3 M Gaussians.
+# training loop asks for them every iteration while the semantics only change at densification.  The upstream model's getter returns
+# `self._semantics.squeeze(-1)` -- a NEW view object on every call [REF scene/gaussian_model.py:126] -- so the cache is keyed on what is
+# stable across views of one parameter: the storage's address, the tensor's in-place version, its shape / stride / offset / dtype.  (An
+# `id()` + weak reference to the view -- round 5 -- never hit with the real model.)  One entry per kind of encoding: a densification step
+# (new storage or a bumped version) replaces it, nothing stale stays alive (a [P,6] float one-hot is 72 MB at 3 M Gaussians).
+# ~0.1 ms per call at 3 M Gaussians.
 _SEM_CACHE = {}
 
 
+def _semantics_key(sem: torch.Tensor):
+    return (sem.untyped_storage().data_ptr(), sem._version, tuple(sem.shape), tuple(sem.stride()), sem.storage_offset(), sem.dtype, str(sem.device))
+
+
 def _per_semantics(sem: torch.Tensor, key, make):
-    import weakref
-    k = (id(sem), key)
-    hit = _SEM_CACHE.get(k)
-    if hit is not None and hit[0]() is sem and hit[1] == sem._version:
-        return hit[2]
-    if len(_SEM_CACHE) > 32:
-        _SEM_CACHE.clear()
+    kind = key[0]
+    want = (_semantics_key(sem), key)
+    hit = _SEM_CACHE.get(kind)
+    if hit is not None and hit[0] == want:
+        return hit[1]
     val = make()
-    _SEM_CACHE[k] = (weakref.ref(sem), sem._version, val)
+    _SEM_CACHE[kind] = (want, val)   # at most one entry per kind
     return val
 
 

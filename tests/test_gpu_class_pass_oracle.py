@@ -1,0 +1,180 @@
+"""The per-class distortion pass and the one-plan training view against the ORACLE (round 6).
+
+Until now `class_distortions` / `forward_with_class_distortions` were compared with the HIP operator run on the class subsets -- HIP
+against HIP; only tools/fuzz_extensions.py reached the float64 oracle, and only as a fallback.  Here both passes are held to the
+free-running float64 oracle directly, per tile shape, on a scene with real overlap along the rays:
+
+  reference of the class pass   = for every class k the oracle's render of the subset {classes == k} -- what the reference's training
+                                  iteration computes with `render(..., semantic_filter_bit = 1 << k, reverse_semantic = True)` and keeps
+                                  `rend_dist` of [REF /root/reference/train.py:94-103] -- and its float64 backward with dL/d rend_dist_k;
+  reference of the one-plan pass = that, plus the oracle's SH render (3 colour channels + allmap gradients) and two precomputed-colour
+                                  renders for the six extra channels [REF gaussian_renderer/__init__.py:327-460: the semantic passes], all
+                                  gradients summed per Gaussian in float64.
+
+Bars: tests/bars.py -- maps 1e-4 (1 + |v|) at the float64 checker's robust pixels, the loose cap elsewhere; gradient rows by
+STRICT_ROW_BARS on Gaussians that are robust in every render they take part in, the loose row cap on the rest."""
+import numpy as np
+import pytest
+import torch
+
+from diff_surfel_rasterization import GaussianRasterizer
+from streetunveiler_amd.synthetic import posed_scene, synthetic_camera, synthetic_gaussians
+from tests import gpu_util as gu
+from tests.bars import bar
+
+pytestmark = pytest.mark.gpu
+KEYS = dict(means3D="dL_dmeans3D", opacities="dL_dopacity", scales="dL_dscales", rotations="dL_drotations", means2D="dL_dmeans2D")
+W, H, P, N_CLS = 352, 208, 24_000, 5
+
+
+def _scene(tile):
+    if tile == (8, 8):   # (one shape through a camera in general position)
+        cam, g = posed_scene(P, W, H, seed=41, scale_lo=2e-3, scale_hi=2e-2, spread=12.0)
+    else:
+        cam, g = synthetic_camera(W, H, index=2), synthetic_gaussians(P, W, H, seed=40 + tile[0], scale_lo=2e-3, scale_hi=2e-2)
+    gen = torch.Generator().manual_seed(5)
+    cls = torch.randint(-1, N_CLS + 1, (P,), generator=gen)   # -1 and N_CLS: in no class
+    gd = torch.rand(N_CLS, H, W, generator=gen) + 0.5
+    return cam, g, cls, gd
+
+
+class _Sum:
+    """Float64 gradients of several renders, scattered to the full set of Gaussians and summed; robust = robust in every render."""
+
+    def __init__(self, g):
+        self.P = g["means3D"].shape[0]
+        self.acc, self.robust, self.visible = {}, np.ones(self.P, bool), np.zeros(self.P, bool)
+
+    def add(self, idx, fwd64, bwd64, margins):
+        idx = np.arange(self.P) if idx is None else np.nonzero(idx)[0]
+        for key, v in bwd64.items():
+            if not key.startswith("dL_") or key in ("dL_dcolors", "dL_dcolors64", "dL_dsh", "dL_dsh64"):   # (colour-side gradients: one render each)
+                continue
+            v = np.asarray(v, np.float64).reshape(len(idx), -1)
+            if key not in self.acc:
+                self.acc[key] = np.zeros((self.P, v.shape[1]))
+            self.acc[key][idx] += v
+        vis = fwd64["radii"] > 0
+        self.visible[idx] |= vis
+        self.robust[idx] &= (margins["gaussian"] > 1.0) | ~vis
+
+
+def _class_references(g, cam, tile, cls, gd, total):
+    """Oracle render + free-running float64 backward of every class subset -> [(k, idx, fwd64, margins)], gradients added to `total`."""
+    out = []
+    bg = np.zeros(3, np.float32)
+    for k in range(N_CLS):
+        idx = (cls == k).numpy()
+        sub = {n: g[n][torch.as_tensor(idx)] for n in g}
+        cols = np.zeros((int(idx.sum()), 3), np.float32)
+        da = torch.zeros(7, H, W); da[6] = gd[k]
+        base, _ = gu.run_oracle(sub, cam, bg, 0, colors=cols, tile=tile)
+        fwd64, bwd64, margins = gu.free_f64_reference(sub, cam, bg, 0, torch.zeros(3, H, W), da, colors=cols, tile=tile, base=base)
+        total.add(idx, fwd64, bwd64, margins)
+        out.append((k, idx, fwd64, margins))
+    return out
+
+
+def _check_maps(dist, radii, refs, tag):
+    for k, idx, fwd64, margins in refs:
+        np.testing.assert_array_equal(radii[idx], fwd64["radii"], err_msg=f"{tag} class {k}: radii")
+        b = np.asarray(fwd64["allmap"][6], np.float64)
+        err = np.abs(dist[k].astype(np.float64) - b) / (1.0 + np.abs(b)) - margins.get("value_noise", 0.0)
+        rob = margins["pixel"] > 1.0
+        assert b.max() > 1e-3, f"{tag} class {k}: the scene has no distortion to speak of"
+        assert err[rob].max(initial=0.0) <= bar("robust_pixel"), f"{tag} class {k}: distortion map off by {err[rob].max():.3e} of (1 + |v|) at a robust pixel"
+        assert err[~rob].max(initial=0.0) <= bar("nonrobust_pixel_cap"), f"{tag} class {k}: distortion map off by {err[~rob].max():.3e} at a non-robust pixel"
+        assert (~rob).mean() <= bar("nonrobust_pixel_budget"), f"{tag} class {k}: {(~rob).mean():.3f} of the pixels non-robust"
+
+
+def _check_rows(grads, total, g, cam, tag, skip=()):
+    hip = {KEYS[n]: v for n, v in grads.items() if n in KEYS}
+    ref = {k: v for k, v in total.acc.items()}
+    errs = gu.gradient_row_errors(hip, ref, np.ones(total.P, bool), scene=(g, cam))
+    rob = total.visible & total.robust
+    assert rob.sum() > 0.4 * total.visible.sum(), f"{tag}: only {rob.sum()} of {total.visible.sum()} visible Gaussians are robust in every render"
+    for key, e in errs.items():
+        if key in skip:
+            continue
+        p999_bar, max_bar = gu.STRICT_ROW_BARS[key]
+        er = e[rob]
+        assert gu.rows_within(er, p999_bar, max_bar), \
+            f"{tag} {key}: robust rows p99.9 {np.quantile(er, 0.999):.2e} (bar {p999_bar:.1e}), max {er.max():.2e} (bar {max_bar:.1e})"
+        r = ref.get(key + "64", ref.get(key)); a = np.asarray(hip[key], np.float64).reshape(total.P, -1)
+        loose = np.abs(a - r).max(1) / (np.abs(r).max() + 1e-30)
+        assert loose[total.visible & ~rob].max(initial=0.0) <= bar("nonrobust_row_cap"), f"{tag} {key}: a non-robust row is off by {loose[total.visible & ~rob].max():.2e} of the tensor scale"
+        assert not np.abs(a[~total.visible]).any(), f"{tag} {key}: gradient on an invisible Gaussian"
+
+
+def _leaves(g, extra=()):
+    t = {k: g[k].to(gu.DEV).clone().requires_grad_() for k in ("means3D", "opacities", "scales", "rotations") + tuple(extra)}
+    t["means2D"] = torch.zeros(g["means3D"].shape[0], 3, device=gu.DEV, requires_grad=True)
+    return t
+
+
+@pytest.mark.parametrize("tile", [(16, 16), (8, 8), (32, 16)])
+def test_class_distortions_against_the_float64_oracle_on_each_class_subset(tile):
+    cam, g, cls, gd = _scene(tile)
+    t = _leaves(g)
+    dist, radii = GaussianRasterizer(gu.settings_for(cam, np.zeros(3, np.float32), 0), tile=None if tile == (16, 16) else tile).class_distortions(
+        t["means3D"], t["means2D"], t["opacities"], t["scales"], t["rotations"], cls.to(gu.DEV), N_CLS)
+    (dist * gd.to(gu.DEV)).sum().backward()
+    torch.cuda.synchronize()
+    total = _Sum(g)
+    refs = _class_references(g, cam, tile, cls, gd, total)
+    _check_maps(dist.detach().cpu().numpy(), radii.cpu().numpy(), refs, f"class pass {tile}")
+    in_no_class = ((cls < 0) | (cls >= N_CLS)).numpy()
+    grads = {n: (v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy() for n, v in t.items()}
+    for n, v in grads.items():
+        assert not np.abs(v[in_no_class]).any(), f"d{n}: a Gaussian in no class received a gradient"
+    _check_rows(grads, total, g, cam, f"class pass {tile}")
+
+
+@pytest.mark.parametrize("tile", [(16, 16), (32, 16)])
+def test_one_plan_training_view_against_the_float64_oracle(tile):
+    """forward_with_class_distortions (the 9-channel render and the class pass on ONE K1 / binning / K8): every output against the oracle,
+    the summed gradients against the float64 backward of the renders the reference would have run."""
+    cam, g, cls, gd = _scene(tile)
+    gen = torch.Generator().manual_seed(9)
+    cols = torch.rand(P, 6, generator=gen)
+    bg9 = torch.rand(9, generator=gen).numpy()
+    gc, ga = torch.randn(9, H, W, generator=gen), torch.randn(7, H, W, generator=gen)
+    t = _leaves(g, extra=("shs",))
+    c6 = cols.to(gu.DEV).clone().requires_grad_()
+    color, radii, allmap, dist = GaussianRasterizer(gu.settings_for(cam, bg9, 3), tile=None if tile == (16, 16) else tile).forward_with_class_distortions(
+        means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], classes=cls.to(gu.DEV),
+        n_classes=N_CLS, shs=t["shs"], extra_colors=c6)
+    torch.autograd.backward([color, allmap, dist], [gc.to(gu.DEV), ga.to(gu.DEV), gd.to(gu.DEV)])
+    torch.cuda.synchronize()
+    total = _Sum(g)
+    # the SH render with the allmap gradients
+    base, _ = gu.run_oracle(g, cam, bg9[:3], 3, tile=tile)
+    fwd64, bwd64, margins = gu.free_f64_reference(g, cam, bg9[:3], 3, gc[:3].contiguous(), ga, tile=tile, base=base)
+    total.add(None, fwd64, bwd64, margins)
+    hip = dict(color=color[:3].detach().cpu().numpy(), allmap=allmap.detach().cpu().numpy())
+    gu.assert_free_parity(hip, None, fwd64, None, margins, tag=f"one plan {tile} SH render ")
+    np.testing.assert_array_equal(radii.cpu().numpy(), fwd64["radii"])
+    dsh64 = np.asarray(bwd64.get("dL_dsh64", bwd64["dL_dsh"]), np.float64)
+    # the six extra channels: two precomputed-colour renders, colour gradients only
+    dcol64 = []
+    for half in range(2):
+        c3 = cols[:, 3 * half:3 * half + 3].contiguous().numpy()
+        b3 = bg9[3 + 3 * half:6 + 3 * half]
+        pb, _ = gu.run_oracle(g, cam, b3, 0, colors=c3, tile=tile)
+        pf, pbw, pm = gu.free_f64_reference(g, cam, b3, 0, gc[3 + 3 * half:6 + 3 * half].contiguous(), torch.zeros(7, H, W), colors=c3, tile=tile, base=pb)
+        total.add(None, pf, pbw, pm)
+        got = color[3 + 3 * half:6 + 3 * half].detach().cpu().numpy()
+        err = np.abs(got.astype(np.float64) - pf["color"]) / (1.0 + np.abs(pf["color"])) - pm.get("value_noise", 0.0)
+        rob = np.broadcast_to(pm["pixel"] > 1.0, err.shape)
+        assert err[rob].max(initial=0.0) <= bar("robust_pixel") and err[~rob].max(initial=0.0) <= bar("nonrobust_pixel_cap"), f"one plan {tile}: extra channels {half}"
+        dcol64.append(np.asarray(pbw.get("dL_dcolors64", pbw["dL_dcolors"]), np.float64))
+    refs = _class_references(g, cam, tile, cls, gd, total)
+    _check_maps(dist.detach().cpu().numpy(), radii.cpu().numpy(), refs, f"one plan {tile}")
+    grads = {n: (v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy() for n, v in t.items()}
+    _check_rows(grads, total, g, cam, f"one plan {tile}")
+    # colour-side gradients: each comes from one render only
+    vis = fwd64["radii"] > 0
+    rob = vis & total.robust
+    for name, got, ref in [("dL_dsh", t["shs"].grad.cpu().numpy(), dsh64), ("dL_dextra", c6.grad.cpu().numpy(), np.concatenate(dcol64, 1))]:
+        e = gu.row_errors(got, ref, np.ones(P, bool))
+        assert gu.rows_within(e[rob], bar("row_p999"), bar("row_max")), f"one plan {tile} {name}: robust rows p99.9 {np.quantile(e[rob], 0.999):.2e}, max {e[rob].max():.2e}"

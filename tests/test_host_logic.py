@@ -485,3 +485,39 @@ def test_posed_scene_and_rig_are_what_they_say():
     for c in rig[1:]:
         zc = (torch.cat([gr["means3D"].double(), torch.ones(P, 1, dtype=torch.float64)], 1) @ c.world_view_transform.double())[:, 2]
         assert float((zc > 0.2).double().mean()) > 0.98          # moved sideways / backwards, never into the scene
+
+
+def test_per_semantics_cache_hits_across_the_views_the_upstream_getter_returns():
+    """The upstream model's `get_semantics` is `self._semantics.squeeze(-1)`: a NEW view object per call [REF scene/gaussian_model.py:126].
+    The cache of the derived class encodings must hit across such views, miss after an in-place change or a new parameter (densification),
+    and never hold more than one entry per kind."""
+    import torch
+    from streetunveiler_amd import gaussian_renderer as gr
+
+    class Model:
+        def __init__(self, n):
+            self._semantics = torch.randint(0, 6, (n, 1))
+
+        @property
+        def get_semantics(self):
+            return self._semantics.squeeze(-1)
+
+    gr._SEM_CACHE.clear()
+    m = Model(500)
+    a, b = m.get_semantics, m.get_semantics
+    assert a is not b
+    made = []
+    make = lambda: made.append(1) or torch.zeros(1)
+    v1 = gr._per_semantics(a, ("probe", 6), make)
+    v2 = gr._per_semantics(b, ("probe", 6), make)
+    assert v1 is v2 and len(made) == 1, "a second view of the same parameter must hit"
+    del gr._SEM_CACHE["probe"]
+    oh = gr._one_hot_classes(m.get_semantics, 6)
+    assert oh.shape == (500, 6) and torch.equal(oh.argmax(1), m._semantics.squeeze(-1)) and gr._one_hot_classes(m.get_semantics, 6) is oh
+    m._semantics[3, 0] = (m._semantics[3, 0] + 1) % 6                      # in-place edit: version bump
+    oh2 = gr._one_hot_classes(m.get_semantics, 6)
+    assert oh2 is not oh and torch.equal(oh2.argmax(1), m._semantics.squeeze(-1))
+    m._semantics = torch.cat([m._semantics, torch.randint(0, 6, (40, 1))])   # densification: a new parameter
+    assert gr._one_hot_classes(m.get_semantics, 6).shape == (540, 6)
+    assert set(gr._SEM_CACHE) == {"one_hot"}, "one entry per kind: nothing stale stays alive"
+    gr._SEM_CACHE.clear()
