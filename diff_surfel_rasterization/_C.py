@@ -86,7 +86,8 @@ def _stream(device):
 
 
 def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile=None,
-           quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=None, forward_only=False, no_precomp_color_grad=False):
+           quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=None, forward_only=False, no_precomp_color_grad=False,
+           binning_capacity=None):
     keep = [_f32c(bg, "bg"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos"), blend_counters]
     if blend_counters is not None and (blend_counters.dtype != torch.int64 or blend_counters.numel() < 16 or not blend_counters.is_cuda):
         raise L.SurfelRasterError("blend_counters must be a CUDA (ROCm) int64 tensor with 16 entries")
@@ -94,7 +95,8 @@ def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W,
                    int(bool(prefiltered)), int(bool(debug)), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
                    int(tile[0]) if tile else 0, int(tile[1]) if tile else 0, (0 if quadrant_cull else L.SR_FLAG_NO_QUADRANT_CULL) | (L.SR_FLAG_BALLOT_RANKING if ballot_ranking else 0) |
                    (0 if row_mapped is None else (L.SR_FLAG_ROW_MAPPED_FORWARD if row_mapped else L.SR_FLAG_QUADRANT_MAPPED_FORWARD)) |
-                   (L.SR_FLAG_FORWARD_ONLY if forward_only else 0) | (L.SR_FLAG_NO_PRECOMP_COLOR_GRAD if no_precomp_color_grad else 0),
+                   (L.SR_FLAG_FORWARD_ONLY if forward_only else 0) | (L.SR_FLAG_NO_PRECOMP_COLOR_GRAD if no_precomp_color_grad else 0) |
+                   (L.SR_FLAG_BINNING_CAPACITY if binning_capacity is not None else 0),
                    _ptr(blend_counters))
     return fr, keep
 
@@ -136,7 +138,7 @@ def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transM
 def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, activations=0, tile=None, mask=None, quadrant_cull=True, blend_counters=None,
-                        ballot_ranking=False, row_mapped=None, forward_only=False, classes=None, n_classes=0):
+                        ballot_ranking=False, row_mapped=None, forward_only=False, classes=None, n_classes=0, binning_capacity=None):
     """`classes` [P] integer tensor + `n_classes` (extension, SURVEY 8f N1 in full): the per-class distortion pass runs on the plan AND the
     binning of this very render (sr_class_forward_shared); the return tuple then ends with (dist[n_classes,H,W], class_state) and
     rasterize_gaussians_backward takes `class_state` / `dL_ddist` to return the gradients of colour, allmap and distortion maps from ONE K8.
@@ -149,7 +151,12 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
     per-call SrFrame.flags / SrFrame.blend_counters (tests and profiling; results are identical).  `ballot_ranking=True`
     (SR_FLAG_BALLOT_RANKING): the binning of this call ranks with match-any ballots, the fallback of the LDS-atomic ranking.
     `row_mapped=True` / `False` (SR_FLAG_ROW_MAPPED_FORWARD / SR_FLAG_QUADRANT_MAPPED_FORWARD): force one of the two forward blend kernels
-    (bit-identical results); None: the device picks per frame."""
+    (bit-identical results); None: the device picks per frame.
+    `binning_capacity=N` (SR_FLAG_BINNING_CAPACITY, round 6): the forward WITHOUT the host read-back of D -- the binning buffer is sized for N
+    duplicates, the returned `num_rendered` is N (hand it to the backward as usual, with the same `binning_capacity`), nothing in the call
+    waits for the GPU, and the whole call can be captured into a HIP graph.  Whether the frame fitted is decided on the device:
+    `forward_status(geom, P)` -> device int32 [D, visible, overflow]; overflow = 1 means nothing was rendered (background image, zero gradients) and
+    the frame has to be rendered again with at least D items.  Results of a frame that fits are bit-identical to the default mode."""
     lib = L.load()
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise L.SurfelRasterError("means3D must have dimensions (num_points, 3)")
@@ -160,8 +167,10 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
     dev = means3D.device
     P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
     with torch.cuda.device(dev), _range("forward"):
+        if binning_capacity is not None and (classes is not None or int(binning_capacity) < 0):
+            raise L.SurfelRasterError("binning_capacity: a non-negative number of duplicates; not with the shared-plan class pass")
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile,
-                          quadrant_cull, blend_counters, ballot_ranking, row_mapped, forward_only)
+                          quadrant_cull, blend_counters, ballot_ranking, row_mapped, forward_only, binning_capacity=binning_capacity)
         mask = _mask(mask, P, dev)
         g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations, mask)
         if keep[0].numel() != g.color_channels:
@@ -175,7 +184,7 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
         D = C.c_uint32(0)
         L.check(lib.sr_forward_plan(C.byref(fr), C.byref(g), _ptr(geom), geom.numel(), _ptr(radii), C.byref(D), stream),
                 "sr_forward_plan")
-        num_rendered = int(D.value)
+        num_rendered = int(D.value) if binning_capacity is None else (max(1, int(binning_capacity)) if P else 0)
         binning = torch.empty((lib.sr_binning_bytes(P, num_rendered, W, H),), dtype=torch.uint8, device=dev)
         L.check(lib.sr_forward_render(C.byref(fr), C.byref(g), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                       _ptr(img), img.numel(), num_rendered, _ptr(color), _ptr(allmap), stream),
@@ -200,8 +209,11 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
 def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap, sh, degree, campos,
                                  geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None, defer_sh=False,
-                                 activations=0, tile=None, after_blend=None, class_state=None, dL_ddist=None, n_classes=0, want_precomp_color_grad=True):
+                                 activations=0, tile=None, after_blend=None, class_state=None, dL_ddist=None, n_classes=0, want_precomp_color_grad=True,
+                                 binning_capacity=None):
     """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry.
+
+    `binning_capacity`: the value the forward was given (then `num_rendered` is that capacity): SR_FLAG_BINNING_CAPACITY for the backward too.
 
     `want_precomp_color_grad=False` (6 / 9 colour channels): dL/dcolors_precomp is not wanted (SR_FLAG_NO_PRECOMP_COLOR_GRAD; an empty
     tensor comes back for it) -- what the autograd shim passes when colors_precomp / extra_colors does not require grad.
@@ -223,7 +235,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
     with torch.cuda.device(dev), _range("backward"):
         skip_cg = (not want_precomp_color_grad) and _channels(colors_precomp) == 6   # ([P,6] precomputed channels: the 6- and the 9-channel pass)
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, False, debug, tile,
-                          no_precomp_color_grad=skip_cg)
+                          no_precomp_color_grad=skip_cg, binning_capacity=binning_capacity)
         # the backward never dereferences opacities (it reads the packed record); pass means3D as a non-NULL stand-in
         g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp, activations)
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -313,7 +325,7 @@ def class_distortions(bg, means3D, classes, opacities, scales, rotations, scale_
         stream = _stream(dev)
         D = C.c_uint32(0)
         L.check(lib.sr_forward_plan(C.byref(fr), C.byref(g), _ptr(geom), geom.numel(), _ptr(radii), C.byref(D), stream), "sr_forward_plan")
-        num_rendered = int(D.value)
+        num_rendered = int(D.value) if binning_capacity is None else (max(1, int(binning_capacity)) if P else 0)
         binning = torch.empty((lib.sr_binning_bytes(P, num_rendered, W, H),), dtype=torch.uint8, device=dev)
         L.check(lib.sr_class_forward_render(C.byref(fr), C.byref(g), int(n_classes), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                             _ptr(cimg), cimg.numel(), num_rendered, _ptr(dist), stream), "sr_class_forward_render")
@@ -395,6 +407,15 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 def _view(buf: torch.Tensor, ptr, nbytes: int, dtype: torch.dtype) -> torch.Tensor:
     off = int(ptr) - buf.data_ptr()
     return buf[off:off + nbytes].view(dtype)
+
+
+def forward_status(geom: torch.Tensor, P: int) -> torch.Tensor:
+    """Device int32 [3] view into the geometry state: [D (the frame's duplicates), visible Gaussians, overflow].  The third word is written
+    by the capacity guard of a `binning_capacity` forward (1 = the frame did not fit: nothing was rendered -- and `visible` was zeroed).  Reading
+    it on the host (`.tolist()`) is the caller's choice of when to synchronise."""
+    v = L.SrGeomView()
+    L.check(L.load().sr_geom_view(_ptr(geom), geom.numel(), int(P), C.byref(v)), "sr_geom_view")
+    return _view(geom, v.frame_counts, 12, torch.int32)
 
 
 def geom_view(geom: torch.Tensor, P: int):

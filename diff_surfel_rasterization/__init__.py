@@ -65,8 +65,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             fused["tile"] = ctx.tile
         if mask is not None:   # only the forward looks at it: masked-out Gaussians get radius 0 and, with that, zero gradients
             fused["mask"] = mask
+        status_holder = None
         if probe:              # tests / profiling: {"quadrant_cull": bool, "blend_counters": int64[16] device tensor, "ballot_ranking": bool}
+            probe = dict(probe)
+            status_holder = probe.pop("_status", None)
             fused.update(probe)
+        ctx.binning_capacity = fused.get("binning_capacity")
         if forward_only and not (probe and "blend_counters" in probe):   # SR_FLAG_FORWARD_ONLY: no backward will follow -- images bit-identical, backward state not written (the counting variant keeps the full forward)
             fused["forward_only"] = True
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix,
@@ -83,6 +87,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             out = _C.rasterize_gaussians(*args, **fused)
         num_rendered, color, allmap, radii, geomBuffer, binningBuffer, imgBuffer = out
+        if status_holder is not None:
+            status_holder["status"] = _C.forward_status(geomBuffer, means3D.shape[0]) if means3D.shape[0] else None
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
         # frame-parallel ranks may exchange the SH gradient in factored form (streetunveiler_amd.parallel): the exchange of the enclosing
@@ -121,6 +127,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             kwargs["activations"] = ctx.activations
         if ctx.tile:
             kwargs["tile"] = ctx.tile
+        if ctx.binning_capacity is not None:
+            kwargs["binning_capacity"] = ctx.binning_capacity
         if colors_precomp.numel() and not ctx.needs_input_grad[3]:
             kwargs["want_precomp_color_grad"] = False   # (constant colours -- render_semantic's one-hot channels: K7 skips their sums)
         if s.debug:
@@ -217,8 +225,14 @@ class _ClassDistortions(torch.autograd.Function):
 
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False, tile=None, quadrant_cull: bool = True,
-                 blend_counters=None, ballot_ranking: bool = False, row_mapped=None):
-        """`fused_activations=True` (extension): `opacities`, `scales`, `rotations` are the RAW parameters
+                 blend_counters=None, ballot_ranking: bool = False, row_mapped=None, binning_capacity=None):
+        """`binning_capacity=N` (extension, round 6: SR_FLAG_BINNING_CAPACITY): the operator WITHOUT the host read-back of the frame's
+        duplicate count between the emission scan and the binning [the reference waits there too: SURVEY.md 7 step 4] -- the binning buffer
+        is sized for N duplicates (e.g. 1.25 x the largest count seen: `last_status`), nothing in forward or backward waits for the GPU, and
+        the whole step can be captured into a HIP graph.  Whether the frame fitted is decided on the device: after a call `self.last_status`
+        is a device int32 [D, visible, overflow]; overflow = 1 means nothing was rendered (background image, zero gradients) and the frame
+        must be rendered again with N >= D.  A frame that fits is bit-identical to the default mode.
+        `fused_activations=True` (extension): `opacities`, `scales`, `rotations` are the RAW parameters
         (`_opacity`, `_scaling`, `_rotation` of the reference's GaussianModel); sigmoid / exp / normalize run inside the
         preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values.
         `tile=(w, h)`: binning tile shape, default the reference's compile-time 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
@@ -240,6 +254,9 @@ class GaussianRasterizer(nn.Module):
             self.probe["ballot_ranking"] = True
         if row_mapped is not None:
             self.probe["row_mapped"] = bool(row_mapped)
+        if binning_capacity is not None:
+            self.probe["binning_capacity"] = int(binning_capacity)
+        self.last_status = None   # binning_capacity mode: device int32 [D, visible, overflow] of the last forward (a view into its state)
 
     def markVisible(self, positions):
         with torch.no_grad():
@@ -294,5 +311,11 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        if "binning_capacity" in self.probe:
+            holder = {}
+            out = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s,
+                                      self.activations, self.tile, mask, dict(self.probe, _status=holder))
+            self.last_status = holder.get("status")
+            return out
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s,
                                    self.activations, self.tile, mask, self.probe or None)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 9
+#define SR_ABI_VERSION 10
 #define SR_TILE 16            /* default 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y); see SrFrame.tile_width */
 #define SR_SPLAT_FLOATS 20    /* floats per packed splat record (80 B) */
 #define SR_GRAD_FLOATS 24     /* floats per gradient record (96 B) */
@@ -120,6 +120,19 @@ typedef struct SrFrame {
                                       * (SrGradients.dL_dcolors NULL) -- the one-hot class channels of render_semantic are constants -- so K7 does not
                                       * form those sums (the channels still feed dL/dalpha); every other gradient is unchanged */
 
+#define SR_FLAG_BINNING_CAPACITY 64u  /* the forward WITHOUT its host read-back (round 6).  By default sr_forward_plan waits once for D, the frame's duplicate
+                                      * count, because the caller sizes the binning buffer from it -- as the reference does.  With this flag, set in EVERY call of
+                                      * the frame (plan, render, backward):
+                                      *   - sr_forward_plan queues K1, the scan and the depth sort and returns at once; *num_rendered_host = 0xFFFFFFFF;
+                                      *   - `num_rendered` of sr_forward_render / sr_binning_bytes / sr_backward* / sr_backward_workspace_bytes is the CAPACITY (in
+                                      *     duplicates) the caller chose for the binning buffer and the workspace -- e.g. 1.25 x the largest D it has seen;
+                                      *   - a one-thread guard kernel compares the frame's D with the capacity on the device.  It fits: results bit-identical to
+                                      *     the default mode.  It does not: nothing is binned, the images hold the background, every gradient is zero, no kernel reads or
+                                      *     writes beyond the buffers, and SrGeomView.frame_counts[2] = 1 -- the caller looks at that word when it next synchronises
+                                      *     anyway (frame_counts[0] = the exact D) and renders the frame again with a larger buffer.
+                                      * No pinned memory, event or host wait is touched: the whole forward + backward can be captured into a HIP graph.
+                                      * Not for the per-class passes (SR_ERR_UNSUPPORTED). */
+
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
  * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp
  * and exactly one of (scales, rotations) / transMat_precomp must be non-NULL. */
@@ -166,7 +179,8 @@ typedef struct SrGeomView {
     const uint8_t* clamped;        /* [P] bit c set when SH colour channel c was clamped at 0 */
     const uint32_t* sorted_gid;    /* the frame_counts[1] visible Gaussians' ids in ascending (depth bits, id) order (room for P; culled ones are dropped) */
     const uint32_t* frame_counts;  /* [2] D (= *num_rendered_host of sr_forward_plan) and the number of Gaussians with at least one tile: what
-                                    * the forward blend picks its mapping by (SR_FLAG_ROW_MAPPED_FORWARD) */
+                                    * the forward blend picks its mapping by (SR_FLAG_ROW_MAPPED_FORWARD).  With SR_FLAG_BINNING_CAPACITY: [3] -- after
+                                    * sr_forward_render [2] = 1 if D exceeded the capacity (and [1] was zeroed: nothing was rendered), else 0 */
 } SrGeomView;
 
 typedef struct SrBinningView {

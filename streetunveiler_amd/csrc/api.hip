@@ -35,6 +35,7 @@ hipError_t run_expand_columns(int P, int tiles_x, int n_tiles, const uint2* rect
 hipError_t run_expand_rows(uint32_t D, int tiles_x, int tiles_y, const uint2* columns, const uint32_t* n_columns, uint32_t* hist, uint32_t* row_total,
                            uint32_t* point_list, uint32_t* tile_counts, int rank_mode, hipStream_t s);
 hipError_t run_tile_ranges_order(int n_tiles, const uint32_t* tile_counts, uint2* ranges, uint32_t* order, hipStream_t s);
+hipError_t run_capacity_guard(uint32_t* counts, uint32_t capacity, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint16_t* hit_mask, int flags,
@@ -328,6 +329,7 @@ FrameDev make_frame(const SrFrame* frame, const SrGaussians* g) {
     f.activations = g->activations;
     f.scale_modifier = frame->scale_modifier;
     f.bg = frame->bg; f.view = frame->viewmatrix; f.proj = frame->projmatrix; f.campos = frame->campos;
+    f.overflow = nullptr;   // (set by the backward entry points in capacity mode)
     return f;
 }
 
@@ -406,6 +408,23 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     // between the scan and the host's wake-up -- else a DMA copy does.
     int sort_mode = kRankUnknown;
     if (int rc = rank_mode(s, (frame->flags & SR_FLAG_BALLOT_RANKING) != 0, &sort_mode)) return rc;   // (first call on a device: ~20 us self-check)
+    if (frame->flags & SR_FLAG_BINNING_CAPACITY) {
+        // the sync-free forward: D stays on the device (SrGeomView.frame_counts); no pinned word, no event, no host wait -- nothing in this
+        // call that a stream capture could not record
+        {
+            StageTimer t(SR_STAGE_SCAN, s);
+            SR_HIP(run_tile_count_scan(P, at<uint32_t>(geom, L.tiles_touched), at<uint32_t>(geom, L.first), at<void>(geom, L.block_base), L.base_bytes, nullptr, s));
+        }
+        if (int rc = debug_sync(frame, s, "emission_scan")) return rc;
+        {
+            StageTimer t(SR_STAGE_DEPTH_SORT, s);
+            SR_HIP(run_depth_sort(P, at<uint32_t>(geom, L.depth_keys), at<uint2>(geom, L.rect), at<uint32_t>(geom, L.sorted_keys),
+                                  at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, sort_mode,
+                                  f.tiles_x, f.tiles_y, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks + 1, s));
+        }
+        *num_rendered_host = 0xFFFFFFFFu;   // unknown to the host
+        return debug_sync(frame, s, "depth_sort");
+    }
     uint32_t* pinned = pinned_words();
     uint32_t* pinned_dev = nullptr;
     if (pinned && (hipHostGetDevicePointer(reinterpret_cast<void**>(&pinned_dev), pinned, 0) != hipSuccess)) pinned_dev = nullptr;
@@ -461,6 +480,8 @@ int bin_duplicates(const SrFrame* frame, const SrGaussians* g, const FrameDev& f
         if (L.temp_bytes < expand_x_hist_bytes(P, f.tiles_x)) return fail(SR_ERR_BUFFER_TOO_SMALL, "geom scratch too small for the column histogram");
         int sort_mode = kRankUnknown;
         if (int rc = rank_mode(s, (frame->flags & SR_FLAG_BALLOT_RANKING) != 0, &sort_mode)) return rc;
+        if (frame->flags & SR_FLAG_BINNING_CAPACITY)   // D = the caller's capacity: does the frame fit?  (else: nothing is binned, the flag is set)
+            SR_HIP(run_capacity_guard(at<uint32_t>(geom, L.block_base) + L.n_scan_blocks, D, s));
         {
             StageTimer t(SR_STAGE_EXPAND_X, s);
             SR_HIP(run_expand_columns(P, f.tiles_x, n_tiles, at<uint2>(geom, L.rect_sorted), at<uint32_t>(geom, L.sorted_gid), at<uint2>(binning, B.columns),
@@ -503,6 +524,7 @@ ClassLayout class_layout(int W, int H, int n_classes) {
 
 int check_class_pass(const SrFrame* frame, const SrGaussians* g, int n_classes) {
     if (int rc = check_common(frame, g)) return rc;
+    if (frame->flags & SR_FLAG_BINNING_CAPACITY) return fail(SR_ERR_UNSUPPORTED, "SR_FLAG_BINNING_CAPACITY serves the operator (sr_forward_* / sr_backward*), not the per-class pass");
     if (n_classes < 1 || n_classes > 6) return fail(SR_ERR_UNSUPPORTED, "n_classes %d not in 1..6", n_classes);
     const int tw = frame->tile_width > 0 ? frame->tile_width : kTile, th = frame->tile_height > 0 ? frame->tile_height : kTile;
     (void)tw; (void)th;   // (every tile shape check_common accepts: 8x8, 16x8, 16x16, 32x8, 32x16)
@@ -634,6 +656,7 @@ size_t sr_class_shared_bytes(int32_t P, int32_t W, int32_t H, int32_t n_classes,
 int sr_class_forward_shared(const SrFrame* frame, const SrGaussians* g, int32_t n_classes, const int32_t* classes, void* geom, size_t geom_bytes,
                             void* binning, size_t binning_bytes, void* class_state, size_t class_state_bytes, uint32_t D, float* out_dist, void* stream) {
     if (int rc = check_common(frame, g)) return rc;
+    if (frame->flags & SR_FLAG_BINNING_CAPACITY) return fail(SR_ERR_UNSUPPORTED, "SR_FLAG_BINNING_CAPACITY serves the operator (sr_forward_* / sr_backward*), not the per-class pass");
     if (n_classes < 1 || n_classes > 6) return fail(SR_ERR_UNSUPPORTED, "n_classes %d not in 1..6", n_classes);
     if (!binning || !class_state || !out_dist || (g->P > 0 && !classes)) return fail(SR_ERR_INVALID_ARGUMENT, "binning / class_state / out_dist / classes is NULL");
     if (g->transMat_precomp) return fail(SR_ERR_UNSUPPORTED, "the per-class pass takes scales and rotations, not a precomputed transMat");
@@ -670,6 +693,7 @@ int sr_class_backward_shared(const SrFrame* frame, const SrGaussians* g, int32_t
                              size_t binning_bytes, void* class_state, size_t class_state_bytes, uint32_t D, const float* dL_ddist, void* workspace,
                              size_t workspace_bytes, void* stream) {
     if (int rc = check_common(frame, g)) return rc;
+    if (frame->flags & SR_FLAG_BINNING_CAPACITY) return fail(SR_ERR_UNSUPPORTED, "SR_FLAG_BINNING_CAPACITY serves the operator (sr_forward_* / sr_backward*), not the per-class pass");
     if (int rc = check_backward_frame(frame)) return rc;
     if (n_classes < 1 || n_classes > 6) return fail(SR_ERR_UNSUPPORTED, "n_classes %d not in 1..6", n_classes);
     const int P = g->P;
@@ -717,6 +741,7 @@ int backward_ctx(const SrFrame* frame, const SrGaussians* g, void* geom, size_t 
     c->s = static_cast<hipStream_t>(stream);
     c->f = make_frame(frame, g);
     c->f.first = at<uint32_t>(geom, c->L.first); c->f.first_base = at<uint32_t>(geom, c->L.block_base); c->f.sh_jac = at<float>(geom, c->L.sh_jac);
+    if (frame->flags & SR_FLAG_BINNING_CAPACITY) c->f.overflow = at<uint32_t>(geom, c->L.block_base) + c->L.n_scan_blocks + 2;   // (frame_counts[2])
     // per-(tile, Gaussian) gradient records in emission order (a Gaussian's duplicates are contiguous).  K7 writes a record --
     // and sets the slot's byte in `written` -- only where some pixel contributed; K8 looks at the byte before it touches the
     // record, so neither the records nor anything but these D bytes need clearing.
@@ -758,6 +783,7 @@ int sr_backward_colors(const SrFrame* frame, const SrGaussians* g, const int32_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     FrameDev f = make_frame(frame, g);
     f.first = at<uint32_t>(geom, L.first); f.first_base = at<uint32_t>(geom, L.block_base); f.sh_jac = at<float>(geom, L.sh_jac);
+    if (frame->flags & SR_FLAG_BINNING_CAPACITY) f.overflow = at<uint32_t>(geom, L.block_base) + L.n_scan_blocks + 2;
     const uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(g->color_channels), 256);
     StageTimer t(SR_STAGE_PREPROCESS_BWD, s);
     SR_HIP(launch_color_gradients(P, f, radii, at<uint8_t>(geom, L.clamped), at<float4>(geom, L.recs), static_cast<const float4*>(workspace), written,

@@ -492,6 +492,21 @@ hipError_t run_expand_rows(uint32_t D, int tiles_x, int tiles_y, const uint2* co
     return hipGetLastError();
 }
 
+// SR_FLAG_BINNING_CAPACITY (the forward without its host read-back): the caller sized the binning buffer from a GUESS of the frame's
+// duplicate count.  counts = [D, visible Gaussians, overflow] in the geometry state (the emission scan's totals; the third word was a
+// per-block count the scan is done with).  If the frame's D exceeds the capacity, the visible count is zeroed -- pass X takes its item
+// count from that word, so nothing is emitted, no list is built, the blend writes the background -- and the overflow word is set: the
+// caller finds out when it next looks (sr_geom_view: frame_counts[2]) and renders that frame again with a buffer of D items.
+__global__ void capacity_guard_kernel(uint32_t* __restrict__ counts, uint32_t capacity) {
+    const uint32_t over = counts[0] > capacity ? 1u : 0u;
+    counts[2] = over;
+    if (over) counts[1] = 0u;
+}
+hipError_t run_capacity_guard(uint32_t* counts, uint32_t capacity, hipStream_t s) {
+    hipLaunchKernelGGL(capacity_guard_kernel, dim3(1), dim3(1), 0, s, counts, capacity);
+    return hipGetLastError();
+}
+
 hipError_t run_tile_ranges_order(int n_tiles, const uint32_t* tile_counts, uint2* ranges, uint32_t* order, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(tile_ranges_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, tile_counts, ranges, order);

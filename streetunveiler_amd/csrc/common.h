@@ -61,6 +61,10 @@ struct FrameDev {
     const uint32_t* first;
     const uint32_t* first_base;
     float* sh_jac;   // [P][9] d rgb / d centre through the SH view direction (geom buffer; K1 writes it, K8 reads it instead of the SH rows)
+    // SR_FLAG_BINNING_CAPACITY (the sync-free forward): the word the capacity guard sets when the frame's duplicates did not fit the
+    // caller's binning buffer (nothing was binned or blended then); the per-Gaussian backward kernels treat every Gaussian as invisible --
+    // zero gradients, no read beyond the buffers.  NULL in the default (read-back) mode.
+    const uint32_t* overflow;
 };
 constexpr int kScanTile = 2048;   // Gaussians per block of the emission-offset scan
 __device__ __forceinline__ uint32_t first_index(const FrameDev& f, uint32_t gid) { return f.first[gid] + f.first_base[gid / kScanTile]; }

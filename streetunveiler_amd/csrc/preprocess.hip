@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_backward_kernel(
     if (i < P) {
         float g_means3D[3] = {0, 0, 0}, g_scales[2] = {0, 0}, g_rot[4] = {0, 0, 0, 0}, g_m2d[2] = {0, 0};
         float dT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dTr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_col[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g_opa = 0.f;
-        const bool vis = radii[i] > 0;
+        const bool vis = radii[i] > 0 && !(f.overflow && *f.overflow);   // (capacity mode, overflowed frame: nothing was rendered)
         float* dsh_g = (!kLdsSH && out.dL_dsh) ? out.dL_dsh + (size_t)i * M * 3 : nullptr;
         float* row = s_sh + tid * kShLdsStride;
         if (vis) {
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void color_gradient_kernel(int P, const int32_
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    if (radii[i] > 0) {
+    if (radii[i] > 0 && !(f.overflow && *f.overflow)) {
         const uint32_t first = first_index(f, (uint32_t)i), end = first + tiles_touched[i];
         // four slots per trip, the next trip's flags in flight behind this trip's records (as in K8; same ascending order of the adds)
         constexpr int kTrip = 4;

@@ -437,7 +437,7 @@ def assert_free_parity(hip, hip_n_contrib, fwd64, bwd64, margins, tag="", report
         return
     vis = fwd64["radii"] > 0
     rob_g = vis & (margins["gaussian"] > 1.0)
-    frac = 1.0 - rob_g.sum() / max(1, vis.sum())
+    frac = 1.0 - rob_g.sum() / max(1, vis.sum()) if vis.any() else 0.0   # (a frame with no visible Gaussian has no non-robust one)
     assert frac <= gaussian_budget, f"{tag}: {frac:.2f} of the visible Gaussians are non-robust"
     errs = gradient_row_errors(hip, bwd64, np.ones_like(vis), scene)
     errs32 = {} if oracle32 is None else gradient_row_errors({k: (v if hip.get(k) is not None else None) for k, v in oracle32.items()}, bwd64,

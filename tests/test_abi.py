@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_sizes(lib):
-    assert lib.sr_abi_version() == 9
+    assert lib.sr_abi_version() == 10
     # pure host arithmetic (no GPU): image state = 3 float planes + 2 u32 planes, 256-B aligned
     assert lib.sr_image_bytes(1920, 1080) >= 1920 * 1080 * 20
     assert lib.sr_backward_workspace_bytes(1000, 5000, 3) >= 5000 * 97

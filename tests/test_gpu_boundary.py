@@ -168,3 +168,95 @@ def test_backward_captures_into_a_hip_graph():
         torch.cuda.synchronize()
         for k, (a, b) in enumerate(zip(ref, out)):
             assert torch.equal(a, b), f"graph replay: gradient {k} differs from the eager call"
+
+
+def test_binning_capacity_forward_without_the_host_readback():
+    """SR_FLAG_BINNING_CAPACITY (round 6): the operator without the `num_rendered` read-back.  A capacity that holds the frame gives the
+    default mode's bits -- images, radii, every gradient -- and the device status [D, visible, 0]; a capacity that does not gives the
+    background, zero gradients, status[2] = 1 with the exact D in status[0], and touches nothing beyond its buffers."""
+    cam, g, dc, da = _scene(60_000, 640, 360, 71)
+    dc, da = dc.to(DEV), da.to(DEV)
+    bg = [0.1, 0.2, 0.3]
+
+    def step(**kw):
+        t = {k: g[k].to(DEV).requires_grad_() for k in NAMES}
+        m2 = torch.zeros(t["means3D"].shape[0], 3, device=DEV, requires_grad=True)
+        r = GaussianRasterizer(settings_for(cam, bg, 3), **kw)
+        color, radii, allmap = r(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], shs=t["shs"])
+        grads = torch.autograd.grad((color * dc).sum() + (allmap * da).sum(), [t[k] for k in NAMES] + [m2])
+        return dict(color=color.detach(), radii=radii, allmap=allmap.detach(), **{"d" + k: v for k, v in zip(NAMES + ("means2D",), grads)}), r
+
+    base, _ = step()
+    from tests.gpu_util import run_hip_raw
+    D = int(run_hip_raw(g, cam, bg, 3)["D"])
+    assert D > 100_000
+    got, r = step(binning_capacity=int(1.25 * D))
+    assert r.last_status.tolist()[0] == D and r.last_status.tolist()[2] == 0 and r.last_status.tolist()[1] == int((base["radii"] > 0).sum())
+    _same(base, got, "capacity 1.25 D")
+    got, r = step(binning_capacity=D)                 # exactly full
+    assert r.last_status.tolist() == [D, int((base["radii"] > 0).sum()), 0]
+    _same(base, got, "capacity D")
+    got, r = step(binning_capacity=D // 2)            # does not fit
+    st = r.last_status.tolist()
+    assert st[0] == D and st[2] == 1 and st[1] == 0, st
+    assert torch.equal(got["radii"], base["radii"])   # (K1 ran: the radii are the frame's)
+    want = torch.tensor(bg, device=DEV).view(3, 1, 1).expand_as(got["color"])
+    assert torch.equal(got["color"], want) and not got["allmap"].any(), "an overflowed frame must hold the background"
+    for k in got:
+        if k.startswith("d"):
+            assert not got[k].any(), f"an overflowed frame must have zero gradients ({k})"
+    # under no_grad (forward-only state) the same
+    with torch.no_grad():
+        t = {k: g[k].to(DEV) for k in NAMES}
+        r = GaussianRasterizer(settings_for(cam, bg, 3), binning_capacity=int(1.1 * D))
+        color, radii, allmap = r(means3D=t["means3D"], means2D=torch.zeros(t["means3D"].shape[0], 3, device=DEV), opacities=t["opacities"], scales=t["scales"],
+                                 rotations=t["rotations"], shs=t["shs"])
+    assert torch.equal(color, base["color"]) and torch.equal(allmap, base["allmap"]) and r.last_status.tolist()[2] == 0
+
+
+def test_whole_step_captures_into_a_hip_graph_with_a_binning_capacity():
+    """With a binning capacity the forward has no host wait either: forward AND backward are captured into ONE HIP graph (through `_C`, as
+    in the backward-only test above), and every replay -- also with new values in the same input tensors -- returns the eager bits."""
+    from diff_surfel_rasterization import _C
+    cam, g, dc, da = _scene(10_000, 256, 256, 61)
+    g = {k: v.to(DEV) for k, v in g.items()}
+    dc, da = dc.to(DEV), da.to(DEV)
+    s = settings_for(cam, [0., 0., 0.], 3)
+    e = torch.empty(0, device=DEV)
+    D0 = _C.rasterize_gaussians(s.bg, g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, s.viewmatrix, s.projmatrix,
+                                s.tanfovx, s.tanfovy, 256, 256, g["shs"], 3, s.campos, False, False)[0]
+    cap = int(1.5 * D0)
+
+    def whole(capacity):
+        kw = {} if capacity is None else dict(binning_capacity=capacity)
+        D, color, allmap, radii, geom, binning, img = _C.rasterize_gaussians(s.bg, g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, s.viewmatrix,
+                                                                             s.projmatrix, s.tanfovx, s.tanfovy, 256, 256, g["shs"], 3, s.campos, False, False, **kw)[:7]
+        grads = _C.rasterize_gaussians_backward(s.bg, g["means3D"], radii, e, g["scales"], g["rotations"], 1.0, e, s.viewmatrix, s.projmatrix,
+                                                s.tanfovx, s.tanfovy, dc, da, g["shs"], 3, s.campos, geom, D, binning, img, False, **kw)
+        return [color, allmap, radii] + [x for x in grads if x is not None and x.numel()], (_C.forward_status(geom, 10_000) if capacity is not None else None)
+
+    ref, _ = whole(None)
+    ref = [x.clone() for x in ref]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        whole(cap)                                    # warm-up on a side stream (rank self-check, allocator)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out, status = whole(cap)
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert status.tolist() == [D0, int((ref[2] > 0).sum()), 0]
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b), "graph replay differs from the eager step"
+    # new parameter values in the SAME tensors: the replay renders the new scene
+    with torch.no_grad():
+        g["opacities"].mul_(0.5); g["means3D"][:, 0].add_(0.05)
+    ref2, _ = whole(None)
+    ref2 = [x.clone() for x in ref2]
+    graph.replay(); torch.cuda.synchronize()
+    assert status.tolist()[2] == 0
+    for a, b in zip(ref2, out):
+        assert torch.equal(a, b), "graph replay on updated inputs differs from the eager step"
