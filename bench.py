@@ -518,11 +518,15 @@ def reference_operating_point_section(deg, dev, P=1_500_000, W=480, H=320, steps
         D = int(_C.rasterize_gaussians(s.bg, t["means3D"].detach(), e, t["opacities"].detach(), t["scales"].detach(), t["rotations"].detach(), 1.0, e, s.viewmatrix,
                                        s.projmatrix, s.tanfovx, s.tanfovy, H, W, t["shs"].detach(), deg, s.campos, False, False)[0])
     rc = GaussianRasterizer(s, binning_capacity=int(1.25 * D) + 1024)
+    ra = GaussianRasterizer(s, tile="auto")   # (600 tiles of 16x16 cannot fill the GPU's wave slots: resolve_tile picks 8x8 here)
     out["duplicates_D"] = D
     out["ms_per_step_default"] = round(timed(lambda: step(r0), steps), 4)
     out["ms_per_step_binning_capacity"] = round(timed(lambda: step(rc), steps), 4)
     out["overflowed"] = int(rc.last_status.tolist()[2])
-    out["msplats_per_s_binning_capacity"] = round(P / out["ms_per_step_binning_capacity"] / 1e3, 1)
+    out["tile_auto"] = list(ra.tile or (16, 16))
+    out["ms_per_step_tile_auto"] = round(timed(lambda: step(ra), steps), 4)
+    out["msplats_per_s_tile_auto"] = round(P / out["ms_per_step_tile_auto"] / 1e3, 1)
+    rc = ra   # per-stage ms of the recommended setting
     torch.cuda.synchronize(); lib.sr_set_stage_timing(1)
     for _ in range(3):
         step(rc)
@@ -530,7 +534,7 @@ def reference_operating_point_section(deg, dev, P=1_500_000, W=480, H=320, steps
     st = _lib.stage_stats(); lib.sr_set_stage_timing(0)
     out["stage_ms"] = {k: round(ms / max(n, 1), 4) for k, (ms, n) in st.items() if n}
     out["stage_ms_sum"] = round(sum(out["stage_ms"].values()), 4)
-    del t, m2, dc, da, r0, rc
+    del t, m2, dc, da, r0, rc, ra
     # ---- the forward's floor on a small frame: 10 k Gaussians, 256x256, under no_grad (an inference loop)
     s, t, m2, dc, da = scene(10_000, 256, 256)
     args_ = lambda: (s.bg, t["means3D"].detach(), e, t["opacities"].detach(), t["scales"].detach(), t["rotations"].detach(), 1.0, e, s.viewmatrix, s.projmatrix,

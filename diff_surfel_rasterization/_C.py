@@ -325,7 +325,7 @@ def class_distortions(bg, means3D, classes, opacities, scales, rotations, scale_
         stream = _stream(dev)
         D = C.c_uint32(0)
         L.check(lib.sr_forward_plan(C.byref(fr), C.byref(g), _ptr(geom), geom.numel(), _ptr(radii), C.byref(D), stream), "sr_forward_plan")
-        num_rendered = int(D.value) if binning_capacity is None else (max(1, int(binning_capacity)) if P else 0)
+        num_rendered = int(D.value)
         binning = torch.empty((lib.sr_binning_bytes(P, num_rendered, W, H),), dtype=torch.uint8, device=dev)
         L.check(lib.sr_class_forward_render(C.byref(fr), C.byref(g), int(n_classes), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                             _ptr(cimg), cimg.numel(), num_rendered, _ptr(dist), stream), "sr_class_forward_render")

@@ -223,6 +223,29 @@ class _ClassDistortions(torch.autograd.Function):
         return g3d, g2d, gop, gsc, grot, None, None, None, None, None, None
 
 
+def resolve_tile(tile, width, height):
+    """`tile` of GaussianRasterizer -> (w, h) or None (= the reference's 16x16).  None reads the process default SURFEL_TILE ("auto", "8x8",
+    "16x8", ...; unset = 16x16, the reference's compile-time BLOCK_X x BLOCK_Y).  "auto" picks by frame size: the blend kernels run one
+    wave (K7) or two (K6) per tile, and a frame with fewer than ~2 000 tiles of 16x16 leaves most of the GPU's 3 072 wave slots empty --
+    the reference's documented runs are such frames (`-r 4`: 480x320 = 600 tiles [REF /root/reference/README.md:195-207]).  Measured fwd+bwd,
+    1.5 M Gaussians (tools/time_r4_tiles.py): 480x320 2.19 ms with 16x16, 1.40 with 8x8; 640x480 2.00 / 1.59; 960x640 2.00 / 1.88 with 16x8;
+    1280x720 and larger: 16x16 is fastest.  Images and gradients do not depend on the tile shape beyond float summation order; the tile
+    lists are the oracle's lists FOR THAT SHAPE, bit for bit."""
+    import os
+    if tile is None:
+        tile = os.environ.get("SURFEL_TILE") or None
+    if tile is None:
+        return None
+    if isinstance(tile, str):
+        if tile.lower() == "auto":
+            tiles16 = ((int(width) + 15) // 16) * ((int(height) + 15) // 16)
+            return (8, 8) if tiles16 < 1600 else ((16, 8) if tiles16 < 3000 else None)
+        w, h = tile.lower().split("x")
+        tile = (int(w), int(h))
+    tile = (int(tile[0]), int(tile[1]))
+    return None if tile == (16, 16) else tile
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False, tile=None, quadrant_cull: bool = True,
                  blend_counters=None, ballot_ranking: bool = False, row_mapped=None, binning_capacity=None):
@@ -235,7 +258,7 @@ class GaussianRasterizer(nn.Module):
         `fused_activations=True` (extension): `opacities`, `scales`, `rotations` are the RAW parameters
         (`_opacity`, `_scaling`, `_rotation` of the reference's GaussianModel); sigmoid / exp / normalize run inside the
         preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values.
-        `tile=(w, h)`: binning tile shape, default the reference's compile-time 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
+        `tile=(w, h)` | "auto" | "8x8" ...: binning tile shape (resolve_tile), default the reference's compile-time 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
         16x16, 32x8, 32x16); images and gradients do not depend on it beyond float summation order.
         `quadrant_cull=False` / `blend_counters` (int64[16] device tensor): this call's SrFrame.flags / SrFrame.blend_counters --
         test and profiling switches with identical results (include/surfel_raster.h); `ballot_ranking=True`: SR_FLAG_BALLOT_RANKING,
@@ -244,7 +267,7 @@ class GaussianRasterizer(nn.Module):
         super().__init__()
         self.raster_settings = raster_settings
         self.activations = 7 if fused_activations else 0
-        self.tile = tile
+        self.tile = resolve_tile(tile, raster_settings.image_width, raster_settings.image_height)
         self.probe = {}
         if not quadrant_cull:
             self.probe["quadrant_cull"] = False

@@ -36,6 +36,7 @@ hipError_t run_expand_rows(uint32_t D, int tiles_x, int tiles_y, const uint2* co
                            uint32_t* point_list, uint32_t* tile_counts, int rank_mode, hipStream_t s);
 hipError_t run_tile_ranges_order(int n_tiles, const uint32_t* tile_counts, uint2* ranges, uint32_t* order, hipStream_t s);
 hipError_t run_capacity_guard(uint32_t* counts, uint32_t capacity, hipStream_t s);
+hipError_t launch_zero_bytes(void* p, size_t n, hipStream_t s);
 // render.hip
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                  const float* extra, float* out_color, float* out_allmap, float* final_T, uint32_t* n_contrib, uint16_t* hit_mask, int flags,
@@ -497,7 +498,7 @@ int bin_duplicates(const SrFrame* frame, const SrGaussians* g, const FrameDev& f
         }
         if (int rc = debug_sync(frame, s, "expand_rows")) return rc;
     } else {
-        SR_HIP(hipMemsetAsync(at<uint32_t>(binning, B.tile_counts), 0, sizeof(uint32_t) * (size_t)n_tiles, s));   // (no partition ran)
+        SR_HIP(launch_zero_bytes(at<uint32_t>(binning, B.tile_counts), sizeof(uint32_t) * (size_t)n_tiles, s));   // (no partition ran)
     }
     {
         StageTimer t(SR_STAGE_RANGES, s);
@@ -623,7 +624,7 @@ int sr_class_backward(const SrFrame* frame, const SrGaussians* g, int32_t n_clas
     uint8_t* written = static_cast<uint8_t*>(workspace) + align_up((size_t)(D > 0 ? D : 1) * record_bytes(3), 256);
     {
         StageTimer t(SR_STAGE_CLASS_BWD, s);
-        if (D > 0) SR_HIP(hipMemsetAsync(written, 0, D, s));
+        if (D > 0) SR_HIP(launch_zero_bytes(written, D, s));
         if (D > 0)
             SR_HIP(launch_class_backward(f, n_classes, at<uint2>(class_image, C.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.columns), at<float4>(geom, L.recs),
                                          at<float>(class_image, C.state), at<uint32_t>(class_image, C.last), at<uint32_t>(class_image, C.tile_total), dL_ddist,
@@ -760,7 +761,7 @@ int sr_backward_blend(const SrFrame* frame, const SrGaussians* g, void* geom, si
     if (!dL_dcolor || !dL_dallmap) return fail(SR_ERR_INVALID_ARGUMENT, "dL_dcolor / dL_dallmap is NULL");
     {
         StageTimer t(SR_STAGE_BLEND_BWD, c.s);
-        if (D > 0) SR_HIP(hipMemsetAsync(c.written, 0, D, c.s));
+        if (D > 0) SR_HIP(launch_zero_bytes(c.written, D, c.s));
         if (D > 0)
             SR_HIP(launch_render_backward(c.f, at<uint2>(binning, c.B.ranges), at<uint32_t>(binning, c.B.order), at<uint32_t>(binning, c.B.point_list), at<float4>(geom, c.L.recs), g->colors_precomp,
                                           at<float>(image, c.I.final_T), at<uint32_t>(image, c.I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, c.B.hit_mask), c.inst_grads, c.written,

@@ -502,6 +502,28 @@ __global__ void capacity_guard_kernel(uint32_t* __restrict__ counts, uint32_t ca
     counts[2] = over;
     if (over) counts[1] = 0u;
 }
+// Zero fill by a kernel of the library's own (the `written` flags of the backward, the tile counters of an empty frame).  Not
+// hipMemsetAsync: captured into a HIP graph, its memset node did not clear a 21 499-byte span on replay (ROCm 7.2: stale `written`
+// flags of the previous replay reached K8 -- tests/test_gpu_boundary.py, the whole-step graph test, replays on CHANGED inputs to see it).
+__global__ __launch_bounds__(256) void zero_bytes_kernel(uint8_t* __restrict__ p, size_t n) {
+    // head up to 16-B alignment and the tail by bytes, the body by 16-B stores
+    const size_t head = (size_t)((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15);
+    const size_t h = head < n ? head : n;
+    const size_t body = (n - h) / 16;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    uint4* q = reinterpret_cast<uint4*>(p + h);
+    for (size_t k = i; k < body; k += stride) q[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < h) p[i] = 0;
+    const size_t tail0 = h + body * 16;
+    if (i < n - tail0) p[tail0 + i] = 0;
+}
+hipError_t launch_zero_bytes(void* p, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const size_t blocks = (n / 16 + 255) / 256;
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks))), dim3(256), 0, s, static_cast<uint8_t*>(p), n);
+    return hipGetLastError();
+}
+
 hipError_t run_capacity_guard(uint32_t* counts, uint32_t capacity, hipStream_t s) {
     hipLaunchKernelGGL(capacity_guard_kernel, dim3(1), dim3(1), 0, s, counts, capacity);
     return hipGetLastError();

@@ -15,6 +15,8 @@
 
 namespace sr {
 
+hipError_t launch_zero_bytes(void* p, size_t n, hipStream_t s);   // binning.hip
+
 constexpr int kClassMax = 8;
 constexpr uint8_t kNoClass = 255;
 
@@ -415,7 +417,7 @@ hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* c
     if (n_classes < 1 || n_classes > kClassMax) return hipErrorInvalidValue;
     const bool two_bands = f.tile_h == 16 && (f.tile_w == 16 || f.tile_w == 32);   // 16x16 and 32x16: two band waves per (tile, class)
     if (!two_bands && !(f.tile_h == 8 && (f.tile_w == 8 || f.tile_w == 16 || f.tile_w == 32))) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(tile_total, 0, sizeof(uint32_t) * (size_t)n_tiles * n_classes, s);
+    hipError_t e = launch_zero_bytes(tile_total, sizeof(uint32_t) * (size_t)n_tiles * n_classes, s);   // (binning.hip: not hipMemsetAsync)
     if (e != hipSuccess) return e;
     const int split = two_bands ? 2 : 1;
     const dim3 grid((unsigned)((n_tiles + kXcds - 1) / kXcds * kXcds) * (unsigned)(split * n_classes));

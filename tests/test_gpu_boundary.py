@@ -258,5 +258,5 @@ def test_whole_step_captures_into_a_hip_graph_with_a_binning_capacity():
     ref2 = [x.clone() for x in ref2]
     graph.replay(); torch.cuda.synchronize()
     assert status.tolist()[2] == 0
-    for a, b in zip(ref2, out):
-        assert torch.equal(a, b), "graph replay on updated inputs differs from the eager step"
+    for k, (a, b) in enumerate(zip(ref2, out)):
+        assert torch.equal(a, b), f"graph replay on updated inputs: output {k} differs from the eager step ({int((a != b).sum())} of {a.numel()} elements, max |d| {(a.double() - b.double()).abs().max().item():.3e})"

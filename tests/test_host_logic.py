@@ -521,3 +521,18 @@ def test_per_semantics_cache_hits_across_the_views_the_upstream_getter_returns()
     assert gr._one_hot_classes(m.get_semantics, 6).shape == (540, 6)
     assert set(gr._SEM_CACHE) == {"one_hot"}, "one entry per kind: nothing stale stays alive"
     gr._SEM_CACHE.clear()
+
+
+def test_resolve_tile_auto_by_frame_size(monkeypatch):
+    """GaussianRasterizer(tile=...): None = the reference's 16x16 unless SURFEL_TILE says otherwise; "auto" = 8x8 for the reference's own
+    `-r 4` frames (480x320: 600 tiles of 16x16 cannot fill 3 072 wave slots), 16x8 in between, 16x16 from ~1280x720 up."""
+    from diff_surfel_rasterization import resolve_tile
+    monkeypatch.delenv("SURFEL_TILE", raising=False)
+    assert resolve_tile(None, 1920, 1080) is None and resolve_tile((16, 16), 480, 320) is None
+    assert resolve_tile("auto", 480, 320) == (8, 8) and resolve_tile("auto", 640, 480) == (8, 8)
+    assert resolve_tile("auto", 960, 640) == (16, 8)
+    assert resolve_tile("auto", 1280, 720) is None and resolve_tile("auto", 1920, 1080) is None and resolve_tile("auto", 3840, 2160) is None
+    assert resolve_tile("32x16", 100, 100) == (32, 16) and resolve_tile((8, 8), 4000, 4000) == (8, 8)
+    monkeypatch.setenv("SURFEL_TILE", "auto")
+    assert resolve_tile(None, 480, 320) == (8, 8) and resolve_tile(None, 1920, 1080) is None
+    assert resolve_tile((32, 8), 480, 320) == (32, 8), "an explicit shape wins over the process default"
