@@ -54,9 +54,13 @@ def parse():
     ap.add_argument("--no-train-step", action="store_true", help="skip the untimed `train_step` section (the reference's 8 rasterizations of a late training iteration vs 2)")
     ap.add_argument("--row-mapped", action="store_true", help="A/B switch: force the row-mapped forward blend (SR_FLAG_ROW_MAPPED_FORWARD; bit-identical results)")
     ap.add_argument("--quadrant-mapped", action="store_true", help="A/B switch: force the quadrant-mapped forward blend (default: picked per frame on the device)")
-    ap.add_argument("--exchange", choices=["factored", "allreduce"], default="factored",
+    ap.add_argument("--exchange", choices=["factored", "allreduce", "compacted"], default="factored",
                     help="N > 1 gradient exchange: factored = all-gather 12-B colour gradients + local SH expansion + all-reduce of "
-                         "the other 40 B/Gaussian; allreduce = plain all-reduce of all 232 B/Gaussian")
+                         "the other 40 B/Gaussian; allreduce = plain all-reduce of all 232 B/Gaussian; compacted = all-gather of the visibility "
+                         "bitmaps (P / 8 B) + all-reduce of the 232 B of the rows reached on at least one rank (parallel.allreduce_visible_rows)")
+    ap.add_argument("--rig", choices=["benchmark", "inside"], default="benchmark",
+                    help="N > 1 camera rig: benchmark = SURVEY 8d's yawed cameras at the origin (each sees ~86 %% of the Gaussians); inside = cameras "
+                         "standing INSIDE the cloud, 80 %% of the Gaussians behind them (synthetic.posed_rig: what a street scene looks like)")
     ap.add_argument("--frames-per-rank", type=int, default=1,
                     help="gradient accumulation: K frames (cameras) per rank and step, ONE gradient exchange per step -- the colour gradients of "
                          "frame j travel while frame j + 1 is computed (factored exchange); value counts all K * N frames")
@@ -593,7 +597,12 @@ def main():
     K = max(1, args.frames_per_rank)
     n_cams = world * K
     # frame j of rank r = camera r * K + j of the yawed camera batch (one camera, the unrotated one, for the plain single-GPU run)
-    cams = [synthetic_camera(W, H) if n_cams == 1 else synthetic_camera(W, H, index=rank * K + j, n_cams=n_cams) for j in range(K)]
+    rig_cams = None
+    if args.rig == "inside":   # cameras in general position inside the cloud; every rank builds the same rig and Gaussians
+        from streetunveiler_amd.synthetic import posed_rig
+        rig_cams, g_cpu = posed_rig(P, W, H, max(n_cams, 1), seed=7, spread=25.0, behind_fraction=0.8)
+    cam_of = (lambda i: rig_cams[i]) if rig_cams is not None else (lambda i: synthetic_camera(W, H) if n_cams == 1 else synthetic_camera(W, H, index=i, n_cams=n_cams))
+    cams = [cam_of(rank * K + j) for j in range(K)]
     cam = cams[0]
     dc_cpu, da_cpu = synthetic_upstream_grads(W, H, seed=1, aux=not args.no_aux)
     params = {k: v.to(dev).requires_grad_() for k, v in g_cpu.items()}
@@ -606,7 +615,7 @@ def main():
     # the camera list is replicated: every rank knows every rank's camera positions ([world, 3], or [world, K, 3] with accumulation)
     all_campos = None
     if multi:
-        all_campos = torch.stack([torch.stack([synthetic_camera(W, H, index=r * K + j, n_cams=n_cams).camera_center for j in range(K)])
+        all_campos = torch.stack([torch.stack([cam_of(r * K + j).camera_center for j in range(K)])
                                   for r in range(world)]).to(dev)
         if K == 1:
             all_campos = all_campos[:, 0]
@@ -636,9 +645,16 @@ def main():
             exchange_log["ms"] += ex.exchange_ms; exchange_log["bytes"] += ex.bytes_sent; exchange_log["calls"] += ex.calls
             exchange_log["early_starts"] += ex.early_starts
         else:
+            seen = None
             for j in range(K):
                 radii = frame(j)
-            if multi:
+                seen = (radii > 0) if seen is None else (seen | (radii > 0))   # (the rows this rank's frames reached)
+            if multi and args.exchange == "compacted":
+                t0 = time.perf_counter()
+                info = par.allreduce_visible_rows([t.grad for t in leaves[:5]], seen)   # the rows reached on at least one rank only
+                exchange_log["ms"] += (time.perf_counter() - t0) * 1e3; exchange_log["calls"] += 1
+                exchange_log["bytes"] += info["bytes_payload"]; exchange_log["rows_union"] = info["rows_union"]
+            elif multi:
                 t0 = time.perf_counter()
                 allreduce_gradients([t.grad for t in leaves[:5]])   # 232 B/Gaussian, one collective over the flat buffer
                 exchange_log["ms"] += (time.perf_counter() - t0) * 1e3; exchange_log["calls"] += 1
@@ -717,6 +733,15 @@ def main():
                 print(f"[rank {rank}] factored exchange unavailable ({type(e).__name__}: {e}); using all-reduce", file=sys.stderr, flush=True)
                 args.exchange = "allreduce"
                 exchange_check = {"ok": False, "fell_back_to": "allreduce", "error": f"{type(e).__name__}: {e}"[:300]}
+
+        if args.exchange == "compacted":   # the rows-of-the-union exchange must give the dense all-reduce's sums (ring order aside)
+            step(); sync()
+            comp = [t.grad.clone() for t in leaves[:5]]
+            args.exchange = "allreduce"; step(); sync(); args.exchange = "compacted"
+            worst = max(float((a - t.grad).abs().max() / (t.grad.abs().max() + 1e-30)) for a, t in zip(comp, leaves[:5]))
+            exchange_check = {"compacted_vs_allreduce_max_rel_err": worst, "ok": bool(worst < 1e-5)}
+            if not exchange_check["ok"]:
+                raise RuntimeError(f"visibility-compacted exchange disagrees with the plain all-reduce ({worst:.2e})")
 
     for _ in range(args.warmup):
         step()
@@ -838,8 +863,13 @@ def main():
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": D, "visible_per_P": round(V / P, 4), "D_per_P": round(D / P, 3),
                        "frames_per_step": world * K, "frames_per_rank": K,
                        "parallelism": (f"frame-sharded dp{world}" if multi else "single GPU") + (f", {K} frames accumulated per exchange" if K > 1 else ""),
+                       "camera_rig": args.rig,
                        **({"gradient_exchange": ("all-gather of 12-B colour gradients (started between K7 and K8) + local SH expansion + "
-                                                 "all-reduce of 40 B/Gaussian" if args.exchange == "factored" else "all-reduce of 232 B/Gaussian"),
+                                                 "all-reduce of 40 B/Gaussian" if args.exchange == "factored" else
+                                                 ("visibility bitmaps all-gathered (P / 8 B), then ONE all-reduce of the 232 B of every row reached on at least one rank"
+                                                  if args.exchange == "compacted" else "all-reduce of 232 B/Gaussian")),
+                           "exchange_rows_union_over_P": (round(timed_exchange.get("rows_union", P) / P, 4) if args.exchange == "compacted" else None),
+                           "exchange_bytes_dense_allreduce_equivalent": P * 232,
                            "exchange_ms_per_step_rank0_host_wait": round(timed_exchange["ms"] / args.steps, 4),
                            "exchange_bytes_sent_per_step_rank0": int(timed_exchange["bytes"] / args.steps),
                            "exchange_early_starts_per_step": timed_exchange["early_starts"] / args.steps,

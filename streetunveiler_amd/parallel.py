@@ -116,6 +116,86 @@ def allreduce_gradients(grads: Sequence[torch.Tensor], group=None, average: bool
             g.div_(world)
 
 
+def pack_visibility(visible: torch.Tensor) -> torch.Tensor:
+    """[P] bool -> uint8 [ceil(P / 8)], bit i & 7 of byte i >> 3 = visible[i] (little-endian bits: numpy's packbits(bitorder="little"))."""
+    v = visible.reshape(-1).to(torch.uint8)
+    pad = (-v.numel()) % 8
+    if pad:
+        v = torch.cat([v, v.new_zeros(pad)])
+    w = (1 << torch.arange(8, device=v.device, dtype=torch.int32)).to(torch.uint8)
+    return (v.view(-1, 8) * w).sum(1, dtype=torch.int32).to(torch.uint8)
+
+
+def unpack_visibility(bits: torch.Tensor, P: int) -> torch.Tensor:
+    w = (1 << torch.arange(8, device=bits.device, dtype=torch.int32)).to(torch.uint8)
+    return ((bits.view(-1, 1) & w) != 0).reshape(-1)[:P]
+
+
+def union_of_visible_rows(visible: torch.Tensor, group=None) -> torch.Tensor:
+    """[P] bool: the Gaussians this rank's frame(s) reached (radii > 0) -> [P] bool: reached on AT LEAST ONE rank.  One all-gather of the
+    packed bitmaps: P / 8 bytes per rank (375 kB at 3 M Gaussians against 696 MB of gradients)."""
+    bits = pack_visibility(visible)
+    world = dist.get_world_size(group)
+    rows = torch.empty(world * bits.numel(), dtype=torch.uint8, device=bits.device)
+    dist.all_gather_into_tensor(rows, bits, group=group)
+    acc = rows.view(world, -1)[0].clone()
+    for r in range(1, world):
+        acc |= rows.view(world, -1)[r]
+    return unpack_visibility(acc, visible.numel())
+
+
+# Bytes this process put on the wire per call of the exchange helpers below (diagnostic: bench.py --gpus N reports it per step)
+WIRE = {"bytes_payload": 0, "bytes_dense_equivalent": 0, "rows_union": 0, "rows_total": 0, "calls": 0}
+
+
+def allreduce_visible_rows(grads: Sequence[torch.Tensor], visible: torch.Tensor, group=None, dense_above: float = 0.85) -> dict:
+    """The gradient exchange WITHOUT the zeros (round 6).  A rank's gradient rows are exact zeros for every Gaussian its frame did not
+    reach, and on a street most Gaussians are behind the camera: the benchmark rig sees 86 %, a camera inside the scene 17 %
+    (bench.py camera_inside_scene) -- 83 % of what the dense all-reduce moves over xGMI is zeros.  Here the ranks
+      1. all-gather their packed visibility bitmaps (P / 8 bytes) and OR them: the rows reached on at least one rank;
+      2. gather those rows of every gradient tensor into ONE [n_union, columns] buffer, SUM all-reduce it, scatter the sums back.
+    Rows outside the union are zero on every rank and stay untouched.  `grads`: tensors with leading dimension P (views of the operator's
+    flat gradient buffer are fine); `visible` [P] bool = radii > 0 of this rank's frame (OR over its frames with accumulation).
+    The sums are what the dense all-reduce returns, up to the order in which a ring adds the ranks' contributions (bit-identical for two
+    ranks, and for any exactly representable sums).  Falls back to the dense path when the union covers more than `dense_above` of the
+    rows (the index gathers then cost more than the zeros).  Needs one host read of the union's size (the buffer's shape): the exchange
+    sits at the step boundary.  -> {"rows_union", "rows_total", "bytes_payload", "bytes_dense_equivalent"} of this call."""
+    grads = [g for g in grads if g is not None and g.numel() > 0]
+    P = int(visible.numel())
+    dense_bytes = sum(g.numel() * g.element_size() for g in grads)
+    info = {"rows_union": P, "rows_total": P, "bytes_payload": dense_bytes, "bytes_dense_equivalent": dense_bytes}
+    if not _exchange_wanted(group) or not grads:
+        return info
+    assert all(g.shape[0] == P for g in grads), "every gradient tensor must have one row per Gaussian"
+    union = union_of_visible_rows(visible, group)
+    idx = union.nonzero(as_tuple=False).reshape(-1)          # (host sync: the compacted buffer's size)
+    n = int(idx.numel())
+    info["rows_union"] = n
+    bitmap_bytes = (P + 7) // 8
+    if n > dense_above * P:
+        allreduce_gradients(grads, group=group)
+        info["bytes_payload"] = dense_bytes + bitmap_bytes
+    elif n > 0:
+        cols = [g.reshape(P, -1) for g in grads]
+        buf = torch.cat([c.index_select(0, idx) for c in cols], dim=1).contiguous()
+        with STALLS.waiting(buf.is_cuda):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for g, c in zip(grads, cols):
+            k = c.shape[1]
+            if c.data_ptr() == g.data_ptr() and c.is_contiguous():
+                c.index_copy_(0, idx, buf[:, off:off + k])
+            else:   # (a non-contiguous gradient: reshape made a copy)
+                c.index_copy_(0, idx, buf[:, off:off + k]); g.copy_(c.view_as(g))
+            off += k
+        info["bytes_payload"] = buf.numel() * buf.element_size() + bitmap_bytes
+    else:
+        info["bytes_payload"] = bitmap_bytes
+    WIRE["bytes_payload"] += info["bytes_payload"]; WIRE["bytes_dense_equivalent"] += dense_bytes
+    WIRE["rows_union"] += n; WIRE["rows_total"] += P; WIRE["calls"] += 1
+    return info
+
+
 class StallClock:
     """Event pairs on the CURRENT (compute) stream around the points where it waits for a collective.  With RCCL `work.wait()` only makes the
     compute stream depend on the communication stream (the host returns at once), so host wall clocks see nothing; the distance between

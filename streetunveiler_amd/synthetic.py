@@ -87,13 +87,13 @@ def posed_scene(P: int, width: int, height: int, seed: int = 0, scale_lo: float 
 
 
 def posed_rig(P: int, width: int, height: int, n_cams: int, seed: int = 0, scale_lo: float = 5e-4, scale_hi: float = 5e-3, spread: float = 10.0,
-              jitter: float = 2.0):
+              jitter: float = 2.0, behind_fraction: float = 0.0):
     """`n_cams` cameras in general position looking at ONE set of Gaussians (a multi-camera step: streetunveiler_amd.parallel): camera 0
     and the Gaussians are `posed_scene(seed)`; camera k > 0 is camera 0 moved by up to `jitter` units sideways / backwards and turned by
     up to ~6 degrees about each axis -- every camera has its own centre (the yawed benchmark batch shares one: the origin), which is what
     the per-view directions of the factored SH-gradient exchange depend on.  -> (cameras, gaussians)"""
     import numpy as np
-    cam0, g = posed_scene(P, width, height, seed=seed, scale_lo=scale_lo, scale_hi=scale_hi, spread=spread)
+    cam0, g = posed_scene(P, width, height, seed=seed, scale_lo=scale_lo, scale_hi=scale_hi, spread=spread, behind_fraction=behind_fraction)
     W2C = cam0.world_view_transform.t().double().numpy()          # [R^T | t]
     R0, c0 = W2C[:3, :3].T, cam0.camera_center.double().numpy()
     gen = torch.Generator().manual_seed(seed + 7919)
