@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~630
 CONFIGS = {
     "c2": (500_000, 1920, 1080, False, "C2: 500k synthetic Gaussians, 1920x1080, SH degree 3, fwd+bwd on 1xMI355X (colour + alpha gradients live)"),
     "c3": (3_000_000, 1920, 1080, True, "C3: 3M Gaussians, 1920x1080, fwd+bwd with depth/normal aux outputs (all 7 aux-map gradients live)"),
+    "train_step": (3_000_000, 1920, 1080, True, "train_step: one training view of the reference's late iterations (render + render_semantic + 5 class-filtered rend_dist) as ONE plan, C3 scene"),
     "c5": (6_000_000, 3840, 2160, True, "C5 scene on the GPUs given: 6M Gaussians, 3840x2160, SH degree 3 (BASELINE quotes it on 8 GPUs with a tile sweep: tools/tile_sweep.py)"),
 }
 
@@ -564,8 +565,85 @@ def reference_operating_point_section(deg, dev, P=1_500_000, W=480, H=320, steps
     return out
 
 
+def train_step_main(args):
+    """`--config train_step`: the work the reference actually does per late training iteration [REF /root/reference/train.py:84-109] as the
+    TIMED region -- `render_train_view` (9-channel render + five per-class distortion maps on ONE preprocess / binning / per-Gaussian
+    backward) forward + backward incl. the allmap post-processing and the loss kernels, on the C3 scene.  One JSON line with the contract's
+    fields; `roofline` = its dominant kernel measured with HIP event pairs on the launch stream inside extra steps; `reference_8_calls_ms` =
+    the same maps the reference's way (8 operator calls through this build) beside it."""
+    assert args.gpus == 1, "--config train_step is a single-GPU mode (the frame-parallel exchange is measured by the default config)"
+    from streetunveiler_amd import _lib
+    from streetunveiler_amd.gaussian_renderer import SurfelModel
+    from streetunveiler_amd.synthetic import synthetic_camera, synthetic_gaussians
+    from streetunveiler_amd.train_pattern import make_weights, one_plan_pattern, reference_pattern
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+    lib = _lib.load()
+    P, W, H, deg = args.gaussians, args.width, args.height, args.sh_degree
+    g = synthetic_gaussians(P, W, H, seed=0)
+    params = {k: v.to(dev).requires_grad_() for k, v in g.items()}
+    sem = torch.randint(0, 6, (P,), generator=torch.Generator().manual_seed(0)).to(dev)
+    sem[sem == 4] = 2   # the reference prunes the sky Gaussians before training
+    pc = SurfelModel(params["means3D"], params["scales"], params["rotations"], params["opacities"], params["shs"], sem, deg, 3)
+    cam = synthetic_camera(W, H).to(dev)
+    weights = make_weights(H, W, dev); bg = torch.zeros(3, device=dev)
+    leaves = list(params.values())
+
+    def step(fn=one_plan_pattern):
+        for t in leaves:
+            t.grad = None
+        m = fn(cam, pc, bg, weights)
+        m["loss"].backward()
+        return m
+    for _ in range(max(args.warmup, 1)):
+        m = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    # per-stage ms on extra steps (HIP event pairs recorded by the library on the launch stream)
+    iters = 5
+    lib.sr_set_stage_timing(1)
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    st = _lib.stage_stats(); lib.sr_set_stage_timing(0)
+    stage_ms = {k: round(v / iters, 4) for k, (v, n) in st.items() if n}
+    # scene statistics
+    with torch.no_grad():
+        from diff_surfel_rasterization import _C
+        e = torch.empty(0, device=dev)
+        D, _, _, radii0, *_ = _C.rasterize_gaussians(bg, params["means3D"].detach(), e, params["opacities"].detach(), params["scales"].detach(), params["rotations"].detach(),
+                                                     1.0, e, cam.world_view_transform, cam.full_proj_transform, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), H, W,
+                                                     params["shs"].detach(), deg, cam.camera_center, False, False)
+        V = int((radii0 > 0).sum())
+    ref_ms = None
+    if not args.no_train_step:   # the reference's eight calls beside it (untimed extra)
+        for _ in range(2):
+            step(reference_pattern)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            step(reference_pattern)
+        torch.cuda.synchronize(); ref_ms = round((time.perf_counter() - t0) * 1e3 / 3, 3)
+    prof_args = argparse.Namespace(**{**vars(args), "tag": "c3"})
+    roof = train_step_roofline(prof_args, stage_ms, D, V, n_classes=5)
+    out = {"metric": "Msplats/s, one training view fwd+bwd (9-channel render + 5 per-class distortion maps on one plan) @1920x1080, 3M Gaussians",
+           "value": round(P / ms / 1e3, 3), "unit": "Msplats/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "train_step: the rasterizer work of one late training iteration of the reference [train.py:84-109] on the C3 scene -- render + "
+                                  "render_semantic + five class-filtered rend_dist maps -- as render_train_view (one K1, one binning, one K8); incl. allmap post-processing and loss kernels",
+                      "baseline_config": "train_step", "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "duplicates_D": int(D), "parallelism": "single GPU"},
+           "roofline": roof, "stage_ms": stage_ms, "stage_ms_sum": round(sum(stage_ms.values()), 4),
+           "reference_8_calls_ms": ref_ms, "speedup_over_the_reference_call_pattern": None if not ref_ms else round(ref_ms / ms, 2)}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.config == "train_step":
+        return train_step_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     from streetunveiler_amd import parallel as par

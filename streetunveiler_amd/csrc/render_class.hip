@@ -159,12 +159,34 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_
     float4 nr[kRecQuads];
 #pragma unroll
     for (int i = 0; i < kRecQuads; ++i) nr[i] = zero4;
+    // (memory pipeline of the walk as in render.hip's K6: list entries two rounds ahead, records one, hit masks stored behind the next staging)
+    uint32_t gid_ahead = 0;
     if ((uint32_t)lane < n_total) load_record_geometry(recs, cls_list[range.x + lane], nr);
+    if (kWave + (uint32_t)lane < n_total) gid_ahead = cls_list[range.x + kWave + lane];
+    unsigned long long hit_prev[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) hit_prev[q] = 0ull;
+    uint32_t n_prev = 0, base_prev = 0;
+    auto store_hits = [&]() {
+        if ((uint32_t)lane < n_prev) {
+            uint32_t hm = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit_prev[q] >> lane) & 1ull) << q;
+            if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base_prev + lane) + part] = (uint8_t)hm;
+            else hit_mask[range.x + base_prev + lane] = (uint16_t)hm;
+        }
+    };
     for (uint32_t base = 0; base < n_total && alive; base += kWave) {
         const uint32_t n = min((uint32_t)kWave, n_total - base);
         uint32_t m = 0;
+        wait_vector_memory();   // (everything in flight is a round old: blend_common.h)
         if ((uint32_t)lane < n) m = stage_entry<QX, QY, 0>(nr, zero4, zero4, Xc, Yc, cull & 1, s_e, lane, yshift) & alive & kQuadMask;
-        if (base + kWave + lane < n_total) load_record_geometry(recs, cls_list[range.x + base + kWave + lane], nr);
+        const uint32_t gid = gid_ahead;
+        store_hits();
+        if (base + 2 * kWave + lane < n_total) gid_ahead = cls_list[range.x + base + 2 * kWave + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        if (base + kWave + lane < n_total) load_record_geometry(recs, gid, nr);
+        __builtin_amdgcn_sched_barrier(0);
         unsigned long long bits = ballot64(m != 0);
         unsigned long long hit[NQ];
 #pragma unroll
@@ -201,15 +223,12 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_
                 if (ballot64(!(done & (1u << q))) == 0) alive &= ~(1u << q);
             }
         }
-        // (entry, quadrant) hit mask for the backward: one byte per band
-        if ((uint32_t)lane < n) {
-            uint32_t hm = 0;
+        // (entry, quadrant) hit mask for the backward: one byte per band -- stored behind the next round's staging, or behind the walk
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit[q] >> lane) & 1ull) << q;
-            if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base + lane) + part] = (uint8_t)hm;
-            else hit_mask[range.x + base + lane] = (uint16_t)hm;
-        }
+        for (int q = 0; q < NQ; ++q) hit_prev[q] = hit[q];
+        n_prev = n; base_prev = base;
     }
+    store_hits();
     // entries behind the point where this band's chain had closed keep whatever hit byte they had: the backward walks to the deepest
     // contributor of EITHER band, but masks every quadrant with its own deepest contributor (`need`), so those bytes are never acted on
     const size_t HW = (size_t)f.H * f.W;
@@ -227,6 +246,36 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_
     }
     deepest = wave_max_u32(deepest);
     if (lane == 0 && deepest) atomicMax(&tile_total[(size_t)tile * n_classes + cls], deepest);
+}
+
+// Stores the record a lane holds in its row of s_out (the round that just ended) at the duplicate's emission index.  kShared: the records
+// already hold what K7 of a colour pass over the SAME binning left there: ADD the fifteen geometry sums (floats 0..14 = quads 0..3) to a
+// written record (rec_quads float4 per record: 6, or 7 after a 9-channel K7) and start a new one -- zero-filled -- elsewhere.
+template <bool kShared>
+__device__ __forceinline__ void class_flush(const float* __restrict__ row, float4* __restrict__ inst_grads, uint8_t* __restrict__ written, uint32_t slot,
+                                            float ox, float oy, int rec_quads) {
+    constexpr int kGQ = kGradQuads;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* accl = reinterpret_cast<const float4*>(row);
+    float4 a0 = accl[0], a1 = accl[1], a2 = accl[2], a3 = accl[3], a4 = accl[4], a5 = accl[5];
+    a0.w = fmaf(ox, a0.x, a0.w); a1.x = fmaf(ox, a0.y, a1.x); a1.y = fmaf(ox, a0.z, a1.y);
+    a1.z = fmaf(oy, a0.x, a1.z); a1.w = fmaf(oy, a0.y, a1.w); a2.x = fmaf(oy, a0.z, a2.x);
+    if (kShared) {
+        float4* o = inst_grads + (size_t)slot * rec_quads;
+        if (written[slot]) {
+            const float4 p0 = o[0], p1 = o[1], p2 = o[2], p3 = o[3];
+            o[0] = make_float4(p0.x + a0.x, p0.y + a0.y, p0.z + a0.z, p0.w + a0.w); o[1] = make_float4(p1.x + a1.x, p1.y + a1.y, p1.z + a1.z, p1.w + a1.w);
+            o[2] = make_float4(p2.x + a2.x, p2.y + a2.y, p2.z + a2.z, p2.w + a2.w); o[3] = make_float4(p3.x + a3.x, p3.y + a3.y, p3.z + a3.z, p3.w + a3.w);
+        } else {
+            o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5;
+            for (int k = kGQ; k < rec_quads; ++k) o[k] = zero4;
+            written[slot] = 1;
+        }
+    } else {
+        float4* o = inst_grads + (size_t)slot * kGQ;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5;
+        written[slot] = 1;
+    }
 }
 
 // One wave per (tile, class): the blend backward of the class-filtered render with the distortion gradient as the only upstream
@@ -281,33 +330,44 @@ void class_backward_kernel(FrameDev f, int n_classes, const uint2* __restrict__ 
     float4 nr[kRecQuads];
 #pragma unroll
     for (int i = 0; i < kRecQuads; ++i) nr[i] = zero4;
-    uint32_t nhit = 0;
-    auto fetch = [&](uint32_t pos) {
-        const uint32_t gid = cls_list[pos];
-        load_record_geometry(recs, gid, nr);
-        nr[4].w = reinterpret_cast<const float*>(recs + (size_t)gid * kRecQuads + 4)[3];   // the radius (emission_index)
-        nr[4].z = __uint_as_float(first_index(f, gid));
-        nhit = decode_hits<QX, QY>(hit_mask[pos]);
-    };
-    if ((uint32_t)((rounds - 1) * kWave + lane) < total) fetch(first_pos + (rounds - 1) * kWave + lane);
+    // Memory pipeline of the walk as in render_bwd.hip's K7 (round 6): the list entry two rounds ahead, the record one round ahead and RAW
+    // (first[] / first_base[] as two registers, the hit mask undecoded), the records of a round stored behind the staging of the next one.
+    uint32_t nfirst = 0, nfbase = 0, nhraw = 0, gid_ahead = 0;
+#define SR_CLASS_FETCH(GID, POS) { const uint32_t gid_ = (GID); load_record_geometry(recs, gid_, nr);                                   \
+        nr[4].w = reinterpret_cast<const float*>(recs + (size_t)gid_ * kRecQuads + 4)[3];   /* the radius (emission_index) */ \
+        nfirst = f.first[gid_]; nfbase = f.first_base[gid_ / kScanTile]; nhraw = hit_mask[(POS)]; }
+    if ((uint32_t)((rounds - 1) * kWave + lane) < total) SR_CLASS_FETCH(cls_list[first_pos + (rounds - 1) * kWave + lane], first_pos + (rounds - 1) * kWave + lane)
+    if (rounds > 1) gid_ahead = cls_list[first_pos + (rounds - 2) * kWave + lane];
+    bool pend = false;
+    uint32_t pslot = 0;
+    float pox = 0.f, poy = 0.f;
     for (int rd = rounds - 1; rd >= 0; --rd) {
         const uint32_t rbase = (uint32_t)rd * kWave;
         const uint32_t n = min((uint32_t)kWave, total - rbase);
         uint32_t m = 0, slot = 0;
+        float ox = 0.f, oy = 0.f;
+        wait_vector_memory();
         if ((uint32_t)lane < n) {
             (void)stage_entry<QX, QY, 0>(nr, zero4, zero4, Xc, Yc, 0, s_e, lane);
-            slot = emission_index(nr, __float_as_uint(nr[4].z), tile % f.tiles_x, tile / f.tiles_x, f);
+            slot = emission_index(nr, nfirst + nfbase, tile % f.tiles_x, tile / f.tiles_x, f);
             uint32_t need = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) need |= (rbase + lane < quad_last[q]) ? (1u << q) : 0u;
-            m = nhit & need;
+            m = decode_hits<QX, QY>((uint16_t)nhraw) & need;
+            // (clamped into the image: the moments of a splat whose centre projects far off-screen are taken about the nearest image point)
+            const float mx = nr[2].y - Xc, my = nr[2].z - Yc;   // the staged centre relative to the tile centre: same bits as stage_entry's
+            ox = -fminf(fmaxf(mx, -Xc), (float)(f.W - 1) - Xc); oy = -fminf(fmaxf(my, -Yc), (float)(f.H - 1) - Yc);
         }
+        if (rd > 0) {
+            SR_CLASS_FETCH(gid_ahead, first_pos + rbase - kWave + lane)
+            if (rd > 1) gid_ahead = cls_list[first_pos + rbase - 2 * kWave + lane];
+        }
+        if (pend) class_flush<kShared>(&s_out[lane][0], inst_grads, written, pslot, pox, poy, rec_quads);
         {
             float4* z = reinterpret_cast<float4*>(&s_out[lane][0]);
 #pragma unroll
             for (int k = 0; k < kGQ; ++k) z[k] = zero4;
         }
-        if (rd > 0) fetch(first_pos + rbase - kWave + lane);
         unsigned long long bits = ballot64(m != 0);
         const unsigned long long wrote = bits;   // every entry with a forward hit gets a record (see K7)
         while (bits) {
@@ -367,35 +427,10 @@ void class_backward_kernel(FrameDev f, int n_classes, const uint2* __restrict__ 
                 if (reduce16_holds_total(lane)) s_out[j][reduce16_index(lane)] = tot;
             }
         }
-        if ((wrote >> lane) & 1ull) {
-            const float4* accl = reinterpret_cast<const float4*>(&s_out[lane][0]);
-            float4 acc[kGQ];
-#pragma unroll
-            for (int k = 0; k < kGQ; ++k) acc[k] = accl[k];
-            const float4 centre = s_e[3][lane];   // (mx, my, ..) = the Gaussian's centre relative to the tile centre
-            // (clamped into the image: the moments of a splat whose centre projects far off-screen are taken about the nearest image point)
-            const float ox = -fminf(fmaxf(centre.x, -Xc), (float)(f.W - 1) - Xc), oy = -fminf(fmaxf(centre.y, -Yc), (float)(f.H - 1) - Yc);
-            acc[0].w = fmaf(ox, acc[0].x, acc[0].w); acc[1].x = fmaf(ox, acc[0].y, acc[1].x); acc[1].y = fmaf(ox, acc[0].z, acc[1].y);
-            acc[1].z = fmaf(oy, acc[0].x, acc[1].z); acc[1].w = fmaf(oy, acc[0].y, acc[1].w); acc[2].x = fmaf(oy, acc[0].z, acc[2].x);
-            if (kShared) {
-                float4* o = inst_grads + (size_t)slot * rec_quads;
-                if (written[slot]) {   // the colour pass left a record here: add the fifteen geometry sums (floats 0..14 = quads 0..3)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { const float4 p = o[k]; o[k] = make_float4(p.x + acc[k].x, p.y + acc[k].y, p.z + acc[k].z, p.w + acc[k].w); }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < kGQ; ++k) o[k] = acc[k];
-                    for (int k = kGQ; k < rec_quads; ++k) o[k] = zero4;
-                    written[slot] = 1;
-                }
-            } else {
-                float4* o = inst_grads + (size_t)slot * kGQ;
-#pragma unroll
-                for (int k = 0; k < kGQ; ++k) o[k] = acc[k];
-                written[slot] = 1;
-            }
-        }
+        pend = ((wrote >> lane) & 1ull) != 0ull; pslot = slot; pox = ox; poy = oy;
     }
+    if (pend) class_flush<kShared>(&s_out[lane][0], inst_grads, written, pslot, pox, poy, rec_quads);
+#undef SR_CLASS_FETCH
 }
 
 hipError_t launch_class_partition(int P, int n_tiles, int n_classes, const float* class_cols, const int32_t* class_i32, const uint2* ranges,
