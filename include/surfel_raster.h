@@ -133,6 +133,10 @@ typedef struct SrFrame {
                                       * No pinned memory, event or host wait is touched: the whole forward + backward can be captured into a HIP graph.
                                       * Not for the per-class passes (SR_ERR_UNSUPPORTED). */
 
+#define SR_FLAG_ONE_SWEEP_SORT 128u   /* sr_forward_plan / sr_debug_radix_sort: the depth sort's four passes as ONE-SWEEP passes (one up-front digit count, then
+                                      * one kernel per pass with decoupled look-back over relaxed-atomic status words: six launches instead of twelve).  Bit-identical
+                                      * order; measured SLOWER on MI355X at the benchmark's size (0.190 vs 0.157 ms at 3 M keys: csrc/radix_sort.hip), hence a flag */
+
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
  * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp
  * and exactly one of (scales, rotations) / transMat_precomp must be non-NULL. */

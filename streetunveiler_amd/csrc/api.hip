@@ -409,6 +409,7 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     // between the scan and the host's wake-up -- else a DMA copy does.
     int sort_mode = kRankUnknown;
     if (int rc = rank_mode(s, (frame->flags & SR_FLAG_BALLOT_RANKING) != 0, &sort_mode)) return rc;   // (first call on a device: ~20 us self-check)
+    const int depth_sort_mode = sort_mode | ((frame->flags & SR_FLAG_ONE_SWEEP_SORT) ? 0x100 : 0);   // (radix_sort.hip kSortOneSweepBit)
     if (frame->flags & SR_FLAG_BINNING_CAPACITY) {
         // the sync-free forward: D stays on the device (SrGeomView.frame_counts); no pinned word, no event, no host wait -- nothing in this
         // call that a stream capture could not record
@@ -420,7 +421,7 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
         {
             StageTimer t(SR_STAGE_DEPTH_SORT, s);
             SR_HIP(run_depth_sort(P, at<uint32_t>(geom, L.depth_keys), at<uint2>(geom, L.rect), at<uint32_t>(geom, L.sorted_keys),
-                                  at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, sort_mode,
+                                  at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, depth_sort_mode,
                                   f.tiles_x, f.tiles_y, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks + 1, s));
         }
         *num_rendered_host = 0xFFFFFFFFu;   // unknown to the host
@@ -453,7 +454,7 @@ int sr_forward_plan(const SrFrame* frame, const SrGaussians* g, void* geom, size
     {
         StageTimer t(SR_STAGE_DEPTH_SORT, s);
         SR_HIP(run_depth_sort(P, at<uint32_t>(geom, L.depth_keys), at<uint2>(geom, L.rect), at<uint32_t>(geom, L.sorted_keys),
-                              at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, sort_mode,
+                              at<uint32_t>(geom, L.sorted_gid), at<uint2>(geom, L.rect_sorted), at<void>(geom, L.temp), L.temp_bytes, depth_sort_mode,
                               f.tiles_x, f.tiles_y, at<uint32_t>(geom, L.block_base) + L.n_scan_blocks + 1, s));   // (+1: the scan's visible count)
     }
     if (int rc = debug_sync(frame, s, "depth_sort")) return rc;
@@ -921,6 +922,7 @@ int sr_debug_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32
     if (temp_bytes < radix_sort_temp_bytes(n)) return fail(SR_ERR_BUFFER_TOO_SMALL, "temp %zu < %zu", temp_bytes, radix_sort_temp_bytes(n));
     int sort_mode = kRankUnknown;
     if (int rc = rank_mode(static_cast<hipStream_t>(stream), (flags & SR_FLAG_BALLOT_RANKING) != 0, &sort_mode)) return rc;
+    if (flags & SR_FLAG_ONE_SWEEP_SORT) sort_mode |= 0x100;   // (radix_sort.hip kSortOneSweepBit)
     SR_HIP(radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, total_bits, temp, temp_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr, sort_mode));
     return SR_OK;
 }

@@ -9,6 +9,7 @@
 // bases itself: no third tiny kernel in the dependency chain).  A 256-thread block owns 2048 consecutive items; each
 // wave owns 512 of them and ranks them 64 at a time with one LDS atomic per item on the (wave, digit) run counter (see the rank
 // phase below).  No atomics on global memory, integer work only, no MFMA.
+#include <cstdlib>
 #include "common.h"
 
 namespace sr {
@@ -56,6 +57,53 @@ __global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __r
     if (tid < bins) hist[(size_t)tid * nblocks + blockIdx.x] = (s_h[0][tid] + s_h[1][tid]) + (s_h[2][tid] + s_h[3][tid]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE-SWEEP passes (round 6; 32-bit keys in four 8-bit passes, from kOneSweepFrom items up).  The classic pass above is three launches in a
+// dependency chain -- histogram, row scan, scatter -- i.e. twelve per depth sort, each a few microseconds of work behind a launch gap.
+// Here ONE kernel counts the digits of all four passes up front (the digit totals of a pass do not depend on the order the earlier passes
+// leave the keys in), and every scatter block obtains "items of my digits in all EARLIER blocks" itself, by decoupled look-back over
+// status words the blocks publish: block ids come from a ticket (so every predecessor is running or done), a status word carries tag,
+// flag and value in 32 bits -- tag = the pass, so one table serves all four passes zeroed once; flag = partial (the block's own count)
+// or inclusive (count + everything before it) -- and is written and polled with RELAXED agent-scope atomics: nothing else has to be
+// ordered against it, and acquire / release at agent scope cost an L2 write-back / invalidate each on this chip of eight L2s
+// (tools/ubench/lookback_ubench.hip: 9 us per pass of 730 blocks relaxed, 740 us with acquire / release).  Same positions as the classic
+// pass, hence the same lists, bit for bit.  Six launches per sort instead of twelve.
+// MEASURED (C3, 3 M keys, profiles/r06_one_sweep_sort.txt) and therefore OFF by default (SR_FLAG_ONE_SWEEP_SORT selects it): the depth sort
+// takes 0.190 ms this way against 0.157 ms classic -- the look-back costs a scatter pass 13 us in situ (27 -> 40 us: all blocks finish
+// counting at the same moment and walk back over each other's partial words), exactly what the histogram + row-scan kernels it replaces
+// cost (7.9 + 4.9 us), and the up-front count of all four digits (23 us: four LDS atomics per key, the top byte takes four values) comes
+// on top.  Kept: built, tested bit-exact on every ranking path, and the number to beat for whoever has a cheaper look-back.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kOneSweepFrom = 1u << 18;
+constexpr int kSortOneSweepBit = 0x100;   // in the `rank_mode` argument of radix_sort_pairs
+constexpr uint32_t kSwInclusive = 1u << 28, kSwValue = (1u << 28) - 1u;   // word = tag << 29 | inclusive << 28 | value
+template <int kSortItems>
+__global__ __launch_bounds__(kRsThreads) void rs_hist_all_kernel(const uint32_t* __restrict__ keys, uint32_t n, int drop, uint32_t* __restrict__ ghist) {
+    constexpr int kSortTile = kRsThreads * kSortItems;
+    __shared__ uint32_t s_h[kRsThreads / 64][4][kRsMaxBins];   // per wave and pass: 16 KB
+    const int tid = threadIdx.x, w = tid >> 6;
+    const uint32_t base = blockIdx.x * (uint32_t)kSortTile;
+    for (int k = tid; k < (kRsThreads / 64) * 4 * kRsMaxBins; k += kRsThreads) (&s_h[0][0][0])[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+        const uint32_t idx = base + (uint32_t)(i * kRsThreads + tid);
+        if (idx < n) {
+            const uint32_t key = keys[idx];
+            if (!(drop && key == kDropKey)) {
+                atomicAdd(&s_h[w][0][key & 255u], 1u); atomicAdd(&s_h[w][1][(key >> 8) & 255u], 1u);
+                atomicAdd(&s_h[w][2][(key >> 16) & 255u], 1u); atomicAdd(&s_h[w][3][key >> 24], 1u);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t c = (s_h[0][p][tid] + s_h[1][p][tid]) + (s_h[2][p][tid] + s_h[3][p][tid]);
+        if (c) atomicAdd(&ghist[p * kRsMaxBins + tid], c);
+    }
+}
+
 // Exclusive scan of every row (one block per digit), row totals out.
 __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t* __restrict__ hist, int stride, const uint32_t* __restrict__ n_dev, uint32_t n_host,
                                                                   int items_per_block, uint32_t* __restrict__ row_total) {
@@ -98,15 +146,19 @@ __device__ __forceinline__ uint2 unpack_rect(uint32_t w, int bx, int by) {
 // unpacks it into aux_out -- instead of the last pass GATHERING aux_src[vals_out[i]]: at 3 M items that gather is 3 M random line fetches,
 // 43 us of a 67 us pass (the other passes take 20), against ~3 us per pass for the extra word.  The ride is reordered through the same LDS
 // buffer as the value, after it (the block keeps its 38 KB of LDS: four blocks per CU).
-template <int kBits, bool kAtomicRank, int kSortItems, bool kWide>   // digit width (compile time; 0 = run-time width <= 8), ranking (common.h take_run_slot), items per thread
+template <int kBits, bool kAtomicRank, int kSortItems, bool kWide, bool kOneSweep = false>   // digit width (compile time; 0 = run-time width <= 8), ranking (common.h take_run_slot), items per thread
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                 uint32_t n_host, const uint32_t* __restrict__ n_dev, int drop, int shift, int bits_rt,
                                                                 const uint32_t* __restrict__ hist,
                                                                 const uint32_t* __restrict__ row_total, int nblocks,
                                                                 const uint2* __restrict__ aux_src, uint2* __restrict__ aux_out,
-                                                                const uint32_t* __restrict__ ride_in, uint32_t* __restrict__ ride_out, int bx, int by) {
+                                                                const uint32_t* __restrict__ ride_in, uint32_t* __restrict__ ride_out, int bx, int by,
+                                                                uint32_t* __restrict__ sw_status = nullptr, uint32_t* __restrict__ sw_ticket = nullptr, uint32_t sw_tag = 0) {
+    // kOneSweep: `hist` is not read, `row_total` = the pass's 256 digit totals (rs_hist_all_kernel), sw_status [blocks][256] the look-back
+    // table, sw_ticket this pass's block counter, sw_tag = (pass + 1) << 29
     constexpr int kSortTile = kRsThreads * kSortItems;
+    __shared__ uint32_t s_bid;
     __shared__ uint32_t s_run[kRsThreads / 64][kRsMaxBins];    // items of digit b held by wave w; then, in place, the next block-local slot for (wave, digit)
     __shared__ uint32_t s_lstart[kRsMaxBins];                  // block-local start of digit b
     __shared__ uint32_t s_gbase[kRsMaxBins];                   // global position of the block's first item of digit b
@@ -118,8 +170,13 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, bins = 1 << bits;
     const uint32_t mask = (uint32_t)bins - 1u;
     const uint32_t n = n_dev ? min(*n_dev, n_host) : n_host;
-    const uint32_t tile_base = blockIdx.x * (uint32_t)kSortTile;
-    if (tile_base >= n) return;
+    if (kOneSweep) {   // the block's id = the order in which it STARTED: every block with a smaller id is running or done
+        if (tid == 0) s_bid = atomicAdd(sw_ticket, 1u);
+        __syncthreads();
+    }
+    const uint32_t bid = kOneSweep ? s_bid : blockIdx.x;
+    const uint32_t tile_base = bid * (uint32_t)kSortTile;
+    if (tile_base >= n) return;   // (one-sweep: no later block looks back at a block without items)
     for (int b = tid; b < (kRsThreads / 64) * kRsMaxBins; b += kRsThreads) (&s_run[0][0])[b] = 0;
     __syncthreads();
     // wave w owns items [wbase, wbase + 512), 64 at a time in order -> stable
@@ -160,9 +217,28 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
         __syncthreads();
         uint32_t bin_base = rincl - rt;
         for (int k = 0; k < w; ++k) bin_base += s_wsum[k];
+        uint32_t before = 0;   // items of digit `tid` in all earlier blocks
+        if (kOneSweep) {
+            if (tid < bins) {
+                uint32_t* mine = sw_status + (size_t)bid * kRsMaxBins + tid;
+                __hip_atomic_store(mine, sw_tag | (bid == 0 ? kSwInclusive : 0u) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bid > 0) {
+                    for (int p = (int)bid - 1; p >= 0; --p) {
+                        uint32_t v;
+                        while ((((v = __hip_atomic_load(sw_status + (size_t)p * kRsMaxBins + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 29) << 29) != sw_tag)
+                            __builtin_amdgcn_s_sleep(1);
+                        before += v & kSwValue;
+                        if (v & kSwInclusive) break;
+                    }
+                    __hip_atomic_store(mine, sw_tag | kSwInclusive | (before + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        } else if (tid < bins) {
+            before = hist[(size_t)tid * nblocks + blockIdx.x];
+        }
         if (tid < bins) {
             s_lstart[tid] = off;
-            s_gbase[tid] = bin_base + hist[(size_t)tid * nblocks + blockIdx.x];
+            s_gbase[tid] = bin_base + before;
             uint32_t run = off;
 #pragma unroll
             for (int k = 0; k < kRsThreads / 64; ++k) { const uint32_t c = s_run[k][tid]; s_run[k][tid] = run; run += c; }
@@ -358,13 +434,17 @@ hipError_t lds_atomic_ranks(const uint32_t* digits, uint32_t* ranks, uint32_t n,
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRsThreads) void rs_zero_words_kernel(uint32_t* __restrict__ p, uint32_t n) {
+    for (uint32_t i = blockIdx.x * kRsThreads + threadIdx.x; i < n; i += gridDim.x * kRsThreads) p[i] = 0u;
+}
 static inline int rs_blocks(uint32_t n, int items = kRsItems) { return (int)((n + (uint32_t)(kRsThreads * items) - 1) / (uint32_t)(kRsThreads * items)); }
 static inline int scan_blocks(uint32_t n) { return (int)((n + kRsTile - 1) / kRsTile); }
 
 // scratch: ping-pong (keys, vals) + histogram table + row totals
 size_t radix_sort_temp_bytes(uint32_t n) {
     const size_t nb = (size_t)rs_blocks(n > 0 ? n : 1);
-    return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 3 + align_up(nb * kRsMaxBins * 4, 256) + align_up(kRsMaxBins * 4, 256);   // (keys, vals, ride)
+    // (keys, vals, ride) | histogram table = the one-sweep status table | row totals, the four passes' digit totals, four tickets
+    return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 3 + align_up(nb * kRsMaxBins * 4, 256) + align_up(kRsMaxBins * 4 * 5 + 64, 256);
 }
 
 // Sorts by key bits [0, total_bits) in passes of <= 8 bits (as even as possible); stable; result in keys_out/vals_out.
@@ -377,6 +457,8 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
                             int total_bits, void* temp, size_t temp_bytes, hipStream_t s, const uint2* aux_src, uint2* aux_out, int rank_mode,
                             int rect_bx, int rect_by, const uint32_t* n_live) {
     if (n == 0) return hipSuccess;
+    const bool sweep_wanted = (rank_mode & kSortOneSweepBit) != 0;   // (rides in the ranking argument: SR_FLAG_ONE_SWEEP_SORT)
+    rank_mode &= ~kSortOneSweepBit;
     if (temp_bytes < radix_sort_temp_bytes(n) || (rank_mode != kRankAtomic && rank_mode != kRankBallot)) return hipErrorInvalidValue;
     int passes = (total_bits + 7) / 8;
     if (passes < 1) passes = 1;
@@ -390,8 +472,19 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
     const bool wide = aux_out && !vals_in && rect_bx > 0 && rect_by > 0 && 2 * (rect_bx + rect_by) <= 32 && passes >= 2 && n >= kSortRideFrom;
     uint32_t* hist = reinterpret_cast<uint32_t*>(t); t += align_up((size_t)nb8 * kRsMaxBins * 4, 256);
     uint32_t* row_total = reinterpret_cast<uint32_t*>(t);
+    uint32_t* ghist = row_total + kRsMaxBins;          // [4][256] digit totals of the four passes (one-sweep)
+    uint32_t* tickets = ghist + 4 * kRsMaxBins;        // [4] block counters, one per pass
     const uint32_t* ki = keys_in; const uint32_t* vi = vals_in;
     int shift = 0, left = total_bits;
+    const bool sweep = sweep_wanted && total_bits == 32 && passes == 4 && n >= kOneSweepFrom && n <= kSwValue;
+    if (sweep) {
+        // status table (in the histogram table's place: the same [blocks][256] words), row totals, digit totals, tickets: zeroed once per sort
+        const size_t zero_bytes = (size_t)(reinterpret_cast<char*>(tickets + 16) - reinterpret_cast<char*>(hist));
+        hipLaunchKernelGGL(rs_zero_words_kernel, dim3(256), dim3(kRsThreads), 0, s, hist, (uint32_t)(zero_bytes / 4));
+        const bool bigh = n >= kSortBigFrom;
+        if (bigh) hipLaunchKernelGGL(rs_hist_all_kernel<kSortItemsBig>, dim3(rs_blocks(n, kSortItemsBig)), dim3(kRsThreads), 0, s, keys_in, n, n_live ? 1 : 0, ghist);
+        else hipLaunchKernelGGL(rs_hist_all_kernel<kRsItems>, dim3(nb8), dim3(kRsThreads), 0, s, keys_in, n, n_live ? 1 : 0, ghist);
+    }
     for (int p = 0; p < passes; ++p) {
         const int remaining_passes = passes - p;
         int bits = left > 0 ? (left + remaining_passes - 1) / remaining_passes : 1;
@@ -406,11 +499,16 @@ hipError_t radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, ui
         const int nb = big ? rs_blocks(n, kSortItemsBig) : nb8;
         const uint32_t* nd = (n_live && p > 0) ? n_live : nullptr;   // the first pass reads everything and drops; the later ones see the survivors
         const int drop = (n_live && p == 0) ? 1 : 0;
-        if (big) hipLaunchKernelGGL(rs_hist_kernel<kSortItemsBig>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, nd, drop, shift, bits, hist, nb);
-        else hipLaunchKernelGGL(rs_hist_kernel<kRsItems>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, nd, drop, shift, bits, hist, nb);
-        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, nd, n, kRsThreads * (big ? kSortItemsBig : kRsItems), row_total);
-#define SR_SCATTER_W(B, A, I, Wd) hipLaunchKernelGGL((rs_scatter_kernel<B, A, I, Wd>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, nd, drop, shift, bits, hist, \
-                                                 row_total, nb, (Wd ? p == 0 : last) ? aux_src : nullptr, last ? aux_out : nullptr, ri, ro, rect_bx, rect_by)
+        if (!sweep) {
+            if (big) hipLaunchKernelGGL(rs_hist_kernel<kSortItemsBig>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, nd, drop, shift, bits, hist, nb);
+            else hipLaunchKernelGGL(rs_hist_kernel<kRsItems>, dim3(nb), dim3(kRsThreads), 0, s, ki, n, nd, drop, shift, bits, hist, nb);
+            hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(kRsThreads), 0, s, hist, nb, nd, n, kRsThreads * (big ? kSortItemsBig : kRsItems), row_total);
+        }
+#define SR_SCATTER_W(B, A, I, Wd) do { if (sweep && B == 8) hipLaunchKernelGGL((rs_scatter_kernel<B == 8 ? 8 : 0, A, I, Wd, B == 8>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, nd, drop, shift, bits, \
+                                                 (const uint32_t*)nullptr, (const uint32_t*)(ghist + p * kRsMaxBins), nb, (Wd ? p == 0 : last) ? aux_src : nullptr, last ? aux_out : nullptr, ri, ro, rect_bx, rect_by, \
+                                                 hist, tickets + p, (uint32_t)(p + 1) << 29);                                                                    \
+                                   else hipLaunchKernelGGL((rs_scatter_kernel<B, A, I, Wd>), dim3(nb), dim3(kRsThreads), 0, s, ki, vi, ko, vo, n, nd, drop, shift, bits, (const uint32_t*)hist, \
+                                                 (const uint32_t*)row_total, nb, (Wd ? p == 0 : last) ? aux_src : nullptr, last ? aux_out : nullptr, ri, ro, rect_bx, rect_by, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u); } while (0)
 #define SR_SCATTER_R(B, A, I) do { if (wide) SR_SCATTER_W(B, A, I, true); else SR_SCATTER_W(B, A, I, false); } while (0)
 #define SR_SCATTER(B, I) do { if (rank_mode == kRankAtomic) SR_SCATTER_R(B, true, I); else SR_SCATTER_R(B, false, I); } while (0)
         switch (bits) {

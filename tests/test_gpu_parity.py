@@ -330,6 +330,9 @@ def test_radix_sort_stability_and_edges():
     # digits shared by most lanes of a row (the peeled path of common.h take_run_slot / wave_count_digit): one key everywhere, one bit,
     # and depth keys -- the bits of floats between 0.5 and 50, whose top byte takes four values
     cases += [(70_001, 0), (300_001, 1), (2_100_000, -1)]
+    # the one-sweep passes (32 bits from 2^18 items up: look-back over the blocks' published digit counts): the threshold itself, one key
+    # everywhere (every block's whole count in one digit), and a size whose last block is ragged
+    cases += [(1 << 18, 32), ((1 << 18) + 1, 0), (4_194_304 + 77, -1)]
     for n, bits in cases:
         if bits == -1:
             keys, bits = rng.uniform(0.5, 50.0, size=n).astype(np.float32).view(np.uint32), 32
@@ -342,7 +345,10 @@ def test_radix_sort_stability_and_edges():
             v = None if vals is None else torch.from_numpy(vals.view(np.int32)).to(dev)
             ko, vo = torch.empty_like(k), torch.empty_like(k)
             tmp = torch.empty(lib.sr_debug_radix_sort_temp_bytes(n), dtype=torch.uint8, device=dev)
-            for flags in (0, _lib.SR_FLAG_BALLOT_RANKING):   # the LDS-atomic ranking and its match-any fallback
+            # the LDS-atomic ranking and its match-any fallback, classic three-launch passes and one-sweep passes (32 bits, >= 2^18 items)
+            for flags in (0, _lib.SR_FLAG_BALLOT_RANKING, _lib.SR_FLAG_ONE_SWEEP_SORT, _lib.SR_FLAG_ONE_SWEEP_SORT | _lib.SR_FLAG_BALLOT_RANKING):
+                if (flags & _lib.SR_FLAG_ONE_SWEEP_SORT) and not (bits == 32 and n >= (1 << 18)):
+                    continue
                 rc = lib.sr_debug_radix_sort(k.data_ptr(), None if v is None else v.data_ptr(), ko.data_ptr(), vo.data_ptr(), n, bits,
                                              tmp.data_ptr(), tmp.numel(), flags, C.c_void_p(torch.cuda.current_stream().cuda_stream))
                 _lib.check(rc, "sr_debug_radix_sort")

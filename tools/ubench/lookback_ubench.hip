@@ -15,6 +15,15 @@ constexpr unsigned kPartial = 1u << 30, kInclusive = 2u << 30, kMask = (1u << 30
 
 // mode 0: publish only (the floor); 1: classic look-back, one thread per digit walks back one block at a time;
 // 2: wave-parallel look-back: the 64 lanes of a wave read 64 predecessors of ONE digit at a time (4 waves x 64 digits each)
+// ORDER (round 6): the round-4 version published and polled with RELEASE / ACQUIRE at agent scope.  On a chip of eight XCDs with one L2
+// each that is a cache write-back per store and an L2 INVALIDATE per poll -- 256 of them per block and step: 86 / 770 / 2 300 us said
+// nothing about look-back and everything about those cache operations.  A status word carries flag AND value, so no other memory has to
+// be ordered against it: RELAXED atomics at agent scope (stores and loads that go to the memory side of the L2s, no write-back, no
+// invalidate) are all the algorithm needs, and a polling thread sleeps between attempts instead of hammering the fabric.
+#ifndef LB_ORDER_STORE
+#define LB_ORDER_STORE __ATOMIC_RELAXED
+#define LB_ORDER_LOAD __ATOMIC_RELAXED
+#endif
 template <int MODE>
 __global__ __launch_bounds__(kDigits) void lookback_kernel(unsigned* __restrict__ status, unsigned* __restrict__ ticket, unsigned* __restrict__ out, unsigned work) {
     __shared__ unsigned s_id;
@@ -25,16 +34,16 @@ __global__ __launch_bounds__(kDigits) void lookback_kernel(unsigned* __restrict_
     unsigned count = 1u + ((b * 2654435761u + d * 40503u) >> 28);
     for (unsigned i = 0; i < work; ++i) count = (count * 1664525u + 1013904223u) & 15u | 1u;
     unsigned* mine = status + (size_t)b * kDigits;
-    __hip_atomic_store(&mine[d], (b == 0 ? kInclusive : kPartial) | count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mine[d], (b == 0 ? kInclusive : kPartial) | count, LB_ORDER_STORE, __HIP_MEMORY_SCOPE_AGENT);
     unsigned excl = 0;
     if (MODE == 1 && b > 0) {
         for (int p = (int)b - 1; p >= 0; --p) {
             unsigned v;
-            do { v = __hip_atomic_load(&status[(size_t)p * kDigits + d], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 30) == 0u);
+            while (((v = __hip_atomic_load(&status[(size_t)p * kDigits + d], LB_ORDER_LOAD, __HIP_MEMORY_SCOPE_AGENT)) >> 30) == 0u) __builtin_amdgcn_s_sleep(1);
             excl += v & kMask;
             if ((v >> 30) == 2u) break;
         }
-        __hip_atomic_store(&mine[d], kInclusive | ((excl + count) & kMask), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine[d], kInclusive | ((excl + count) & kMask), LB_ORDER_STORE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (MODE == 2 && b > 0) {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -46,7 +55,7 @@ __global__ __launch_bounds__(kDigits) void lookback_kernel(unsigned* __restrict_
             while (!done && hi >= 0) {
                 const int p = hi - lane;
                 unsigned v = kInclusive;                        // lanes past block 0 behave like an inclusive zero
-                if (p >= 0) { do { v = __hip_atomic_load(&status[(size_t)p * kDigits + dd], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 30) == 0u); }
+                if (p >= 0) { while (((v = __hip_atomic_load(&status[(size_t)p * kDigits + dd], LB_ORDER_LOAD, __HIP_MEMORY_SCOPE_AGENT)) >> 30) == 0u) __builtin_amdgcn_s_sleep(1); }
                 const unsigned long long inc = __builtin_amdgcn_ballot_w64((v >> 30) == 2u);
                 const int first_inc = inc ? __builtin_ctzll(inc) : 64;   // nearest inclusive predecessor among these 64
                 unsigned x = lane <= first_inc ? (v & kMask) : 0u;
@@ -59,7 +68,7 @@ __global__ __launch_bounds__(kDigits) void lookback_kernel(unsigned* __restrict_
         }
         __syncthreads();
         excl = s_excl[d];
-        __hip_atomic_store(&mine[d], kInclusive | ((excl + count) & kMask), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine[d], kInclusive | ((excl + count) & kMask), LB_ORDER_STORE, __HIP_MEMORY_SCOPE_AGENT);
     }
     out[(size_t)b * kDigits + d] = excl;
 }
