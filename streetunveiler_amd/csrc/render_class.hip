@@ -116,7 +116,10 @@ __device__ __forceinline__ void load_record_geometry(const float4* __restrict__ 
 
 // One wave per (tile band, class): QX x 1 quadrants per wave; SPLIT = 2: the reference's 16x16 tile as two 16x8 band waves (two pixels per
 // lane), SPLIT = 1: the 8x8 / 16x8 / 32x8 tiles of BASELINE config 5's sweep.  A single transmittance / distortion chain.
-template <int QX, int SPLIT>
+// QY = 2 (SPLIT = 1; round 6): the whole 16x16 tile in ONE wave, four pixels per lane -- a class chain keeps five registers per pixel (the colour
+// pass: fourteen), so the band split that buys the colour forward its sixth wave per SIMD buys nothing here and costs a second staging of
+// every entry (profiles/r05_train_step_hbm_traffic.json: 2.36 x the algorithmic bytes).
+template <int QX, int SPLIT, int QY = 1>
 __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_classes, const uint2* __restrict__ cls_ranges, const uint32_t* __restrict__ tile_order,
                                                               const uint32_t* __restrict__ cls_list, const float4* __restrict__ recs,
                                                               float* __restrict__ out_dist,       // [n_classes, H, W]
@@ -124,7 +127,8 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_
                                                               uint32_t* __restrict__ cls_last,    // [n_classes, H, W]: last contributor (position in the class's list, 1-based)
                                                               uint32_t* __restrict__ tile_total,  // [tiles, n_classes]: deepest contributor of the class in the tile (zeroed by the caller)
                                                               uint16_t* __restrict__ hit_mask, int cull) {
-    constexpr int QY = 1, NQ = QX;
+    constexpr int NQ = QX * QY;
+    static_assert(QY == 1 || SPLIT == 1, "a whole-tile wave is not split into bands");
     constexpr uint32_t kQuadMask = (1u << NQ) - 1u;
     __shared__ float4 s_e[entry_quads<0>()][kWave];
     const int lane = threadIdx.x;
@@ -142,14 +146,14 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_
     const int lx = lane & 7, ly = lane >> 3;
     const uint2 range = cls_ranges[(size_t)tile * n_classes + cls];
     const uint32_t n_total = range.y - range.x;
-    const float yl = (float)(ly - QY * 4) + yshift;
+    const float yl0 = (float)(ly - QY * 4) + yshift;   // quadrant row 0; row 1 (QY = 2) adds 8
     float xl[NQ], T[NQ], M1[NQ], M2[NQ], dist[NQ];
     uint32_t lastc[NQ];
     uint32_t done = 0, alive = 0;   // bit q: pixel (lane, q) finished / some pixel of quadrant q still open
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int px = tx0 + q * 8 + lx, py = ty0 + ly;
-        xl[q] = (float)(q * 8 + lx - QX * 4);
+        const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
+        xl[q] = (float)((q % QX) * 8 + lx - QX * 4);
         const bool outside = !(px < f.W && py < f.H);
         T[q] = 1.f; M1[q] = M2[q] = dist[q] = 0.f; lastc[q] = 0;
         if (outside) done |= 1u << q;
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_
 #pragma unroll
             for (int q = 0; q < NQ; ++q) hm |= (uint32_t)((hit_prev[q] >> lane) & 1ull) << q;
             if (SPLIT == 2) reinterpret_cast<uint8_t*>(hit_mask)[2 * (size_t)(range.x + base_prev + lane) + part] = (uint8_t)hm;
+            else if (QY == 2) hit_mask[range.x + base_prev + lane] = (uint16_t)((hm & ((1u << QX) - 1u)) | ((hm >> QX) << 8));   // (decode_hits: a byte per quadrant row)
             else hit_mask[range.x + base_prev + lane] = (uint16_t)hm;
         }
     };
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_
             for (int q = 0; q < NQ; ++q) {
                 if (!(mj & (1u << q))) continue;  // wave-uniform
                 Hit h;
-                const bool valid = intersect(xl[q], yl, e0, e1, e2, e3, h) & !(done & (1u << q));
+                const bool valid = intersect(xl[q], yl0 + (float)((q / QX) * 8), e0, e1, e2, e3, h) & !(done & (1u << q));
                 if (ballot64(valid) == 0) continue;
                 hit[q] |= 1ull << j;
                 if (valid) {
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(kWave) void class_forward_kernel(FrameDev f, int n_
     uint32_t deepest = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int px = tx0 + q * 8 + lx, py = ty0 + ly;
+        const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
         if (px < f.W && py < f.H) {
             const size_t pix = (size_t)py * f.W + px;
             out_dist[cls * HW + pix] = dist[q];
@@ -454,10 +459,15 @@ hipError_t launch_class_forward(const FrameDev& f, int n_classes, const uint2* c
     if (!two_bands && !(f.tile_h == 8 && (f.tile_w == 8 || f.tile_w == 16 || f.tile_w == 32))) return hipErrorInvalidValue;
     hipError_t e = launch_zero_bytes(tile_total, sizeof(uint32_t) * (size_t)n_tiles * n_classes, s);   // (binning.hip: not hipMemsetAsync)
     if (e != hipSuccess) return e;
-    const int split = two_bands ? 2 : 1;
+#ifndef SR_CLASS_FWD_WHOLE_TILE
+#define SR_CLASS_FWD_WHOLE_TILE 1   // the reference's 16x16 tile as ONE wave per (tile, class) instead of two band waves (A/B: 0)
+#endif
+    const bool whole = SR_CLASS_FWD_WHOLE_TILE && two_bands && f.tile_w == 16;
+    const int split = (two_bands && !whole) ? 2 : 1;
     const dim3 grid((unsigned)((n_tiles + kXcds - 1) / kXcds * kXcds) * (unsigned)(split * n_classes));
 #define SR_CF_SHAPE(QX, SPLIT) hipLaunchKernelGGL((class_forward_kernel<QX, SPLIT>), grid, dim3(kWave), 0, s, f, n_classes, cls_ranges, tile_order, cls_list, recs, out_dist, cls_state, cls_last, tile_total, hit_mask, cull)
-    if (two_bands) { if (f.tile_w == 16) SR_CF_SHAPE(2, 2); else SR_CF_SHAPE(4, 2); }
+    if (whole) hipLaunchKernelGGL((class_forward_kernel<2, 1, 2>), grid, dim3(kWave), 0, s, f, n_classes, cls_ranges, tile_order, cls_list, recs, out_dist, cls_state, cls_last, tile_total, hit_mask, cull);
+    else if (two_bands) { if (f.tile_w == 16) SR_CF_SHAPE(2, 2); else SR_CF_SHAPE(4, 2); }
     else if (f.tile_w == 8) SR_CF_SHAPE(1, 1); else if (f.tile_w == 16) SR_CF_SHAPE(2, 1); else SR_CF_SHAPE(4, 1);
 #undef SR_CF_SHAPE
     return hipGetLastError();
