@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the untimed `train_step` section (the reference's 8 rasterizations of a late training iteration vs 2)")
     ap.add_argument("--row-mapped", action="store_true", help="A/B switch: force the row-mapped forward blend (SR_FLAG_ROW_MAPPED_FORWARD; bit-identical results)")
+    ap.add_argument("--backward-kernel", choices=["one_wave", "coop"], default=None, help="A/B switch: force the one-wave-per-tile / the cooperative blend backward (default: by tile count)")
     ap.add_argument("--quadrant-mapped", action="store_true", help="A/B switch: force the quadrant-mapped forward blend (default: picked per frame on the device)")
     ap.add_argument("--exchange", choices=["factored", "allreduce", "compacted"], default="factored",
                     help="N > 1 gradient exchange: factored = all-gather 12-B colour gradients + local SH expansion + all-reduce of "
@@ -689,7 +690,7 @@ def main():
                                                             1.0, c.world_view_transform.to(dev), c.full_proj_transform.to(dev), deg,
                                                             c.camera_center.to(dev), False, False)
     settings = make_settings(cam)
-    rasterizers = [GaussianRasterizer(settings if j == 0 else make_settings(cams[j]), row_mapped=True if args.row_mapped else (False if args.quadrant_mapped else None)) for j in range(K)]
+    rasterizers = [GaussianRasterizer(settings if j == 0 else make_settings(cams[j]), row_mapped=True if args.row_mapped else (False if args.quadrant_mapped else None), backward_kernel=args.backward_kernel) for j in range(K)]
     # the camera list is replicated: every rank knows every rank's camera positions ([world, 3], or [world, K, 3] with accumulation)
     all_campos = None
     if multi:

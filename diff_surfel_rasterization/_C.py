@@ -87,7 +87,7 @@ def _stream(device):
 
 def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile=None,
            quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=None, forward_only=False, no_precomp_color_grad=False,
-           binning_capacity=None):
+           binning_capacity=None, backward_kernel=None):
     keep = [_f32c(bg, "bg"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos"), blend_counters]
     if blend_counters is not None and (blend_counters.dtype != torch.int64 or blend_counters.numel() < 16 or not blend_counters.is_cuda):
         raise L.SurfelRasterError("blend_counters must be a CUDA (ROCm) int64 tensor with 16 entries")
@@ -96,7 +96,8 @@ def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W,
                    int(tile[0]) if tile else 0, int(tile[1]) if tile else 0, (0 if quadrant_cull else L.SR_FLAG_NO_QUADRANT_CULL) | (L.SR_FLAG_BALLOT_RANKING if ballot_ranking else 0) |
                    (0 if row_mapped is None else (L.SR_FLAG_ROW_MAPPED_FORWARD if row_mapped else L.SR_FLAG_QUADRANT_MAPPED_FORWARD)) |
                    (L.SR_FLAG_FORWARD_ONLY if forward_only else 0) | (L.SR_FLAG_NO_PRECOMP_COLOR_GRAD if no_precomp_color_grad else 0) |
-                   (L.SR_FLAG_BINNING_CAPACITY if binning_capacity is not None else 0),
+                   (L.SR_FLAG_BINNING_CAPACITY if binning_capacity is not None else 0) |
+                   ({None: 0, "one_wave": L.SR_FLAG_ONE_WAVE_BACKWARD, "coop": L.SR_FLAG_COOP_BACKWARD}[backward_kernel]),
                    _ptr(blend_counters))
     return fr, keep
 
@@ -138,7 +139,7 @@ def _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transM
 def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, activations=0, tile=None, mask=None, quadrant_cull=True, blend_counters=None,
-                        ballot_ranking=False, row_mapped=None, forward_only=False, classes=None, n_classes=0, binning_capacity=None):
+                        ballot_ranking=False, row_mapped=None, forward_only=False, classes=None, n_classes=0, binning_capacity=None, backward_kernel=None):
     """`classes` [P] integer tensor + `n_classes` (extension, SURVEY 8f N1 in full): the per-class distortion pass runs on the plan AND the
     binning of this very render (sr_class_forward_shared); the return tuple then ends with (dist[n_classes,H,W], class_state) and
     rasterize_gaussians_backward takes `class_state` / `dL_ddist` to return the gradients of colour, allmap and distortion maps from ONE K8.
@@ -170,7 +171,8 @@ def rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotation
         if binning_capacity is not None and (classes is not None or int(binning_capacity) < 0):
             raise L.SurfelRasterError("binning_capacity: a non-negative number of duplicates; not with the shared-plan class pass")
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile,
-                          quadrant_cull, blend_counters, ballot_ranking, row_mapped, forward_only, binning_capacity=binning_capacity)
+                          quadrant_cull, blend_counters, ballot_ranking, row_mapped, forward_only, binning_capacity=binning_capacity,
+                          backward_kernel=backward_kernel)   # ("one_wave" / "coop" also force the forward's band / cooperative kernel)
         mask = _mask(mask, P, dev)
         g = _gaussians(means3D, opacities, scales, rotations, sh, colors_precomp, transMat_precomp, activations, mask)
         if keep[0].numel() != g.color_channels:
@@ -210,8 +212,10 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dcolor, dL_dallmap, sh, degree, campos,
                                  geomBuffer, num_rendered, binningBuffer, imgBuffer, debug, opacities=None, defer_sh=False,
                                  activations=0, tile=None, after_blend=None, class_state=None, dL_ddist=None, n_classes=0, want_precomp_color_grad=True,
-                                 binning_capacity=None):
-    """`opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry.
+                                 binning_capacity=None, backward_kernel=None):
+    """`backward_kernel`: None = the library picks the blend backward by the frame's tile count (the cooperative four-waves-per-tile kernel
+    below 2 600 tiles of 16x16, one wave per tile above); "one_wave" / "coop" force one (SR_FLAG_ONE_WAVE_BACKWARD / SR_FLAG_COOP_BACKWARD: A/B, tests).
+    `opacities` is not needed (opacity is kept in the packed geometry state); accepted for symmetry.
 
     `binning_capacity`: the value the forward was given (then `num_rendered` is that capacity): SR_FLAG_BINNING_CAPACITY for the backward too.
 
@@ -235,7 +239,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors_precomp, scales, rot
     with torch.cuda.device(dev), _range("backward"):
         skip_cg = (not want_precomp_color_grad) and _channels(colors_precomp) == 6   # ([P,6] precomputed channels: the 6- and the 9-channel pass)
         fr, keep = _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, False, debug, tile,
-                          no_precomp_color_grad=skip_cg, binning_capacity=binning_capacity)
+                          no_precomp_color_grad=skip_cg, binning_capacity=binning_capacity, backward_kernel=backward_kernel)
         # the backward never dereferences opacities (it reads the packed record); pass means3D as a non-NULL stand-in
         g = _gaussians(means3D, means3D, scales, rotations, sh, colors_precomp, transMat_precomp, activations)
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)

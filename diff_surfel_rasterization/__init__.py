@@ -69,7 +69,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if probe:              # tests / profiling: {"quadrant_cull": bool, "blend_counters": int64[16] device tensor, "ballot_ranking": bool}
             probe = dict(probe)
             status_holder = probe.pop("_status", None)
+            ctx.backward_kernel = probe.get("backward_kernel")   # (forward AND backward: the few-tile kernels are picked by one rule)
             fused.update(probe)
+        else:
+            ctx.backward_kernel = None
         ctx.binning_capacity = fused.get("binning_capacity")
         if forward_only and not (probe and "blend_counters" in probe):   # SR_FLAG_FORWARD_ONLY: no backward will follow -- images bit-identical, backward state not written (the counting variant keeps the full forward)
             fused["forward_only"] = True
@@ -129,6 +132,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             kwargs["tile"] = ctx.tile
         if ctx.binning_capacity is not None:
             kwargs["binning_capacity"] = ctx.binning_capacity
+        if ctx.backward_kernel is not None:
+            kwargs["backward_kernel"] = ctx.backward_kernel
         if colors_precomp.numel() and not ctx.needs_input_grad[3]:
             kwargs["want_precomp_color_grad"] = False   # (constant colours -- render_semantic's one-hot channels: K7 skips their sums)
         if s.debug:
@@ -229,8 +234,11 @@ def resolve_tile(tile, width, height):
     wave (K7) or two (K6) per tile, and a frame with fewer than ~2 000 tiles of 16x16 leaves most of the GPU's 3 072 wave slots empty --
     the reference's documented runs are such frames (`-r 4`: 480x320 = 600 tiles [REF /root/reference/README.md:195-207]).  Measured fwd+bwd,
     1.5 M Gaussians (tools/time_r4_tiles.py): 480x320 2.19 ms with 16x16, 1.40 with 8x8; 640x480 2.00 / 1.59; 960x640 2.00 / 1.88 with 16x8;
-    1280x720 and larger: 16x16 is fastest.  Images and gradients do not depend on the tile shape beyond float summation order; the tile
-    lists are the oracle's lists FOR THAT SHAPE, bit for bit."""
+    1280x720 and larger: 16x16 is fastest.  CAUTION: the tile shape is not invisible.  The reference's algorithm truncates a splat at the tiles
+    its 3-sigma bounding box touches, while an opaque splat's alpha >= 1/255 footprint reaches 3.3 sigma: smaller tiles drop more of that
+    fringe (a scene of large splats: 2.7 % of the pixels differ by more than 1e-4 between 8x8 and 16x16, up to 4e-2).  The tile lists are
+    the oracle's lists FOR THAT SHAPE, bit for bit -- not the reference's 16x16 lists.  For small frames WITHOUT that change the default
+    path already switches the blend backward to four waves per 16x16 tile (backward_kernel): 480x320 2.16 -> 1.60 ms on the reference's lists."""
     import os
     if tile is None:
         tile = os.environ.get("SURFEL_TILE") or None
@@ -248,7 +256,7 @@ def resolve_tile(tile, width, height):
 
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings, fused_activations: bool = False, tile=None, quadrant_cull: bool = True,
-                 blend_counters=None, ballot_ranking: bool = False, row_mapped=None, binning_capacity=None):
+                 blend_counters=None, ballot_ranking: bool = False, row_mapped=None, binning_capacity=None, backward_kernel=None):
         """`binning_capacity=N` (extension, round 6: SR_FLAG_BINNING_CAPACITY): the operator WITHOUT the host read-back of the frame's
         duplicate count between the emission scan and the binning [the reference waits there too: SURVEY.md 7 step 4] -- the binning buffer
         is sized for N duplicates (e.g. 1.25 x the largest count seen: `last_status`), nothing in forward or backward waits for the GPU, and
@@ -259,7 +267,7 @@ class GaussianRasterizer(nn.Module):
         (`_opacity`, `_scaling`, `_rotation` of the reference's GaussianModel); sigmoid / exp / normalize run inside the
         preprocess kernel and their adjoints inside its backward, so the returned gradients are w.r.t. the raw values.
         `tile=(w, h)` | "auto" | "8x8" ...: binning tile shape (resolve_tile), default the reference's compile-time 16x16 (BASELINE config 5 sweeps 8x8, 16x8,
-        16x16, 32x8, 32x16); images and gradients do not depend on it beyond float summation order.
+        16x16, 32x8, 32x16); images depend on it at the truncation fringe of the 3-sigma bounding box (resolve_tile).
         `quadrant_cull=False` / `blend_counters` (int64[16] device tensor): this call's SrFrame.flags / SrFrame.blend_counters --
         test and profiling switches with identical results (include/surfel_raster.h); `ballot_ranking=True`: SR_FLAG_BALLOT_RANKING,
         the binning's fallback ranking (identical lists); `row_mapped=True` / `False`: force the row-mapped / the quadrant-mapped
@@ -279,6 +287,8 @@ class GaussianRasterizer(nn.Module):
             self.probe["row_mapped"] = bool(row_mapped)
         if binning_capacity is not None:
             self.probe["binning_capacity"] = int(binning_capacity)
+        if backward_kernel is not None:   # "one_wave" / "coop": force one of the two blend-backward kernels (default: picked by the tile count)
+            self.probe["backward_kernel"] = backward_kernel
         self.last_status = None   # binning_capacity mode: device int32 [D, visible, overflow] of the last forward (a view into its state)
 
     def markVisible(self, positions):

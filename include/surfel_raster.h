@@ -137,6 +137,15 @@ typedef struct SrFrame {
                                       * one kernel per pass with decoupled look-back over relaxed-atomic status words: six launches instead of twelve).  Bit-identical
                                       * order; measured SLOWER on MI355X at the benchmark's size (0.190 vs 0.157 ms at 3 M keys: csrc/radix_sort.hip), hence a flag */
 
+#define SR_FLAG_ONE_WAVE_BACKWARD 256u /* both blend kernels, 16x16 tile with three colour channels: force the full-size forms (two band waves per tile forward, one
+                                      * wave per tile backward) ... */
+#define SR_FLAG_COOP_BACKWARD 512u     /* ... or the cooperative ones (four waves per tile, one per 8x8 quadrant, ONE staging of every entry; backward: one record per
+                                      * duplicate as before; forward: images and state bit-identical to the band kernel's -- measured no faster anywhere, so it
+                                      * only runs with this flag).  Set in sr_forward_render and in the backward.  Without either
+                                      * flag the library picks by the frame's tile count: cooperative below 2 600 tiles of 16x16 (the reference's `-r 4` frames:
+                                      * 600 tiles cannot fill the GPU with one wave each), one wave per tile above.  Same tile lists either way; gradients
+                                      * agree up to the order of a four-term sum.  The flags exist for the A/B and the tests */
+
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
  * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp
  * and exactly one of (scales, rotations) / transMat_precomp must be non-NULL. */

@@ -43,7 +43,7 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
                                  unsigned long long* counters, const uint32_t* frame_counts, hipStream_t s);
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, bool precomp_color_grads, hipStream_t s);
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, bool precomp_color_grads, hipStream_t s, int coop_mode);
 hipError_t launch_pair_decisions(const FrameDev& f, const uint2* ranges, const uint32_t* point_list, const float4* recs,
                                  unsigned long long* valid_bits, unsigned long long* use3d_bits, hipStream_t s);
 hipError_t launch_class_partition(int P, int n_tiles, int n_classes, const float* class_cols, const int32_t* class_i32, const uint2* ranges,
@@ -560,7 +560,8 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
         if (rows && quads) return fail(SR_ERR_INVALID_ARGUMENT, "SR_FLAG_ROW_MAPPED_FORWARD and SR_FLAG_QUADRANT_MAPPED_FORWARD exclude each other");
         if (rows && (!(f.tile_w == 16 && f.tile_h == 16 && f.colors == 3) || frame->blend_counters || (frame->flags & SR_FLAG_NO_QUADRANT_CULL)))
             return fail(SR_ERR_UNSUPPORTED, "SR_FLAG_ROW_MAPPED_FORWARD: 16x16 tile, three colour channels, no counters, culling on");
-        const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0) | (rows ? 4 : 0) | (quads ? 8 : 0);
+        const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0) | (rows ? 4 : 0) | (quads ? 8 : 0) |
+                          ((frame->flags & SR_FLAG_ONE_WAVE_BACKWARD) ? 16 : 0) | ((frame->flags & SR_FLAG_COOP_BACKWARD) ? 32 : 0);   // (the few-tile kernels: never / always)
         const GeomLayout GL = geom_layout(g->P);   // (D and the visible count, left in the geometry state by the emission scan)
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
                                      out_allmap, fwd_only ? nullptr : at<float>(image, I.final_T), fwd_only ? nullptr : at<uint32_t>(image, I.n_contrib),
@@ -766,7 +767,8 @@ int sr_backward_blend(const SrFrame* frame, const SrGaussians* g, void* geom, si
         if (D > 0)
             SR_HIP(launch_render_backward(c.f, at<uint2>(binning, c.B.ranges), at<uint32_t>(binning, c.B.order), at<uint32_t>(binning, c.B.point_list), at<float4>(geom, c.L.recs), g->colors_precomp,
                                           at<float>(image, c.I.final_T), at<uint32_t>(image, c.I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, c.B.hit_mask), c.inst_grads, c.written,
-                                          !(frame->flags & SR_FLAG_NO_PRECOMP_COLOR_GRAD), c.s));
+                                          !(frame->flags & SR_FLAG_NO_PRECOMP_COLOR_GRAD), c.s,
+                                          (frame->flags & SR_FLAG_ONE_WAVE_BACKWARD) ? 1 : ((frame->flags & SR_FLAG_COOP_BACKWARD) ? 2 : 0)));
     }
     return debug_sync(frame, c.s, "render_backward");
 }

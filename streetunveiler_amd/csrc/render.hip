@@ -456,6 +456,131 @@ void render_forward_rows_kernel(FrameDev f, const uint2* __restrict__ ranges, co
     render_forward_rows_body<QX, QY, SPLIT>(s_e, s_hit, f, ranges, tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K6, cooperative form (round 6): FOUR waves per 16x16 tile, one per 8x8 quadrant (one pixel per lane), one workgroup, ONE staging of every
+// entry (each wave stages 16 of the round's 64 into the shared s_e).  For frames with few tiles -- the reference's own `-r 4` runs:
+// 480x320 = 600 tiles [REF /root/reference/README.md:195-207] -- where two band waves per tile leave most wave slots empty.  Same lists, same
+// staging arithmetic, same `intersect`, the same per-pixel sequence of operations as render_forward_kernel: images, per-pixel state and hit
+// masks are bit-identical to the band kernel's (a test requires it).  Three colour channels; culling always on.
+// MEASURED, and therefore only run when asked for (SR_FLAG_COOP_BACKWARD in sr_forward_render): 1.5 M Gaussians at 480x320 0.481 ms against
+// the band kernel's 0.487 (8x8 tiles: 0.37); C3 0.968 against 0.852 -- the three barriers per round make every quadrant wait for the slowest
+// one, which costs what the single staging saves.  The BACKWARD's cooperative form is the one that pays on small frames (render_bwd.hip).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(4 * kWave) void render_forward_coop_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
+                                                                          const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
+                                                                          float* __restrict__ out_color, float* __restrict__ out_allmap, float* __restrict__ final_T,
+                                                                          uint32_t* __restrict__ n_contrib, uint16_t* __restrict__ hit_mask) {
+    constexpr int NC = 3, kStage = kWave / 4;
+    __shared__ float4 s_e[entry_quads<NC>()][kWave];
+    __shared__ uint32_t s_m[kWave];
+    __shared__ uint8_t s_hitq[4][kWave];
+    __shared__ uint32_t s_alive[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = (int)tile_order[blockIdx.x];
+    const int tx0 = (tile % f.tiles_x) * 16, ty0 = (tile / f.tiles_x) * 16;
+    const float Xc = (float)(tx0 + 8), Yc = (float)(ty0 + 8);
+    const int lx = lane & 7, ly = lane >> 3, qx = w & 1, qy = w >> 1;
+    const int px = tx0 + qx * 8 + lx, py = ty0 + qy * 8 + ly;
+    const float xl = (float)(qx * 8 + lx - 8), yl = (float)(qy * 8 + ly - 8);
+    const uint2 range = ranges[tile];
+    const uint32_t n_total = range.y - range.x;
+    float T = (px < f.W && py < f.H) ? 1.f : -1.f;   // > 0: live; < 0: done, |T| = final transmittance (render_forward_body)
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, Dsum = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
+    uint32_t lastc = 0, medc = 0xFFFFFFFFu;
+    if (lane == 0) s_alive[w] = 0u;
+    __syncthreads();
+    if (ballot64(T > 0.f) != 0ull && lane == 0) s_alive[w] = 1u;
+    __syncthreads();
+    const bool stager = lane < kStage;
+    const int se = w * kStage + lane;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nr[kRecQuads];
+    uint32_t gid_ahead = 0;
+    if (stager && (uint32_t)se < n_total) load_record18(recs, point_list[range.x + se], nr);
+    if (stager && kWave + (uint32_t)se < n_total) gid_ahead = point_list[range.x + kWave + se];
+    uint32_t hm_prev = 0, n_prev = 0, base_prev = 0;
+    for (uint32_t base = 0; base < n_total; base += kWave) {
+        const uint32_t alive = (s_alive[0] ? 1u : 0u) | (s_alive[1] ? 2u : 0u) | (s_alive[2] ? 4u : 0u) | (s_alive[3] ? 8u : 0u);   // (uniform: read behind a barrier)
+        if (!alive) break;
+        const uint32_t n = min((uint32_t)kWave, n_total - base);
+        wait_vector_memory();
+        if (stager) {
+            uint32_t m = 0;
+            if ((uint32_t)se < n) m = stage_entry<2, 2, NC>(nr, zero4, zero4, Xc, Yc, 1, s_e, se) & alive;
+            s_m[se] = m;
+            const uint32_t gid = gid_ahead;
+            if (hit_mask && (uint32_t)se < n_prev) hit_mask[range.x + base_prev + se] = (uint16_t)((hm_prev & 3u) | ((hm_prev >> 2) << 8));   // (decode_hits<2, 2>: a byte per quadrant row)
+            if (base + 2 * kWave + se < n_total) gid_ahead = point_list[range.x + base + 2 * kWave + se];
+            __builtin_amdgcn_sched_barrier(0);
+            if (base + kWave + se < n_total) load_record18(recs, gid, nr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        s_hitq[w][lane] = 0;
+        __syncthreads();
+        unsigned long long bits = ballot64(((s_m[lane] >> w) & 1u) != 0u);
+        unsigned long long hit = 0ull;
+        bool open = true;   // some pixel of this quadrant is still live
+        while (bits && open) {
+            const int j = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+            const uint32_t contributor = base + (uint32_t)j + 1u;
+            Hit h;
+            const bool valid = intersect(xl, yl, e0, e1, e2, e3, h) & (T > 0.f);
+            if (ballot64(valid) == 0) continue;
+            hit |= 1ull << j;
+            const float4 e4 = s_e[4][j], e5 = s_e[5][j];
+            if (valid) {
+                const float test_T = T * (1.f - h.alpha);
+                const bool go = !(test_T < kTStop);   // else: done, and this entry is NOT blended
+                if (go) {
+                    const float wgt = h.alpha * T;
+                    const float A = 1.f - T;
+                    const float mm = kFN * (1.f - kNear * fast_rcp(h.depth));
+                    dist += (mm * mm * A + M2 - 2.f * mm * M1) * wgt;
+                    Dsum += h.depth * wgt;
+                    M1 += mm * wgt;
+                    M2 += mm * mm * wgt;
+                    if (T > 0.5f) { med = h.depth; medc = contributor; }
+                    N0 += e4.x * wgt; N1 += e4.y * wgt; N2 += e4.z * wgt;
+                    C0 += e4.w * wgt; C1 += e5.x * wgt; C2 += e5.y * wgt;
+                    lastc = contributor;
+                }
+                T = go ? test_T : -T;
+            }
+            if (ballot64(T > 0.f) == 0) open = false;
+        }
+        s_hitq[w][lane] = (uint8_t)((hit >> lane) & 1ull);
+        const bool quadrant_done = ballot64(T > 0.f) == 0ull;   // (evaluated by all 64 lanes, then acted on by one)
+        if (lane == 0 && quadrant_done) s_alive[w] = 0u;
+        __syncthreads();
+        if (stager) {   // the round's hit masks: stored behind the NEXT staging (or behind the walk)
+            hm_prev = (uint32_t)s_hitq[0][se] | ((uint32_t)s_hitq[1][se] << 1) | ((uint32_t)s_hitq[2][se] << 2) | ((uint32_t)s_hitq[3][se] << 3);
+            n_prev = n; base_prev = base;
+        }
+        __syncthreads();   // (s_hitq / s_m / s_e are rewritten by the next round)
+    }
+    if (stager && hit_mask && (uint32_t)se < n_prev) hit_mask[range.x + base_prev + se] = (uint16_t)((hm_prev & 3u) | ((hm_prev >> 2) << 8));
+    const size_t HW = (size_t)f.H * f.W;
+    if (px < f.W && py < f.H) {
+        const size_t pix = (size_t)py * f.W + px;
+        const float Tq = fabsf(T);
+        if (final_T) {
+            final_T[pix] = Tq; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
+            n_contrib[pix] = lastc; n_contrib[HW + pix] = medc;
+        }
+        out_color[pix] = C0 + Tq * f.bg[0];
+        out_color[HW + pix] = C1 + Tq * f.bg[1];
+        out_color[2 * HW + pix] = C2 + Tq * f.bg[2];
+        out_allmap[pix] = Dsum;
+        out_allmap[HW + pix] = 1.f - Tq;
+        out_allmap[2 * HW + pix] = N0; out_allmap[3 * HW + pix] = N1; out_allmap[4 * HW + pix] = N2;
+        out_allmap[5 * HW + pix] = med;
+        out_allmap[6 * HW + pix] = dist;
+    }
+}
+
 // The reference's 16x16 tile with three colour channels picks its mapping per FRAME, on the device: counts[0] = D, the frame's duplicates,
 // counts[1] = its visible Gaussians (both fall out of the emission scan, radix_sort.hip).  Splats that touch few tiles touch few 4x4 cells
 // of a quadrant, and the rows win; large splats fill quadrants, and one entry on all 64 lanes wins (3 M Gaussians: 1280x720, D / visible
@@ -526,6 +651,7 @@ __global__ __launch_bounds__(kWave) void pair_decisions_kernel(FrameDev f, const
     else if (f.tile_w == 32 && f.tile_h == 16) { F(4, 2); }                     \
     else return hipErrorInvalidValue;
 
+// (bit 5 of `flags`: the cooperative forward -- measured and NOT picked by itself: see render_forward_coop_kernel)
 // flags: bit 0 = quadrant culling on (SR_FLAG_NO_QUADRANT_CULL clear), bit 1 = counter variant (counters != NULL), bit 2 / bit 3 = the row-mapped /
 // the quadrant-mapped kernel forced (else, for the 16x16 tile with three channels and culling on, the device picks per frame: frame_counts)
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
@@ -545,6 +671,9 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
         if (f.colors == 9) { SR_LAUNCH_FWD(false, 9, 2, 1, 2); }
         else if (f.colors == 6) { if (count) SR_LAUNCH_FWD(true, 6, 2, 2, 1); else SR_LAUNCH_FWD(false, 6, 2, 1, 2); }
         else if (count)         SR_LAUNCH_FWD(true, 3, 2, 2, 1);
+        else if (cull && !(flags & (4 | 8)) && (flags & 32))   // (explicitly asked for: SR_FLAG_COOP_BACKWARD in sr_forward_render)
+                                hipLaunchKernelGGL(render_forward_coop_kernel, dim3(n_tiles), dim3(4 * kWave), 0, s, f, ranges, tile_order, point_list, recs, out_color,
+                                                   out_allmap, final_T, n_contrib, hit_mask);
         else if (flags & 4)     hipLaunchKernelGGL((render_forward_rows_kernel<2, 1, 2>), dim3((n_tiles + kXcds - 1) / kXcds * kXcds * 2), block, 0, s, f, ranges,
                                                    tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);
         else if (cull && !(flags & 8) && frame_counts)

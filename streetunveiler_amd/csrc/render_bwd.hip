@@ -275,6 +275,190 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
   }   // band
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K7, cooperative form (round 6): FOUR waves per 16x16 tile, one per 8x8 quadrant (one pixel per lane), one workgroup.
+// For frames with FEW tiles -- the reference's own runs render 480x320 = 600 tiles [REF /root/reference/README.md:195-207] -- where one wave
+// per tile leaves most of the GPU's 3 072 wave slots empty.  Same tile lists, same staging (each wave stages 16 of the round's 64 entries
+// into the SHARED s_e), same per-pair arithmetic; every wave walks the entries whose hit mask carries ITS quadrant, reduces its own 21
+// sums per entry into its slice of s_part, and after a barrier the workgroup adds the (up to four) slices of every entry in quadrant
+// order and stores ONE record per duplicate, as K7 does -- K8 is unchanged, no atomics, deterministic.  What it costs: a wave reduction per
+// (entry, quadrant) pair instead of per entry (7.66 M instead of 4.07 M at C3: that is why it is NOT the kernel for full-size frames --
+// DESIGN.md 4, measured in tools/notes_round6_measured.md) and three barriers per round.  Gradients equal K7's up to the order of a four-term sum.
+// ---------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void render_backward_coop_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
+                                 const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
+                                 const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                 const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dallmap,
+                                 const uint16_t* __restrict__ hit_mask, float4* __restrict__ inst_grads, uint8_t* __restrict__ written) {
+    static_assert(NC == 3, "three colour channels (the operator's own call); the 6- / 9-channel passes keep the one-wave kernel");
+    constexpr int kGQ = kGradQuads, kStage = kWave / 4;   // entries of a round staged per wave
+    __shared__ float4 s_e[entry_quads<NC>()][kWave];
+    __shared__ uint32_t s_m[kWave], s_slot[kWave], s_ql[4];
+    __shared__ float s_ox[kWave], s_oy[kWave];
+    __shared__ __attribute__((aligned(16))) float s_part[4][kWave][kGQ * 4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = (int)tile_order[blockIdx.x];
+    const int tx0 = (tile % f.tiles_x) * 16, ty0 = (tile / f.tiles_x) * 16;
+    const float Xc = (float)(tx0 + 8), Yc = (float)(ty0 + 8);
+    const int lx = lane & 7, ly = lane >> 3, qx = w & 1, qy = w >> 1;   // wave w = quadrant (w % 2, w / 2) = bit w of the hit masks
+    const uint2 range = ranges[tile];
+    const size_t HW = (size_t)f.H * f.W;
+    const int px = tx0 + qx * 8 + lx, py = ty0 + qy * 8 + ly;
+    const bool inside = px < f.W && py < f.H;
+    const size_t pix = inside ? (size_t)py * f.W + px : 0;
+    const float xq = (float)(qx * 8 + lx - 8), yq = (float)(qy * 8 + ly - 8);
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const float fin_D = inside ? final_T[HW + pix] : 0.f, fin_D2 = inside ? final_T[2 * HW + pix] : 0.f;
+    const uint32_t lastc = inside ? n_contrib[pix] : 0u, medc = inside ? n_contrib[HW + pix] : 0u;
+    const float gr = inside ? dL_dcolor[pix] : 0.f, gg = inside ? dL_dcolor[HW + pix] : 0.f, gb = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+    const float g_depth = inside ? dL_dallmap[pix] : 0.f, g_accum = inside ? dL_dallmap[HW + pix] : 0.f;
+    const float gn0 = inside ? dL_dallmap[2 * HW + pix] : 0.f, gn1 = inside ? dL_dallmap[3 * HW + pix] : 0.f, gn2 = inside ? dL_dallmap[4 * HW + pix] : 0.f;
+    const float g_median = inside ? dL_dallmap[5 * HW + pix] : 0.f, g_reg = inside ? dL_dallmap[6 * HW + pix] : 0.f;
+    const float a0 = (1.f - T_final) * g_reg, a1 = fin_D * g_reg, a2 = fin_D2 * g_reg;
+    float T = T_final, Z = -T_final * (g_accum - (f.bg[0] * gr + f.bg[1] * gg + f.bg[2] * gb));
+    {
+        const uint32_t ql = wave_max_u32(lastc);   // deepest entry any pixel of this wave's quadrant needs
+        if (lane == 0) s_ql[w] = ql;
+    }
+    __syncthreads();
+    const uint32_t ql0 = s_ql[0], ql1 = s_ql[1], ql2 = s_ql[2], ql3 = s_ql[3];
+    const uint32_t total = max(max(ql0, ql1), max(ql2, ql3));
+    const int rounds = (int)((total + kWave - 1) / kWave);
+    const bool stager = lane < kStage;
+    const int se = w * kStage + lane;          // the entry of the round this lane stages (lanes < 16 of each wave)
+    const bool holds_total = reduce24_holds_total(lane) && reduce24_index(lane) < 21;
+    // the walk's memory pipeline as in the one-wave kernel: list entries two rounds ahead, records one, raw
+    float4 nr[kRecQuads];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t nfirst = 0, nfbase = 0, nhraw = 0, gid_ahead = 0;
+    if (stager && rounds > 0 && (uint32_t)((rounds - 1) * kWave + se) < total) {
+        const uint32_t pos = range.x + (rounds - 1) * kWave + se;
+        const uint32_t gid = point_list[pos];
+        load_record(recs, gid, nr); nfirst = f.first[gid]; nfbase = f.first_base[gid / kScanTile];
+        nhraw = hit_mask[pos];
+    }
+    if (stager && rounds > 1) gid_ahead = point_list[range.x + (rounds - 2) * kWave + se];
+    for (int rd = rounds - 1; rd >= 0; --rd) {
+        const uint32_t rbase = (uint32_t)rd * kWave;
+        const uint32_t n = min((uint32_t)kWave, total - rbase);
+        wait_vector_memory();
+        if (stager) {
+            uint32_t m = 0;
+            if ((uint32_t)se < n) {
+                (void)stage_entry<2, 2, NC>(nr, zero4, zero4, Xc, Yc, 0, s_e, se);
+                const uint32_t at = rbase + (uint32_t)se;
+                const uint32_t need = (at < ql0 ? 1u : 0u) | (at < ql1 ? 2u : 0u) | (at < ql2 ? 4u : 0u) | (at < ql3 ? 8u : 0u);
+                m = decode_hits<2, 2>((uint16_t)nhraw) & need;
+                s_slot[se] = emission_index(nr, nfirst + nfbase, tile % f.tiles_x, tile / f.tiles_x, f);
+                const float mx = nr[2].y - Xc, my = nr[2].z - Yc;
+                s_ox[se] = -fminf(fmaxf(mx, -Xc), (float)(f.W - 1) - Xc); s_oy[se] = -fminf(fmaxf(my, -Yc), (float)(f.H - 1) - Yc);
+            }
+            s_m[se] = m;
+            if (rd > 0) {   // (the next round is always full)
+                const uint32_t gid = gid_ahead;
+                load_record(recs, gid, nr); nfirst = f.first[gid]; nfbase = f.first_base[gid / kScanTile];
+                nhraw = hit_mask[range.x + rbase - kWave + se];
+                if (rd > 1) gid_ahead = point_list[range.x + rbase - 2 * kWave + se];
+            }
+        }
+        __syncthreads();
+        const uint32_t mine = s_m[lane];
+        unsigned long long bits = ballot64(((mine >> w) & 1u) != 0u);   // the round's entries that reached a pixel of THIS quadrant in the forward
+        while (bits) {
+            const int j = 63 - __clzll((long long)bits);
+            bits &= ~(1ull << j);
+            const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+            const uint32_t cidx = rbase + (uint32_t)j;
+            float v[24];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                v[k] = 0.f;
+                if (k < 21) asm volatile("" : "+v"(v[k]));
+            }
+            Hit h;
+            const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc);
+            if (valid) {   // (the per-pair arithmetic of render_backward_kernel, one quadrant)
+                const float4 e4 = s_e[4][j], e5 = s_e[5][j];
+                const float Twx = e2.y, Twy = e2.z;
+                const float one_m_inv = fast_rcp(1.f - h.alpha);
+                T *= one_m_inv;
+                const float wgt = h.alpha * T;
+                const float phi = fmaf(e4.w, gr, fmaf(e5.x, gg, fmaf(e5.y, gb, fmaf(h.depth, g_depth, fmaf(e4.x, gn0, fmaf(e4.y, gn1, e4.z * gn2))))));
+                const float inv_depth = fast_rcp(h.depth);
+                const float m_d = fmaf(inv_depth, -kFN * kNear, kFN);
+                const float t1 = fmaf(m_d, a0, -a1);
+#if SR_DETACH_WEIGHT
+                const float psi = phi;
+#else
+                const float psi = phi + fmaf(m_d, t1 - a1, a2);
+#endif
+                const float dL_dalpha = T * psi - one_m_inv * Z;
+                Z = fmaf(wgt, psi, Z);
+                const float med_add = (cidx == medc - (SR_MEDIAN_CONTRIBUTOR_MINUS_ONE ? 1u : 0u)) ? g_median : 0.f;
+                const float dL_dz = fmaf(wgt, fmaf(t1 * (inv_depth * inv_depth), 2.f * kFN * kNear, g_depth), med_add);
+                const float dL_dG = e3.z * dL_dalpha;
+                v[18] = wgt * gr; v[19] = wgt * gg; v[20] = wgt * gb;
+                v[15] = wgt * gn0; v[16] = wgt * gn1; v[17] = wgt * gn2;
+                v[14] = h.G * dL_dalpha;
+                v[11] = dL_dz;
+                if (h.use3d) {
+                    const float gG = -dL_dG * h.G;
+                    const float dpx = (gG * h.sx + dL_dz * Twx) * h.pz_inv, dpy = (gG * h.sy + dL_dz * Twy) * h.pz_inv;
+                    const float dpz = -(dpx * h.sx + dpy * h.sy);
+                    v[0] = dpx; v[1] = dpy; v[2] = dpz;
+                    v[3] = xq * dpx; v[4] = xq * dpy; v[5] = xq * dpz;
+                    v[6] = yq * dpx; v[7] = yq * dpy; v[8] = yq * dpz;
+                    v[9] = dL_dz * h.sx; v[10] = dL_dz * h.sy;
+                } else {
+                    const float gG = -dL_dG * h.G * kFilterInvSquare;
+                    v[12] = gG * h.dx; v[13] = gG * h.dy;
+                }
+            }
+            const float tot = wave_reduce24<21>(v, lane);
+            if (holds_total) s_part[w][j][reduce24_index(lane)] = tot;
+        }
+        __syncthreads();
+        {   // one record per entry with a hit: the quadrants' slices added in quadrant order; thread (entry j, group g) takes quads g and g + 4
+            const int j = lane, g = w;
+            const uint32_t m = s_m[j];
+            if (m) {
+                auto sum_quad = [&](int k) {
+                    float4 a = zero4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (m & (1u << q)) { const float4 p = *reinterpret_cast<const float4*>(&s_part[q][j][4 * k]); a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+                    return a;
+                };
+                const float ox = s_ox[j], oy = s_oy[j];
+                float4* o = inst_grads + (size_t)s_slot[j] * kGQ;
+                if (g == 0) {
+                    float4 a0q = sum_quad(0), a4q = sum_quad(4);
+                    a0q.w = fmaf(ox, a0q.x, a0q.w);
+                    o[0] = a0q; o[4] = a4q;
+                    written[s_slot[j]] = 1;   // K8 reads this 1-B flag (zeroed per call) before it touches the record
+                } else if (g == 1) {
+                    const float4 s0 = sum_quad(0);
+                    float4 a1q = sum_quad(1), a5q = sum_quad(5);
+                    a1q.x = fmaf(ox, s0.y, a1q.x); a1q.y = fmaf(ox, s0.z, a1q.y); a1q.z = fmaf(oy, s0.x, a1q.z); a1q.w = fmaf(oy, s0.y, a1q.w);
+                    a5q.y = 0.f; a5q.z = 0.f; a5q.w = 0.f;   // slots 21..23: not in use with three channels (the reduction leaves copies there)
+                    o[1] = a1q; o[5] = a5q;
+                } else if (g == 2) {
+                    const float4 s0 = sum_quad(0);
+                    float4 a2q = sum_quad(2);
+                    a2q.x = fmaf(oy, s0.z, a2q.x);
+                    o[2] = a2q;
+                } else {
+                    o[3] = sum_quad(3);
+                }
+            }
+        }
+        __syncthreads();   // (the next round's staging overwrites s_e / s_m / s_slot)
+    }
+}
+
 #define SR_FOR_TILE_SHAPE(F)                                                    \
     if (f.tile_w == 16 && f.tile_h == 16) { F(2, 2); }                          \
     else if (f.tile_w == 8 && f.tile_h == 8) { F(1, 1); }                       \
@@ -283,12 +467,25 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
     else if (f.tile_w == 32 && f.tile_h == 16) { F(4, 2); }                     \
     else return hipErrorInvalidValue;
 
+// coop_mode: 0 = by tile count (the cooperative kernel below kCoopBelowTiles tiles of 16x16 with three colour channels), 1 = never, 2 = always (A/B, tests)
+constexpr int kCoopBelowTiles = 2600;
+static inline bool coop_few_tiles(const FrameDev& f, int coop_mode) {
+    if (!(f.tile_w == 16 && f.tile_h == 16 && f.colors == 3) || coop_mode == 1) return false;
+    return coop_mode == 2 || f.tiles_x * f.tiles_y < kCoopBelowTiles;
+}
+
 // flags: bit 0 = quadrant culling on (SR_FLAG_NO_QUADRANT_CULL clear), bit 1 = counter variant (counters != NULL), bit 2 = row-mapped kernel
 hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
                                   const float* extra, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, bool precomp_color_grads, hipStream_t s) {
+                                  const float* dL_dallmap, const uint16_t* hit_mask, float4* inst_grads, uint8_t* written, bool precomp_color_grads, hipStream_t s,
+                                  int coop_mode) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
+    if (coop_few_tiles(f, coop_mode)) {   // few tiles (the reference's `-r 4` frames): four quadrant waves per tile instead of one wave
+        hipLaunchKernelGGL((render_backward_coop_kernel<3>), dim3(n_tiles), dim3(4 * kWave), 0, s, f, ranges, tile_order, point_list, recs, final_T, n_contrib,
+                           dL_dcolor, dL_dallmap, hit_mask, inst_grads, written);
+        return hipGetLastError();
+    }
     if (!precomp_color_grads && f.tile_w == 16 && f.tile_h == 16 && f.colors != 3) {   // (the reference tile only: elsewhere the sums are formed and nobody reads them)
 #define SR_LAUNCH_BWD_NOXG(NCH) hipLaunchKernelGGL((render_backward_kernel<NCH, 2, 2, 1, false>), dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, extra, \
                                                    final_T, n_contrib, dL_dcolor, dL_dallmap, hit_mask, inst_grads, written)

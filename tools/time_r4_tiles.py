@@ -15,8 +15,8 @@ s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoV
 t = {k: v.to(dev).requires_grad_() for k, v in g.items()}
 m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
 dc, da = (x.to(dev) for x in synthetic_upstream_grads(W, H, seed=1))
-for tile in [None, (8, 8), (16, 8), (32, 8), (32, 16)]:
-    r = GaussianRasterizer(s, tile=tile)
+for tile, bk in [(None, "one_wave"), (None, "coop"), (None, None), ((8, 8), None), ((16, 8), None), ((32, 8), None), ((32, 16), None)]:
+    r = GaussianRasterizer(s, tile=tile, backward_kernel=bk)
     def step():
         for v in list(t.values()) + [m2]: v.grad = None
         c, radii, am = r(means3D=t["means3D"], means2D=m2, shs=t["shs"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
@@ -28,4 +28,4 @@ for tile in [None, (8, 8), (16, 8), (32, 8), (32, 16)]:
     lib.sr_set_stage_timing(1)
     for _ in range(3): step()
     torch.cuda.synchronize(); st = _lib.stage_stats(); lib.sr_set_stage_timing(0)
-    print(tile or (16, 16), f"{ms:.3f} ms/step", {k: round(v / max(n, 1), 3) for k, (v, n) in st.items() if n}, flush=True)
+    print(tile or (16, 16), bk or "", f"{ms:.3f} ms/step", {k: round(v / max(n, 1), 3) for k, (v, n) in st.items() if n}, flush=True)
