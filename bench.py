@@ -484,7 +484,8 @@ def reference_operating_point_section(deg, dev, P=1_500_000, W=480, H=320, steps
     """NOT the headline metric -- reported beside it: the reference's DOCUMENTED operating point.  Every example run of the reference uses
     `-r 4` [REF /root/reference/README.md:195-207]: Waymo's 1920x1280 frames rendered at 480x320, with a Waymo-segment-sized model.  At
     that size a step is a few hundred microseconds of kernels, and what the host does between them shows: the forward's read-back of the
-    duplicate count (the reference waits there too) keeps the host from queueing ahead.  Reported: fwd+bwd per step in the default mode, with a
+    duplicate count (the reference waits there too) keeps the host from queueing ahead.  Reported: fwd+bwd per step in the default mode (which
+    below 2 600 tiles runs the cooperative blend backward), with the one-wave backward forced, with 8x8 tiles (`tile="auto"`), with a
     binning capacity (SR_FLAG_BINNING_CAPACITY: no host wait anywhere), per-stage ms, and -- on a 10 k-Gaussian frame -- the forward's
     floor in the three ways of calling it (default / capacity / capacity inside a HIP graph)."""
     from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
@@ -524,15 +525,17 @@ def reference_operating_point_section(deg, dev, P=1_500_000, W=480, H=320, steps
         D = int(_C.rasterize_gaussians(s.bg, t["means3D"].detach(), e, t["opacities"].detach(), t["scales"].detach(), t["rotations"].detach(), 1.0, e, s.viewmatrix,
                                        s.projmatrix, s.tanfovx, s.tanfovy, H, W, t["shs"].detach(), deg, s.campos, False, False)[0])
     rc = GaussianRasterizer(s, binning_capacity=int(1.25 * D) + 1024)
-    ra = GaussianRasterizer(s, tile="auto")   # (600 tiles of 16x16 cannot fill the GPU's wave slots: resolve_tile picks 8x8 here)
+    ra = GaussianRasterizer(s, tile="auto")   # (optional: 8x8 tiles here -- moves the algorithm's tile-granular 3-sigma truncation)
     out["duplicates_D"] = D
-    out["ms_per_step_default"] = round(timed(lambda: step(r0), steps), 4)
+    out["ms_per_step_default"] = round(timed(lambda: step(r0), steps), 4)          # below 2 600 tiles: the four-wave cooperative blend backward
+    out["msplats_per_s_default"] = round(P / out["ms_per_step_default"] / 1e3, 1)
+    out["ms_per_step_one_wave_backward"] = round(timed(lambda: step(GaussianRasterizer(s, backward_kernel="one_wave")), steps), 4)
     out["ms_per_step_binning_capacity"] = round(timed(lambda: step(rc), steps), 4)
     out["overflowed"] = int(rc.last_status.tolist()[2])
     out["tile_auto"] = list(ra.tile or (16, 16))
     out["ms_per_step_tile_auto"] = round(timed(lambda: step(ra), steps), 4)
     out["msplats_per_s_tile_auto"] = round(P / out["ms_per_step_tile_auto"] / 1e3, 1)
-    rc = ra   # per-stage ms of the recommended setting
+    rc = r0   # per-stage ms of the default
     torch.cuda.synchronize(); lib.sr_set_stage_timing(1)
     for _ in range(3):
         step(rc)
