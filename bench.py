@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the untimed `train_step` section (the reference's 8 rasterizations of a late training iteration vs 2)")
     ap.add_argument("--row-mapped", action="store_true", help="A/B switch: force the row-mapped forward blend (SR_FLAG_ROW_MAPPED_FORWARD; bit-identical results)")
-    ap.add_argument("--backward-kernel", choices=["one_wave", "coop"], default=None, help="A/B switch: force the one-wave-per-tile / the cooperative blend backward (default: by tile count)")
+    ap.add_argument("--backward-kernel", choices=["one_wave", "coop", "rows"], default=None, help="A/B switch: force the one-wave-per-tile / the cooperative blend backward (default: by tile count)")
     ap.add_argument("--quadrant-mapped", action="store_true", help="A/B switch: force the quadrant-mapped forward blend (default: picked per frame on the device)")
     ap.add_argument("--exchange", choices=["factored", "allreduce", "compacted"], default="factored",
                     help="N > 1 gradient exchange: factored = all-gather 12-B colour gradients + local SH expansion + all-reduce of "

@@ -20,6 +20,7 @@ Empty tensors stand for "not provided", as in the reference.  No CPU fallback: C
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -85,6 +86,11 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+# SURFEL_EXTRA_FLAGS: SrFrame.flags bits OR-ed into every call of this process (A/B runs of opt-in switches such as SR_FLAG_ONE_SWEEP_SORT
+# under an unchanged caller; results are bit-identical by the switches' own contracts).
+_EXTRA_FLAGS = int(os.environ.get("SURFEL_EXTRA_FLAGS", "0"), 0)
+
+
 def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, debug, tile=None,
            quadrant_cull=True, blend_counters=None, ballot_ranking=False, row_mapped=None, forward_only=False, no_precomp_color_grad=False,
            binning_capacity=None, backward_kernel=None):
@@ -97,7 +103,7 @@ def _frame(bg, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W,
                    (0 if row_mapped is None else (L.SR_FLAG_ROW_MAPPED_FORWARD if row_mapped else L.SR_FLAG_QUADRANT_MAPPED_FORWARD)) |
                    (L.SR_FLAG_FORWARD_ONLY if forward_only else 0) | (L.SR_FLAG_NO_PRECOMP_COLOR_GRAD if no_precomp_color_grad else 0) |
                    (L.SR_FLAG_BINNING_CAPACITY if binning_capacity is not None else 0) |
-                   ({None: 0, "one_wave": L.SR_FLAG_ONE_WAVE_BACKWARD, "coop": L.SR_FLAG_COOP_BACKWARD}[backward_kernel]),
+                   ({None: 0, "one_wave": L.SR_FLAG_ONE_WAVE_BACKWARD, "coop": L.SR_FLAG_COOP_BACKWARD, "rows": L.SR_FLAG_ROW_BACKWARD}[backward_kernel]) | _EXTRA_FLAGS,
                    _ptr(blend_counters))
     return fr, keep
 

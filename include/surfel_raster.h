@@ -146,6 +146,13 @@ typedef struct SrFrame {
                                       * 600 tiles cannot fill the GPU with one wave each), one wave per tile above.  Same tile lists either way; gradients
                                       * agree up to the order of a four-term sum.  The flags exist for the A/B and the tests */
 
+#define SR_FLAG_ROW_BACKWARD 1024u     /* 16x16 tile, three colour channels, culling on: the ROW-MAPPED blend pair -- the forward (row-mapped kernel) writes its hit masks
+                                      * per (entry, 4x4 cell) instead of per (entry, 8x8 quadrant), and the backward's four 16-lane rows each walk their own cell's
+                                      * list (render_backward_rows_kernel).  Must be set in sr_forward_render AND in the backward of the same frame (the hit-mask
+                                      * format differs).  Images bit-identical; gradients agree with the one-wave kernel's up to the order of additions.
+                                      * MEASURED SLOWER (C3: K7 2.55 ms against 1.65: the per-entry sums are scattered into LDS with float atomics, ~100 LDS cycles
+                                      * per wave instruction -- csrc/render_bwd.hip): built and kept as the measured answer, picked nowhere */
+
 /* Per-Gaussian inputs == the keyword arguments of GaussianRasterizer.forward
  * (/root/reference/gaussian_renderer/__init__.py:129-138).  Exactly one of shs / colors_precomp
  * and exactly one of (scales, rotations) / transMat_precomp must be non-NULL. */

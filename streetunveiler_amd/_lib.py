@@ -23,6 +23,7 @@ SR_FLAG_BINNING_CAPACITY = 64
 SR_FLAG_ONE_SWEEP_SORT = 128
 SR_FLAG_ONE_WAVE_BACKWARD = 256
 SR_FLAG_COOP_BACKWARD = 512
+SR_FLAG_ROW_BACKWARD = 1024
 SR_ABI_VERSION = 10
 SR_STAGE_NAMES = ["preprocess", "depth_sort", "scan", "expand_x", "expand_y", "ranges", "blend_fwd", "blend_bwd",
                   "preprocess_bwd", "class_partition", "class_fwd", "class_bwd"]

@@ -560,8 +560,12 @@ int sr_forward_render(const SrFrame* frame, const SrGaussians* g, void* geom, si
         if (rows && quads) return fail(SR_ERR_INVALID_ARGUMENT, "SR_FLAG_ROW_MAPPED_FORWARD and SR_FLAG_QUADRANT_MAPPED_FORWARD exclude each other");
         if (rows && (!(f.tile_w == 16 && f.tile_h == 16 && f.colors == 3) || frame->blend_counters || (frame->flags & SR_FLAG_NO_QUADRANT_CULL)))
             return fail(SR_ERR_UNSUPPORTED, "SR_FLAG_ROW_MAPPED_FORWARD: 16x16 tile, three colour channels, no counters, culling on");
+        const bool cells = (frame->flags & SR_FLAG_ROW_BACKWARD) != 0;
+        if (cells && (!(f.tile_w == 16 && f.tile_h == 16 && f.colors == 3) || frame->blend_counters || (frame->flags & SR_FLAG_NO_QUADRANT_CULL) || quads || fwd_only))
+            return fail(SR_ERR_UNSUPPORTED, "SR_FLAG_ROW_BACKWARD: 16x16 tile, three colour channels, no counters, culling on, the row-mapped forward, a backward to follow");
         const int flags = ((frame->flags & SR_FLAG_NO_QUADRANT_CULL) ? 0 : 1) | (frame->blend_counters ? 2 : 0) | (rows ? 4 : 0) | (quads ? 8 : 0) |
-                          ((frame->flags & SR_FLAG_ONE_WAVE_BACKWARD) ? 16 : 0) | ((frame->flags & SR_FLAG_COOP_BACKWARD) ? 32 : 0);   // (the few-tile kernels: never / always)
+                          ((frame->flags & SR_FLAG_ONE_WAVE_BACKWARD) ? 16 : 0) | ((frame->flags & SR_FLAG_COOP_BACKWARD) ? 32 : 0) |   // (the few-tile kernels: never / always)
+                          (cells ? 64 : 0);
         const GeomLayout GL = geom_layout(g->P);   // (D and the visible count, left in the geometry state by the emission scan)
         SR_HIP(launch_render_forward(f, at<uint2>(binning, B.ranges), at<uint32_t>(binning, B.order), at<uint32_t>(binning, B.point_list), recs, g->colors_precomp, out_color,
                                      out_allmap, fwd_only ? nullptr : at<float>(image, I.final_T), fwd_only ? nullptr : at<uint32_t>(image, I.n_contrib),
@@ -768,7 +772,8 @@ int sr_backward_blend(const SrFrame* frame, const SrGaussians* g, void* geom, si
             SR_HIP(launch_render_backward(c.f, at<uint2>(binning, c.B.ranges), at<uint32_t>(binning, c.B.order), at<uint32_t>(binning, c.B.point_list), at<float4>(geom, c.L.recs), g->colors_precomp,
                                           at<float>(image, c.I.final_T), at<uint32_t>(image, c.I.n_contrib), dL_dcolor, dL_dallmap, at<uint16_t>(binning, c.B.hit_mask), c.inst_grads, c.written,
                                           !(frame->flags & SR_FLAG_NO_PRECOMP_COLOR_GRAD), c.s,
-                                          (frame->flags & SR_FLAG_ONE_WAVE_BACKWARD) ? 1 : ((frame->flags & SR_FLAG_COOP_BACKWARD) ? 2 : 0)));
+                                          (frame->flags & SR_FLAG_ROW_BACKWARD) ? 3
+                                          : ((frame->flags & SR_FLAG_ONE_WAVE_BACKWARD) ? 1 : ((frame->flags & SR_FLAG_COOP_BACKWARD) ? 2 : 0))));
     }
     return debug_sync(frame, c.s, "render_backward");
 }

@@ -416,6 +416,8 @@ __device__ __forceinline__ void dpp_fold_rows(float (&v)[24]) {
         : "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]));
     }
 }
+// LDS float add without a return value (ds_add_f32): one wave's adds to an address land in program order
+__device__ __forceinline__ void lds_add_f32(float* p, float x) { (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int reduce24_index(int l) { return ((l & 2) ? 2 : ((l >> 4) & 1)) + 3 * ((l >> 5) & 1) + 6 * ((l >> 2) & 1) + 12 * ((l >> 3) & 1); }
 __device__ __forceinline__ bool reduce24_holds_total(int l) { return (l & 1) == 0 && !((l & 2) && (l & 16)); }
 template <int NV = 24>

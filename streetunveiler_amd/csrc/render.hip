@@ -303,8 +303,12 @@ void render_forward_kernel(FrameDev f, const uint2* __restrict__ ranges, const u
 // operations as render_forward_kernel: bit-identical images, state and hit masks.  The rows' entry indices travel packed in one SGPR
 // (next set bit of the row's 64-bit mask: scalar unit), every lane extracts its row's byte and reads the staged entry at ITS address.
 // ---------------------------------------------------------------------------------------------
-template <int QX, int QY, int SPLIT>
-__device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], uint8_t (*s_hit)[kWave], const FrameDev& f, const uint2* __restrict__ ranges,
+// kCells (round 6, the row-mapped BACKWARD's input: render_backward_rows_kernel): the hit masks are kept per (entry, 4x4 CELL) instead of per
+// (entry, quadrant) -- a row IS a cell here, so the exact bit costs nothing: bit 4 q + c of the band's byte = cell c of quadrant q of the band
+// (16x16 tile: low byte = upper band, high byte = lower band, i.e. bit 4 q + c of the 16-bit word with q = the tile's quadrant).  The
+// bytes wait in LDS as s_hit[q][entry][cell] (one word per (q, entry)).
+template <int QX, int QY, int SPLIT, bool kCells = false>
+__device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], uint8_t (*s_hit)[kCells ? 4 * kWave : kWave], const FrameDev& f, const uint2* __restrict__ ranges,
                                                          const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list,
                                                          const float4* __restrict__ recs, float* __restrict__ out_color, float* __restrict__ out_allmap,
                                                          float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint16_t* __restrict__ hit_mask) {
@@ -364,7 +368,7 @@ __device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], u
         if (base + kWave + lane < n_total) load_record18(recs, gid, nr);   // (last: see render_forward_body)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) s_hit[q][lane] = 0;
+        for (int q = 0; q < NQ; ++q) { if (kCells) reinterpret_cast<uint32_t*>(&s_hit[q][0])[lane] = 0u; else s_hit[q][lane] = 0; }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (!(alive & (1u << q))) continue;
@@ -388,7 +392,7 @@ __device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], u
                 if (ballot64(valid) == 0ull) continue;
                 const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                 if (valid) {
-                    s_hit[q][j] = 1;   // (every valid lane of the row stores the same byte)
+                    if (kCells) s_hit[q][4 * j + (lane >> 4)] = 1; else s_hit[q][j] = 1;   // (every valid lane of the row stores the same byte)
                     const uint32_t contributor = base + j + 1u;
                     const float test_T = T[q] * (1.f - h.alpha);
                     const bool go = !(test_T < kTStop);
@@ -414,7 +418,12 @@ __device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], u
         if (hit_mask) {
             uint32_t hm = 0;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) hm |= (uint32_t)s_hit[q][lane] << q;
+            for (int q = 0; q < NQ; ++q) {
+                if (kCells) {   // four 0 / 1 bytes -> a nibble: the products land on distinct bits (21 + c), no carries
+                    const uint32_t wd = reinterpret_cast<const uint32_t*>(&s_hit[q][0])[lane];
+                    hm |= (((wd * 0x00204081u) >> 21) & 15u) << (4 * q);
+                } else hm |= (uint32_t)s_hit[q][lane] << q;
+            }
             hm_prev = hm; n_prev = n; base_prev = base;
         }
     }
@@ -446,14 +455,15 @@ __device__ __forceinline__ void render_forward_rows_body(float4 (*s_e)[kWave], u
     }
 }
 
-template <int QX, int QY, int SPLIT>
+template <int QX, int QY, int SPLIT, bool kCells = false>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(QX * QY <= 2 ? 6 : 1, QX * QY <= 2 ? 6 : 8)))
 void render_forward_rows_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list,
                                 const float4* __restrict__ recs, float* __restrict__ out_color, float* __restrict__ out_allmap, float* __restrict__ final_T,
                                 uint32_t* __restrict__ n_contrib, uint16_t* __restrict__ hit_mask) {
+    static_assert(!kCells || (QX == 2 && QY == 1 && SPLIT == 2), "cell-granular hit masks: the 16x16 tile's band waves (eight cells per band byte)");
     __shared__ float4 s_e[entry_quads<3>()][kWave];
-    __shared__ uint8_t s_hit[QX * QY][kWave];   // (entry, quadrant) reached a pixel: the backward's exact visit list
-    render_forward_rows_body<QX, QY, SPLIT>(s_e, s_hit, f, ranges, tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);
+    __shared__ __attribute__((aligned(4))) uint8_t s_hit[QX * QY][kCells ? 4 * kWave : kWave];   // (entry, quadrant [, cell]) reached a pixel: the backward's exact visit list
+    render_forward_rows_body<QX, QY, SPLIT, kCells>(s_e, s_hit, f, ranges, tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);
 }
 
 
@@ -651,7 +661,8 @@ __global__ __launch_bounds__(kWave) void pair_decisions_kernel(FrameDev f, const
     else if (f.tile_w == 32 && f.tile_h == 16) { F(4, 2); }                     \
     else return hipErrorInvalidValue;
 
-// (bit 5 of `flags`: the cooperative forward -- measured and NOT picked by itself: see render_forward_coop_kernel)
+// (bit 5 of `flags`: the cooperative forward -- measured and NOT picked by itself: see render_forward_coop_kernel;
+//  bit 6: the row-mapped kernel writing CELL-granular hit masks -- what render_backward_rows_kernel reads; 16x16, three channels, culling on)
 // flags: bit 0 = quadrant culling on (SR_FLAG_NO_QUADRANT_CULL clear), bit 1 = counter variant (counters != NULL), bit 2 / bit 3 = the row-mapped /
 // the quadrant-mapped kernel forced (else, for the 16x16 tile with three channels and culling on, the device picks per frame: frame_counts)
 hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const uint32_t* tile_order, const uint32_t* point_list, const float4* recs,
@@ -674,6 +685,8 @@ hipError_t launch_render_forward(const FrameDev& f, const uint2* ranges, const u
         else if (cull && !(flags & (4 | 8)) && (flags & 32))   // (explicitly asked for: SR_FLAG_COOP_BACKWARD in sr_forward_render)
                                 hipLaunchKernelGGL(render_forward_coop_kernel, dim3(n_tiles), dim3(4 * kWave), 0, s, f, ranges, tile_order, point_list, recs, out_color,
                                                    out_allmap, final_T, n_contrib, hit_mask);
+        else if (flags & 64)    hipLaunchKernelGGL((render_forward_rows_kernel<2, 1, 2, true>), dim3((n_tiles + kXcds - 1) / kXcds * kXcds * 2), block, 0, s, f, ranges,
+                                                   tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);   // (cell-granular hit masks)
         else if (flags & 4)     hipLaunchKernelGGL((render_forward_rows_kernel<2, 1, 2>), dim3((n_tiles + kXcds - 1) / kXcds * kXcds * 2), block, 0, s, f, ranges,
                                                    tile_order, point_list, recs, out_color, out_allmap, final_T, n_contrib, hit_mask);
         else if (cull && !(flags & 8) && frame_counts)

@@ -459,6 +459,189 @@ void render_backward_coop_kernel(FrameDev f, const uint2* __restrict__ ranges, c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K7, row-mapped (round 6; three colour channels, the 16x16 tile): the wave's four 16-lane rows are the four 4x4 CELLS of a quadrant and every
+// row walks ITS OWN list -- the entries of the round that reached a pixel of its cell in the forward (render_forward_rows_kernel<.., kCells>
+// writes the exact (entry, cell) bits) -- so one wave step serves four different entries instead of one entry on 64 lanes of which 0.29 take
+// part (C3: 5.6 M steps instead of 7.66 M quadrant tests).  What it costs: the 21 sums are reduced per STEP inside each 16-lane row (two
+// bank-masked DPP levels + two quad levels) and ADDED to the entry's row of s_out with LDS float atomics (one wave: program order, so the
+// sums are deterministic), instead of once per entry across the wave.  Same staging, same `intersect`, same per-pair arithmetic, same
+// records and flush as render_backward_kernel; the per-entry sums differ from its by the order of the additions.
+// MEASURED at C3 (profiles/r06_c3rows_*): 2.55 ms against the one-wave kernel's 1.65 -- 5.56 M steps instead of 7.66 M tests, but (i) a step costs
+// 182 vector instructions (per-lane entry addresses, 64-bit per-lane list cursors, the in-row reduction per step): SQ_INSTS_VALU 1 048 M against
+// 1 008 M, nothing saved; (ii) the scatter-accumulate is what bounds it: a ds_add_f32 wave instruction with 16 active lanes on distinct addresses
+// holds the CU's LDS pipe ~100 cycles (SQ_LDS_IDX_ACTIVE 1 274 M against 161 M: the LDS is busy 2.07 of the 2.6 ms, SQ_WAIT_INST_LDS 1 002 M of
+// 3 930 M wave cycles).  With the quad levels of the reduction left to the LDS as well (six atomic adds per lane, four lanes per address): 9.8 ms.
+// Opt-in (SR_FLAG_ROW_BACKWARD), tested, NOT a default anywhere: the measured answer to "walk per-cell contributor lists with LDS adds".
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void render_backward_rows_kernel(FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
+                                 const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
+                                 const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                 const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dallmap,
+                                 const uint16_t* __restrict__ hit_mask, float4* __restrict__ inst_grads, uint8_t* __restrict__ written) {
+    constexpr int NC = 3, QX = 2, QY = 2, NQ = 4, kGQ = kGradQuads;
+    __shared__ float4 s_e[entry_quads<NC>()][kWave];
+    __shared__ __attribute__((aligned(16))) float s_out[kWave][kGQ * 4];
+    const int lane = threadIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];
+    const int tx0 = (tile % f.tiles_x) * 16, ty0 = (tile / f.tiles_x) * 16;
+    const float Xc = (float)(tx0 + 8), Yc = (float)(ty0 + 8);
+    // row r = lane / 16 <-> cell (r & 1, r >> 1) of a quadrant; lane % 16 <-> pixel (l & 3, (l >> 2) & 3) of the cell (as in the row-mapped K6)
+    const int row = lane >> 4;
+    const int lx = (row & 1) * 4 + (lane & 3), ly = (row >> 1) * 4 + ((lane >> 2) & 3);
+    const uint2 range = ranges[tile];
+    const size_t HW = (size_t)f.H * f.W;
+    const float bg0 = f.bg[0], bg1 = f.bg[1], bg2 = f.bg[2];
+    const float xl0 = (float)(lx - 8), yl0 = (float)(ly - 8);
+    float gr[NQ], gg[NQ], gb[NQ], gn0[NQ], gn1[NQ], gn2[NQ], g_depth[NQ], g_median[NQ], a0[NQ], a1[NQ], a2[NQ];
+    uint32_t lastc[NQ], medc[NQ], quad_last[NQ];
+    float T[NQ], Z[NQ];
+    uint32_t total = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int px = tx0 + (q % QX) * 8 + lx, py = ty0 + (q / QX) * 8 + ly;
+        const bool inside = px < f.W && py < f.H;
+        const size_t pix = inside ? (size_t)py * f.W + px : 0;
+        const float T_final = inside ? final_T[pix] : 0.f;
+        const float fin_D = inside ? final_T[HW + pix] : 0.f, fin_D2 = inside ? final_T[2 * HW + pix] : 0.f;
+        lastc[q] = inside ? n_contrib[pix] : 0u;
+        medc[q] = inside ? n_contrib[HW + pix] : 0u;
+        gr[q] = inside ? dL_dcolor[pix] : 0.f; gg[q] = inside ? dL_dcolor[HW + pix] : 0.f; gb[q] = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+        g_depth[q] = inside ? dL_dallmap[pix] : 0.f;
+        const float g_accum = inside ? dL_dallmap[HW + pix] : 0.f;
+        gn0[q] = inside ? dL_dallmap[2 * HW + pix] : 0.f; gn1[q] = inside ? dL_dallmap[3 * HW + pix] : 0.f; gn2[q] = inside ? dL_dallmap[4 * HW + pix] : 0.f;
+        g_median[q] = inside ? dL_dallmap[5 * HW + pix] : 0.f;
+        const float g_reg = inside ? dL_dallmap[6 * HW + pix] : 0.f;
+        const float bg_dot = bg0 * gr[q] + bg1 * gg[q] + bg2 * gb[q];
+        a0[q] = (1.f - T_final) * g_reg; a1[q] = fin_D * g_reg; a2[q] = fin_D2 * g_reg;
+        T[q] = T_final; Z[q] = -T_final * (g_accum - bg_dot);
+        quad_last[q] = wave_max_u32(lastc[q]);
+        total = max(total, quad_last[q]);
+    }
+    const int rounds = (int)((total + kWave - 1) / kWave);
+    float4 nr[kRecQuads];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t nfirst = 0, nfbase = 0, nhraw = 0, gid_ahead = 0;
+    if (rounds > 0 && (uint32_t)((rounds - 1) * kWave + lane) < total) {
+        const uint32_t pos = range.x + (rounds - 1) * kWave + lane;
+        const uint32_t gid = point_list[pos];
+        load_record(recs, gid, nr); nfirst = f.first[gid]; nfbase = f.first_base[gid / kScanTile];
+        nhraw = hit_mask[pos];
+    }
+    if (rounds > 1) gid_ahead = point_list[range.x + (rounds - 2) * kWave + lane];
+    // after the in-row reduction the lanes of quad (bit 2, bit 3 of the lane) hold the row's totals of values k + 6 bit2 + 12 bit3, k = 0..5
+    const int vbase = 6 * ((lane >> 2) & 1) + 12 * ((lane >> 3) & 1);
+    bool pend = false;
+    uint32_t pslot = 0;
+    for (int rd = rounds - 1; rd >= 0; --rd) {
+        const uint32_t rbase = (uint32_t)rd * kWave;
+        const uint32_t n = min((uint32_t)kWave, total - rbase);
+        uint32_t cm = 0, slot = 0;   // cm: bit 4 q + c = this lane's ENTRY reached a pixel of cell c of quadrant q in the forward
+        float ox = 0.f, oy = 0.f;
+        wait_vector_memory();
+        if ((uint32_t)lane < n) {
+            (void)stage_entry<QX, QY, NC>(nr, zero4, zero4, Xc, Yc, 0, s_e, lane);
+            slot = emission_index(nr, nfirst + nfbase, tile % f.tiles_x, tile / f.tiles_x, f);
+            uint32_t need = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) need |= (rbase + lane < quad_last[q]) ? (15u << (4 * q)) : 0u;
+            cm = nhraw & need;
+            const float mx = nr[2].y - Xc, my = nr[2].z - Yc;
+            ox = -fminf(fmaxf(mx, -Xc), (float)(f.W - 1) - Xc); oy = -fminf(fmaxf(my, -Yc), (float)(f.H - 1) - Yc);
+        }
+        if (rd > 0) {
+            const uint32_t gid = gid_ahead;
+            load_record(recs, gid, nr); nfirst = f.first[gid]; nfbase = f.first_base[gid / kScanTile];
+            nhraw = hit_mask[range.x + rbase - kWave + lane];
+            if (rd > 1) gid_ahead = point_list[range.x + rbase - 2 * kWave + lane];
+        }
+        if (pend) flush_record<kGQ, true>(&s_out[lane][0], inst_grads, written, pslot, 0.f, 0.f, false);
+        {
+            float4* z = reinterpret_cast<float4*>(&s_out[lane][0]);
+#pragma unroll
+            for (int k = 0; k < kGQ; ++k) z[k] = (k == 5) ? make_float4(0.f, 0.f, ox, oy) : zero4;
+        }
+        const unsigned long long wrote = ballot64(cm != 0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const unsigned long long b0 = ballot64(((cm >> (4 * q)) & 1u) != 0u), b1 = ballot64(((cm >> (4 * q + 1)) & 1u) != 0u),
+                                     b2 = ballot64(((cm >> (4 * q + 2)) & 1u) != 0u), b3 = ballot64(((cm >> (4 * q + 3)) & 1u) != 0u);
+            if ((b0 | b1 | b2 | b3) == 0ull) continue;   // wave-uniform
+            unsigned long long brow = row == 0 ? b0 : (row == 1 ? b1 : (row == 2 ? b2 : b3));
+            const float xq = xl0 + (float)((q % QX) * 8), yq = yl0 + (float)((q / QX) * 8);
+            while (ballot64(brow != 0ull) != 0ull) {
+                const bool act = brow != 0ull;
+                const uint32_t j = act ? (uint32_t)(63 - __clzll((long long)brow)) : 0u;   // back to front
+                brow &= ~(1ull << j);
+                const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+                const uint32_t cidx = rbase + j;
+                float v[24];
+#pragma unroll
+                for (int k = 0; k < 24; ++k) {
+                    v[k] = 0.f;
+                    if (k < 21) asm volatile("" : "+v"(v[k]));
+                }
+                Hit h;
+                const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc[q]) & act;
+                if (valid) {   // (the per-pair arithmetic of render_backward_kernel)
+                    const float4 e4 = s_e[4][j], e5 = s_e[5][j];
+                    const float Twx = e2.y, Twy = e2.z;
+                    const float one_m_inv = fast_rcp(1.f - h.alpha);
+                    T[q] *= one_m_inv;
+                    const float w = h.alpha * T[q];
+                    const float phi = fmaf(e4.w, gr[q], fmaf(e5.x, gg[q], fmaf(e5.y, gb[q], fmaf(h.depth, g_depth[q],
+                                      fmaf(e4.x, gn0[q], fmaf(e4.y, gn1[q], e4.z * gn2[q]))))));
+                    const float inv_depth = fast_rcp(h.depth);
+                    const float m_d = fmaf(inv_depth, -kFN * kNear, kFN);
+                    const float t1 = fmaf(m_d, a0[q], -a1[q]);
+#if SR_DETACH_WEIGHT
+                    const float psi = phi;
+#else
+                    const float psi = phi + fmaf(m_d, t1 - a1[q], a2[q]);
+#endif
+                    const float dL_dalpha = T[q] * psi - one_m_inv * Z[q];
+                    Z[q] = fmaf(w, psi, Z[q]);
+                    const float med_add = (cidx == medc[q] - (SR_MEDIAN_CONTRIBUTOR_MINUS_ONE ? 1u : 0u)) ? g_median[q] : 0.f;
+                    const float dL_dz = fmaf(w, fmaf(t1 * (inv_depth * inv_depth), 2.f * kFN * kNear, g_depth[q]), med_add);
+                    const float dL_dG = e3.z * dL_dalpha;
+                    v[18] += w * gr[q]; v[19] += w * gg[q]; v[20] += w * gb[q];
+                    v[15] += w * gn0[q]; v[16] += w * gn1[q]; v[17] += w * gn2[q];
+                    v[14] += h.G * dL_dalpha;
+                    v[11] += dL_dz;
+                    if (h.use3d) {
+                        const float gG = -dL_dG * h.G;
+                        const float dpx = (gG * h.sx + dL_dz * Twx) * h.pz_inv, dpy = (gG * h.sy + dL_dz * Twy) * h.pz_inv;
+                        const float dpz = -(dpx * h.sx + dpy * h.sy);
+                        v[0] += dpx; v[1] += dpy; v[2] += dpz;
+                        v[3] = fmaf(xq, dpx, v[3]); v[4] = fmaf(xq, dpy, v[4]); v[5] = fmaf(xq, dpz, v[5]);
+                        v[6] = fmaf(yq, dpx, v[6]); v[7] = fmaf(yq, dpy, v[7]); v[8] = fmaf(yq, dpz, v[8]);
+                        v[9] = fmaf(dL_dz, h.sx, v[9]); v[10] = fmaf(dL_dz, h.sy, v[10]);
+                    } else {
+                        const float gG = -dL_dG * h.G * kFilterInvSquare;
+                        v[12] = fmaf(gG, h.dx, v[12]);
+                        v[13] = fmaf(gG, h.dy, v[13]);
+                    }
+                }
+                dpp_fold_rows<21>(v);   // v[0..5]: value k + vbase, summed over the lanes {l, l^4, l^8, l^12} of the row
+                float* orow = &s_out[j][vbase];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { v[k] += dpp_mov<0x4E>(v[k]); }   // quad_perm:[2,3,0,1] = lane ^ 2
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { v[k] += dpp_mov<0xB1>(v[k]); }   // quad_perm:[1,0,3,2] = lane ^ 1: every lane of the quad holds the six totals
+                const int i = lane & 3;
+                const float t0 = i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3]));
+                const float t4 = i == 0 ? v[4] : v[5];
+                if (act && vbase + i < 21) lds_add_f32(orow + i, t0);
+                if (act && i < 2 && vbase + 4 + i < 21) lds_add_f32(orow + 4 + i, t4);
+            }
+        }
+        pend = ((wrote >> lane) & 1ull) != 0ull; pslot = slot;
+    }
+    if (pend) flush_record<kGQ, true>(&s_out[lane][0], inst_grads, written, pslot, 0.f, 0.f, false);
+}
+
 #define SR_FOR_TILE_SHAPE(F)                                                    \
     if (f.tile_w == 16 && f.tile_h == 16) { F(2, 2); }                          \
     else if (f.tile_w == 8 && f.tile_h == 8) { F(1, 1); }                       \
@@ -467,7 +650,8 @@ void render_backward_coop_kernel(FrameDev f, const uint2* __restrict__ ranges, c
     else if (f.tile_w == 32 && f.tile_h == 16) { F(4, 2); }                     \
     else return hipErrorInvalidValue;
 
-// coop_mode: 0 = by tile count (the cooperative kernel below kCoopBelowTiles tiles of 16x16 with three colour channels), 1 = never, 2 = always (A/B, tests)
+// coop_mode: 0 = by tile count (the cooperative kernel below kCoopBelowTiles tiles of 16x16 with three colour channels), 1 = never, 2 = always (A/B, tests),
+// 3 = the row-mapped kernel: the forward must have written CELL-granular hit masks (launch_render_forward flags bit 6)
 constexpr int kCoopBelowTiles = 2600;
 static inline bool coop_few_tiles(const FrameDev& f, int coop_mode) {
     if (!(f.tile_w == 16 && f.tile_h == 16 && f.colors == 3) || coop_mode == 1) return false;
@@ -481,6 +665,12 @@ hipError_t launch_render_backward(const FrameDev& f, const uint2* ranges, const 
                                   int coop_mode) {
     const int n_tiles = f.tiles_x * f.tiles_y;
     if (n_tiles == 0) return hipSuccess;
+    if (coop_mode == 3) {
+        if (!(f.tile_w == 16 && f.tile_h == 16 && f.colors == 3)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(render_backward_rows_kernel, dim3(n_tiles), dim3(kWave), 0, s, f, ranges, tile_order, point_list, recs, final_T, n_contrib,
+                           dL_dcolor, dL_dallmap, hit_mask, inst_grads, written);
+        return hipGetLastError();
+    }
     if (coop_few_tiles(f, coop_mode)) {   // few tiles (the reference's `-r 4` frames): four quadrant waves per tile instead of one wave
         hipLaunchKernelGGL((render_backward_coop_kernel<3>), dim3(n_tiles), dim3(4 * kWave), 0, s, f, ranges, tile_order, point_list, recs, final_T, n_contrib,
                            dL_dcolor, dL_dallmap, hit_mask, inst_grads, written);

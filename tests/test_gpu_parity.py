@@ -1127,3 +1127,38 @@ def test_cooperative_backward_equals_the_one_wave_backward(size):
         # (HIP vs HIP: summation order only)
         assert np.abs(coop[k] - one[k]).max() <= bar("class_grads_vs_operator") * scale, f"{k}: cooperative vs one-wave differ by {np.abs(coop[k] - one[k]).max() / scale:.2e} of the tensor scale"
         assert_grads_close(coop[k], bwd[k], bar("oracle32_grad_rel"), "coop " + k)
+
+
+@pytest.mark.parametrize("size", [(480, 320, 150_000), (1280, 720, 300_000)])
+def test_row_mapped_backward_equals_the_one_wave_backward(size, kernel="rows"):
+    """The row-mapped blend pair (SR_FLAG_ROW_BACKWARD: the forward keeps its hit masks per (entry, 4x4 cell), the backward's four 16-lane rows walk
+    their own cell's list and add their per-step sums to the entry's record row in LDS) against the default pair on the same tile lists: forward
+    bit-identical, every gradient equal up to the order of the additions, held to the oracle by the same bar, bit-identical reruns."""
+    from diff_surfel_rasterization import GaussianRasterizer
+    from tests.gpu_util import DEV, assert_grads_close, run_oracle, settings_for
+    from tests.bars import bar
+    W, H, P = size
+    cam = synthetic_camera(W, H, index=2)
+    g = synthetic_gaussians(P, W, H, seed=33, scale_lo=1e-3, scale_hi=8e-3)
+    dc, da = synthetic_upstream_grads(W, H, seed=4)
+    bg = np.array([0.1, 0.0, 0.2], np.float32)
+
+    def step(k_):
+        t = {k: v.to(DEV).requires_grad_() for k, v in g.items()}
+        m2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+        c, r, a = GaussianRasterizer(settings_for(cam, bg, 3), backward_kernel=k_)(means3D=t["means3D"], means2D=m2, shs=t["shs"], opacities=t["opacities"],
+                                                                                  scales=t["scales"], rotations=t["rotations"])
+        ((c * dc.to(DEV)).sum() + (a * da.to(DEV)).sum()).backward()
+        torch.cuda.synchronize()
+        out = dict(color=c.detach(), allmap=a.detach(), radii=r, dL_dmeans3D=t["means3D"].grad, dL_dopacity=t["opacities"].grad, dL_dscales=t["scales"].grad,
+                   dL_drotations=t["rotations"].grad, dL_dsh=t["shs"].grad, dL_dmeans2D=m2.grad)
+        return {k: v.cpu().numpy() for k, v in out.items()}
+    one, rows, rows2 = step("one_wave"), step(kernel), step(kernel)
+    _, bwd = run_oracle(g, cam, bg, 3, dc, da)
+    for k in ("color", "allmap", "radii"):
+        assert np.array_equal(one[k], rows[k]), f"row-mapped pair: {k} differs from the default forward's"
+    for k in [k_ for k_ in one if k_.startswith("dL_")]:
+        assert np.array_equal(rows[k], rows2[k]), f"{k}: the row-mapped backward is not deterministic"
+        scale = np.abs(one[k]).max() + 1e-30
+        assert np.abs(rows[k] - one[k]).max() <= bar("class_grads_vs_operator") * scale, f"{k}: row-mapped vs one-wave differ by {np.abs(rows[k] - one[k]).max() / scale:.2e} of the tensor scale"
+        assert_grads_close(rows[k], bwd[k], bar("oracle32_grad_rel"), kernel + " " + k)
