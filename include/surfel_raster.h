@@ -219,6 +219,9 @@ int sr_abi_version(void);
 /* Which of the named compile-time switches (include/surfel_switches.h: SURVEY.md Appendix A's (!) items) this library was built with
  * at a NON-default value: SR_SWITCH_BITS, 0 for the shipped configuration. */
 uint32_t sr_build_switches(void);
+/* The content digest of the sources this library was built from (csrc/*, include/*.h, the build script; 16 hex digits, "unknown" for a build
+ * that did not pass one): the in-tree build rebuilds on a mismatch and the Python loader refuses a library that is not its tree's. */
+const char* sr_source_digest(void);
 const char* sr_last_error(void);
 
 /* Sizes of the three state buffers (bytes). num_rendered = D from sr_forward_plan. */

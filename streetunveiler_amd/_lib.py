@@ -63,7 +63,7 @@ class SrImageView(C.Structure):
 
 
 # every symbol include/surfel_raster.h declares (checked by tests/test_abi.py)
-EXPORTS = ["sr_abi_version", "sr_build_switches", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
+EXPORTS = ["sr_abi_version", "sr_build_switches", "sr_source_digest", "sr_last_error", "sr_geom_bytes", "sr_binning_bytes", "sr_image_bytes",
            "sr_backward_workspace_bytes", "sr_geom_view", "sr_binning_view", "sr_image_view", "sr_forward_plan", "sr_sh_gradient_expand", "sr_knn_workspace_bytes", "sr_knn_mean_dist2",
            "sr_forward_render", "sr_backward", "sr_backward_blend", "sr_backward_colors", "sr_backward_geometry", "sr_debug_pair_decisions", "sr_class_image_bytes", "sr_class_forward_render", "sr_class_backward", "sr_class_shared_bytes", "sr_class_forward_shared", "sr_class_backward_shared", "sr_mark_visible", "sr_set_stage_timing", "sr_stage_stats", "sr_debug_radix_sort", "sr_debug_radix_sort_temp_bytes", "sr_debug_lds_atomic_ranks", "sr_rank_mode", "sr_postprocess_forward",
            "sr_postprocess_backward"]
@@ -85,6 +85,15 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m streetunveiler_amd.build` "
             "(or __graft_entry__.build()). There is no CPU fallback for the rasterizer.")
     lib = C.CDLL(LIB_PATH)
+    # the in-tree library must be the one built from the sources next to it (it travels prebuilt to the GPU box); SURFEL_RASTER_LIB -- a
+    # variant or A/B build chosen on purpose -- is taken as it is
+    if not os.environ.get("SURFEL_RASTER_LIB"):
+        from .build import source_digest
+        lib.sr_source_digest.restype = C.c_char_p
+        have, want = lib.sr_source_digest().decode(), source_digest()
+        if have != want:
+            raise SurfelRasterError(f"{LIB_PATH} was built from other sources (digest {have}, the tree's is {want}): rebuild it with "
+                                    "`python -m streetunveiler_amd.build`")
     lib.sr_abi_version.restype = C.c_int
     lib.sr_build_switches.restype = C.c_uint32
     lib.sr_last_error.restype = C.c_char_p

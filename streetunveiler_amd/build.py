@@ -35,6 +35,7 @@ SOURCES = [
     ("postprocess.hip", []),
     ("knn.hip", ["-ffp-contract=off"]),         # squared distances bit-identical to the brute-force oracle
     ("api.hip", []),
+    ("build_id.hip", []),                       # + -DSR_SOURCE_DIGEST="..." (build()): recompiled whenever anything else is
 ]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "blend_common.h"), os.path.join(os.path.dirname(HERE), "include", "surfel_raster.h"),
            os.path.join(os.path.dirname(HERE), "include", "surfel_switches.h")]
@@ -69,6 +70,19 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+def embedded_digest(lib: str):
+    """The source digest a built library carries (csrc/build_id.hip), read from the file without loading it; None if it has none."""
+    try:
+        data = open(lib, "rb").read()
+    except OSError:
+        return None
+    i = data.find(b"SR_SOURCE_DIGEST=")
+    if i < 0:
+        return None
+    j = data.find(b"\0", i)
+    return data[i + len(b"SR_SOURCE_DIGEST="):j].decode("ascii", "replace")
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -88,16 +102,19 @@ def build_variant(name: str, force: bool = False, verbose: bool = False) -> str:
 def build(force: bool = False, verbose: bool = False, libdir: str = LIBDIR, defines=()) -> str:
     os.makedirs(libdir, exist_ok=True)
     lib = os.path.join(libdir, "libsurfel_raster.so")
-    # a library newer than every source, header and this script is current even where its object files did not travel (the variants' .o
-    # files are not shipped to the GPU box)
-    if not force and not _stale(lib, [os.path.join(CSRC, src) for src, _ in SOURCES] + HEADERS + [__file__]):
+    # A library is current when it CARRIES the digest of the sources next to it (content, not time stamps: a checkout or a copy resets
+    # those) -- even where its object files did not travel (the variants' .o files are not shipped to the GPU box).
+    digest = source_digest()
+    if not force and embedded_digest(lib) == digest:
         return lib
     objs, jobs = [], []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(libdir, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s, __file__] + HEADERS):
+        if src == "build_id.hip":   # always: it is what stamps the library (one second of hipcc)
+            jobs.append([HIPCC] + COMMON + list(defines) + extra + ['-DSR_SOURCE_DIGEST="' + digest + '"', "-c", s, "-o", o])
+        elif force or _stale(o, [s, __file__] + HEADERS):
             jobs.append([HIPCC] + COMMON + list(defines) + extra + ["-c", s, "-o", o])
 
     def run(cmd):
@@ -110,8 +127,9 @@ def build(force: bool = False, verbose: bool = False, libdir: str = LIBDIR, defi
 
     with ThreadPoolExecutor(max_workers=max(4, (os.cpu_count() or 4))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(lib, objs):
-        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs)
+    run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs)
+    if embedded_digest(lib) != digest:
+        raise RuntimeError(f"{lib}: built, but it carries digest {embedded_digest(lib)!r} instead of {digest!r}")
     return lib
 
 

@@ -134,3 +134,14 @@ def test_roctx_ranges_are_opt_in_and_balanced():
         if flag == "1" and "OSError" in r.stderr:
             pytest.skip("libroctx64 not present on this machine")
         assert r.returncode == 0 and f"roctx {flag == '1'}" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_library_carries_the_digest_of_the_tree(lib):
+    """The prebuilt .so travels to the GPU box next to the sources: it must BE the build of those sources.  build() decides by this digest
+    (content of csrc/*, include/*.h and the build script -- not time stamps), the loader refuses a mismatch, sr_source_digest() reports it."""
+    from streetunveiler_amd import build as sb
+    want = sb.source_digest()
+    assert sb.embedded_digest(sb.LIB) == want
+    lib.sr_source_digest.restype = ctypes.c_char_p
+    assert lib.sr_source_digest().decode() == want
+    assert sb.embedded_digest(__file__) is None   # (a file without the tag)
