@@ -418,7 +418,7 @@ def test_bench_measurement_helpers(tmp_path, monkeypatch):
     info = bench.rccl_topology(str(log), "nccl", 8)
     assert info["channels"] == 32 and info["coll_channels"] == 32 and info["nranks_in_log"] == 8 and info["version"].startswith("RCCL version")
     log.write_text("host:1:2 [0] NCCL INFO Channel 00/01 : 0 1\n")
-    assert bench.rccl_topology(str(log), "nccl", 2)["channels"] == 1            # what bench.py refuses to time
+    assert bench.rccl_topology(str(log), "nccl", 2)["channels"] == 1            # what bench.py flags in its JSON line (and refuses with SURFEL_REQUIRE_MULTI_CHANNEL=1)
     assert bench.rccl_topology(str(log), "gloo", 2)["channels"] is None          # nothing to read for another backend
     assert bench.rccl_topology(str(tmp_path / "missing.log"), "nccl", 2)["channels"] is None
     # --- predicted wire time: C3, 8 ranks, factored exchange ---
