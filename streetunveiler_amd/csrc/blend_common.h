@@ -416,6 +416,36 @@ __device__ __forceinline__ void dpp_fold_rows(float (&v)[24]) {
         : "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]));
     }
 }
+// ---------------------------------------------------------------------------------------------
+// Zeros from the LDS (round 6).  The backward kernels clear 15..24 accumulator registers per list entry; as v_mov instructions that was 8 % of K7's
+// vector instructions.  The same registers filled by broadcast ds_read_b128 of a small block of zeros cost the vector unit nothing: the loads issue
+// down the LDS port -- which these kernels leave three-quarters idle -- beside the entry's own four, and the compiler's counter tracking lets the
+// ray-splat test start while they are in flight.  Four copies of the block, picked by the entry slot: an address that changes per entry keeps the
+// loads inside the entry loop (a loop-invariant address would be hoisted and the zeros copied with -- v_mov).  The block is written through an
+// opaque register, so its contents are not a constant the loads could be folded into.  C3: K7 1.670 -> 1.615 ms, bit-identical (same-box A/B).
+// ---------------------------------------------------------------------------------------------
+constexpr int kZeroCopies = 4;
+template <int kQuads>
+__device__ __forceinline__ void lds_zeros_init(float4 (*s_zero)[kZeroCopies], int lane) {   // by every lane of (one of) the workgroup's waves; same-wave readers need no barrier
+    float zo = 0.f;
+    asm volatile("" : "+v"(zo));
+    if (lane < kQuads * kZeroCopies) s_zero[lane / kZeroCopies][lane % kZeroCopies] = make_float4(zo, zo, zo, zo);
+}
+template <int kN, int kLen>
+__device__ __forceinline__ void lds_zeros_load(const float4 (*s_zero)[kZeroCopies], int slot, float (&v)[kLen]) {   // v[0 .. kN) from the LDS, the rest plain zeros
+    const int zi = slot & (kZeroCopies - 1);
+#pragma unroll
+    for (int k = 0; k < (kN + 3) / 4; ++k) {
+        const float4 z = s_zero[k][zi];
+        if (4 * k < kN) v[4 * k] = z.x;
+        if (4 * k + 1 < kN) v[4 * k + 1] = z.y;
+        if (4 * k + 2 < kN) v[4 * k + 2] = z.z;
+        if (4 * k + 3 < kN) v[4 * k + 3] = z.w;
+    }
+#pragma unroll
+    for (int k = kN; k < kLen; ++k) v[k] = 0.f;
+}
+
 // LDS float add without a return value (ds_add_f32): one wave's adds to an address land in program order
 __device__ __forceinline__ void lds_add_f32(float* p, float x) { (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int reduce24_index(int l) { return ((l & 2) ? 2 : ((l >> 4) & 1)) + 3 * ((l >> 5) & 1) + 6 * ((l >> 2) & 1) + 12 * ((l >> 3) & 1); }

@@ -63,7 +63,9 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
     constexpr int kGQ = NC == 9 ? kGradQuads + 1 : kGradQuads;   // quads per gradient record (27 values with 9 channels)
     __shared__ float4 s_e[entry_quads<NC>()][kWave];
     __shared__ __attribute__((aligned(16))) float s_out[kWave][kGQ * 4];
+    __shared__ float4 s_zero[6][kZeroCopies];   // the per-entry accumulators start from zeros read from the LDS (blend_common.h lds_zeros_load)
     const int lane = threadIdx.x;
+    lds_zeros_init<6>(s_zero, lane);
     const int tile = (int)tile_order[blockIdx.x];   // longest lists first
     constexpr int NQ = QX * QY;   // 8x8 quadrants per tile = pixels per lane
     static_assert(BANDS == 1 || QY == 1, "a banded walk handles one quadrant row per band");
@@ -197,11 +199,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
             constexpr int NV = (NC == 3 || !kXG) ? 21 : 24;   // slots 21..23 carry colour channels 3..5 only
             float v[24];
-#pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                v[k] = 0.f;
-                if (k < NV) asm volatile("" : "+v"(v[k]));   // opaque zero: every quadrant block accumulates in place (no phi copies of constants)
-            }
+            lds_zeros_load<NV>(s_zero, j, v);   // (no v_mov: six broadcast LDS loads beside the entry's own)
             float w6 = 0.f, w7 = 0.f, w8 = 0.f;   // colour channels 6..8 (9-channel variant)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -299,7 +297,9 @@ void render_backward_coop_kernel(FrameDev f, const uint2* __restrict__ ranges, c
     __shared__ uint32_t s_m[kWave], s_slot[kWave], s_ql[4];
     __shared__ float s_ox[kWave], s_oy[kWave];
     __shared__ __attribute__((aligned(16))) float s_part[4][kWave][kGQ * 4];
+    __shared__ float4 s_zero[6][kZeroCopies];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (w == 0) lds_zeros_init<6>(s_zero, lane);   // (read behind the first __syncthreads below)
     const int tile = (int)tile_order[blockIdx.x];
     const int tx0 = (tile % f.tiles_x) * 16, ty0 = (tile / f.tiles_x) * 16;
     const float Xc = (float)(tx0 + 8), Yc = (float)(ty0 + 8);
@@ -373,11 +373,7 @@ void render_backward_coop_kernel(FrameDev f, const uint2* __restrict__ ranges, c
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
             const uint32_t cidx = rbase + (uint32_t)j;
             float v[24];
-#pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                v[k] = 0.f;
-                if (k < 21) asm volatile("" : "+v"(v[k]));
-            }
+            lds_zeros_load<21>(s_zero, j, v);
             Hit h;
             const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc);
             if (valid) {   // (the per-pair arithmetic of render_backward_kernel, one quadrant)
@@ -488,6 +484,7 @@ void render_backward_rows_kernel(FrameDev f, const uint2* __restrict__ ranges, c
     const int tile = (int)tile_order[blockIdx.x];
     const int tx0 = (tile % f.tiles_x) * 16, ty0 = (tile / f.tiles_x) * 16;
     const float Xc = (float)(tx0 + 8), Yc = (float)(ty0 + 8);
+    // (its accumulators are cleared with v_mov: every row reads a different entry per step, the block of zeros has no uniform slot to follow)
     // row r = lane / 16 <-> cell (r & 1, r >> 1) of a quadrant; lane % 16 <-> pixel (l & 3, (l >> 2) & 3) of the cell (as in the row-mapped K6)
     const int row = lane >> 4;
     const int lx = (row & 1) * 4 + (lane & 3), ly = (row >> 1) * 4 + ((lane >> 2) & 3);
