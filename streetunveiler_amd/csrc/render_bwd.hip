@@ -196,6 +196,14 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
             bits &= ~(1ull << j);
             const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+            // Three channels: normal and colour of the entry are fetched HERE, beside the geometry, once per entry -- inside the `valid` block (once per
+            // quadrant test, as the 6- / 9-channel instantiations at their register limit still do) every test waited for its own LDS round trip.
+            // 162 -> 168 registers: exactly the three-waves budget.  K7 1.605 -> 1.560 ms at C3, bit-identical (same-box A/B).
+            constexpr bool kEntryColoursUpFront = NC == 3 || QX * QY >= 4;   // (6 / 9 channels on four or more pixels per lane run two waves per SIMD: registers to spare)
+            float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f), e5 = e4;
+            if (kEntryColoursUpFront) { e4 = s_e[4][j]; e5 = s_e[5][j]; }
+            float4 e6_up = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NC == 9 && kEntryColoursUpFront) e6_up = s_e[6][j];
             const uint32_t cidx = rbase + (uint32_t)j;  // 0-based contributor index
             constexpr int NV = (NC == 3 || !kXG) ? 21 : 24;   // slots 21..23 carry colour channels 3..5 only
             float v[24];
@@ -208,7 +216,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                 const float xq = xl0 + (float)((q % QX) * 8), yq = yl0 + (float)((q / QX) * 8);
                 const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc[q]);
                 if (valid) {
-                    const float4 e4 = s_e[4][j], e5 = s_e[5][j];
+                    if (!kEntryColoursUpFront) { e4 = s_e[4][j]; e5 = s_e[5][j]; }
                     const float Twx = e2.y, Twy = e2.z;
                     const float one_m_inv = fast_rcp(1.f - h.alpha);
                     T[q] *= one_m_inv;                 // transmittance in front of this entry
@@ -220,7 +228,7 @@ void render_backward_kernel(FrameDev f, const uint2* __restrict__ ranges, const 
                     float phi = fmaf(e4.w, gr[q], fmaf(e5.x, gg[q], fmaf(e5.y, gb[q], fmaf(h.depth, g_depth[q],
                                 fmaf(e4.x, gn0[q], fmaf(e4.y, gn1[q], e4.z * gn2[q]))))));
                     if (NC >= 6) phi = fmaf(e5.z, gc3[q], fmaf(e5.w, gc4[q], fmaf(e3.w, gc5[q], phi)));
-                    if (NC == 9) { const float4 e6 = s_e[6][j]; phi = fmaf(e6.x, gc6[q], fmaf(e6.y, gc7[q], fmaf(e6.z, gc8[q], phi))); }
+                    if (NC == 9) { const float4 e6 = kEntryColoursUpFront ? e6_up : s_e[6][j]; phi = fmaf(e6.x, gc6[q], fmaf(e6.y, gc7[q], fmaf(e6.z, gc8[q], phi))); }
                     const float inv_depth = fast_rcp(h.depth);
                     const float m_d = fmaf(inv_depth, -kFN * kNear, kFN);
                     const float t1 = fmaf(m_d, a0[q], -a1[q]);
@@ -371,13 +379,13 @@ void render_backward_coop_kernel(FrameDev f, const uint2* __restrict__ ranges, c
             const int j = 63 - __clzll((long long)bits);
             bits &= ~(1ull << j);
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+            const float4 e4 = s_e[4][j], e5 = s_e[5][j];   // (up front, beside the geometry: see render_backward_kernel)
             const uint32_t cidx = rbase + (uint32_t)j;
             float v[24];
             lds_zeros_load<21>(s_zero, j, v);
             Hit h;
             const bool valid = intersect(xq, yq, e0, e1, e2, e3, h) & (cidx < lastc);
             if (valid) {   // (the per-pair arithmetic of render_backward_kernel, one quadrant)
-                const float4 e4 = s_e[4][j], e5 = s_e[5][j];
                 const float Twx = e2.y, Twy = e2.z;
                 const float one_m_inv = fast_rcp(1.f - h.alpha);
                 T *= one_m_inv;

@@ -18,6 +18,45 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // an LDS quad load the compiler cannot split (it turned the float4 loads of the padded rows into ds_read2_b32 pairs: 6-way bank conflicts)
 __device__ __forceinline__ f4 lds_read_b128(uint32_t byte_addr) { f4 x; asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(byte_addr)); return x; }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p; }
+template <int kPat> __device__ __forceinline__ float swz(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), kPat)); }
+// dpp_fold_rows<21> with the partner's value fetched by ds_swizzle (LDS crossbar, no vector instruction) and a plain add: 2 x 1.05 ns per pair of
+// registers instead of 2 x 1.8 ns of DPP adds.  Same value layout afterwards (v[0..5]: value k + 6 bit2 + 12 bit3 over {l, l^4, l^8, l^12}).
+__device__ __forceinline__ void swz_fold_rows21(float (&v)[24], int lane) {
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+    float t[12], u[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { t[k] = swz<0x201F>(v[k]); u[k] = (k + 12 < 21) ? swz<0x201F>(v[k + 12]) : 0.f; }   // lane ^ 8
+    // (the second add of a pair runs under the exec mask of the lanes that keep the other register: a real branch -- the empty asm keeps the
+    // compiler from turning it into 21 selects)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[k] += t[k];
+    if (b3) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = v[k + 12] + u[k];
+        v[9] = 0.f; v[10] = 0.f; v[11] = 0.f;
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { t[k] = swz<0x101F>(v[k]); u[k] = swz<0x101F>(v[k + 6]); }                           // lane ^ 4
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] += t[k];
+    if (b2) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = v[k + 6] + u[k];
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+    }
+}
+__device__ __forceinline__ float wave_reduce24_swz(float (&v)[24], int lane) {
+    swz_fold_rows21(v, lane);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fold32(v[k], v[k + 3]);
+    float z = 0.f;
+    fold16(v[0], v[1]); fold16(v[2], z);
+    float a = v[0], b = v[2];
+    a += dpp_mov<0x4E>(a); b += dpp_mov<0x4E>(b);
+    a += dpp_mov<0xB1>(a); b += dpp_mov<0xB1>(b);
+    return (lane & 2) ? b : a;
+}
 constexpr int kRow = 68;   // floats per row of the transposition array
 
 template <int MODE>
@@ -75,8 +114,8 @@ void k(float* __restrict__ out, const float4* __restrict__ ein, int iters, int f
             v[9] = fmaf(dz, sx, v[9]); v[10] = fmaf(dz, sy, v[10]);
             v[12] = fmaf(gG, e3.x - xq, v[12]); v[13] = fmaf(gG, e3.y - yq, v[13]);
         }
-        if (MODE == 0) {
-            const float tot = wave_reduce24<21>(v, lane);
+        if (MODE == 0 || MODE == 8) {
+            const float tot = MODE == 8 ? wave_reduce24_swz(v, lane) : wave_reduce24<21>(v, lane);
             if (holds_total) s_out[j][reduce24_index(lane)] = tot;
             acc += tot * 1e-9f;
         } else if (MODE == 1 || MODE == 2 || MODE == 5 || MODE == 6 || MODE == 7) {
@@ -184,11 +223,12 @@ int main(int argc, char** argv) {
     const int iters = 1000;
     if (argc > 2) {   // one mode, one fill: for counter passes (rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS)
         const int m = atoi(argv[1]), fill = atoi(argv[2]);
-        const float t = m == 0 ? run<0>(d, e, iters, fill) : m == 1 ? run<1>(d, e, iters, fill) : m == 2 ? run<2>(d, e, iters, fill) : m == 3 ? run<3>(d, e, iters, fill) : m == 5 ? run<5>(d, e, iters, fill) : m == 6 ? run<6>(d, e, iters, fill) : m == 7 ? run<7>(d, e, iters, fill) : run<4>(d, e, iters, fill);
+        const float t = m == 0 ? run<0>(d, e, iters, fill) : m == 1 ? run<1>(d, e, iters, fill) : m == 2 ? run<2>(d, e, iters, fill) : m == 3 ? run<3>(d, e, iters, fill) : m == 5 ? run<5>(d, e, iters, fill) : m == 6 ? run<6>(d, e, iters, fill) : m == 7 ? run<7>(d, e, iters, fill) : m == 8 ? run<8>(d, e, iters, fill) : run<4>(d, e, iters, fill);
         printf("mode %d fill %d: %.1f ns per entry and SIMD\n", m, fill, t * 1e6 / (12.0 * iters));
         return 0;
     }
     for (int fill = 0; fill <= 3; ++fill) {
+        const float t8 = run<8>(d, e, iters, fill);
         const float t5 = run<5>(d, e, iters, fill), t6 = run<6>(d, e, iters, fill), t7 = run<7>(d, e, iters, fill);
         const float t4 = run<4>(d, e, iters, fill), t0 = run<0>(d, e, iters, fill), t1 = run<1>(d, e, iters, fill), t2 = run<2>(d, e, iters, fill), t3 = run<3>(d, e, iters, fill);
         // ns per entry and SIMD: 12 waves per SIMD in total, iters entries each
@@ -196,6 +236,7 @@ int main(int argc, char** argv) {
         printf("fill %d: none %.1f | wave_reduce24 %.1f | lds b32 %.1f | lds addtid %.1f | dpp level + lds %.1f   (ns per entry and SIMD, three waves per SIMD)\n",
                fill, ns(t4), ns(t0), ns(t1), ns(t2), ns(t3));
         printf("        b32 writes only %.1f | b128 reads only %.1f | addtid writes only %.1f\n", ns(t5), ns(t6), ns(t7));
+        printf("        ds_swizzle folds + adds instead of DPP adds %.1f\n", ns(t8));
     }
     return 0;
 }
