@@ -459,8 +459,16 @@ __device__ __forceinline__ float wave_reduce24(float (&v)[24], int lane) {
     fold16(v[0], v[1]);                        // bit4 clear: value 0 (+ ...), bit4 set: value 1; summed over all four rows
     fold16(v[2], z);                           // bit4 clear: value 2; bit4 set: nothing
     float a = v[0], b = v[2];
-    a += dpp_mov<0x4E>(a); b += dpp_mov<0x4E>(b);    // quad_perm:[2,3,0,1] = lane ^ 2
-    a += dpp_mov<0xB1>(a); b += dpp_mov<0xB1>(b);    // quad_perm:[1,0,3,2] = lane ^ 1: every lane of a quad holds the totals
+    // the two quad levels as four DPP adds (written out: left to the compiler the last level became v_mov 0 + v_mov_dpp + v_add per value, the add
+    // sunk into the caller's `holds_total` branch); the s_nops are the two wait states between a vector write and its DPP read
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"   // lane ^ 2
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"   // lane ^ 1: every lane of a quad holds the totals
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        : "+v"(a), "+v"(b));
     return (lane & 2) ? b : a;
 }
 
@@ -504,8 +512,12 @@ __device__ __forceinline__ float wave_reduce16(float (&v)[16]) {
     fold32(v[0], v[2]); fold32(v[1], v[3]);   // lanes < 32: values 0 / 1 (+ 4 bit2 + 8 bit3), lanes >= 32: values 2 / 3
     fold16(v[0], v[1]);                       // bit4 clear: value 0 or 2, bit4 set: value 1 or 3; summed over all four rows
     float a = v[0];
-    a += dpp_mov<0x4E>(a);                    // quad_perm:[2,3,0,1] = lane ^ 2
-    a += dpp_mov<0xB1>(a);                    // quad_perm:[1,0,3,2] = lane ^ 1
+    asm volatile(   // (written out as in wave_reduce24)
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"   // lane ^ 2
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"   // lane ^ 1
+        : "+v"(a));
     return a;
 }
 
