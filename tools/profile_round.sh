@@ -17,6 +17,10 @@ rocprofv3 --pmc SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACT
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_FLAT --kernel-trace --output-format csv -d $D -o sq3 -- $B --steps 3 --warmup 1 > $D/sq3.log 2>&1 || true
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D -o grbm -- $B --steps 3 --warmup 1 > $D/grbm.log 2>&1
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $D -o l2 -- $B --steps 3 --warmup 1 > $D/l2.log 2>&1 || true
+# counters first, then the plain bench run: bench.py quotes the newest profiles/<round>_<cfg>_{hbm_traffic,sq_counters}.json whose source digest is the
+# current one, so the fresh counter files go into the box's profiles/ BEFORE the run whose line is kept (it used to quote the previous profile)
+python tools/collect_profiles.py $D ${TAG}_${CFG}${SUF} $D/out
+if [ -z "$SUF" ]; then cp $D/out/${TAG}_${CFG}_hbm_traffic.json $D/out/${TAG}_${CFG}_sq_counters.json profiles/; fi
 python bench.py --config $CFG $EXTRA 2>$D/bench.err | tail -1 > $D/bench.json
 python tools/collect_profiles.py $D ${TAG}_${CFG}${SUF} $D/out
 ls $D/out
