@@ -31,6 +31,9 @@
 // [REF /root/reference/gaussian_renderer/__init__.py:149-165].
 #include "blend_common.h"
 
+#ifndef SR_K6_COLOURS_UP_FRONT
+#define SR_K6_COLOURS_UP_FRONT 1
+#endif
 namespace sr {
 
 // exact (entry, quadrant) hit mask for the backward: K7 visits only the pairs that reached a pixel in the forward.  16 bits per list entry;
@@ -149,6 +152,12 @@ __device__ __forceinline__ void render_forward_body(float4 (*s_e)[kWave], const 
             const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & alive;
             if (!mj) continue;
             const float4 e0 = s_e[0][j], e1 = s_e[1][j], e2 = s_e[2][j], e3 = s_e[3][j];
+            // 6 / 9 channels (four waves per SIMD, registers to spare): normal and colours of the entry fetched here, once per entry, beside its geometry --
+            // inside the quadrant test every test with a hit waited for its own LDS round trip (render_backward_kernel does the same).  The three-channel
+            // kernel lives on its sixth wave at 80 registers and keeps the loads where they are.
+            constexpr bool kColoursUpFront = SR_K6_COLOURS_UP_FRONT && NC != 3 && !kStats;
+            float4 u4 = make_float4(0.f, 0.f, 0.f, 0.f), u5 = u4, u6 = u4;
+            if (kColoursUpFront) { u4 = s_e[4][j]; u5 = s_e[5][j]; if (NC == 9) u6 = s_e[6][j]; }
             const uint32_t contributor = base + (uint32_t)j + 1u;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -171,7 +180,7 @@ __device__ __forceinline__ void render_forward_body(float4 (*s_e)[kWave], const 
                 }
                 if (ballot64(valid) == 0) continue;
                 hit[q] |= 1ull << j;
-                const float4 e4 = s_e[4][j], e5 = s_e[5][j];
+                const float4 e4 = kColoursUpFront ? u4 : s_e[4][j], e5 = kColoursUpFront ? u5 : s_e[5][j];
                 if (valid) {
                     const float test_T = T[q] * (1.f - h.alpha);
                     const bool go = !(test_T < kTStop);   // else: done, and this entry is NOT blended
@@ -187,7 +196,7 @@ __device__ __forceinline__ void render_forward_body(float4 (*s_e)[kWave], const 
                         N0[q] += e4.x * w; N1[q] += e4.y * w; N2[q] += e4.z * w;
                         C0[q] += e4.w * w; C1[q] += e5.x * w; C2[q] += e5.y * w;
                         if (NC >= 6) { C3[q] += e5.z * w; C4[q] += e5.w * w; C5[q] += e3.w * w; }
-                        if (NC == 9) { const float4 e6 = s_e[6][j]; C6[q] += e6.x * w; C7[q] += e6.y * w; C8[q] += e6.z * w; }
+                        if (NC == 9) { const float4 e6 = kColoursUpFront ? u6 : s_e[6][j]; C6[q] += e6.x * w; C7[q] += e6.y * w; C8[q] += e6.z * w; }
                         lastc[q] = contributor;
                     }
                     T[q] = go ? test_T : -T[q];
