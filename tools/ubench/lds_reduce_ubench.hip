@@ -158,6 +158,47 @@ void k(float* __restrict__ out, const float4* __restrict__ ein, int iters, int f
             tot += dpp_mov<0xB1>(tot);   // the other half's sum (lane ^ 1)
             if (rt == 0 && rk < 24) out[(size_t)blockIdx.x * 24 + rk] = tot;
             acc += tot * 1e-9f;
+        } else if (MODE == 9 || MODE == 10) {
+            // the reduction of the PREVIOUS entry, one entry late: its eight quad loads are issued in front of this entry's 21 stores (one wave's LDS
+            // operations execute in order: the loads still see the previous partials), the adds follow the stores
+            f4 x[8];
+            const uint32_t a = lds_addr(rrow);
+            if (rk < 21) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = lds_read_b128(a + 16 * i);
+            }
+            // the moments' shift applied per lane (six fmac), as the real kernel would have to
+            v[3] = fmaf(e5.z, v[0], v[3]); v[4] = fmaf(e5.z, v[1], v[4]); v[5] = fmaf(e5.z, v[2], v[5]);
+            v[6] = fmaf(e5.w, v[0], v[6]); v[7] = fmaf(e5.w, v[1], v[7]); v[8] = fmaf(e5.w, v[2], v[8]);
+            if (MODE == 9) {
+#pragma unroll
+                for (int i = 0; i < 21; ++i) s_t[i * kRow + lane] = v[i];
+            } else {
+                const uint32_t base = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)s_t;
+                asm volatile(
+                    "s_mov_b32 m0, %21\n"
+                    "ds_write_addtid_b32 %0 offset:0\n"    "ds_write_addtid_b32 %1 offset:272\n"   "ds_write_addtid_b32 %2 offset:544\n"
+                    "ds_write_addtid_b32 %3 offset:816\n"  "ds_write_addtid_b32 %4 offset:1088\n"  "ds_write_addtid_b32 %5 offset:1360\n"
+                    "ds_write_addtid_b32 %6 offset:1632\n" "ds_write_addtid_b32 %7 offset:1904\n"  "ds_write_addtid_b32 %8 offset:2176\n"
+                    "ds_write_addtid_b32 %9 offset:2448\n" "ds_write_addtid_b32 %10 offset:2720\n" "ds_write_addtid_b32 %11 offset:2992\n"
+                    "ds_write_addtid_b32 %12 offset:3264\n" "ds_write_addtid_b32 %13 offset:3536\n" "ds_write_addtid_b32 %14 offset:3808\n"
+                    "ds_write_addtid_b32 %15 offset:4080\n" "ds_write_addtid_b32 %16 offset:4352\n" "ds_write_addtid_b32 %17 offset:4624\n"
+                    "ds_write_addtid_b32 %18 offset:4896\n" "ds_write_addtid_b32 %19 offset:5168\n" "ds_write_addtid_b32 %20 offset:5440\n"
+                    :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]),
+                       "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]),
+                       "s"(__builtin_amdgcn_readfirstlane(base))
+                    : "memory");
+            }
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if (rk < 21) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(x[i])); s0 += x[i].x; s1 += x[i].y; s2 += x[i].z; s3 += x[i].w; }
+            }
+            float tot = (s0 + s1) + (s2 + s3);
+            tot += dpp_mov<0xB1>(tot);
+            if (rt == 0 && rk < 24) out[(size_t)blockIdx.x * 24 + rk] = tot;
+            acc += tot * 1e-9f;
         } else if (MODE == 3) {
             // lane ^ 8 level in registers (24 DPP adds, as dpp_fold_rows' first level), then 12 values per lane through the LDS
             asm volatile(
@@ -223,12 +264,12 @@ int main(int argc, char** argv) {
     const int iters = 1000;
     if (argc > 2) {   // one mode, one fill: for counter passes (rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS)
         const int m = atoi(argv[1]), fill = atoi(argv[2]);
-        const float t = m == 0 ? run<0>(d, e, iters, fill) : m == 1 ? run<1>(d, e, iters, fill) : m == 2 ? run<2>(d, e, iters, fill) : m == 3 ? run<3>(d, e, iters, fill) : m == 5 ? run<5>(d, e, iters, fill) : m == 6 ? run<6>(d, e, iters, fill) : m == 7 ? run<7>(d, e, iters, fill) : m == 8 ? run<8>(d, e, iters, fill) : run<4>(d, e, iters, fill);
+        const float t = m == 0 ? run<0>(d, e, iters, fill) : m == 1 ? run<1>(d, e, iters, fill) : m == 2 ? run<2>(d, e, iters, fill) : m == 3 ? run<3>(d, e, iters, fill) : m == 5 ? run<5>(d, e, iters, fill) : m == 6 ? run<6>(d, e, iters, fill) : m == 7 ? run<7>(d, e, iters, fill) : m == 8 ? run<8>(d, e, iters, fill) : m == 9 ? run<9>(d, e, iters, fill) : m == 10 ? run<10>(d, e, iters, fill) : run<4>(d, e, iters, fill);
         printf("mode %d fill %d: %.1f ns per entry and SIMD\n", m, fill, t * 1e6 / (12.0 * iters));
         return 0;
     }
     for (int fill = 0; fill <= 3; ++fill) {
-        const float t8 = run<8>(d, e, iters, fill);
+        const float t8 = run<8>(d, e, iters, fill), t9 = run<9>(d, e, iters, fill), t10 = run<10>(d, e, iters, fill);
         const float t5 = run<5>(d, e, iters, fill), t6 = run<6>(d, e, iters, fill), t7 = run<7>(d, e, iters, fill);
         const float t4 = run<4>(d, e, iters, fill), t0 = run<0>(d, e, iters, fill), t1 = run<1>(d, e, iters, fill), t2 = run<2>(d, e, iters, fill), t3 = run<3>(d, e, iters, fill);
         // ns per entry and SIMD: 12 waves per SIMD in total, iters entries each
@@ -236,7 +277,7 @@ int main(int argc, char** argv) {
         printf("fill %d: none %.1f | wave_reduce24 %.1f | lds b32 %.1f | lds addtid %.1f | dpp level + lds %.1f   (ns per entry and SIMD, three waves per SIMD)\n",
                fill, ns(t4), ns(t0), ns(t1), ns(t2), ns(t3));
         printf("        b32 writes only %.1f | b128 reads only %.1f | addtid writes only %.1f\n", ns(t5), ns(t6), ns(t7));
-        printf("        ds_swizzle folds + adds instead of DPP adds %.1f\n", ns(t8));
+        printf("        ds_swizzle folds + adds instead of DPP adds %.1f | LDS, one entry late (loads in front of the stores): b32 %.1f, addtid %.1f\n", ns(t8), ns(t9), ns(t10));
     }
     return 0;
 }
